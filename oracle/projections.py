@@ -1,0 +1,501 @@
+"""Oracle projections / constraints / metrics (TEST INFRASTRUCTURE -- see oracle/__init__.py).
+
+Reference files (all under xframe/):
+* projects/fxs/projectLibrary/fxs_Projections.py  ReciprocalProjection 443-930,
+  RealProjection 26-155, ShrinkWrapParts 178-298
+* projects/fxs/projectLibrary/fxs_IO_methods.py   HIOProjection 24-64, error_reduction 67-68,
+  l2 error 97-128, deg2 invariant diff 408-447, main error 746-765
+* projects/fxs/projectLibrary/misk.py             square 159-168, abs 221-225, add_above_zero_index 326-329
+* projects/fxs/projectLibrary/fxs_invariant_tools.py  harmonic_coeff_to_deg2_invariants_3d 915-923
+* library/pythonLibrary.py                        create_threshold_projection 1289-1320
+* library/mathLibrary.py                          ExponentialRamp 1033-1054, LinearRamp 1056-1129,
+  gaussian_fourier_transformed_spherical 616-624, get_test_function 1456-1466, midpoint_rule 1492-1496
+"""
+import numpy as np
+from scipy.interpolate import griddata
+from .fourier import SphericalIntegrator
+
+
+# ----------------------------------------------------------------------------- ramps
+class ExponentialRamp:
+    """mathLibrary.py:1033-1054."""
+
+    def __init__(self, start, stop, exponent, stop_argument=1):
+        self.start, self.stop, self.stop_argument = start, stop, stop_argument
+        if stop < start:
+            exponent *= exponent / abs(exponent) * -1
+        else:
+            exponent *= exponent / abs(exponent)
+        self.exponent = exponent
+        self.A = (self.start - self.stop) / (1 - np.exp(self.exponent * self.stop_argument))
+        self.B = self.start - self.A
+
+    def eval(self, x):
+        if self.start > self.stop:
+            return np.maximum(self.A * np.exp(x * self.exponent) + self.B, self.stop)
+        return np.minimum(self.A * np.exp(x * self.exponent) + self.B, self.stop)
+
+    __call__ = eval
+
+
+def _is_number(v):
+    return np.issubdtype(np.array(v).dtype, np.number)
+
+
+class LinearRamp:
+    """mathLibrary.py:1056-1129."""
+
+    def __init__(self, start, stop=False, slope=False, default_start=False, default_stop=False):
+        self.default_stop, self.default_start = default_stop, default_start
+        self.start = tuple(start) if isinstance(start, (list, tuple)) else (start, 0)
+        self.undefined = False
+        if not _is_number(self.start[0]):
+            if default_start == False:  # noqa: E712  (reference compares with ==)
+                self.undefined = True
+            else:
+                self.start = (default_start, 0)
+        self.stop, self.stop_is_defined = self._parse_stop(stop)
+        self.slope_is_defined = not isinstance(slope, bool)
+        self.slope = slope
+        if not self.undefined:
+            self._set_model_parameters()
+
+    def _parse_stop(self, stop):
+        valid = False
+        if isinstance(stop, (list, tuple)):
+            stop = list(stop)
+            val_is_num = _is_number(stop[0])
+            if not val_is_num and _is_number(self.default_stop):
+                stop[0] = self.default_stop
+                val_is_num = True
+            if _is_number(stop[1]) and val_is_num and stop[1] >= self.start[1]:
+                valid = True
+        if not valid:
+            stop = False
+        return stop, valid
+
+    def _set_model_parameters(self):
+        start, stop, slope = self.start, self.stop, self.slope
+        if (not self.stop_is_defined) and (not self.slope_is_defined):
+            self.A = 0
+            self.B = start[0]
+            self.C = np.nan
+        elif self.stop_is_defined:
+            self.C = stop[0]
+            self.A = 0 if (stop[1] - start[1]) == 0 else (stop[0] - start[0]) / (stop[1] - start[1])
+            if self.slope_is_defined:
+                self.A = slope
+        elif slope == 0:
+            self.C = np.nan
+            self.A = slope
+        else:
+            self.C = np.sign(slope) * np.inf
+            self.A = slope
+        self.B = start[0] - self.A * start[1]
+
+    def eval(self, x):
+        if self.undefined:
+            return np.nan
+        val = self.A * x + self.B
+        if self.A < 0:
+            val = max(val, self.C)
+        elif self.A > 0:
+            val = min(val, self.C)
+        return val
+
+    __call__ = eval
+
+
+# ----------------------------------------------------------------------------- small operators
+def square_grid(data):
+    """misk.py:159-168: I = F conj(F), complex out."""
+    return data * data.conj()
+
+
+def abs_value(data):
+    """misk.py:221-225: |rho| stored in a complex array."""
+    return np.sqrt((data * data.conj()).real).astype(complex)
+
+
+def add_above_zero_index(a, b):
+    """misk.py:326-329."""
+    result = a + b
+    result[0] = a[0]
+    return result
+
+
+def harmonic_coeff_to_deg2_invariants_3d(Ilm):
+    """fxs_invariant_tools.py:915-923: B_l = I_l I_l^dagger -> (L+1, Nq, Nq)."""
+    return np.array(tuple(Il @ Il.T.conj() for Il in Ilm))
+
+
+def gaussian_fourier_transformed_spherical(q, sigma):
+    """mathLibrary.py:616-624 (note the q**4: np.square(q)**2)."""
+    a = 1 / (2 * sigma ** 2)
+    return np.sqrt(np.pi / a) * np.exp(-np.pi ** 2 * np.square(q) ** 2 / a)
+
+
+def get_test_function(support, slope):
+    """mathLibrary.py:1456-1466."""
+    center = np.mean(support)
+    size = support[1] - center
+
+    def test_function(data):
+        non_zero = (data > support[0]) & (data < support[1])
+        values = np.zeros_like(data)
+        values[non_zero] = np.exp(-slope * size ** 2 / (size ** 2 - (data[non_zero] - center) ** 2))
+        return values
+    return test_function
+
+
+def regrid_1d(values, old_points, new_points, interpolation='cubic'):
+    """ReGrider.regrid_cart for a 1-D grid (gridLibrary.py:635-656): scipy griddata, fill 0."""
+    return griddata(old_points[:, None], values, new_points[:, None], method=interpolation,
+                    fill_value=0.0, rescale=False).reshape(len(new_points))
+
+
+# ----------------------------------------------------------------------------- reciprocal projection
+class ReciprocalProjection:
+    """fxs_Projections.py:443-930, dimensions == 3 only.
+
+    ``data`` keys as produced by ``load_invariants`` (_database_.py:566-609):
+    average_intensity (values on data_radial_points), data_radial_points, max_order,
+    data_projection_matrices (sequence over l of (Nd, min(2l+1,Nd)) complex), xray_wavelength.
+    ``opt`` = resolved ``projections.reciprocal`` settings (dict).
+    """
+
+    def __init__(self, radial_points, data, max_order, opt):
+        self.opt = opt
+        q_d = np.asarray(data['data_radial_points'])
+        aint_d = np.asarray(data['average_intensity'])
+        self.data_radial_points = q_d
+        self.data_max_q, self.data_min_q = np.max(q_d), np.min(q_d)
+        self.data_max_order = data['max_order']
+        self.xray_wavelength = data.get('xray_wavelength', 1.0)
+        # 473-476 (midpoint_rule: mathLibrary.py:1492-1496)
+        self.integrated_intensity = (q_d[1] - q_d[0]) * np.sum(aint_d * q_d ** 2, axis=0) * 2 * np.sqrt(np.pi)
+        self.radial_points = np.asarray(radial_points)
+        self.max_q = np.max(self.radial_points)
+        self.positive_orders = np.arange(max_order + 1)
+        self.used_order_ids = np.asarray(opt['used_order_ids'])
+        self.used_orders = {int(o): int(i) for o, i in zip(self.positive_orders, self.used_order_ids)}   # 492
+        self.number_of_particles = [opt['number_of_particles']['initial']]
+        # ---- _regrid_data 639-676 (always regrids: see SURVEY appendix C)
+        interp = opt['regrid']['interpolation']
+        order_ids = list(self.used_orders.values())
+        dpm = data['data_projection_matrices']
+        self.average_intensity = regrid_1d(aint_d, q_d, self.radial_points, interp)
+        pm = []
+        for o_id in order_ids:
+            m = np.asarray(dpm[o_id])
+            cols = [regrid_1d(m[:, c], q_d, self.radial_points, interp) for c in range(m.shape[1])]
+            pm.append(np.stack(cols, axis=1))
+        self.regridded_projection_matrices = pm
+        nq = len(self.radial_points)
+        # 506-511
+        self.full_projection_matrices = [np.zeros((nq, min(nq, 2 * o + 1)), dtype=complex) for o in range(max_order + 1)]
+        for oid, p in zip(self.used_order_ids, pm):
+            self.full_projection_matrices[oid] = p
+        # ---- modify_projection_matrices 679-714
+        self.projection_matrices = self._modify(pm)
+        assert self.projection_matrices[0].shape[0] == nq
+        # ---- generate_radial_mask 578-629
+        self.radial_mask = self._radial_mask(opt.get('q_mask', None))
+        # ---- approximate_unknowns precompute 753-754
+        D2 = np.diag(self.radial_points) ** 2
+        self.PDs = tuple(self.projection_matrices[i].T.conj() @ D2 for i in order_ids)
+        # calc_deg2_invariants 631-637
+        self.deg2_invariants = harmonic_coeff_to_deg2_invariants_3d(self.projection_matrices)
+        self.fixed_intensity = None
+
+    def _modify(self, pm):
+        opt = self.opt
+        used_orders = self.used_orders
+        keys = np.array(tuple(used_orders))
+        odd = keys % 2 == 1
+        proj = [np.array(m, dtype=complex) for m in pm]
+        if opt.get('odd_orders_to_0', False):
+            for o in keys[odd]:
+                proj[used_orders[int(o)]][:] = 0
+        if opt.get('use_averaged_intensity', False):
+            zero_id = used_orders[0]
+            proj[zero_id] = (self.average_intensity.astype(complex)[:, None].real * 2 * np.sqrt(np.pi)).astype(complex)
+        for p in proj:
+            p[:] *= 2
+        return proj
+
+    def _radial_mask(self, mask_opt):
+        q = self.radial_points
+        n_orders = len(self.positive_orders)
+        data_mask = np.full((n_orders, len(q)), False) | ((q >= self.data_min_q) & (q <= self.data_max_q))
+        mask = True
+        if isinstance(mask_opt, dict):
+            mtype = mask_opt['type']
+            if mtype == 'none':
+                mask = True
+            elif mtype == 'manual' and mask_opt['manual']['type'] == 'region':
+                region = mask_opt['manual']['region']
+                mask = np.full((n_orders, len(q)), False)
+                if (region[0] == False) and (region[1] != False):  # noqa: E712
+                    mask[:] = (q < region[1])[None, :]
+                elif (region[0] != False) and (region[1] == False):  # noqa: E712
+                    mask[:] = (q >= region[0])[None, :]
+                elif (region[0] != False) and (region[1] != False):  # noqa: E712
+                    mask[:] = ((q >= region[0]) & (q < region[1]))[None, :]
+                else:
+                    mask[:] = True
+            else:
+                raise NotImplementedError(mtype)
+        return mask & data_mask
+
+    # 752-767
+    def approximate_unknowns(self, Ilm):
+        unknowns = []
+        for PD, oid in zip(self.PDs, self.used_orders.values()):
+            u, s, vh = np.linalg.svd(PD @ Ilm[oid], full_matrices=False)
+            unknowns.append(u @ vh)
+        return tuple(unknowns)
+
+    # 832-849 + 866-871
+    def mtip_projection(self, Ilm, unknowns):
+        out = [np.array(c) for c in Ilm]
+        rm = self.radial_mask
+        pmat = self.projection_matrices
+        for o_id in self.used_orders.values():
+            tmp = pmat[o_id] @ unknowns[o_id]
+            out[o_id][rm[o_id], ...] = tmp[rm[o_id], ...]
+        if 0 in self.used_orders:
+            zero_id = self.used_orders[0]
+            out[zero_id][rm[zero_id], ...] = pmat[zero_id][rm[zero_id], ...]
+            out[zero_id][:] /= np.sqrt(self.number_of_particles[0])
+        return out
+
+    # 899-909
+    def project_to_modified_intensity(self, reciprocal_density, square, new_intensity):
+        non_zero = (square.real >= 0) & (new_intensity.real >= 0)
+        mult = np.zeros(reciprocal_density.shape, dtype=float)
+        with np.errstate(divide='ignore', invalid='ignore'):
+            mult[non_zero] = np.sqrt(new_intensity.real[non_zero] / square.real[non_zero])
+        return reciprocal_density * mult
+
+    # 911-923 (fixed intensity is |F| of the last pair: reconstruct.py:899-902)
+    def project_to_fixed_intensity(self, reciprocal_density, square):
+        fixed = self.fixed_intensity
+        non_zero = (square.real >= 0) & (fixed >= 0)
+        mult = np.zeros(reciprocal_density.shape, dtype=float)
+        with np.errstate(divide='ignore', invalid='ignore'):
+            mult[non_zero] = np.sqrt(fixed[non_zero] / square.real[non_zero])
+        return reciprocal_density * mult
+
+
+# ----------------------------------------------------------------------------- real-space projection
+class RealProjection:
+    """fxs_Projections.py:26-155; opt = resolved ``projections.real.projections``."""
+
+    def __init__(self, opt, real_r, particle_radius=None, auto_correlation=None):
+        self.opt = opt
+        self.enforce_initial_support = True
+        sup = opt['support']['initial_support']
+        if sup['type'] == 'max_radius':
+            support_mask = np.where(real_r < sup['max_radius'], True, False)        # 137-140
+        elif sup['type'] == 'auto_correlation':
+            thr = sup['auto_correlation']['threshold']
+            support_mask = auto_correlation >= thr * np.max(auto_correlation)
+            support_mask[real_r > particle_radius] = 0
+        else:
+            raise AssertionError(sup['type'])
+        self._initial_mask = ~support_mask
+        self._mask = [self._initial_mask.copy()]
+
+    @property
+    def initial_support(self):
+        return ~self._initial_mask.copy()
+
+    @property
+    def support(self):
+        return ~self._mask[0]
+
+    @support.setter
+    def support(self, support):                                                      # 53-58
+        if self.enforce_initial_support:
+            self._mask[0] = self._initial_mask | (~support)
+        else:
+            self._mask[0] = ~support
+
+    def projection(self, data):
+        """assemble_projection 110-130: in place; returns [data, mask_dict]."""
+        mask = False
+        mask_dict = {}
+        for key in self.opt['apply']:
+            if key == 'support':
+                m = self._mask[0]
+                data[m] = 0
+                p_mask = m
+            elif key == 'value_threshold':
+                p_mask = _threshold_projection(data, self.opt['value_threshold'].get('threshold', 0.0))
+            elif key == 'limit_imag':
+                thresh = self.opt['limit_imag'].get('threshold', 0.0)
+                imag = data.imag
+                p_mask = np.abs(imag) >= thresh
+                imag[p_mask] = 0
+            else:
+                continue       # 113-118: unknown generators (e.g. 'assert_real') are ignored
+            mask_dict[key] = p_mask
+            mask = mask | p_mask
+            mask_dict['all'] = mask
+        return [data, mask_dict]
+
+
+def _is_num(v):
+    return isinstance(v, (float, int)) and not isinstance(v, bool)
+
+
+def _threshold_projection(density, threshold):
+    """pythonLibrary.py:1289-1320 (in place on .real)."""
+    lo, hi = threshold
+    real = density.real
+    if _is_num(lo) and not _is_num(hi):
+        bad = real < lo
+        real[bad] = lo
+        return bad
+    if _is_num(hi) and not _is_num(lo):
+        bad = real > hi
+        real[bad] = hi
+        return bad
+    if not _is_num(lo) and not _is_num(hi):
+        return False
+    small, big = real < lo, real > hi
+    real[small] = lo
+    real[big] = hi
+    return small | big
+
+
+def hybrid_input_output(without_projection, projection_out, _input, beta, considered=('all',)):
+    """fxs_IO_methods.py:40-64."""
+    out, mask_dict = projection_out
+    if len(considered) == 1:
+        invalid = mask_dict[considered[0]]
+    else:
+        invalid = False
+        for name in considered:
+            invalid = invalid | mask_dict[name]
+    diff = without_projection - out
+    negative_feedback = _input - beta * diff
+    return np.where(invalid, negative_feedback, out)
+
+
+def error_reduction(out_without_projection, out, _input):
+    """fxs_IO_methods.py:67-68."""
+    return np.array(out[0])
+
+
+def l2_rel_diff_error(integrator, values, projected_values, mask=True):
+    """fxs_IO_methods.py:97-128 (real flavour: projected_values = [P, masks]).
+
+    Reference quirk kept on purpose: with ``mask = True`` (no initial-support restriction) the
+    statement ``square[~mask] = 0`` evaluates ``~True == -2`` and zeroes radial shell N-2."""
+    diff = values - projected_values
+    square_diff = (diff * diff.conj()).real
+    square = (values * values.conj()).real
+    neg = -2 if mask is True else ~mask
+    square_diff[neg] = 0
+    square[neg] = 0
+    diff_l2 = integrator.integrate(square_diff)
+    value_l2 = integrator.integrate(square)
+    return diff_l2 / value_l2 if value_l2 != 0 else np.inf
+
+
+def l2_cache_split(data_shape, itemsize, L2_cache):
+    """pythonLibrary.py:1160-1181 get_L2_cache_split_parameters -> splitting dimension."""
+    units = L2_cache * 1024 / itemsize
+    sub = np.array([np.prod(np.array(data_shape[i:])) for i in range(len(data_shape))])
+    if sub[0] > units:
+        return int(np.nonzero(sub // units)[0][-1])
+    return -1
+
+
+def select_real_error_mask(data_shape, inside_initial_support, initial_mask, cache_aware=True, L2_cache=512):
+    """Which mask the reference's real l2 metric really uses.
+
+    ``generate_real_l2_rel_diff_error_routine`` (fxs_IO_methods.py:287-300) picks the cache-aware
+    variant when ``settings.general.cache_aware`` (default True, general.py:25, L2_cache=512 kB,
+    general.py:27); that variant falls back to the plain routine **without forwarding the mask**
+    when the grid fits into L2_cache/2 (fxs_IO_methods.py:131-151, 203-205).  So grids with
+    <= 16384 points (config 1 and smaller) are evaluated with mask=True (+ the shell N-2 quirk),
+    larger grids with the initial-support mask."""
+    mask = initial_mask if inside_initial_support else True
+    if cache_aware and l2_cache_split(data_shape, 16, L2_cache / 2) < 0:
+        mask = True
+    return mask
+
+
+class Deg2InvariantDiff:
+    """fxs_IO_methods.py:408-447 (_generate_deg2_invariant_diff_3d)."""
+
+    def __init__(self, reference_invariant, used_orders, n_particles, invariant_mask):
+        self.order_array = np.array(tuple(used_orders.values()))
+        self.zero_id = used_orders[0]
+        self.mask = np.zeros(reference_invariant.shape, dtype=bool)
+        self.mask[:] = ~invariant_mask[self.order_array]
+        rm = reference_invariant.copy()
+        rm[self.mask] = 0
+        self.reference_masked = rm
+        self.reference = rm.copy()
+        norm = np.sum(self.reference * self.reference.conj(), axis=(1, 2))
+        self.non_zero = norm != 0
+        self.non_zero_norm = norm[self.non_zero]
+        self.n_particles = n_particles
+        self.n_orders = len(norm)
+
+    def __call__(self, Ilm):
+        Bl = harmonic_coeff_to_deg2_invariants_3d(Ilm)[self.order_array].copy()
+        Bl[self.mask] = 0
+        self.reference[self.zero_id] = self.reference_masked[self.zero_id] / self.n_particles[0]
+        diff = self.reference - Bl
+        norm_diff = np.sum((diff * diff.conj()).real, axis=(1, 2))
+        errors = np.full(self.n_orders, -1, dtype=float)
+        errors[self.non_zero] = (norm_diff[self.non_zero] / self.non_zero_norm).real
+        return errors
+
+
+# ----------------------------------------------------------------------------- shrink wrap
+class ShrinkWrap:
+    """fxs_Projections.py:178-298 (mode 'threshold')."""
+
+    def __init__(self, qs, shape, threshold=0.06):
+        self.qgrid = np.broadcast_to(np.asarray(qs)[:, None, None], shape)
+        self.default_sigma = np.pi / np.max(qs)                                  # 189-193
+        self._threshold = threshold
+        self._sigma = self.default_sigma
+        self.gaussian_values = gaussian_fourier_transformed_spherical(self.qgrid, self._sigma)
+
+    @property
+    def threshold(self):
+        return self._threshold
+
+    @threshold.setter
+    def threshold(self, value):                                                   # 218-227
+        self._threshold = 0 if value < 0 else (1 if value >= 1 else value)
+
+    @property
+    def gaussian_sigma(self):
+        return self._sigma
+
+    @gaussian_sigma.setter
+    def gaussian_sigma(self, value):                                              # 233-243
+        valid_type = _is_number(value) and not isinstance(value, bool)
+        valid = bool(value > 0) if valid_type else False
+        self._sigma = value if valid else self.default_sigma
+        self.gaussian_values = gaussian_fourier_transformed_spherical(self.qgrid, self._sigma)
+
+    def multiply_with_ft_gaussian(self, data):                                    # 294-298
+        return data * self.gaussian_values
+
+    def get_new_mask(self, convolution_data):                                     # 245-258
+        c = np.array(convolution_data.real)
+        c[c < 0] = 0
+        max_value, min_value = c.max(), c.min()
+        return c >= min_value + self._threshold * (max_value - min_value)
+
+
+__all__ = [n for n in dir() if not n.startswith('_')] + ['SphericalIntegrator']

@@ -1,0 +1,439 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by running the REFERENCE's own numeric code (build container only).
+
+Run:  python tests/golden/make_golden.py            (needs /root/reference; never runs on the GPU box)
+
+The reference package cannot be imported whole (``xframe/_version.py`` is generated at install
+time), so its numeric modules are imported one by one under stub parent packages (SURVEY.md
+appendix D).  The third-party ``shtns`` module is absent; the oracle's numpy SHT
+(``oracle/sht.py``, pinned by analytic known answers) is injected at the reference's
+``xframe.library.mathLibrary.shtns`` slot (``mathLibrary.py:29-34``, factory 498-500), i.e. the
+fixtures pin everything *except* the SHT arithmetic itself.
+
+Only inputs and outputs (data) are written to ``tests/golden/*.npz``; no reference source is copied.
+"""
+import importlib
+import os
+import sys
+import tempfile
+import types
+import warnings
+from importlib.machinery import ModuleSpec
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.abspath(os.path.join(HERE, '..', '..'))
+sys.path.insert(0, ROOT)
+REF = '/root/reference/xframe'
+
+warnings.simplefilter('ignore')
+np.seterr(all='ignore')
+
+
+def bootstrap():
+    os.environ['HOME'] = tempfile.mkdtemp(prefix='xframe_home_')
+
+    def stub(name, path):
+        m = types.ModuleType(name)
+        m.__path__ = [path]
+        spec = ModuleSpec(name, None, is_package=True)
+        spec.submodule_search_locations = [path]
+        m.__spec__ = spec
+        sys.modules[name] = m
+        return m
+    stub('xframe', REF)
+    stub('xframe.projects', REF + '/projects')
+    stub('xframe.projects.fxs', REF + '/projects/fxs')
+    stub('xframe.projects.fxs.projectLibrary', REF + '/projects/fxs/projectLibrary')
+    mods = {}
+    for n in ['xframe.settings', 'xframe.library.pythonLibrary', 'xframe.library.mathLibrary',
+              'xframe.library.gridLibrary', 'xframe.Multiprocessing']:
+        mods[n] = importlib.import_module(n)
+    return mods
+
+
+class ShAdapter:
+    """The ``sh`` surface of shtns_plugin.py:11-274 on top of oracle.sht.SHT."""
+
+    def __init__(self, l_max, mode_flag='complex', output_order='l', anti_aliazing_degree=2,
+                 n_phi=False, n_theta=False):
+        from oracle.sht import SHT
+        assert mode_flag == 'complex'
+        s = SHT(l_max, n_theta, n_phi, anti_aliazing_degree)
+        self._s = s
+        self.l_max = l_max
+        self.n_coeff = s.n_coeff
+        self.phi, self.theta = s.phi, s.theta
+        self.m, self.l = s.m, s.l
+        self.cplx_m_indices, self.cplx_l_indices = s.cplx_m_indices, s.cplx_l_indices
+        self.cplx_l_split_indices = s.cplx_l_split_indices
+        lp1 = np.arange(l_max + 2)
+        index = (lp1 * (lp1 + 1) / 2).astype(int)
+        self.cplx_m_split_indices = np.concatenate((index[-1] - index[-2::-1], index[-1] + index[1:-2]))
+        self.forward_l, self.inverse_l = s.forward_l, s.inverse_l
+        self.forward_m, self.inverse_m = s.forward_m, s.inverse_m
+        self.forward_d, self.inverse_d = s.forward_d, s.inverse_d
+        self.test = s.test
+
+
+def dictns(pl, d):
+    return pl.DictNamespace.dict_to_dictnamespace(d)
+
+
+def cplx(rng, shape):
+    return rng.normal(size=shape) + 1j * rng.normal(size=shape)
+
+
+def main():
+    mods = bootstrap()
+    settings = mods['xframe.settings']
+    pl = mods['xframe.library.pythonLibrary']
+    ml = mods['xframe.library.mathLibrary']
+    gl = mods['xframe.library.gridLibrary']
+    ml.shtns = ShAdapter
+
+    from oracle import mtip as OM
+    from oracle.fourier import FourierPair
+    from oracle.sht import SHT
+    from xframe_amd.fxs import synthetic as S
+
+    out = {}
+
+    # ------------------------------------------------------------------ G1: weights (a1, a2)
+    pre = 'xframe.projects.fxs.projectLibrary.'
+    ht = importlib.import_module(pre + 'hankel_transforms')
+    for (N, L, kappa) in [(8, 3, 2.0), (8, 3, np.pi)]:
+        tag = f'G1_N{N}_L{L}_k{kappa:.3f}'
+        w = ht.calc_spherical_mid_weights(np.arange(L + 1), N, kappa)
+        out[tag + '_mid_raw'] = w
+        a = ht.assemble_weights(w, np.arange(L + 1), 123.0, reciprocity_coefficient=kappa, dimensions=3, mode='midpoint')
+        out[tag + '_mid_fwd'], out[tag + '_mid_inv'] = a['forward'], a['inverse']
+        wt = ht.calc_spherical_trapz_weights(np.arange(L + 1), N, kappa)
+        out[tag + '_trapz_raw'] = wt
+        a = ht.assemble_weights(wt, np.arange(L + 1), 123.0, reciprocity_coefficient=kappa, dimensions=3, mode='trapz')
+        out[tag + '_trapz_fwd'], out[tag + '_trapz_inv'] = a['forward'], a['inverse']
+    # checksums at the BASELINE sizes
+    for cfg, (N, L) in {1: (32, 8), 2: (64, 16), 3: (128, 32)}.items():
+        w = ht.calc_spherical_mid_weights(np.arange(L + 1), N, 2.0)
+        out[f'G1_cfg{cfg}_mid_raw_sums'] = np.array([w.sum(), np.abs(w).sum(), (w * np.arange(w.size).reshape(w.shape)).sum()])
+        out[f'G1_cfg{cfg}_mid_raw_sample'] = w[::max(1, L // 4), ::max(1, N // 8), ::max(1, N // 8)].copy()
+
+    # ------------------------------------------------------------------ G2: Hankel apply (a3) + FT (a5)
+    N, L, kappa = 16, 4, 2.0
+    rng = np.random.default_rng(42)
+    hts = importlib.import_module(pre + 'harmonic_transforms')
+    fts = importlib.import_module(pre + 'fourier_transforms')
+    gp = importlib.import_module(pre + 'ft_grid_pairs')
+    ht_opt = {'dimensions': 3, 'max_order': L, 'n_phi': 0, 'n_theta': 0, 'n_radial_points': N}
+    cht = hts.HarmonicTransform('complex', ht_opt)
+    Qd = S.data_cutoff(N)
+    q_data = S.midpoint_points(Qd, N)
+    max_q = float(np.max(q_data))                     # reconstruct.py:258-261
+    grid_pair = gp.get_grid({'type': 'midpoint', 'reciprocity_coefficient': kappa, **ht_opt, **cht.grid_param,
+                             'max_q': max_q, 'n_radial_points_from_data': N})
+    rs = grid_pair.realGrid[:, 0, 0, 0]
+    qs = grid_pair.reciprocalGrid[:, 0, 0, 0]
+    out['G2_rs'], out['G2_qs'] = rs, qs
+    out['G2_theta'], out['G2_phi'] = cht.grid_param['thetas'], cht.grid_param['phis']
+    wraw = ht.calc_spherical_mid_weights(np.arange(L + 1), N, kappa)
+    wd = {'weights': wraw, 'posHarmOrders': np.arange(L + 1)}
+    r_max = np.max(rs)
+    zht, izht = ht.generate_ht(wraw, np.arange(L + 1), r_max, reciprocity_coefficient=kappa, dimensions=3,
+                               use_gpu=False, mode='midpoint')
+    nlm = (L + 1) ** 2
+    c_direct = cplx(rng, (N, nlm))
+    sh = cht._sh
+    c_ml = [np.array(c_direct[:, idx]) for idx in sh.cplx_m_indices]
+    f_ml = zht(c_ml)
+    i_ml = izht(c_ml)
+    f_direct = np.zeros((N, nlm), complex)
+    i_direct = np.zeros((N, nlm), complex)
+    for m_id, idx in enumerate(sh.cplx_m_indices):
+        f_direct[:, idx] = f_ml[m_id]
+        i_direct[:, idx] = i_ml[m_id]
+    out['G2_in'], out['G2_fwd'], out['G2_inv'] = c_direct, f_direct, i_direct
+    ft, ift = fts.generate_ft(r_max, wd, cht, 3, pos_orders=np.arange(L + 1), reciprocity_coefficient=kappa,
+                              use_gpu=False, mode='midpoint')
+    shape = (N, len(cht.grid_param['thetas']), len(cht.grid_param['phis']))
+    g_in = cplx(rng, shape)
+    out['G2_grid_in'], out['G2_ft'], out['G2_ift'] = g_in, ft(g_in), ift(g_in)
+    # trapz flavour
+    wraw_t = ht.calc_spherical_trapz_weights(np.arange(L + 1), N, kappa)
+    zht_t, izht_t = ht.generate_ht(wraw_t, np.arange(L + 1), r_max, reciprocity_coefficient=kappa, dimensions=3,
+                                   use_gpu=False, mode='trapz')
+    f_ml = zht_t(c_ml)
+    f_direct_t = np.zeros((N, nlm), complex)
+    for m_id, idx in enumerate(sh.cplx_m_indices):
+        f_direct_t[:, idx] = f_ml[m_id]
+    out['G2_trapz_fwd'] = f_direct_t
+
+    # ------------------------------------------------------------------ synthetic invariants on the data grid
+    class T:
+        def __init__(s, fp):
+            s.fp, s.rs, s.thetas, s.phis = fp, fp.rs, fp.sht.theta, fp.sht.phi
+
+        def ft(s, x):
+            return s.fp.ft(x)
+
+        def forward_l(s, x):
+            return s.fp.sht.forward_l(x)
+
+    def make_settings(N, L, extra=None):
+        o = OM.deep_update(OM.default_settings(), S.config_overrides(1))
+        o = OM.deep_update(o, {'grid': {'n_radial_points': N, 'max_order': L},
+                               'projections': {'reciprocal': {'used_order_ids': np.arange(L + 1)}},
+                               'GPU': {'use': False}, 'multi_process': {'use': False}})
+        if extra:
+            o = OM.deep_update(o, extra)
+        return o
+
+    def ref_data(data):
+        d = dict(data)
+        d['average_intensity'] = gl.SampledFunction(gl.NestedArray(data['data_radial_points'][:, None], 1),
+                                                    data['average_intensity'], coord_sys='cartesian')
+        return d
+
+    data, rho_true = S.make_invariants(T(FourierPair(SHT(L), N, Qd, kappa)), N, L)
+    for l in range(L + 1):
+        out[f'D16_pm{l}'] = data['data_projection_matrices'][l]
+    out['D16_aint'], out['D16_q'] = data['average_intensity'], data['data_radial_points']
+
+    opt = make_settings(N, L, {'projections': {'reciprocal': {
+        'q_mask': {'type': 'manual', 'manual': {'type': 'region', 'region': [False, float(qs[N - 3])]}}}}})
+    settings.project = dictns(pl, opt)
+
+    # ------------------------------------------------------------------ G3/G4: reciprocal projection (a7-a10)
+    fp_ = importlib.import_module(pre + 'fxs_Projections')
+    rp = fp_.ReciprocalProjection(grid_pair.reciprocalGrid, ref_data(data), L)
+    out['G3_integrated_intensity'] = np.array(rp.integrated_intensity)
+    out['G3_radial_mask'] = rp.radial_mask
+    for l in range(L + 1):
+        out[f'G3_pm{l}'] = np.asarray(rp.projection_matrices[l], dtype=complex)
+    Ilm = [cplx(rng, (N, 2 * l + 1)) for l in range(L + 1)]
+    unk = rp.approximate_unknowns(Ilm)
+    unk = tuple(np.array(u) for u in unk)
+    proj = rp.mtip_projection(Ilm, unk)
+    for l in range(L + 1):
+        out[f'G3_Ilm{l}'], out[f'G3_unk{l}'], out[f'G3_proj{l}'] = Ilm[l], unk[l], proj[l]
+        out[f'G3_VU{l}'] = rp.projection_matrices[l] @ unk[l]
+    out['G3_deg2'] = rp.deg2_invariants
+    F = cplx(rng, shape)
+    I = (F * F.conj())
+    I.flat[5] = 0.0
+    F.flat[5] = 0.0                                     # exact-zero intensity point
+    Inew = (rng.normal(size=shape) + 0.3).astype(complex)   # has negative real parts
+    Inew.flat[5] = 1.0
+    Inew.flat[7] = 0.0
+    out['G4_F'], out['G4_I'], out['G4_Inew'] = F, I, Inew
+    out['G4_Fnew'] = np.array(rp.project_to_modified_intensity(F, I, Inew))
+
+    # ------------------------------------------------------------------ G5/G6: real projection, HIO, ER, error (a11-a13)
+    io = importlib.import_module(pre + 'fxs_IO_methods')
+    real_opt = settings.project.projections.real
+    metadata = {'integrated_intensity': rp.integrated_intensity, 'real_grid': grid_pair.realGrid, 'auto_correlation': False}
+    real_pr = fp_.RealProjection(real_opt.projections, metadata)
+    out['G5_initial_support'] = real_pr.initial_support
+    sup = rng.random(shape) > 0.4
+    rho_in = cplx(rng, shape)
+    rho_in.imag *= 2.0                                   # some |imag| >= 2
+    rho_prev = cplx(rng, shape)
+    res = {}
+    for enforce in (True, False):
+        real_pr.enforce_initial_support = enforce
+        real_pr.support = sup
+        w = np.array(rho_in)
+        work = np.array(rho_in)
+        pout = real_pr.projection(work)
+        hio = io.HIOProjection(0.37, considered_projections=['all'])
+        new = hio.projection(w, pout, rho_prev)
+        er = io.error_reduction(w, pout, rho_prev)
+        tag = f'G5_enf{int(enforce)}'
+        out[tag + '_P'], out[tag + '_maskall'], out[tag + '_hio'], out[tag + '_er'] = \
+            np.array(pout[0]), np.array(pout[1]['all']), new, er
+        settings.general.cache_aware = True
+        e1 = io.generate_real_l2_rel_diff_error_routine(grid_pair, inside_initial_support=True,
+                                                        initial_mask=real_pr.initial_support)(w, pout)
+        settings.general.cache_aware = False
+        e2 = io.generate_real_l2_rel_diff_error_routine(grid_pair, inside_initial_support=True,
+                                                        initial_mask=real_pr.initial_support)(w, pout)
+        e3 = io.generate_real_l2_rel_diff_error_routine(grid_pair, inside_initial_support=False)(w, pout)
+        out[tag + '_err'] = np.array([e1, e2, e3])
+    out['G5_support'], out['G5_rho_in'], out['G5_rho_prev'] = sup, rho_in, rho_prev
+    settings.general.cache_aware = True
+    vals = rng.random(shape)
+    out['G6_vals'] = vals
+    out['G6_integral'] = np.array(ml.SphericalIntegrator(grid_pair.realGrid[:]).integrate(vals))
+
+    # ------------------------------------------------------------------ G7: shrink wrap + ramps (a15)
+    sw = fp_.ShrinkWrapParts(grid_pair.realGrid, grid_pair.reciprocalGrid, real_pr.initial_support)
+    out['G7_default_sigma'] = np.array(sw.default_sigma)
+    sw.gaussian_sigma = 7.5
+    sw.threshold = 0.11
+    out['G7_gauss_q'] = np.array(sw.gaussian_values[:, 0, 0])
+    conv = cplx(rng, shape)
+    out['G7_conv'] = conv
+    out['G7_mask'] = sw.get_new_mask(np.array(conv))
+    sig = [[20, [False, 5], -2], False]
+    r0 = ml.LinearRamp(*sig[0], default_start=sw.default_sigma, default_stop=sw.default_sigma)
+    r1 = ml.LinearRamp(*[sig[1]], default_start=sw.default_sigma, default_stop=sw.default_sigma)
+    rt = ml.LinearRamp(*[0.09])
+    r3 = ml.LinearRamp(*[0.08, [0, 0], 0])
+    out['G7_sigma_ramp0'] = np.array([r0(i) for i in range(12)], dtype=float)
+    out['G7_sigma_ramp1'] = np.array([r1(i) for i in range(12)], dtype=float)
+    out['G7_thr_ramp'] = np.array([rt(i) for i in range(12)], dtype=float)
+    out['G7_thr_ramp_default'] = np.array([r3(i) for i in range(12)], dtype=float)
+    # G8: beta ramp
+    er_ = ml.ExponentialRamp(0.5, 0.4, -1 / 250, 500)
+    out['G8_beta'] = np.array([er_.eval(s) for s in range(0, 600, 7)])
+    er2 = ml.ExponentialRamp(0.01, 0.002, -1 / 200, 200)
+    out['G8_beta2'] = np.array([er2.eval(s) for s in range(0, 300, 7)])
+    # G9: B_l from I_lm
+    it = importlib.import_module(pre + 'fxs_invariant_tools')
+    out['G9_Bl'] = it.harmonic_coeff_to_deg2_invariants_3d(Ilm)
+    # deg2 invariant diff metric (a19)
+    inv_mask = rp.radial_mask[:, :, None] * rp.radial_mask[:, None, :]
+    d2 = io._generate_deg2_invariant_diff_3d(qs, rp.deg2_invariants, rp.used_orders, rp.number_of_particles, inv_mask)
+    out['G9_deg2_diff'] = d2(None, None, Ilm)
+
+    np.savez_compressed(os.path.join(HERE, 'operators_N16_L4.npz'), **out)
+    print('operators fixture:', len(out), 'arrays')
+
+    # ------------------------------------------------------------------ G10/G11: the reference's own MTIP loop
+    run_mtip_golden(mods, N=16, L=4, name='mtip_N16_L4', n_hio=12, n_er=8, with_steps=True)
+    run_mtip_golden(mods, N=32, L=8, name='mtip_cfg1_N32_L8', n_hio=60, n_er=40, with_steps=False)
+
+
+def run_mtip_golden(mods, N, L, name, n_hio, n_er, with_steps):
+    settings = mods['xframe.settings']
+    pl = mods['xframe.library.pythonLibrary']
+    gl = mods['xframe.library.gridLibrary']
+    from oracle import mtip as OM
+    from oracle.fourier import FourierPair
+    from oracle.sht import SHT
+    from xframe_amd.fxs import synthetic as S
+    kappa = 2.0
+    Qd = S.data_cutoff(N)
+
+    class T:
+        def __init__(s, fp):
+            s.fp, s.rs, s.thetas, s.phis = fp, fp.rs, fp.sht.theta, fp.sht.phi
+
+        def ft(s, x):
+            return s.fp.ft(x)
+
+        def forward_l(s, x):
+            return s.fp.sht.forward_l(x)
+    data, rho_true = S.make_invariants(T(FourierPair(SHT(L), N, Qd, kappa)), N, L)
+    o = OM.deep_update(OM.default_settings(), S.config_overrides(1))
+    o = OM.deep_update(o, {'grid': {'n_radial_points': N, 'max_order': L},
+                           'projections': {'reciprocal': {'used_order_ids': np.arange(L + 1)}},
+                           'GPU': {'use': False}, 'multi_process': {'use': False},
+                           'main_loop': {'error': {'methods': {'reciprocal': {
+                               'calculate': ['deg2_invariant_l2_diff'], 'deg2_invariant_l2_diff': {'order': 2}}}}}})
+    o['main_loop']['sub_loops']['main']['methods']['HIO']['iterations'] = n_hio
+    o['main_loop']['sub_loops']['main']['methods']['ER']['iterations'] = n_er
+    o['main_loop']['sub_loops']['main']['iterations'] = 2 if with_steps else 1
+    settings.project = pl.DictNamespace.dict_to_dictnamespace(o)
+
+    for k in list(sys.modules):
+        if k.endswith('fxs.reconstruct'):
+            del sys.modules[k]
+    cwd = os.getcwd()
+    rc = importlib.import_module('xframe.projects.fxs.reconstruct')
+    os.chdir(cwd)
+    import xframe
+    hts = importlib.import_module('xframe.projects.fxs.projectLibrary.harmonic_transforms')
+    gp = importlib.import_module('xframe.projects.fxs.projectLibrary.ft_grid_pairs')
+    ht = importlib.import_module('xframe.projects.fxs.projectLibrary.hankel_transforms')
+
+    d = dict(data)
+    d['average_intensity'] = gl.SampledFunction(gl.NestedArray(data['data_radial_points'][:, None], 1),
+                                                data['average_intensity'], coord_sys='cartesian')
+    MT = rc.MTIP
+    MT.dimensions = 3
+    MT.mtip_data = d
+    MT.data_q_limits = [data['data_radial_points'].min(), data['data_radial_points'].max()]
+    MT.data_number_of_radial_points = N
+    MT.max_q = float(MT.data_q_limits[1])
+    mock = gp.get_grid({**o['fourier_transform'], 'dimensions': 3, **o['grid'], 'phis': np.array([1.0, 2.0]),
+                        'thetas': np.array([1.0, 2.0]), 'max_q': MT.max_q, 'n_radial_points_from_data': N})
+    MT.reciprocal_radial_points = mock.reciprocalGrid[:, 0, 0, 0]
+    MT.real_radial_points = mock.realGrid[:, 0, 0, 0]
+    MT.fourier_transform_weights = {'weights': ht.calc_spherical_mid_weights(np.arange(L + 1), N, kappa),
+                                    'posHarmOrders': np.arange(L + 1), 'mode': 'midpoint'}
+    MT.preinit_was_called = True
+    # quiet printing helpers
+    rc.xprint = lambda *a, **k: None
+    mp = mods['xframe.Multiprocessing']
+    if not hasattr(mp, 'comm_module'):
+        mp.comm_module = None
+    m = MT(pl.RecipeFactory({}))
+    m.generate_phasing_loop()
+
+    # stored initial density (the reference seeds from os.urandom, reconstruct.py:1119-1120)
+    om = OM.MTIP(o, data)
+    rho0 = om.density_guess(np.random.default_rng(1000))
+    ops = m.process_factory.operatorDict
+    out = {'rho0': rho0, 'N': np.array(N), 'L': np.array(L), 'n_hio': np.array(n_hio), 'n_er': np.array(n_er),
+           'loop_iterations_main': np.array(o['main_loop']['sub_loops']['main']['iterations'])}
+
+    if with_steps:
+        # single steps through the reference's sketches from a stored state (G10)
+        F0 = ops['fourier_transform'](rho0)
+        rho_s = ops['inverse_fourier_transform'](F0)
+        out['step_rho_in'] = np.array(rho_s)
+        hio = m.projection_objects['hio']
+        real_pr = m.projection_objects['real']
+        sup = np.random.default_rng(5).random(rho_s.shape) > 0.3
+        for enforce in (True, False):
+            real_pr.enforce_initial_support = enforce
+            real_pr.support = sup
+            for meth in ('HIO', 'ER', 'HIO_ft_stab', 'ER_ft_stab'):
+                hio.beta = 0.45
+                m.results.setdefault('errors', {'real': {'l2_projection_diff': []},
+                                                'reciprocal': {'deg2_invariant_l2_diff': []}, 'main': []})
+                m.init_error_dict()
+                Fn, rn = m.routines[meth].run(np.array(F0), np.array(rho_s))
+                tag = f'step_{meth}_enf{int(enforce)}'
+                out[tag + '_F'], out[tag + '_rho'] = np.array(Fn), np.array(rn)
+                out[tag + '_err'] = np.array(m.results['errors']['real']['l2_projection_diff'][-1])
+                out[tag + '_deg2'] = np.array(m.results['errors']['reciprocal']['deg2_invariant_l2_diff'][-1])
+        out['step_support'] = sup
+        sw = m.projection_objects['sw']
+        sw.gaussian_sigma = 20.0
+        sw.threshold = 0.09
+        out['step_SW_mask'] = np.array(m.routines['SW'].run(np.array(rho_s)))
+        real_pr.enforce_initial_support = True
+        real_pr.support = real_pr.initial_support
+
+    # full trajectory with the stored rho0 injected in place of the os.urandom guess
+    m2 = MT(pl.RecipeFactory({}))
+    m2.generate_density_guess_method = lambda *a, **k: (lambda: np.array(rho0))
+    m2.generate_phasing_loop()
+    res = m2.phasing_loop()
+    out['traj_main'] = res['error_dict']['main']
+    out['traj_real_err'] = res['error_dict']['real']['l2_projection_diff']
+    out['traj_deg2'] = res['error_dict']['reciprocal']['deg2_invariant_l2_diff']
+    out['traj_last_real_density'] = res['last_real_density']
+    out['traj_real_density'] = res['real_density']
+    out['traj_last_reciprocal_density'] = res['last_reciprocal_density']
+    out['traj_final_error'] = np.array(res['final_error'])
+    out['traj_support_mask'] = res['support_mask']
+    out['traj_last_support_mask'] = res['last_support_mask']
+    out['traj_initial_density'] = res['initial_density']
+    out['traj_loop_iterations'] = np.array(res['loop_iterations'])
+    out['traj_last_deg2_invariant'] = res['last_deg2_invariant']
+    out['traj_n_particles'] = res['n_particles']
+    for l, u in enumerate(res['fxs_unknowns']):
+        out[f'traj_unk{l}'] = np.array(u)
+        out[f'traj_VU{l}'] = m2.rprojection.projection_matrices[l] @ np.array(u)
+    for l in range(L + 1):
+        out[f'data_pm{l}'] = data['data_projection_matrices'][l]
+    out['data_aint'], out['data_q'] = data['average_intensity'], data['data_radial_points']
+    np.savez_compressed(os.path.join(HERE, name + '.npz'), **out)
+    print(name, 'final error', res['final_error'], 'steps', len(res['error_dict']['main']))
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,231 @@
+"""Pin the CPU oracle against golden vectors captured from the reference's own code
+(tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+
+from oracle import hankel as OH
+from oracle import mtip as OM
+from oracle import projections as OP
+from oracle.fourier import FourierPair, SphericalIntegrator
+from oracle.sht import SHT
+from helpers import rel_l2, data_from_golden, golden_settings
+
+TIGHT = 1e-13
+
+
+@pytest.mark.parametrize('kappa', [2.0, np.pi])
+def test_G1_weights(golden_ops, kappa):
+    g = golden_ops
+    N, L = 8, 3
+    tag = f'G1_N{N}_L{L}_k{kappa:.3f}'
+    w = OH.spherical_mid_weights(L, N, kappa)
+    assert rel_l2(w, g[tag + '_mid_raw']) < TIGHT
+    a = OH.assemble_weights(w, 123.0, kappa)
+    assert rel_l2(a['forward'], g[tag + '_mid_fwd']) < TIGHT
+    assert rel_l2(a['inverse'], g[tag + '_mid_inv']) < TIGHT
+    wt = OH.spherical_trapz_weights(L, N, kappa)
+    assert rel_l2(wt, g[tag + '_trapz_raw']) < TIGHT
+    a = OH.assemble_weights(wt, 123.0, kappa)
+    assert rel_l2(a['forward'], g[tag + '_trapz_fwd']) < TIGHT
+    assert rel_l2(a['inverse'], g[tag + '_trapz_inv']) < TIGHT
+
+
+@pytest.mark.parametrize('cfg,N,L', [(1, 32, 8), (2, 64, 16), (3, 128, 32)])
+def test_G1_weight_checksums(golden_ops, cfg, N, L):
+    w = OH.spherical_mid_weights(L, N, 2.0)
+    sums = np.array([w.sum(), np.abs(w).sum(), (w * np.arange(w.size).reshape(w.shape)).sum()])
+    assert np.allclose(sums, golden_ops[f'G1_cfg{cfg}_mid_raw_sums'], rtol=1e-11)
+    sample = w[::max(1, L // 4), ::max(1, N // 8), ::max(1, N // 8)]
+    assert rel_l2(sample, golden_ops[f'G1_cfg{cfg}_mid_raw_sample']) < TIGHT
+
+
+def _fp16(g):
+    N, L = 16, 4
+    max_q = float(np.max(g['D16_q']))
+    return FourierPair(SHT(L), N, max_q, 2.0, 'midpoint')
+
+
+def test_G2_grids_hankel_ft(golden_ops):
+    g = golden_ops
+    fp = _fp16(g)
+    assert rel_l2(fp.rs, g['G2_rs']) < TIGHT and rel_l2(fp.qs, g['G2_qs']) < TIGHT
+    assert rel_l2(fp.sht.theta, g['G2_theta']) < TIGHT and rel_l2(fp.sht.phi, g['G2_phi']) < TIGHT
+    assert rel_l2(fp.hankel(g['G2_in']), g['G2_fwd']) < TIGHT
+    assert rel_l2(fp.ihankel(g['G2_in']), g['G2_inv']) < TIGHT
+    assert rel_l2(fp.ft(g['G2_grid_in']), g['G2_ft']) < TIGHT
+    assert rel_l2(fp.ift(g['G2_grid_in']), g['G2_ift']) < TIGHT
+    # CPU 'ml' list path == direct path
+    sh = fp.sht
+    c_ml = [np.array(g['G2_in'][:, idx]) for idx in sh.cplx_m_indices]
+    f_ml = OH.apply_ml(fp.w['forward'], c_ml)
+    for m_id, idx in enumerate(sh.cplx_m_indices):
+        assert rel_l2(f_ml[m_id], g['G2_fwd'][:, idx]) < TIGHT
+    # trapz flavour
+    wt = OH.assemble_weights(OH.spherical_trapz_weights(4, 16, 2.0), fp.r_max, 2.0)
+    assert rel_l2(OH.apply_direct(wt['forward'], g['G2_in'], trapz=True), g['G2_trapz_fwd']) < TIGHT
+
+
+def _rp16(g):
+    N, L = 16, 4
+    fp = _fp16(g)
+    data = data_from_golden(g, L, prefix='D16_')
+    opt = golden_settings(N, L, {'projections': {'reciprocal': {
+        'q_mask': {'type': 'manual', 'manual': {'type': 'region', 'region': [False, float(fp.qs[N - 3])]}}}}})
+    return fp, opt, OP.ReciprocalProjection(fp.qs, data, L, opt['projections']['reciprocal'])
+
+
+def test_G3_reciprocal_projection(golden_ops):
+    g = golden_ops
+    L = 4
+    fp, opt, rp = _rp16(g)
+    assert np.isclose(rp.integrated_intensity, g['G3_integrated_intensity'], rtol=1e-13)
+    assert (rp.radial_mask == g['G3_radial_mask']).all()
+    assert not rp.radial_mask[:, 0].any()          # shell 0 below data_min_q
+    for l in range(L + 1):
+        assert rel_l2(rp.projection_matrices[l], g[f'G3_pm{l}']) < 1e-12
+    Ilm = [g[f'G3_Ilm{l}'] for l in range(L + 1)]
+    unk = rp.approximate_unknowns(Ilm)
+    proj = rp.mtip_projection(Ilm, unk)
+    for l in range(L + 1):
+        assert rel_l2(rp.projection_matrices[l] @ unk[l], g[f'G3_VU{l}']) < 1e-11
+        assert rel_l2(proj[l], g[f'G3_proj{l}']) < 1e-11
+    assert rel_l2(rp.deg2_invariants, g['G3_deg2']) < 1e-12
+
+
+def test_G4_modulus_replacement(golden_ops):
+    g = golden_ops
+    fp, opt, rp = _rp16(g)
+    out = rp.project_to_modified_intensity(g['G4_F'], g['G4_I'], g['G4_Inew'])
+    ref = g['G4_Fnew']
+    finite = np.isfinite(ref)
+    assert (np.isfinite(out) == finite).all()
+    assert rel_l2(out[finite], ref[finite]) < TIGHT
+
+
+def test_G5_real_projection_hio_er_error(golden_ops):
+    g = golden_ops
+    N, L = 16, 4
+    fp = _fp16(g)
+    opt = golden_settings(N, L)
+    shape = g['G5_rho_in'].shape
+    real_r = np.broadcast_to(fp.rs[:, None, None], shape)
+    integ = SphericalIntegrator(fp.rs, fp.sht.n_theta)
+    for enforce in (True, False):
+        pr = OP.RealProjection(opt['projections']['real']['projections'], real_r, opt['particle_radius'])
+        assert (pr.initial_support == g['G5_initial_support']).all()
+        pr.enforce_initial_support = enforce
+        pr.support = g['G5_support']
+        w = np.array(g['G5_rho_in'])
+        work = np.array(g['G5_rho_in'])
+        pout = pr.projection(work)
+        tag = f'G5_enf{int(enforce)}'
+        assert rel_l2(pout[0], g[tag + '_P']) == 0
+        assert (pout[1]['all'] == g[tag + '_maskall']).all()
+        hio = OP.hybrid_input_output(w, pout, g['G5_rho_prev'], 0.37)
+        assert rel_l2(hio, g[tag + '_hio']) < TIGHT
+        assert rel_l2(OP.error_reduction(w, pout, None), g[tag + '_er']) == 0
+        e_in = OP.l2_rel_diff_error(integ, w, pout[0], pr.initial_support)
+        e_all = OP.l2_rel_diff_error(integ, w, pout[0], True)
+        # reference: [cache-aware routine (grid fits L2 -> mask dropped), plain masked, plain unmasked]
+        m_sel = OP.select_real_error_mask(shape, True, pr.initial_support)
+        assert m_sel is True
+        e_sel = OP.l2_rel_diff_error(integ, w, pout[0], m_sel)
+        assert np.allclose([e_sel, e_in, e_all], g[tag + '_err'], rtol=1e-12)
+        big = OP.select_real_error_mask((64, 32, 64), True, pr.initial_support)
+        assert big is not True
+    assert np.isclose(integ.integrate(g['G6_vals']), g['G6_integral'], rtol=1e-13)
+
+
+def test_G7_shrinkwrap_and_ramps(golden_ops):
+    g = golden_ops
+    fp = _fp16(g)
+    shape = g['G7_conv'].shape
+    sw = OP.ShrinkWrap(fp.qs, shape)
+    assert np.isclose(sw.default_sigma, g['G7_default_sigma'], rtol=1e-14)
+    sw.gaussian_sigma = 7.5
+    sw.threshold = 0.11
+    assert rel_l2(sw.gaussian_values[:, 0, 0], g['G7_gauss_q']) < TIGHT
+    assert (sw.get_new_mask(g['G7_conv']) == g['G7_mask']).all()
+    ds = sw.default_sigma
+    r0 = OP.LinearRamp(*[20, [False, 5], -2], default_start=ds, default_stop=ds)
+    r1 = OP.LinearRamp(*[False], default_start=ds, default_stop=ds)
+    rt = OP.LinearRamp(*[0.09])
+    r3 = OP.LinearRamp(*[0.08, [0, 0], 0])
+    assert np.allclose([r0(i) for i in range(12)], g['G7_sigma_ramp0'], rtol=1e-14)
+    assert np.allclose([r1(i) for i in range(12)], g['G7_sigma_ramp1'], rtol=1e-14)
+    assert np.allclose([rt(i) for i in range(12)], g['G7_thr_ramp'], rtol=1e-14)
+    assert np.allclose([r3(i) for i in range(12)], g['G7_thr_ramp_default'], rtol=1e-14)
+
+
+def test_G8_beta_ramp(golden_ops):
+    g = golden_ops
+    e = OP.ExponentialRamp(0.5, 0.4, -1 / 250, 500)
+    assert np.allclose([e.eval(s) for s in range(0, 600, 7)], g['G8_beta'], rtol=1e-14)
+    e = OP.ExponentialRamp(0.01, 0.002, -1 / 200, 200)
+    assert np.allclose([e.eval(s) for s in range(0, 300, 7)], g['G8_beta2'], rtol=1e-14)
+
+
+def test_G9_deg2_invariants(golden_ops):
+    g = golden_ops
+    L = 4
+    Ilm = [g[f'G3_Ilm{l}'] for l in range(L + 1)]
+    assert rel_l2(OP.harmonic_coeff_to_deg2_invariants_3d(Ilm), g['G9_Bl']) < TIGHT
+    fp, opt, rp = _rp16(g)
+    inv_mask = rp.radial_mask[:, :, None] * rp.radial_mask[:, None, :]
+    d2 = OP.Deg2InvariantDiff(rp.deg2_invariants, rp.used_orders, rp.number_of_particles, inv_mask)
+    assert np.allclose(d2(Ilm), g['G9_deg2_diff'], rtol=1e-11)
+
+
+def _mtip_from_golden(g, extra=None):
+    N, L = int(g['N']), int(g['L'])
+    data = data_from_golden(g, L)
+    o = golden_settings(N, L, {'main_loop': {'error': {'methods': {'reciprocal': {
+        'calculate': ['deg2_invariant_l2_diff'], 'deg2_invariant_l2_diff': {'order': 2}}}}}})
+    o['main_loop']['sub_loops']['main']['methods']['HIO']['iterations'] = int(g['n_hio'])
+    o['main_loop']['sub_loops']['main']['methods']['ER']['iterations'] = int(g['n_er'])
+    o['main_loop']['sub_loops']['main']['iterations'] = int(g['loop_iterations_main'])
+    if extra:
+        o = OM.deep_update(o, extra)
+    return OM.MTIP(o, data)
+
+
+def test_G10_single_steps(golden_mtip16):
+    g = golden_mtip16
+    m = _mtip_from_golden(g)
+    rho_s = g['step_rho_in']
+    for enforce in (True, False):
+        m.real_pr.enforce_initial_support = enforce
+        m.real_pr.support = g['step_support']
+        for meth in ('HIO', 'ER', 'HIO_ft_stab', 'ER_ft_stab'):
+            m.create_initial_state(g['rho0'])          # resets error lists
+            m.beta = 0.45
+            Fn, rn = m.step(meth.replace('_ft_stab', ''), np.array(rho_s), meth.endswith('_ft_stab'))
+            tag = f'step_{meth}_enf{int(enforce)}'
+            assert rel_l2(Fn, g[tag + '_F']) < 1e-10, tag
+            assert rel_l2(rn, g[tag + '_rho']) < 1e-10, tag
+            assert np.isclose(m.errors['real']['l2_projection_diff'][-1], g[tag + '_err'], rtol=1e-9)
+            assert np.allclose(m.errors['reciprocal']['deg2_invariant_l2_diff'][-1], g[tag + '_deg2'], rtol=1e-8)
+    m.sw.gaussian_sigma = 20.0
+    m.sw.threshold = 0.09
+    assert (m.sw_step(np.array(rho_s)) == g['step_SW_mask']).all()
+
+
+@pytest.mark.parametrize('which', ['mtip16', 'cfg1'])
+def test_G10_trajectory(golden_mtip16, golden_cfg1, which):
+    g = golden_mtip16 if which == 'mtip16' else golden_cfg1
+    m = _mtip_from_golden(g)
+    res = m.phasing_loop(rho0=g['rho0'])
+    n = len(g['traj_main'])
+    assert len(res['error_dict']['main']) == n
+    assert int(res['loop_iterations']) == int(g['traj_loop_iterations'])
+    assert rel_l2(res['initial_density'], g['traj_initial_density']) < 1e-12
+    # HIO is chaotic: early steps tight, whole trajectory loose (SURVEY section 8 d)
+    k = min(20, n)
+    assert np.allclose(res['error_dict']['main'][:k], g['traj_main'][:k], rtol=1e-6)
+    assert np.allclose(res['error_dict']['main'], g['traj_main'], rtol=1e-3)
+    assert rel_l2(res['last_real_density'], g['traj_last_real_density']) < 1e-4
+    assert rel_l2(res['last_reciprocal_density'], g['traj_last_reciprocal_density']) < 1e-4
+    assert (res['last_support_mask'] != g['traj_last_support_mask']).mean() < 1e-3
+    assert np.isclose(res['final_error'], g['traj_final_error'], rtol=1e-3)
+    assert rel_l2(res['last_deg2_invariant'], g['traj_last_deg2_invariant']) < 1e-4
+    assert res['n_particles'].shape == g['traj_n_particles'].shape
