@@ -1,0 +1,168 @@
+/* mtip_hip.h -- C ABI of libmtip_hip.so, the MI355X (gfx950) MTIP phasing engine.
+ *
+ * This is the drop-in boundary for the hot path of European-XFEL/xFrame's
+ * `xframe/projects/fxs/reconstruct.py` (reference file:line cited per entry point; paths are
+ * relative to the reference checkout).  The reference binds its GPU code through PyOpenCL
+ * (`xframe/externalLibraries/openCL_plugin.py:154-226`) behind
+ * `Multiprocessing.comm_module.add_gpu_process` (`xframe/control/communicators.py:79-82`);
+ * a maintainer replaces that with a ctypes binding of the functions below.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative MTIP_E* code; nothing throws across the ABI;
+ *     `mtip_last_error(ctx)` returns a human readable message (ctx may be NULL for create errors);
+ *   - host buffers are caller-owned, C-contiguous; complex128 = interleaved (re,im) doubles
+ *     (numpy complex128); masks are uint8 (numpy bool); device memory is library-owned;
+ *   - a ctx is bound to one device and one hipStream_t; it is not thread-safe; several ctxs may
+ *     be used concurrently (one per GPU / per process);
+ *   - array shapes: grid  (n_batch, Nq, n_theta, n_phi);  coeff 'direct' (n_batch, Nq, (L+1)^2)
+ *     with index l(l+1)+m  (`xframe/externalLibraries/shtns_plugin.py:24,105-114,250-261`).
+ */
+#ifndef MTIP_HIP_H
+#define MTIP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mtip_ctx mtip_ctx;
+typedef struct { double re, im; } mtip_cdouble;
+
+enum {
+    MTIP_OK = 0,
+    MTIP_EINVAL = -1,      /* bad argument / shape                        */
+    MTIP_ENODEV = -2,      /* no usable HIP device                        */
+    MTIP_EHIP = -3,        /* a HIP runtime call or kernel launch failed  */
+    MTIP_ENOMEM = -4,
+    MTIP_ESTATE = -5       /* call order violated (e.g. run before setup) */
+};
+
+/* phasing methods: the sketches of reconstruct.py:565-596 */
+enum { MTIP_HIO = 0, MTIP_ER = 1, MTIP_HIO_NON_FXS = 2, MTIP_ER_NON_FXS = 3 };
+
+/* SHT load-side prologues (fused elementwise stages) */
+enum { MTIP_PRE_NONE = 0, MTIP_PRE_SQUARE = 1 /* |x|^2, misk.py:159-168 */, MTIP_PRE_ABS = 2 /* |x|, misk.py:221-225 */ };
+
+typedef struct {
+    int32_t n_radial;      /* Nq: grid.n_radial_points                                   */
+    int32_t l_max;         /* L : grid.max_order                                         */
+    int32_t n_theta;       /* Gauss-Legendre nodes (shtns_plugin.py:94-101 for defaults) */
+    int32_t n_phi;         /* power of two, > 2L                                         */
+    int32_t n_batch;       /* restarts resident in this ctx (>=1)                        */
+    int32_t hankel_trapz;  /* 0: midpoint/gauss rule (hankel_transforms.py:702-731);
+                              1: trapz/Zernike (671-700: weights have Nq-1 rows, reads f[p+1]) */
+    int32_t fused;         /* 1: algebraically fused step, 0: reference operator order */
+    int32_t reserved;
+} mtip_cfg;
+
+/* ---- life cycle ------------------------------------------------------------------------------
+ * replaces Multiprocessing.get_number_of_gpus (xframe/Multiprocessing.py:892-898) and the
+ * OpenCL context/buffer creation of openCL_plugin.py:28-61,118-152 */
+int mtip_device_count(void);
+mtip_ctx* mtip_create(const mtip_cfg* cfg, int device);
+void mtip_destroy(mtip_ctx* ctx);
+const char* mtip_last_error(const mtip_ctx* ctx);
+int mtip_get_cfg(const mtip_ctx* ctx, mtip_cfg* out);
+int mtip_synchronize(mtip_ctx* ctx);
+
+/* ---- one-off setup (host side of rows a1, a2, a4, a7 of SURVEY section 8) -------------------- */
+/* cos(theta) north->south and Gauss weights, n_theta each (shtns_plugin.py:130-133). The library
+ * builds the orthonormal Condon-Shortley Legendre tables itself. */
+int mtip_set_angular_grid(mtip_ctx* ctx, const double* cos_theta, const double* gauss_weights);
+/* radial points r_p, q_k (ft_grid_pairs.py:282-291), Nq each */
+int mtip_set_radial_grid(mtip_ctx* ctx, const double* r, const double* q);
+/* raw real Hankel weights w[l][p][k] exactly as calc_spherical_mid_weights / _trapz_weights return
+ * them (hankel_transforms.py:399-410 / 322-333), shape (L+1, Np, Nq) with Np = Nq (midpoint) or Nq-1
+ * (trapz); fwd_scale=(r_max/N)^3 sqrt(2/pi), inv_scale=(q_max/N)^3 sqrt(2/pi) (assemble_weights_mid,
+ * 426-452); the (-i)^l / (+i)^l phases are applied in the kernel epilogue. */
+int mtip_set_hankel_weights(mtip_ctx* ctx, const double* w_raw, double fwd_scale, double inv_scale);
+/* modified projection matrix V_l (fxs_Projections.py:679-714), shape (Nq, k_l) row-major, its radial
+ * mask row (578-629, Nq bytes) and whether order l takes part in the projection (used_orders, 492). */
+int mtip_set_projection_matrix(mtip_ctx* ctx, int l, const mtip_cdouble* V, int k_l,
+                               const uint8_t* radial_mask, int used);
+int mtip_set_number_of_particles(mtip_ctx* ctx, double n_particles);   /* fxs_Projections.py:497,870 */
+/* reference B_l = V_l V_l^+ masks for the deg2_invariant_l2_diff metric are derived internally
+ * (fxs_IO_methods.py:408-447); enable = 1 evaluates it every step. */
+int mtip_set_deg2_metric(mtip_ctx* ctx, int enable);
+/* real-space constraints (fxs_Projections.py:72-130, pythonLibrary.py:1289-1320):
+ * flags bit0 support, bit1 value lower bound, bit2 value upper bound, bit3 limit_imag;
+ * hio_mask_flags: which of those feed the HIO mask gamma ('considered_projections',
+ * fxs_IO_methods.py:40-64; ['all'] = same as flags). */
+int mtip_set_real_constraints(mtip_ctx* ctx, uint32_t flags, double value_lo, double value_hi,
+                              double imag_threshold, uint32_t hio_mask_flags);
+/* initial support S0 (fxs_Projections.py:133-155), (Nq, n_theta, n_phi) bytes, shared by the batch;
+ * resets every restart's support to S0 and enforce_initial_support to 1 (fxs_Projections.py:34). */
+int mtip_set_initial_support(mtip_ctx* ctx, const uint8_t* support);
+/* error metric weights (fxs_IO_methods.py:97-128 with mathLibrary.py:1223-1235):
+ * E = sum m(x) wr[q] wt[theta] |w-P|^2 / sum m(x) wr[q] wt[theta] |w|^2 ;
+ * use_initial_support_mask: m = S0, else m = 1. */
+int mtip_set_error_weights(mtip_ctx* ctx, const double* radial_w, const double* theta_w,
+                           int use_initial_support_mask);
+
+/* ---- state ------------------------------------------------------------------------------------ */
+/* inject a starting density for restart `batch` (reconstruct.py:957-966: rho0 -> F0=FT(rho0),
+ * rho0'=IFT(F0) is done by mtip_init_state) */
+int mtip_set_density(mtip_ctx* ctx, int batch, const mtip_cdouble* rho);
+int mtip_init_state(mtip_ctx* ctx);
+/* which = 0 latest pair, 1 best pair (reconstruct.py:934-938) */
+int mtip_get_density(mtip_ctx* ctx, int batch, int which, mtip_cdouble* rho);
+int mtip_get_reciprocal_density(mtip_ctx* ctx, int batch, int which, mtip_cdouble* F);
+int mtip_get_support(mtip_ctx* ctx, int batch, int which, uint8_t* support);
+int mtip_set_support(mtip_ctx* ctx, int batch, const uint8_t* support, int enforce_initial_support);
+/* fxs_unknowns U_l of the last step (k_l x (2l+1), row-major), fxs_Projections.py:752-767 */
+int mtip_get_unknowns(mtip_ctx* ctx, int batch, int l, mtip_cdouble* U);
+/* best_error per restart (n_batch doubles) and the number of steps done */
+int mtip_get_best_error(mtip_ctx* ctx, double* best_error, int64_t* n_steps_done);
+/* take the best pair as the latest one (reconstruct.py:945-949) */
+int mtip_select_best(mtip_ctx* ctx);
+
+/* ---- the loop (reconstruct.py:854-951) ------------------------------------------------------------
+ * runs n_steps steps of `method` for every restart without host synchronisation; betas[n_steps] is the
+ * HIO beta per step (ExponentialRamp, reconstruct.py:911).  real_err (n_steps x n_batch, may be NULL)
+ * receives the l2_projection_diff error per step; deg2_err (n_steps x n_batch x (L+1), may be NULL)
+ * the deg2_invariant_l2_diff metric when enabled. The call returns after the results are on the host. */
+int mtip_run(mtip_ctx* ctx, int method, int ft_stab, int n_steps, const double* betas,
+             double* real_err, double* deg2_err);
+/* same, but only enqueues (no download, no sync): errors stay on the device until mtip_fetch_errors */
+int mtip_run_async(mtip_ctx* ctx, int method, int ft_stab, int n_steps, const double* betas);
+int mtip_fetch_errors(mtip_ctx* ctx, int64_t first_step, int64_t n_steps, double* real_err, double* deg2_err);
+/* one shrink-wrap update (reconstruct.py:598-605, 877-885; fxs_Projections.py:245-258):
+ * enforce_initial_support_b = (last main error_b > error_limit); enforced[n_batch] (may be NULL)
+ * returns the decision per restart. */
+int mtip_shrinkwrap(mtip_ctx* ctx, double sigma, double threshold, double error_limit, uint8_t* enforced);
+/* B_l = I_l I_l^+ of FT(latest rho) (reconstruct.py:757-765, 992-993), (L+1, Nq, Nq) complex */
+int mtip_last_deg2_invariant(mtip_ctx* ctx, int batch, mtip_cdouble* Bl);
+
+/* ---- single operators on host arrays (parity tests; the operator registry of
+ *      reconstruct.py:370,391,445,485).  All arrays carry the leading n_batch dimension. ------------ */
+int mtip_op_sht_forward(mtip_ctx* ctx, const mtip_cdouble* grid, mtip_cdouble* coeff, int prologue);
+int mtip_op_sht_inverse(mtip_ctx* ctx, const mtip_cdouble* coeff, mtip_cdouble* grid);
+int mtip_op_hankel(mtip_ctx* ctx, const mtip_cdouble* coeff_in, mtip_cdouble* coeff_out, int inverse);
+int mtip_op_fourier_transform(mtip_ctx* ctx, const mtip_cdouble* grid_in, mtip_cdouble* grid_out, int inverse);
+/* approximate_unknowns + mtip_projection (fxs_Projections.py:752-767, 832-872) on 'direct' coefficients */
+int mtip_op_project_coefficients(mtip_ctx* ctx, const mtip_cdouble* Ilm, mtip_cdouble* Ilm_projected);
+/* project_to_modified_intensity (fxs_Projections.py:899-909): F' = F sqrt(Re I'/|F|^2) */
+int mtip_op_modulus_replacement(mtip_ctx* ctx, const mtip_cdouble* F, const mtip_cdouble* I_new, mtip_cdouble* F_new);
+/* real_projection + hybrid_input_output / error_reduction + l2 error (fxs_Projections.py:110-130,
+ * fxs_IO_methods.py:40-68, 97-128) using the ctx's current support of each restart */
+int mtip_op_real_space_update(mtip_ctx* ctx, const mtip_cdouble* w, const mtip_cdouble* rho_prev, int method,
+                              double beta, mtip_cdouble* rho_new, double* error);
+int mtip_op_deg2_invariants(mtip_ctx* ctx, const mtip_cdouble* Ilm, mtip_cdouble* Bl);
+/* generic y = M x used by the GPU-process boundary test (tests/test_framework_integration.py:230-400
+ * of the reference: gpu_func(vects) == matrix @ vects), float64 row-major */
+int mtip_op_apply_matrix(mtip_ctx* ctx, const double* matrix, const double* vects, double* out,
+                         int n_rows, int n_cols, int n_vec);
+
+/* ---- timing ----------------------------------------------------------------------------------- */
+/* average duration (ms) and launch count of kernel family `name` ("sht_fwd", "sht_inv", "hankel",
+ * "proj", "real_update", ...) measured with hipEvents on the ctx stream since the last reset;
+ * enable with mtip_profile(ctx, 1). */
+int mtip_profile(mtip_ctx* ctx, int enable);
+int mtip_profile_get(mtip_ctx* ctx, const char* name, double* total_ms, int64_t* launches);
+int mtip_profile_reset(mtip_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MTIP_HIP_H */

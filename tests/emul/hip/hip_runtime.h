@@ -1,0 +1,167 @@
+// CPU emulation of the small HIP subset used by xframe_amd/csrc  --  TEST INFRASTRUCTURE ONLY.
+//
+// Purpose: run the *unchanged* kernel sources of xframe_amd/csrc on the host (g++ -x c++ -I tests/emul)
+// at toy sizes, so that index arithmetic, LDS usage, barrier placement and out-of-bounds accesses can be
+// checked (also under -fsanitize=address) in the build container, which has no GPU.  One OS thread per
+// GPU thread, one block at a time; __syncthreads = std::barrier; wave collectives (shuffles, f64 MFMA)
+// are emulated with a per-wave exchange buffer.  Nothing here is ever loaded by the product: the
+// Python loader only opens libmtip_hip.so, and the -m gpu parity tests run the real HIP build.
+#pragma once
+#include <atomic>
+#include <cmath>
+#include <condition_variable>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+#define __shared__ static thread_local
+#define __align__(n) __attribute__((aligned(n)))
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct double2 { double x, y; };
+static inline double2 make_double2(double x, double y) { return double2{x, y}; }
+struct int2 { int x, y; };
+
+typedef int hipError_t;
+typedef void* hipStream_t;
+typedef void* hipEvent_t;
+enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2 };
+enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
+
+namespace emul {
+// One OS worker thread runs one block at a time; the GPU threads of that block are cooperative fibers
+// (ucontext) that yield at __syncthreads() / wave collectives.  Deterministic and fast enough for CI.
+constexpr int WAVE = 64;
+constexpr size_t DYN_SMEM_MAX = 160 * 1024;
+struct alignas(16) WaveBuf { double d[WAVE * 4]; long long i[WAVE]; };
+struct Worker;
+extern thread_local Worker* W;
+extern thread_local dim3 t_idx;          // of the fiber currently running on this worker
+extern thread_local int t_linear;
+extern thread_local dim3 b_idx;
+extern thread_local unsigned char* dyn_smem;
+extern dim3 b_dim, g_dim;
+void launch(dim3 grid, dim3 block, size_t smem, const std::function<void()>& body);
+void block_barrier();
+void wave_barrier();
+WaveBuf& wave_buf();
+inline int lane() { return t_linear % WAVE; }
+inline int wave() { return t_linear / WAVE; }
+}  // namespace emul
+
+#define threadIdx (emul::t_idx)
+#define blockIdx (emul::b_idx)
+#define blockDim (emul::b_dim)
+#define gridDim (emul::g_dim)
+static const int warpSize = 64;
+
+#define HIP_DYNAMIC_SHARED(type, var) type* var = reinterpret_cast<type*>(emul::dyn_smem);
+#define hipLaunchKernelGGL(kernel, grid, block, smem, stream, ...) \
+    emul::launch((grid), (block), (smem), [&]() { kernel(__VA_ARGS__); })
+
+static inline void __syncthreads() { emul::block_barrier(); }
+
+template <typename T>
+static inline T __shfl(T v, int src_lane, int width = 64) {
+    static_assert(sizeof(T) <= 8, "shfl type");
+    long long raw = 0;
+    std::memcpy(&raw, &v, sizeof(T));
+    emul::wave_buf().i[emul::lane()] = raw;
+    emul::wave_barrier();
+    int base = (emul::lane() / width) * width;
+    long long r = emul::wave_buf().i[base + (src_lane % width)];
+    emul::wave_barrier();
+    T out;
+    std::memcpy(&out, &r, sizeof(T));
+    return out;
+}
+template <typename T>
+static inline T __shfl_xor(T v, int mask, int width = 64) { return __shfl(v, (emul::lane() % width) ^ mask, width); }
+template <typename T>
+static inline T __shfl_down(T v, unsigned delta, int width = 64) {
+    int l = emul::lane() % width;
+    return __shfl(v, (l + (int)delta < width) ? l + (int)delta : l, width);
+}
+template <typename T>
+static inline T __shfl_up(T v, unsigned delta, int width = 64) {
+    int l = emul::lane() % width;
+    return __shfl(v, (l - (int)delta >= 0) ? l - (int)delta : l, width);
+}
+
+typedef double emul_v4f64 __attribute__((vector_size(32)));
+// v_mfma_f64_16x16x4_f64: A[i=l&15][k=l>>4], B[k=l>>4][j=l&15]; D reg r of lane l = D[(l>>4)+4r][l&15]
+static inline emul_v4f64 __builtin_amdgcn_mfma_f64_16x16x4f64(double a, double b, emul_v4f64 c, int, int, int) {
+    int l = emul::lane();
+    emul::wave_buf().d[l] = a;
+    emul::wave_buf().d[64 + l] = b;
+    emul::wave_barrier();
+    auto& buf = emul::wave_buf();
+    emul_v4f64 d = c;
+    int col = l & 15;
+    for (int r = 0; r < 4; ++r) {
+        int row = (l >> 4) + 4 * r;
+        double acc = c[r];
+        for (int k = 0; k < 4; ++k) acc = std::fma(buf.d[row + 16 * k], buf.d[64 + col + 16 * k], acc);
+        d[r] = acc;
+    }
+    emul::wave_barrier();
+    return d;
+}
+
+static std::mutex emul_atomic_mutex;
+static inline double atomicAdd(double* p, double v) {
+    std::lock_guard<std::mutex> g(emul_atomic_mutex);
+    double o = *p; *p = o + v; return o;
+}
+static inline int atomicAdd(int* p, int v) {
+    std::lock_guard<std::mutex> g(emul_atomic_mutex);
+    int o = *p; *p = o + v; return o;
+}
+static inline unsigned atomicAdd(unsigned* p, unsigned v) {
+    std::lock_guard<std::mutex> g(emul_atomic_mutex);
+    unsigned o = *p; *p = o + v; return o;
+}
+static inline void __threadfence() { std::atomic_thread_fence(std::memory_order_seq_cst); }
+static inline double rsqrt(double x) { return 1.0 / std::sqrt(x); }
+static inline double fmin_(double a, double b) { return a < b ? a : b; }
+using std::fma;
+using std::sqrt;
+using std::fabs;
+using std::fmax;
+using std::fmin;
+
+// ---- runtime API ----------------------------------------------------------------------------
+static inline const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "hipSuccess" : "emul error"; }
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+static inline hipError_t hipSetDevice(int) { return hipSuccess; }
+static inline hipError_t hipMalloc(void** p, size_t n) { *p = std::calloc(1, n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
+template <typename T> static inline hipError_t hipMalloc(T** p, size_t n) { return hipMalloc((void**)p, n); }
+static inline hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
+static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { std::memcpy(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { std::memmove(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemset(void* d, int v, size_t n) { std::memset(d, v, n); return hipSuccess; }
+static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { std::memset(d, v, n); return hipSuccess; }
+static inline hipError_t hipStreamCreate(hipStream_t* s) { *s = nullptr; return hipSuccess; }
+static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = nullptr; return hipSuccess; }
+static inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }

@@ -1,0 +1,289 @@
+"""Parity checks of the HIP path (through the C ABI) against the oracle and the golden fixtures.
+
+Each function takes ``lib_path``: ``None`` = the real libmtip_hip.so (``-m gpu`` tests on the MI355X box);
+the CPU pre-flight suite passes tests/emul/libmtip_emul.so (same kernel sources compiled for the host).
+Tolerances (SURVEY section 8 d / BASELINE.md section 5, fp64 end to end):
+  per operator rel-L2 <= 1e-12 (Hankel, elementwise, GEMMs), <= 1e-10 (SHT; polar factor via V_l U_l),
+  one full step <= 1e-9, 20-step trajectory <= 1e-6.
+"""
+import numpy as np
+
+from helpers import rel_l2, data_from_golden, golden_settings, OracleTransforms
+from oracle import mtip as OM
+from oracle import projections as OP
+from oracle.fourier import FourierPair
+from oracle.sht import SHT
+from xframe_amd.fxs import reconstruct as R
+from xframe_amd.fxs import synthetic as S
+from xframe_amd.fxs.engine import Engine
+
+TOL_OP = 1e-12
+TOL_SHT = 1e-10
+TOL_STEP = 1e-9
+TOL_TRAJ = 1e-6
+
+
+def cplx(rng, shape):
+    return rng.normal(size=shape) + 1j * rng.normal(size=shape)
+
+
+def transforms_engine(N, L, lib_path, n_batch=2, mode='midpoint'):
+    max_q = float(np.max(S.midpoint_points(S.data_cutoff(N), N)))
+    e = Engine({'grid': {'n_radial_points': N, 'max_order': L}, 'fourier_transform': {'type': mode}}, None,
+               n_batch=n_batch, lib_path=lib_path, max_q=max_q)
+    fp = FourierPair(SHT(L), N, max_q, 2.0, mode)
+    return e, fp
+
+
+def check_transforms(N, L, lib_path, seed=0, mode='midpoint'):
+    e, fp = transforms_engine(N, L, lib_path, mode=mode)
+    sht = fp.sht
+    assert (e.n_theta, e.n_phi) == (sht.n_theta, sht.n_phi)
+    rng = np.random.default_rng(seed)
+    g = cplx(rng, (2,) + e.shape)
+    co = cplx(rng, (2, N, e.nlm))
+    assert rel_l2(e.sht_forward(g), sht.forward_d(g)) < TOL_SHT
+    assert rel_l2(e.sht_forward(g, 1), sht.forward_d(g * g.conj())) < TOL_SHT
+    assert rel_l2(e.sht_forward(g, 2), sht.forward_d(np.abs(g))) < TOL_SHT
+    assert rel_l2(e.sht_inverse(co), sht.inverse_d(co)) < TOL_SHT
+    assert rel_l2(e.hankel(co), fp.hankel(co)) < TOL_OP
+    assert rel_l2(e.hankel(co, True), fp.ihankel(co)) < TOL_OP
+    assert rel_l2(e.fourier_transform(g), fp.ft(g)) < TOL_SHT
+    assert rel_l2(e.fourier_transform(g, True), fp.ift(g)) < TOL_SHT
+    # size-independent properties: SHT round trip on band-limited data, linearity, Friedel symmetry of FT(real)
+    band = e.sht_inverse(co)
+    assert rel_l2(e.sht_forward(band), co) < TOL_SHT
+    a, b = 0.3 - 1.1j, -2.0 + 0.5j
+    lin = e.fourier_transform(a * g + b * g[::-1])
+    assert rel_l2(lin, a * e.fourier_transform(g) + b * e.fourier_transform(g[::-1])) < TOL_SHT
+    e.close()
+
+
+def check_transforms_golden(golden_ops, lib_path):
+    g = golden_ops
+    N, L = 16, 4
+    max_q = float(np.max(g['D16_q']))
+    e = Engine({'grid': {'n_radial_points': N, 'max_order': L}}, None, n_batch=1, lib_path=lib_path, max_q=max_q)
+    assert rel_l2(e.rs, g['G2_rs']) < 1e-14 and rel_l2(e.qs, g['G2_qs']) < 1e-14
+    assert rel_l2(e.theta, g['G2_theta']) < 1e-14 and rel_l2(e.phi, g['G2_phi']) < 1e-14
+    assert rel_l2(e.hankel(g['G2_in'])[0], g['G2_fwd']) < TOL_OP
+    assert rel_l2(e.hankel(g['G2_in'], True)[0], g['G2_inv']) < TOL_OP
+    assert rel_l2(e.fourier_transform(g['G2_grid_in'])[0], g['G2_ft']) < TOL_SHT
+    assert rel_l2(e.fourier_transform(g['G2_grid_in'], True)[0], g['G2_ift']) < TOL_SHT
+    e.close()
+    e = Engine({'grid': {'n_radial_points': N, 'max_order': L}, 'fourier_transform': {'type': 'trapz'}}, None,
+               n_batch=1, lib_path=lib_path, max_q=max_q)
+    # golden trapz weights were assembled with the midpoint grid's r_max
+    import xframe_amd.fxs.hostsetup as hs
+    fs, ivs = hs.hankel_scales(float(np.max(g['G2_rs'])), N, 2.0)
+    e._ck(e.lib.mtip_set_hankel_weights(e.ctx, e.raw_weights.ctypes.data, fs, ivs))
+    assert rel_l2(e.hankel(g['G2_in'])[0], g['G2_trapz_fwd']) < TOL_OP
+    e.close()
+
+
+def _engine_and_oracle(g, lib_path, prefix='data_', n_batch=1, fused=False, extra=None):
+    N, L = (int(g['N']), int(g['L'])) if 'N' in g else (16, 4)
+    data = data_from_golden(g, L, prefix=prefix)
+    opt = golden_settings(N, L, extra)
+    e = Engine(opt, data, n_batch=n_batch, lib_path=lib_path, fused=fused)
+    om = OM.MTIP(opt, data)
+    return e, om, opt, data
+
+
+def check_operators_golden(golden_ops, lib_path):
+    """G3 (projection, through V_l U_l), G4 (modulus replacement incl. zero / negative points),
+    G5 (real projection + HIO + ER + error metric incl. masks), G9 (B_l)."""
+    g = golden_ops
+    N, L = 16, 4
+    extra = {'projections': {'reciprocal': {'q_mask': {'type': 'manual', 'manual': {
+        'type': 'region', 'region': [False, float(g['G2_qs'][N - 3])]}}}}}
+    e, om, opt, data = _engine_and_oracle(g, lib_path, prefix='D16_', extra=extra)
+    assert np.isclose(e.rsetup.integrated_intensity, g['G3_integrated_intensity'], rtol=1e-13)
+    assert (e.rsetup.radial_mask == g['G3_radial_mask']).all()
+    for l in range(L + 1):
+        assert rel_l2(e.rsetup.projection_matrices[l], g[f'G3_pm{l}']) < 1e-12
+    Ilm = np.concatenate([g[f'G3_Ilm{l}'] for l in range(L + 1)], axis=1)
+    proj = e.project_coefficients(Ilm)[0]
+    ref = np.concatenate([g[f'G3_proj{l}'] for l in range(L + 1)], axis=1)
+    assert rel_l2(proj, ref) < TOL_SHT
+    U = e.unknowns(0)
+    for l in range(L + 1):
+        assert rel_l2(e.rsetup.projection_matrices[l] @ U[l], g[f'G3_VU{l}']) < TOL_SHT
+    assert rel_l2(e.deg2_invariants(Ilm)[0], g['G9_Bl']) < TOL_OP
+    out = e.modulus_replacement(g['G4_F'], g['G4_Inew'])[0]
+    fin = np.isfinite(g['G4_Fnew'])
+    assert (np.isfinite(out) == fin).all()
+    assert rel_l2(out[fin], g['G4_Fnew'][fin]) < TOL_OP
+    e.close()
+    e, om, opt, data = _engine_and_oracle(g, lib_path, prefix='D16_')
+    assert (e.initial_support == g['G5_initial_support']).all()
+    for enforce in (True, False):
+        e.set_support(0, g['G5_support'], enforce)
+        tag = f'G5_enf{int(enforce)}'
+        new, err = e.real_space_update(g['G5_rho_in'], g['G5_rho_prev'], 'HIO', 0.37)
+        assert rel_l2(new[0], g[tag + '_hio']) < TOL_OP
+        assert np.isclose(err[0], g[tag + '_err'][0], rtol=1e-11)       # the variant the reference selects
+        new, _ = e.real_space_update(g['G5_rho_in'], g['G5_rho_prev'], 'ER', 0.37)
+        assert rel_l2(new[0], g[tag + '_er']) < TOL_OP
+    e.close()
+
+
+def check_steps_golden(golden_mtip16, lib_path, fused):
+    """G10: single HIO / ER (+ft_stab) steps and one SW update from a stored state, vs the reference's sketches."""
+    g = golden_mtip16
+    extra = {'main_loop': {'error': {'methods': {'reciprocal': {
+        'calculate': ['deg2_invariant_l2_diff'], 'deg2_invariant_l2_diff': {'order': 2}}}}}}
+    e, om, opt, data = _engine_and_oracle(g, lib_path, fused=fused, extra=extra)
+    for enforce in (True, False):
+        for meth in ('HIO', 'ER', 'HIO_ft_stab', 'ER_ft_stab'):
+            e.set_density(0, g['rho0'])
+            e.init_state()
+            assert rel_l2(e.density(0), g['step_rho_in']) < TOL_STEP
+            e.set_support(0, g['step_support'], enforce)
+            err, deg2 = e.run(meth.replace('_ft_stab', ''), meth.endswith('_ft_stab'), [0.45])
+            tag = f'step_{meth}_enf{int(enforce)}'
+            assert rel_l2(e.reciprocal_density(0), g[tag + '_F']) < TOL_STEP, tag
+            assert rel_l2(e.density(0), g[tag + '_rho']) < TOL_STEP, tag
+            assert np.isclose(err[0, 0], g[tag + '_err'], rtol=1e-8), tag
+            assert np.allclose(deg2[0, 0], g[tag + '_deg2'], rtol=1e-7), tag
+    e.set_density(0, g['rho0'])
+    e.init_state()
+    e.shrinkwrap(20.0, 0.09, np.inf)
+    assert (e.support(0) != g['step_SW_mask']).sum() == 0
+    e.close()
+
+
+def check_trajectory_golden(g, lib_path, fused, n_restarts=1, max_steps=None):
+    """G10: whole trajectory from the stored initial density vs the reference's own loop."""
+    N, L = int(g['N']), int(g['L'])
+    data = data_from_golden(g, L)
+    opt = golden_settings(N, L, {'main_loop': {'error': {'methods': {'reciprocal': {
+        'calculate': ['deg2_invariant_l2_diff'], 'deg2_invariant_l2_diff': {'order': 2}}}}}})
+    main = opt['main_loop']['sub_loops']['main']
+    main['methods']['HIO']['iterations'] = int(g['n_hio'])
+    main['methods']['ER']['iterations'] = int(g['n_er'])
+    main['iterations'] = int(g['loop_iterations_main'])
+    R.MTIP.preinit(opt, data)
+    m = R.MTIP(n_restarts=n_restarts, initial_densities=[g['rho0']] * n_restarts, lib_path=lib_path, fused=fused)
+    m.generate_phasing_loop()
+    res = m.phasing_loop()
+    n = len(g['traj_main'])
+    for b in range(n_restarts):
+        r = res[b]
+        assert len(r['error_dict']['main']) == n
+        assert int(r['loop_iterations']) == int(g['traj_loop_iterations'])
+        assert rel_l2(r['initial_density'], g['traj_initial_density']) < TOL_STEP
+        k = min(20, n)
+        assert np.allclose(r['error_dict']['main'][:k], g['traj_main'][:k], rtol=TOL_TRAJ)
+        assert np.allclose(r['error_dict']['main'], g['traj_main'], rtol=1e-3)
+        assert np.allclose(r['error_dict']['reciprocal']['deg2_invariant_l2_diff'][:k], g['traj_deg2'][:k], rtol=1e-5)
+        assert rel_l2(r['last_real_density'], g['traj_last_real_density']) < 1e-4
+        assert rel_l2(r['last_reciprocal_density'], g['traj_last_reciprocal_density']) < 1e-4
+        assert rel_l2(r['real_density'], g['traj_real_density']) < 1e-4
+        assert (r['last_support_mask'] != g['traj_last_support_mask']).mean() < 1e-3
+        assert (r['support_mask'] != g['traj_support_mask']).mean() < 1e-3
+        assert np.isclose(r['final_error'], g['traj_final_error'], rtol=1e-3)
+        assert rel_l2(r['last_deg2_invariant'], g['traj_last_deg2_invariant']) < 1e-4
+        L_ = int(g['L'])
+        for l in range(L_ + 1):
+            assert r['fxs_unknowns'][l].shape == g[f'traj_unk{l}'].shape
+            vu = m.engine.rsetup.projection_matrices[l] @ r['fxs_unknowns'][l]
+            ref = g[f'traj_VU{l}']
+            assert np.linalg.norm(vu - ref) <= 1e-4 * max(np.linalg.norm(ref), 1e-30) + 1e-12
+        assert r['n_particles'].shape == g['traj_n_particles'].shape
+    m.engine.close()
+    return res
+
+
+def check_short_trajectory_vs_oracle(g, lib_path, fused, n_hio=3, n_er=2, n_restarts=2):
+    """A few HIO + SW + ER steps against the oracle (cheap enough for the CPU emulation)."""
+    N, L = int(g['N']), int(g['L'])
+    data = data_from_golden(g, L)
+    opt = golden_settings(N, L, {'main_loop': {'error': {'methods': {'reciprocal': {
+        'calculate': ['deg2_invariant_l2_diff'], 'deg2_invariant_l2_diff': {'order': 2}}}}}})
+    main = opt['main_loop']['sub_loops']['main']
+    main['methods']['HIO']['iterations'] = n_hio
+    main['methods']['ER']['iterations'] = n_er
+    main['iterations'] = 2
+    ref = OM.MTIP(opt, data).phasing_loop(rho0=g['rho0'])
+    R.MTIP.preinit(opt, data)
+    m = R.MTIP(n_restarts=n_restarts, initial_densities=[g['rho0']] * n_restarts, lib_path=lib_path, fused=fused)
+    m.generate_phasing_loop()
+    res = m.phasing_loop()
+    for b in range(n_restarts):
+        r = res[b]
+        assert np.allclose(r['error_dict']['main'], ref['error_dict']['main'], rtol=1e-8)
+        assert np.allclose(r['error_dict']['reciprocal']['deg2_invariant_l2_diff'],
+                           ref['error_dict']['reciprocal']['deg2_invariant_l2_diff'], rtol=1e-7)
+        for k in ('real_density', 'last_real_density', 'reciprocal_density', 'last_reciprocal_density',
+                  'initial_density', 'last_deg2_invariant'):
+            assert rel_l2(r[k], ref[k]) < 1e-8, k
+        assert (r['support_mask'] != ref['support_mask']).sum() == 0
+        assert (r['last_support_mask'] != ref['last_support_mask']).sum() == 0
+        assert np.isclose(r['final_error'], ref['final_error'], rtol=1e-8)
+        assert r['loop_iterations'] == ref['loop_iterations']
+    m.engine.close()
+
+
+def synthetic_problem(cfg, lib_path=None, N=None, L=None):
+    """Synthetic invariants for a BASELINE config, generated with the HIP transforms (product path)."""
+    n, l = S._SIZES[cfg]
+    N, L = N or n, L or l
+    eng = Engine({'grid': {'n_radial_points': N, 'max_order': L}}, None, n_batch=1, lib_path=lib_path,
+                 max_q=S.data_cutoff(N))
+    data, rho = S.make_invariants(eng, N, L)
+    eng.close()
+    return data, rho
+
+
+def check_full_size_properties(cfg, lib_path=None, n_steps=12):
+    """At BASELINE sizes the oracle is too slow for step-by-step comparison: check size-independent properties.
+    * FT round trip of a band-limited density, SHT(iSHT(c)) == c
+    * fused step == reference-order step (<= 1e-9) from the same state
+    * identical restarts in one batch stay bit-identical; ER error is non-increasing; projected coefficients
+      reproduce the data B_l on the masked shells
+    """
+    data, rho_true = synthetic_problem(cfg, lib_path)
+    N, L = S._SIZES[cfg]
+    opt = S.config_overrides(cfg)
+    rng = np.random.default_rng(7)
+    out = {}
+    eng = {}
+    for fused in (False, True):
+        e = Engine(opt, data, n_batch=2, lib_path=lib_path, fused=fused)
+        eng[fused] = e
+        import xframe_amd.fxs.hostsetup as hs
+        rho0 = hs.bump_density(e.rs, e.shape, S.PARTICLE_RADIUS, 0.3, 2, np.random.default_rng(1000),
+                               e.rsetup.integrated_intensity, e.int_wr, e.int_wt)
+        for b in range(2):
+            e.set_density(b, rho0)
+        e.init_state()
+        betas = np.full(n_steps, 0.45)
+        err_h, _ = e.run('HIO', True, betas[:n_steps // 2])
+        err_e, _ = e.run('ER', True, betas[:n_steps - n_steps // 2])
+        out[fused] = (np.concatenate([err_h, err_e]), e.density(0), e.reciprocal_density(0), e.density(1))
+    errs_a, rho_a, F_a, rho_a1 = out[False]
+    errs_b, rho_b, F_b, _ = out[True]
+    assert np.array_equal(rho_a, rho_a1)                       # identical restarts stay identical
+    assert np.array_equal(errs_a[:, 0], errs_a[:, 1])
+    assert rel_l2(rho_b, rho_a) < 1e-7 and rel_l2(F_b, F_a) < 1e-7     # fused == reference order (12 steps)
+    assert np.allclose(errs_b[0], errs_a[0], rtol=TOL_STEP)             # first step tight
+    er = errs_a[n_steps // 2:, 0]
+    assert np.all(np.diff(er) <= 1e-12 + 1e-9 * er[:-1])     # error reduction does not increase the error
+    e = eng[False]
+    c = cplx(rng, (2, N, e.nlm))
+    assert rel_l2(e.sht_forward(e.sht_inverse(c)), c) < TOL_SHT
+    band = e.sht_inverse(c)
+    # projected coefficients: B_l of the projection equals the data B_l on masked shells (U_l unitary)
+    Ilm = e.sht_forward(e.fourier_transform(rho_true), 1)
+    proj = e.project_coefficients(Ilm)[0]
+    l = 2
+    m = e.rsetup.radial_mask[l]
+    V = e.rsetup.projection_matrices[l]
+    Pl = proj[:, l * l:(l + 1) ** 2]
+    B_proj = (Pl @ Pl.conj().T)[np.ix_(m, m)]
+    B_ref = (V @ V.conj().T)[np.ix_(m, m)]
+    assert rel_l2(B_proj, B_ref) < 1e-9
+    for x in eng.values():
+        x.close()
+    return errs_a

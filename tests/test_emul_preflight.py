@@ -1,0 +1,78 @@
+"""CPU pre-flight of the HIP kernel sources: the unchanged xframe_amd/csrc/*.hip files are compiled for the
+host against tests/emul (fibers emulate the GPU threads of a block) and pushed through the same C ABI and
+the same parity cases as the -m gpu suite, at toy sizes.  This catches index / barrier / out-of-bounds bugs
+before any GPU minute is spent; it is NOT the parity claim (that is tests/test_gpu_parity.py on the MI355X)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import parity_cases as PC
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+EMUL_DIR = os.path.join(HERE, 'emul')
+EMUL_LIB = os.path.join(EMUL_DIR, 'libmtip_emul.so')
+
+
+@pytest.fixture(scope='session')
+def emul_lib():
+    r = subprocess.run(['make', '-C', EMUL_DIR, '-j6'], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    return EMUL_LIB
+
+
+@pytest.mark.parametrize('N,L', [(16, 4), (10, 7), (8, 2)])
+def test_transforms(emul_lib, N, L):
+    PC.check_transforms(N, L, emul_lib, seed=N + L)
+
+
+def test_transforms_trapz(emul_lib):
+    PC.check_transforms(12, 3, emul_lib, seed=3, mode='trapz')
+
+
+def test_transforms_golden(emul_lib, golden_ops):
+    PC.check_transforms_golden(golden_ops, emul_lib)
+
+
+def test_operators_golden(emul_lib, golden_ops):
+    PC.check_operators_golden(golden_ops, emul_lib)
+
+
+@pytest.mark.parametrize('fused', [False, True])
+def test_single_steps_golden(emul_lib, golden_mtip16, fused):
+    PC.check_steps_golden(golden_mtip16, emul_lib, fused)
+
+
+@pytest.mark.parametrize('fused', [False, True])
+def test_short_trajectory_vs_oracle(emul_lib, golden_mtip16, fused):
+    PC.check_short_trajectory_vs_oracle(golden_mtip16, emul_lib, fused)
+
+
+def test_wide_projection_matrices(emul_lib):
+    """k_l = Nq < 2l+1 (the reference's integration test uses 8 radial points with max_order 15,
+    tests/test_fxs_integration.py:326-355): polar factor of a wide matrix, compared through V_l U_l."""
+    from helpers import rel_l2
+    from oracle.fourier import FourierPair
+    from oracle.sht import SHT
+    from oracle import mtip as OM
+    from helpers import OracleTransforms, golden_settings
+    from xframe_amd.fxs import synthetic as S
+    from xframe_amd.fxs.engine import Engine
+    N, L = 8, 7
+    fpd = FourierPair(SHT(L), N, S.data_cutoff(N), 2.0)
+    data, _ = S.make_invariants(OracleTransforms(fpd), N, L)
+    opt = golden_settings(N, L)
+    e = Engine(opt, data, n_batch=1, lib_path=emul_lib)
+    om = OM.MTIP(opt, data)
+    rng = np.random.default_rng(1)
+    Ilm = PC.cplx(rng, (1, N, e.nlm))
+    proj = e.project_coefficients(Ilm)[0]
+    Il = [Ilm[0][:, l * l:(l + 1) ** 2] for l in range(L + 1)]
+    unk = om.rp.approximate_unknowns(Il)
+    ref = np.concatenate(om.rp.mtip_projection(Il, unk), axis=1)
+    assert rel_l2(proj, ref) < 1e-10
+    U = e.unknowns(0)
+    for l in range(L + 1):
+        assert U[l].shape == (min(2 * l + 1, N), 2 * l + 1)
+    e.close()

@@ -1,0 +1,62 @@
+"""Parity of the HIP path on a real MI355X, through the C ABI, against the oracle and the golden fixtures
+captured from the reference (run with `pytest -m gpu`)."""
+import numpy as np
+import pytest
+
+import parity_cases as PC
+
+pytestmark = pytest.mark.gpu
+
+
+def test_library_loaded_and_device_present():
+    from xframe_amd.fxs import _lib
+    lib = _lib.load()
+    assert lib.mtip_device_count() >= 1
+
+
+@pytest.mark.parametrize('N,L', [(16, 4), (10, 7), (8, 2), (32, 8), (64, 16)])
+def test_transforms(N, L):
+    PC.check_transforms(N, L, None, seed=N + L)
+
+
+def test_transforms_trapz():
+    PC.check_transforms(12, 3, None, seed=3, mode='trapz')
+
+
+def test_transforms_golden(golden_ops):
+    PC.check_transforms_golden(golden_ops, None)
+
+
+def test_operators_golden(golden_ops):
+    PC.check_operators_golden(golden_ops, None)
+
+
+@pytest.mark.parametrize('fused', [False, True])
+def test_single_steps_golden(golden_mtip16, fused):
+    PC.check_steps_golden(golden_mtip16, None, fused)
+
+
+@pytest.mark.parametrize('fused', [False, True])
+def test_short_trajectory_vs_oracle(golden_mtip16, fused):
+    PC.check_short_trajectory_vs_oracle(golden_mtip16, None, fused)
+
+
+@pytest.mark.parametrize('fused', [False, True])
+def test_trajectory_golden_16(golden_mtip16, fused):
+    PC.check_trajectory_golden(golden_mtip16, None, fused, n_restarts=2)
+
+
+@pytest.mark.parametrize('fused', [False, True])
+def test_trajectory_golden_cfg1(golden_cfg1, fused):
+    """BASELINE config 1 (32 shells x L=8, 60 HIO + SW + 40 ER): the reference's own loop, 100 steps."""
+    PC.check_trajectory_golden(golden_cfg1, None, fused, n_restarts=1)
+
+
+def test_config2_properties():
+    PC.check_full_size_properties(2)
+
+
+def test_config3_properties_full_size():
+    """128 shells x L_max = 32 (the metric's configuration)."""
+    errs = PC.check_full_size_properties(3, n_steps=8)
+    assert np.isfinite(errs).all()

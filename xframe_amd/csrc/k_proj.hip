@@ -1,0 +1,276 @@
+// Reciprocal-space (B_l / V_l) projection, rows a8, a9, a18, a19 of SURVEY section 8.
+//   approximate_unknowns  xframe/projects/fxs/projectLibrary/fxs_Projections.py:752-767
+//        U_l = polar unitary factor of A_l = V_l^+ D^2 I_l   (reference: u @ vh of numpy svd)
+//   mtip_projection       fxs_Projections.py:832-849, 866-871
+//        I'_l[mask_l] = (V_l U_l)[mask_l];  I'_0[mask_0] = V_0[mask_0];  I'_0 /= sqrt(N_particles)
+//   B_l = I_l I_l^+       fxs_invariant_tools.py:915-923;  metric fxs_IO_methods.py:408-447
+//
+// The polar factor is computed with a one-sided (Hestenes) Jacobi SVD on X_l = A_l^+ (n_l x k_l,
+// k_l <= n_l, stored column-major so that column operations are contiguous):
+//   X V_r = W (orthogonal columns), sigma_c = |W_c|,  polar(X) = W Sigma^-1 V_r^+,  U_l = polar(X)^+.
+#include "mtip_internal.h"
+
+#define JAC_TG 8            // threads cooperating on one column pair
+#define JAC_MAX_SWEEPS 40
+#define JAC_TOL 1e-14
+
+// X_l[c][r] = sum_q q^2 V_l[q][c] conj(I_l[q][r])      (= conj(A_l[c][r]))
+__global__ void __launch_bounds__(256) k_proj_X(const double2* __restrict__ Ilm, double2* __restrict__ X,
+                                                const double2* __restrict__ V, const double* __restrict__ qv,
+                                                const int* __restrict__ kl, const int* __restrict__ used,
+                                                const int* __restrict__ voff, const int* __restrict__ xoff,
+                                                int N, int L, int xtot) {
+    const int l = blockIdx.y, b = blockIdx.z;
+    if (!used[l]) return;
+    const int k = kl[l], n = 2 * l + 1;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= k * n) return;
+    const int nlm = (L + 1) * (L + 1);
+    const int cidx = e / n, r = e - cidx * n;
+    const double2* Vl = V + voff[l] + cidx;
+    const double2* Il = Ilm + (size_t)b * N * nlm + l * l + r;
+    double2 acc = make_double2(0.0, 0.0);
+    for (int q = 0; q < N; ++q) {
+        const double q2 = qv[q] * qv[q];
+        const double2 v = Vl[(size_t)q * k];
+        const double2 iv = Il[(size_t)q * nlm];
+        const double2 p = cmulc(v, iv);
+        acc.x = fma(q2, p.x, acc.x);
+        acc.y = fma(q2, p.y, acc.y);
+    }
+    X[(size_t)b * xtot + xoff[l] + (size_t)cidx * n + r] = acc;
+}
+
+// tournament pairing of round r: players 0..Cp-1 (Cp even), pair index pi in [0, Cp/2)
+__device__ __forceinline__ void jacobi_pair(int r, int pi, int Cp, int* a, int* b) {
+    const int M = Cp - 1;
+    if (pi == 0) {
+        *a = r % M;
+        *b = M;
+    } else {
+        *a = (r + pi) % M;
+        *b = (r - pi + M) % M;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_polar_jacobi(double2* __restrict__ Xall, double2* __restrict__ Vrall,
+                                                      double2* __restrict__ Uall, const int* __restrict__ kl,
+                                                      const int* __restrict__ used, const int* __restrict__ xoff,
+                                                      const int* __restrict__ roff, int xtot, int rtot) {
+    __shared__ int s_rotated;
+    __shared__ double s_isig[128];                        // k_l <= 2*63+1
+    const int l = blockIdx.x, b = blockIdx.y;
+    if (!used[l]) return;                                  // uniform per block
+    const int k = kl[l], n = 2 * l + 1;
+    double2* X = Xall + (size_t)b * xtot + xoff[l];
+    double2* Vr = Vrall + (size_t)b * rtot + roff[l];
+    double2* U = Uall + (size_t)b * xtot + xoff[l];
+    const int tid = threadIdx.x;
+    for (int e = tid; e < k * k; e += blockDim.x) {
+        const int cc = e / k, i = e - cc * k;
+        Vr[e] = make_double2(cc == i ? 1.0 : 0.0, 0.0);
+    }
+    __syncthreads();
+    const int Cp = k + (k & 1);
+    const int rounds = Cp - 1;
+    const int pairs = Cp / 2;
+    const int ngroups = blockDim.x / JAC_TG;
+    const int group = tid / JAC_TG, t = tid - group * JAC_TG;
+    const int per_group = (pairs + ngroups - 1) / ngroups;
+    if (k > 1) {
+        for (int sweep = 0; sweep < JAC_MAX_SWEEPS; ++sweep) {
+            if (tid == 0) s_rotated = 0;
+            __syncthreads();
+            for (int r = 0; r < rounds; ++r) {
+                for (int it = 0; it < per_group; ++it) {
+                    const int pi = group + it * ngroups;
+                    int ci = 0, cj = 0;
+                    bool valid = pi < pairs;
+                    if (valid) {
+                        jacobi_pair(r, pi, Cp, &ci, &cj);
+                        valid = (ci < k) && (cj < k);
+                    }
+                    double2* xi = X + (size_t)ci * n;
+                    double2* xj = X + (size_t)cj * n;
+                    double alpha = 0.0, beta = 0.0, gr = 0.0, gi = 0.0;
+                    if (valid) {
+                        for (int row = t; row < n; row += JAC_TG) {
+                            const double2 a = xi[row], c2 = xj[row];
+                            alpha += cabs2(a);
+                            beta += cabs2(c2);
+                            gr += a.x * c2.x + a.y * c2.y;     // conj(a) * c2
+                            gi += a.x * c2.y - a.y * c2.x;
+                        }
+                    }
+                    for (int o = JAC_TG / 2; o > 0; o >>= 1) {
+                        alpha += __shfl_xor(alpha, o, JAC_TG);
+                        beta += __shfl_xor(beta, o, JAC_TG);
+                        gr += __shfl_xor(gr, o, JAC_TG);
+                        gi += __shfl_xor(gi, o, JAC_TG);
+                    }
+                    const double g2 = gr * gr + gi * gi;
+                    if (valid && g2 > (JAC_TOL * JAC_TOL) * alpha * beta && g2 > 0.0) {
+                        const double gabs = sqrt(g2);
+                        const double zeta = (beta - alpha) / (2.0 * gabs);
+                        const double tt = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                        const double cs = 1.0 / sqrt(1.0 + tt * tt);
+                        const double sn = cs * tt;
+                        // e^{-i phi} = conj(gamma)/|gamma|
+                        const double2 em = make_double2(gr / gabs, -gi / gabs);
+                        for (int row = t; row < n; row += JAC_TG) {
+                            const double2 a = xi[row];
+                            const double2 bj = cmul(em, xj[row]);
+                            xi[row] = make_double2(cs * a.x - sn * bj.x, cs * a.y - sn * bj.y);
+                            xj[row] = make_double2(sn * a.x + cs * bj.x, sn * a.y + cs * bj.y);
+                        }
+                        double2* vi = Vr + (size_t)ci * k;
+                        double2* vj = Vr + (size_t)cj * k;
+                        for (int row = t; row < k; row += JAC_TG) {
+                            const double2 a = vi[row];
+                            const double2 bj = cmul(em, vj[row]);
+                            vi[row] = make_double2(cs * a.x - sn * bj.x, cs * a.y - sn * bj.y);
+                            vj[row] = make_double2(sn * a.x + cs * bj.x, sn * a.y + cs * bj.y);
+                        }
+                        if (t == 0) s_rotated = 1;
+                    }
+                }
+                __syncthreads();
+            }
+            const int rotated = s_rotated;
+            __syncthreads();
+            if (!rotated) break;
+        }
+    }
+    // U[i][j] = sum_c Vr[i][c] conj(W[j][c]) / sigma_c
+    for (int cc = tid; cc < k; cc += blockDim.x) {
+        const double2* wc = X + (size_t)cc * n;
+        double s2 = 0.0;
+        for (int row = 0; row < n; ++row) s2 += cabs2(wc[row]);
+        s_isig[cc] = s2 > 1e-300 ? 1.0 / sqrt(s2) : 0.0;
+    }
+    __syncthreads();
+    for (int e = tid; e < k * n; e += blockDim.x) {
+        const int i = e / n, j = e - i * n;
+        double2 acc = make_double2(0.0, 0.0);
+        for (int cc = 0; cc < k; ++cc) {
+            const double inv = s_isig[cc];
+            const double2 p = cmulc(Vr[(size_t)cc * k + i], X[(size_t)cc * n + j]);
+            acc.x = fma(inv, p.x, acc.x);
+            acc.y = fma(inv, p.y, acc.y);
+        }
+        U[e] = acc;
+    }
+}
+
+// I'_l = mask ? V_l U_l : I_l  (+ the l = 0 rules)
+__global__ void __launch_bounds__(256) k_proj_apply(const double2* __restrict__ Ilm, double2* __restrict__ out,
+                                                    const double2* __restrict__ V, const double2* __restrict__ Uall,
+                                                    const uint8_t* __restrict__ rmask, const int* __restrict__ kl,
+                                                    const int* __restrict__ used, const int* __restrict__ voff,
+                                                    const int* __restrict__ xoff, int N, int L, int xtot,
+                                                    double inv_sqrt_np, long long total) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int nlm = (L + 1) * (L + 1);
+    const int lm = (int)(idx % nlm);
+    const long long bq = idx / nlm;
+    const int q = (int)(bq % N);
+    const long long b = bq / N;
+    const int l = isqrt_lm(lm);
+    const int j = lm - l * l;
+    double2 v = Ilm[idx];
+    if (used[l] && rmask[(size_t)l * N + q]) {
+        const int k = kl[l], n = 2 * l + 1;
+        const double2* Vl = V + voff[l] + (size_t)q * k;
+        if (l == 0) {
+            v = Vl[0];                                   // fxs_Projections.py:840
+        } else {
+            const double2* U = Uall + (size_t)b * xtot + xoff[l] + j;
+            double2 acc = make_double2(0.0, 0.0);
+            for (int i = 0; i < k; ++i) acc = cadd(acc, cmul(Vl[i], U[(size_t)i * n]));
+            v = acc;
+        }
+    }
+    if (l == 0 && used[0]) v = cscale(v, inv_sqrt_np);     // fxs_Projections.py:870
+    out[idx] = v;
+}
+
+void launch_project_coefficients(mtip_ctx* c, const double2* Ilm, double2* out) {
+    ProfScope ps(c, "proj");
+    int max_kn = 1;
+    for (int l = 0; l <= c->L; ++l) max_kn = std::max(max_kn, c->kl[l] * (2 * l + 1));
+    hipLaunchKernelGGL(k_proj_X, dim3((unsigned)div_up(max_kn, 256), (unsigned)(c->L + 1), (unsigned)c->B), dim3(256), 0,
+                       c->stream, Ilm, c->d_X, (const double2*)c->d_V, (const double*)c->d_q, (const int*)c->d_kl,
+                       (const int*)c->d_used, (const int*)c->d_voff, (const int*)c->d_xoff, c->N, c->L, c->xtot);
+    hipLaunchKernelGGL(k_polar_jacobi, dim3((unsigned)(c->L + 1), (unsigned)c->B), dim3(256), 0, c->stream, c->d_X,
+                       c->d_Vr, c->d_U, (const int*)c->d_kl, (const int*)c->d_used, (const int*)c->d_xoff,
+                       (const int*)c->d_uoff, c->xtot, c->utot);
+    const long long total = (long long)c->B * c->N * c->nlm;
+    hipLaunchKernelGGL(k_proj_apply, dim3((unsigned)div_up(total, 256)), dim3(256), 0, c->stream, Ilm, out,
+                       (const double2*)c->d_V, (const double2*)c->d_U, (const uint8_t*)c->d_rmask, (const int*)c->d_kl,
+                       (const int*)c->d_used, (const int*)c->d_voff, (const int*)c->d_xoff, c->N, c->L, c->xtot,
+                       1.0 / std::sqrt(c->n_particles), total);
+}
+
+// ---- B_l = I_l I_l^+ ------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_deg2(const double2* __restrict__ Ilm, double2* __restrict__ Bl, int N, int L) {
+    const int l = blockIdx.y, b = blockIdx.z;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= N * N) return;
+    const int nlm = (L + 1) * (L + 1);
+    const int i = e / N, j = e - i * N;
+    const double2* Ii = Ilm + ((size_t)b * N + i) * nlm + l * l;
+    const double2* Ij = Ilm + ((size_t)b * N + j) * nlm + l * l;
+    double2 acc = make_double2(0.0, 0.0);
+    for (int m = 0; m < 2 * l + 1; ++m) acc = cadd(acc, cmulc(Ii[m], Ij[m]));
+    Bl[(((size_t)b * (L + 1) + l) * N + i) * N + j] = acc;
+}
+
+void launch_deg2(mtip_ctx* c, const double2* Ilm, double2* Bl) {
+    ProfScope ps(c, "deg2");
+    hipLaunchKernelGGL(k_deg2, dim3((unsigned)div_up((long long)c->N * c->N, 256), (unsigned)(c->L + 1), (unsigned)c->B),
+                       dim3(256), 0, c->stream, Ilm, Bl, c->N, c->L);
+}
+
+// deg2_invariant_l2_diff: sum |ref - mask*B|^2 / norm per order (fxs_IO_methods.py:408-447)
+__global__ void __launch_bounds__(256) k_deg2_metric(const double2* __restrict__ Ilm, const double2* __restrict__ Bref,
+                                                     const double* __restrict__ Bnorm, const uint8_t* __restrict__ rmask,
+                                                     const int* __restrict__ used, double* __restrict__ out, int N, int L,
+                                                     double inv_np) {
+    __shared__ double red[256];
+    const int l = blockIdx.x, b = blockIdx.y;
+    const int nlm = (L + 1) * (L + 1);
+    double acc = 0.0;
+    if (used[l]) {
+        const double rs = (l == 0) ? inv_np : 1.0;
+        for (int e = threadIdx.x; e < N * N; e += blockDim.x) {
+            const int i = e / N, j = e - i * N;
+            double2 bij = make_double2(0.0, 0.0);
+            if (rmask[(size_t)l * N + i] && rmask[(size_t)l * N + j]) {
+                const double2* Ii = Ilm + ((size_t)b * N + i) * nlm + l * l;
+                const double2* Ij = Ilm + ((size_t)b * N + j) * nlm + l * l;
+                for (int m = 0; m < 2 * l + 1; ++m) bij = cadd(bij, cmulc(Ii[m], Ij[m]));
+            }
+            const double2 r = Bref[((size_t)l * N + i) * N + j];
+            const double dx = r.x * rs - bij.x, dy = r.y * rs - bij.y;
+            acc += dx * dx + dy * dy;
+        }
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double nrm = Bnorm[l];
+        out[(size_t)b * (L + 1) + l] = (used[l] && nrm != 0.0) ? red[0] / nrm : -1.0;
+    }
+}
+
+void launch_deg2_metric(mtip_ctx* c, const double2* Ilm, double* out) {
+    ProfScope ps(c, "deg2_metric");
+    hipLaunchKernelGGL(k_deg2_metric, dim3((unsigned)(c->L + 1), (unsigned)c->B), dim3(256), 0, c->stream, Ilm,
+                       (const double2*)c->d_Bref, (const double*)c->d_Bnorm, (const uint8_t*)c->d_rmask,
+                       (const int*)c->d_used, out, c->N, c->L, 1.0 / c->n_particles);
+}

@@ -1,0 +1,867 @@
+// C ABI of libmtip_hip.so (include/mtip_hip.h): context, one-off uploads, the device-resident phasing loop
+// (xframe/projects/fxs/reconstruct.py:854-951 -- one step = sketches 518-528 + 576-593) and the
+// single-operator entry points used by the parity tests.
+#include "mtip_internal.h"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+static std::string g_create_error;
+
+#define CTX_CHECK(c)                       \
+    do {                                   \
+        if ((c) == nullptr) return MTIP_EINVAL; \
+    } while (0)
+#define FAIL(c, code, msg)      \
+    do {                        \
+        (c)->err = (msg);       \
+        return (code);          \
+    } while (0)
+
+static int post_launch(mtip_ctx* c, const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        c->err = std::string(what) + ": " + hipGetErrorString(e);
+        return MTIP_EHIP;
+    }
+    return MTIP_OK;
+}
+
+template <typename T>
+static int dev_alloc(mtip_ctx* c, T** p, size_t n) {
+    hipError_t e = hipMalloc((void**)p, std::max<size_t>(n, 1) * sizeof(T));
+    if (e != hipSuccess) {
+        c->err = std::string("hipMalloc: ") + hipGetErrorString(e);
+        *p = nullptr;
+        return MTIP_ENOMEM;
+    }
+    return MTIP_OK;
+}
+
+extern "C" {
+
+int mtip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char* mtip_last_error(const mtip_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+void mtip_destroy(mtip_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    void* ptrs[] = {c->d_cost, c->d_gw, c->d_P, c->d_r, c->d_q, c->d_poff, c->d_tw, c->d_W, c->d_kl, c->d_used, c->d_voff,
+                    c->d_xoff, c->d_uoff, c->d_V, c->d_rmask, c->d_Bref, c->d_Bnorm, c->d_S0, c->d_sup, c->d_err_wr,
+                    c->d_err_wt, c->d_rho, c->d_Fp, c->d_slot, c->d_best_err, c->d_last_err, c->d_err_hist,
+                    c->d_deg2_hist, c->d_F, c->d_T1, c->d_T2, c->d_fixed, c->d_g, c->d_c[0], c->d_c[1], c->d_c[2],
+                    c->d_c[3], c->d_c[4], c->d_c[5], c->d_X, c->d_Vr, c->d_U, c->d_partial, c->d_minmax, c->d_Bl};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+static bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+mtip_ctx* mtip_create(const mtip_cfg* cfg, int device) {
+    if (!cfg) {
+        g_create_error = "cfg is NULL";
+        return nullptr;
+    }
+    const int ndev = mtip_device_count();
+    if (ndev <= 0) {
+        g_create_error = "no HIP device visible (libmtip_hip needs an MI355X; there is no CPU fallback)";
+        return nullptr;
+    }
+    if (device < 0 || device >= ndev) {
+        g_create_error = "device index out of range";
+        return nullptr;
+    }
+    if (cfg->n_radial < 2 || cfg->l_max < 0 || cfg->l_max > 63 || cfg->n_batch < 1 || !is_pow2(cfg->n_phi) ||
+        cfg->n_phi < 4 || cfg->n_phi > 512 || cfg->n_phi <= 2 * cfg->l_max || cfg->n_theta <= cfg->l_max) {
+        g_create_error = "invalid cfg: need Nq>=2, 0<=L<=63, n_batch>=1, n_phi a power of two in [4,512] and > 2L, n_theta > L";
+        return nullptr;
+    }
+    if (hipSetDevice(device) != hipSuccess) {
+        g_create_error = "hipSetDevice failed";
+        return nullptr;
+    }
+    mtip_ctx* c = new mtip_ctx();
+    c->cfg = *cfg;
+    c->device = device;
+    c->N = cfg->n_radial;
+    c->L = cfg->l_max;
+    c->nt = cfg->n_theta;
+    c->np = cfg->n_phi;
+    c->B = cfg->n_batch;
+    c->nlm = (c->L + 1) * (c->L + 1);
+    c->nm = 2 * c->L + 1;
+    c->Np = cfg->hankel_trapz ? c->N - 1 : c->N;
+    c->G = (size_t)c->N * c->nt * c->np;
+    c->C = (size_t)c->N * c->nlm;
+    const int L = c->L, N = c->N, B = c->B;
+    int rc = MTIP_OK;
+    auto A = [&](int r) { if (rc == MTIP_OK) rc = r; };
+    if (hipStreamCreate(&c->stream) != hipSuccess) A(MTIP_EHIP);
+    (void)hipEventCreate(&c->ev0);
+    (void)hipEventCreate(&c->ev1);
+    A(dev_alloc(c, &c->d_cost, c->nt));
+    A(dev_alloc(c, &c->d_gw, c->nt));
+    A(dev_alloc(c, &c->d_P, (size_t)(L + 1) * (L + 2) / 2 * c->nt));
+    A(dev_alloc(c, &c->d_poff, L + 2));
+    A(dev_alloc(c, &c->d_tw, c->np / 2));
+    A(dev_alloc(c, &c->d_r, N));
+    A(dev_alloc(c, &c->d_q, N));
+    A(dev_alloc(c, &c->d_W, (size_t)(L + 1) * c->Np * N));
+    // projection layout
+    c->kl.assign(L + 1, 0);
+    c->used.assign(L + 1, 0);
+    c->voff.assign(L + 2, 0);
+    c->xoff.assign(L + 2, 0);
+    c->uoff.assign(L + 2, 0);
+    c->have_V.assign(L + 1, 0);
+    for (int l = 0; l <= L; ++l) {
+        const int n = 2 * l + 1, k = std::min(n, N);
+        c->kl[l] = k;                               // default; mtip_set_projection_matrix may give a smaller k_l
+        c->voff[l + 1] = c->voff[l] + N * k;
+        c->xoff[l + 1] = c->xoff[l] + k * n;
+        c->uoff[l + 1] = c->uoff[l] + k * k;
+    }
+    c->vtot = c->voff[L + 1];
+    c->xtot = c->xoff[L + 1];
+    c->utot = c->uoff[L + 1];
+    A(dev_alloc(c, &c->d_kl, L + 1));
+    A(dev_alloc(c, &c->d_used, L + 1));
+    A(dev_alloc(c, &c->d_voff, L + 2));
+    A(dev_alloc(c, &c->d_xoff, L + 2));
+    A(dev_alloc(c, &c->d_uoff, L + 2));
+    A(dev_alloc(c, &c->d_V, (size_t)c->vtot));
+    A(dev_alloc(c, &c->d_rmask, (size_t)(L + 1) * N));
+    A(dev_alloc(c, &c->d_Bref, (size_t)(L + 1) * N * N));
+    A(dev_alloc(c, &c->d_Bnorm, L + 1));
+    A(dev_alloc(c, &c->d_S0, c->G));
+    A(dev_alloc(c, &c->d_sup, (size_t)3 * B * c->G));
+    A(dev_alloc(c, &c->d_err_wr, N));
+    A(dev_alloc(c, &c->d_err_wt, c->nt));
+    A(dev_alloc(c, &c->d_rho, (size_t)3 * B * c->G));
+    A(dev_alloc(c, &c->d_Fp, (size_t)3 * B * c->G));
+    A(dev_alloc(c, &c->d_slot, (size_t)B * SL_N));
+    A(dev_alloc(c, &c->d_best_err, B));
+    A(dev_alloc(c, &c->d_last_err, B));
+    c->err_cap = 4096;
+    A(dev_alloc(c, &c->d_err_hist, (size_t)c->err_cap * B));
+    A(dev_alloc(c, &c->d_deg2_hist, (size_t)c->err_cap * B * (L + 1)));
+    A(dev_alloc(c, &c->d_F, (size_t)B * c->G));
+    A(dev_alloc(c, &c->d_T1, (size_t)B * c->G));
+    A(dev_alloc(c, &c->d_T2, (size_t)B * c->G));
+    A(dev_alloc(c, &c->d_fixed, (size_t)B * c->G));
+    A(dev_alloc(c, &c->d_g, (size_t)B * N * c->nt * c->nm));
+    for (int i = 0; i < 6; ++i) A(dev_alloc(c, &c->d_c[i], (size_t)B * c->C));
+    A(dev_alloc(c, &c->d_X, (size_t)B * c->xtot));
+    A(dev_alloc(c, &c->d_Vr, (size_t)B * c->utot));
+    A(dev_alloc(c, &c->d_U, (size_t)B * c->xtot));
+    c->n_partial_blocks = div_up((long long)c->G, 256 * 4);
+    A(dev_alloc(c, &c->d_partial, (size_t)B * c->n_partial_blocks * 2));
+    A(dev_alloc(c, &c->d_minmax, (size_t)B * c->n_partial_blocks * 2));
+    if (rc != MTIP_OK) {
+        g_create_error = c->err.empty() ? "allocation failed" : c->err;
+        mtip_destroy(c);
+        return nullptr;
+    }
+    (void)hipMemcpy(c->d_kl, c->kl.data(), (L + 1) * sizeof(int), hipMemcpyHostToDevice);
+    (void)hipMemcpy(c->d_voff, c->voff.data(), (L + 2) * sizeof(int), hipMemcpyHostToDevice);
+    (void)hipMemcpy(c->d_xoff, c->xoff.data(), (L + 2) * sizeof(int), hipMemcpyHostToDevice);
+    (void)hipMemcpy(c->d_uoff, c->uoff.data(), (L + 2) * sizeof(int), hipMemcpyHostToDevice);
+    (void)hipMemset(c->d_used, 0, (L + 1) * sizeof(int));
+    (void)hipMemset(c->d_V, 0, (size_t)c->vtot * sizeof(double2));
+    (void)hipMemset(c->d_rmask, 0, (size_t)(L + 1) * N);
+    (void)hipMemset(c->d_sup, 1, (size_t)3 * B * c->G);
+    (void)hipMemset(c->d_S0, 1, c->G);
+    // default slots
+    std::vector<int> slots((size_t)B * SL_N, 0);
+    for (int b = 0; b < B; ++b) {
+        slots[b * SL_N + SL_CUR] = 0;
+        slots[b * SL_N + SL_OUT] = 1;
+        slots[b * SL_N + SL_BEST] = 0;
+        slots[b * SL_N + SL_ENFORCE] = 1;
+    }
+    (void)hipMemcpy(c->d_slot, slots.data(), slots.size() * sizeof(int), hipMemcpyHostToDevice);
+    std::vector<double> inf(B, HUGE_VAL);
+    (void)hipMemcpy(c->d_best_err, inf.data(), B * sizeof(double), hipMemcpyHostToDevice);
+    (void)hipMemcpy(c->d_last_err, inf.data(), B * sizeof(double), hipMemcpyHostToDevice);
+    return c;
+}
+
+int mtip_get_cfg(const mtip_ctx* c, mtip_cfg* out) {
+    CTX_CHECK(c);
+    if (!out) return MTIP_EINVAL;
+    *out = c->cfg;
+    return MTIP_OK;
+}
+
+int mtip_synchronize(mtip_ctx* c) {
+    CTX_CHECK(c);
+    MTIP_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    return post_launch(c, "synchronize");
+}
+
+// ---- one-off setup ------------------------------------------------------------------------------------
+int mtip_set_angular_grid(mtip_ctx* c, const double* cos_theta, const double* gauss_weights) {
+    CTX_CHECK(c);
+    if (!cos_theta || !gauss_weights) FAIL(c, MTIP_EINVAL, "null angular grid");
+    (void)hipSetDevice(c->device);
+    MTIP_HIP_CHECK(c, hipMemcpy(c->d_cost, cos_theta, c->nt * sizeof(double), hipMemcpyHostToDevice));
+    MTIP_HIP_CHECK(c, hipMemcpy(c->d_gw, gauss_weights, c->nt * sizeof(double), hipMemcpyHostToDevice));
+    build_legendre_tables(c, cos_theta);
+    c->have_angular = true;
+    return MTIP_OK;
+}
+
+int mtip_set_radial_grid(mtip_ctx* c, const double* r, const double* q) {
+    CTX_CHECK(c);
+    if (!r || !q) FAIL(c, MTIP_EINVAL, "null radial grid");
+    (void)hipSetDevice(c->device);
+    MTIP_HIP_CHECK(c, hipMemcpy(c->d_r, r, c->N * sizeof(double), hipMemcpyHostToDevice));
+    MTIP_HIP_CHECK(c, hipMemcpy(c->d_q, q, c->N * sizeof(double), hipMemcpyHostToDevice));
+    c->have_radial = true;
+    return MTIP_OK;
+}
+
+int mtip_set_hankel_weights(mtip_ctx* c, const double* w_raw, double fwd_scale, double inv_scale) {
+    CTX_CHECK(c);
+    if (!w_raw) FAIL(c, MTIP_EINVAL, "null weights");
+    (void)hipSetDevice(c->device);
+    MTIP_HIP_CHECK(c, hipMemcpy(c->d_W, w_raw, (size_t)(c->L + 1) * c->Np * c->N * sizeof(double), hipMemcpyHostToDevice));
+    c->fwd_scale = fwd_scale;
+    c->inv_scale = inv_scale;
+    c->have_weights = true;
+    return MTIP_OK;
+}
+
+int mtip_set_projection_matrix(mtip_ctx* c, int l, const mtip_cdouble* V, int k_l, const uint8_t* radial_mask, int used) {
+    CTX_CHECK(c);
+    if (l < 0 || l > c->L) FAIL(c, MTIP_EINVAL, "order out of range");
+    const int kmax = std::min(2 * l + 1, c->N);
+    if (k_l < 1 || k_l > kmax) FAIL(c, MTIP_EINVAL, "k_l must be in [1, min(2l+1, Nq)]");
+    if (used && (!V || !radial_mask)) FAIL(c, MTIP_EINVAL, "null projection matrix");
+    (void)hipSetDevice(c->device);
+    // the storage slot has room for kmax columns; a narrower matrix is zero padded (zero columns of V
+    // do not contribute to V_l U_l)
+    std::vector<double2> tmp((size_t)c->N * kmax, make_double2(0.0, 0.0));
+    if (V)
+        for (int q = 0; q < c->N; ++q)
+            for (int i = 0; i < k_l; ++i) tmp[(size_t)q * kmax + i] = make_double2(V[(size_t)q * k_l + i].re, V[(size_t)q * k_l + i].im);
+    MTIP_HIP_CHECK(c, hipMemcpy(c->d_V + c->voff[l], tmp.data(), tmp.size() * sizeof(double2), hipMemcpyHostToDevice));
+    if (radial_mask) MTIP_HIP_CHECK(c, hipMemcpy(c->d_rmask + (size_t)l * c->N, radial_mask, c->N, hipMemcpyHostToDevice));
+    c->used[l] = used ? 1 : 0;
+    MTIP_HIP_CHECK(c, hipMemcpy(c->d_used, c->used.data(), (c->L + 1) * sizeof(int), hipMemcpyHostToDevice));
+    c->have_V[l] = 1;
+    c->bref_dirty = true;
+    return MTIP_OK;
+}
+
+int mtip_set_number_of_particles(mtip_ctx* c, double n) {
+    CTX_CHECK(c);
+    if (!(n > 0)) FAIL(c, MTIP_EINVAL, "number of particles must be > 0");
+    c->n_particles = n;
+    return MTIP_OK;
+}
+
+// reference B_l = V_l V_l^+ masked (fxs_Projections.py:631-637, fxs_IO_methods.py:408-425), host side one-off
+static int build_bref(mtip_ctx* c) {
+    const int N = c->N, L = c->L;
+    std::vector<double2> V((size_t)c->vtot);
+    std::vector<uint8_t> rm((size_t)(L + 1) * N);
+    MTIP_HIP_CHECK(c, hipMemcpy(V.data(), c->d_V, V.size() * sizeof(double2), hipMemcpyDeviceToHost));
+    MTIP_HIP_CHECK(c, hipMemcpy(rm.data(), c->d_rmask, rm.size(), hipMemcpyDeviceToHost));
+    std::vector<double2> Bref((size_t)(L + 1) * N * N, make_double2(0.0, 0.0));
+    std::vector<double> norm(L + 1, 0.0);
+    for (int l = 0; l <= L; ++l) {
+        const int k = c->kl[l];
+        const double2* Vl = V.data() + c->voff[l];
+        for (int i = 0; i < N; ++i)
+            for (int j = 0; j < N; ++j) {
+                if (!(rm[(size_t)l * N + i] && rm[(size_t)l * N + j])) continue;
+                double re = 0, im = 0;
+                for (int cidx = 0; cidx < k; ++cidx) {
+                    const double2 a = Vl[(size_t)i * k + cidx], b = Vl[(size_t)j * k + cidx];
+                    re += a.x * b.x + a.y * b.y;
+                    im += a.y * b.x - a.x * b.y;
+                }
+                Bref[((size_t)l * N + i) * N + j] = make_double2(re, im);
+                norm[l] += re * re + im * im;
+            }
+    }
+    MTIP_HIP_CHECK(c, hipMemcpy(c->d_Bref, Bref.data(), Bref.size() * sizeof(double2), hipMemcpyHostToDevice));
+    MTIP_HIP_CHECK(c, hipMemcpy(c->d_Bnorm, norm.data(), norm.size() * sizeof(double), hipMemcpyHostToDevice));
+    c->bref_dirty = false;
+    return MTIP_OK;
+}
+
+int mtip_set_deg2_metric(mtip_ctx* c, int enable) {
+    CTX_CHECK(c);
+    c->deg2_enable = enable ? 1 : 0;
+    return MTIP_OK;
+}
+
+int mtip_set_real_constraints(mtip_ctx* c, uint32_t flags, double lo, double hi, double imag_thr, uint32_t hio_flags) {
+    CTX_CHECK(c);
+    c->rp.flags = flags;
+    c->rp.hio_flags = hio_flags;
+    c->rp.lo = lo;
+    c->rp.hi = hi;
+    c->rp.imag_thr = imag_thr;
+    return MTIP_OK;
+}
+
+int mtip_set_initial_support(mtip_ctx* c, const uint8_t* support) {
+    CTX_CHECK(c);
+    if (!support) FAIL(c, MTIP_EINVAL, "null support");
+    (void)hipSetDevice(c->device);
+    MTIP_HIP_CHECK(c, hipMemcpy(c->d_S0, support, c->G, hipMemcpyHostToDevice));
+    std::vector<int> slots((size_t)c->B * SL_N);
+    MTIP_HIP_CHECK(c, hipMemcpy(slots.data(), c->d_slot, slots.size() * sizeof(int), hipMemcpyDeviceToHost));
+    for (int b = 0; b < c->B; ++b) {
+        slots[b * SL_N + SL_SUP] = 0;
+        slots[b * SL_N + SL_SUP_BEST] = 0;
+        slots[b * SL_N + SL_ENFORCE] = 1;
+        MTIP_HIP_CHECK(c, hipMemcpy(c->d_sup + (size_t)b * c->G, support, c->G, hipMemcpyHostToDevice));
+    }
+    MTIP_HIP_CHECK(c, hipMemcpy(c->d_slot, slots.data(), slots.size() * sizeof(int), hipMemcpyHostToDevice));
+    c->have_support = true;
+    return MTIP_OK;
+}
+
+int mtip_set_error_weights(mtip_ctx* c, const double* radial_w, const double* theta_w, int use_mask) {
+    CTX_CHECK(c);
+    if (!radial_w || !theta_w) FAIL(c, MTIP_EINVAL, "null error weights");
+    (void)hipSetDevice(c->device);
+    MTIP_HIP_CHECK(c, hipMemcpy(c->d_err_wr, radial_w, c->N * sizeof(double), hipMemcpyHostToDevice));
+    MTIP_HIP_CHECK(c, hipMemcpy(c->d_err_wt, theta_w, c->nt * sizeof(double), hipMemcpyHostToDevice));
+    c->err_use_mask = use_mask ? 1 : 0;
+    c->have_errw = true;
+    return MTIP_OK;
+}
+
+// ---- pipelines ------------------------------------------------------------------------------------------
+static int require_transforms(mtip_ctx* c) {
+    if (!c->have_angular) FAIL(c, MTIP_ESTATE, "mtip_set_angular_grid has not been called");
+    if (!c->have_weights) FAIL(c, MTIP_ESTATE, "mtip_set_hankel_weights has not been called");
+    return MTIP_OK;
+}
+static int require_loop(mtip_ctx* c) {
+    int r = require_transforms(c);
+    if (r) return r;
+    if (!c->have_radial) FAIL(c, MTIP_ESTATE, "mtip_set_radial_grid has not been called");
+    if (!c->have_support) FAIL(c, MTIP_ESTATE, "mtip_set_initial_support has not been called");
+    if (!c->have_errw) FAIL(c, MTIP_ESTATE, "mtip_set_error_weights has not been called");
+    for (int l = 0; l <= c->L; ++l)
+        if (!c->have_V[l]) FAIL(c, MTIP_ESTATE, "mtip_set_projection_matrix missing for some order");
+    if (!c->state_ready) FAIL(c, MTIP_ESTATE, "mtip_init_state has not been called");
+    return MTIP_OK;
+}
+
+// grid -> grid Fourier transform, fourier_transforms.py:57-85 (in_slot/out via epilogue possible)
+static void ft_pipeline(mtip_ctx* c, const double2* in, int in_slot, double2* out, int inverse, int prologue,
+                        const InvEpilogue& epi, double2* ca, double2* cb) {
+    launch_sht_forward(c, in, ca, prologue, in_slot);
+    launch_hankel(c, ca, cb, inverse);
+    launch_sht_inverse(c, cb, out, epi);
+}
+
+static int ensure_hist(mtip_ctx* c, long long need) {
+    if (need <= c->err_cap) return MTIP_OK;
+    long long cap = c->err_cap;
+    while (cap < need) cap *= 2;
+    double *nh = nullptr, *nd = nullptr;
+    int r = dev_alloc(c, &nh, (size_t)cap * c->B);
+    if (r) return r;
+    r = dev_alloc(c, &nd, (size_t)cap * c->B * (c->L + 1));
+    if (r) return r;
+    MTIP_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    MTIP_HIP_CHECK(c, hipMemcpy(nh, c->d_err_hist, (size_t)c->n_steps_done * c->B * sizeof(double), hipMemcpyDeviceToDevice));
+    MTIP_HIP_CHECK(c, hipMemcpy(nd, c->d_deg2_hist, (size_t)c->n_steps_done * c->B * (c->L + 1) * sizeof(double), hipMemcpyDeviceToDevice));
+    (void)hipFree(c->d_err_hist);
+    (void)hipFree(c->d_deg2_hist);
+    c->d_err_hist = nh;
+    c->d_deg2_hist = nd;
+    c->err_cap = cap;
+    return MTIP_OK;
+}
+
+// one phasing step for the whole batch (reference operator order), see file header
+static void enqueue_step(mtip_ctx* c, int method, int ft_stab, double beta) {
+    const bool fxs = (method == MTIP_HIO || method == MTIP_ER);
+    double2 **cc = c->d_c;
+    InvEpilogue store;
+    // 1  F = FT(rho_cur)
+    launch_sht_forward(c, c->d_rho, cc[0], MTIP_PRE_NONE, SL_CUR);
+    launch_hankel(c, cc[0], cc[1], 0);
+    launch_sht_inverse(c, cc[1], c->d_F, store);
+    if (fxs) {
+        // 2-3 I_lm = SHT(|F|^2);  4-5 projection;  6-7 I' = iSHT, F' = F sqrt(I'/I) -> Fp[out]
+        launch_sht_forward(c, c->d_F, cc[2], MTIP_PRE_SQUARE);
+        if (c->deg2_enable) launch_deg2_metric(c, cc[2], c->d_deg2_hist + (size_t)c->n_steps_done * c->B * (c->L + 1));
+        launch_project_coefficients(c, cc[2], cc[3]);
+        InvEpilogue mod;
+        mod.mode = EPI_MODULUS;
+        mod.F = c->d_F;
+        mod.out_slot = SL_OUT;
+        launch_sht_inverse(c, cc[3], c->d_Fp, mod);
+    } else {
+        launch_modulus_fixed_slots(c, c->d_F);
+    }
+    // 9  rho' = IFT(F')
+    launch_sht_forward(c, c->d_Fp, cc[4], MTIP_PRE_NONE, SL_OUT);
+    launch_hankel(c, cc[4], cc[5], 1);
+    if (c->cfg.fused && ft_stab) {
+        // rho'' = rho + IFT(F' - F) on shells > 0, IFT(F') on shell 0, using SHT(F) == Hankel(SHT(rho)) = cc[1]
+        launch_hankel(c, cc[1], cc[0], 1);
+        launch_coeff_diff(c, cc[5], cc[0], cc[4]);
+        launch_sht_inverse(c, cc[4], c->d_T1, store);
+        // prev enters twice: as the add-back (rho_rt = 0 path) -- handled by passing a zero round trip
+        launch_real_update(c, c->d_T1, c->d_rho, c->d_T2 /*zeros*/, c->d_rho, method, beta, 1);
+    } else {
+        launch_sht_inverse(c, cc[5], c->d_T1, store);
+        const double2* rt = nullptr;
+        if (ft_stab) {
+            // rho_rt = IFT(F)
+            launch_sht_forward(c, c->d_F, cc[0], MTIP_PRE_NONE);
+            launch_hankel(c, cc[0], cc[4], 1);
+            launch_sht_inverse(c, cc[4], c->d_T2, store);
+            rt = c->d_T2;
+        }
+        launch_real_update(c, c->d_T1, c->d_rho, rt, c->d_rho, method, beta, 1);
+    }
+    launch_finish_step(c, c->n_steps_done);
+    c->n_steps_done += 1;
+}
+
+int mtip_run_async(mtip_ctx* c, int method, int ft_stab, int n_steps, const double* betas) {
+    CTX_CHECK(c);
+    int r = require_loop(c);
+    if (r) return r;
+    if (method < 0 || method > 3) FAIL(c, MTIP_EINVAL, "unknown method");
+    if (n_steps < 0 || (n_steps > 0 && !betas)) FAIL(c, MTIP_EINVAL, "bad n_steps / betas");
+    (void)hipSetDevice(c->device);
+    r = ensure_hist(c, c->n_steps_done + n_steps);
+    if (r) return r;
+    if (c->deg2_enable && c->bref_dirty) {
+        r = build_bref(c);
+        if (r) return r;
+    }
+    const bool fxs = (method == MTIP_HIO || method == MTIP_ER);
+    if (!fxs) {
+        if (!c->fixed_valid) {
+            launch_abs_to_fixed(c);                  // reconstruct.py:899-902
+            c->fixed_valid = true;
+        }
+    } else {
+        c->fixed_valid = false;
+    }
+    if (c->cfg.fused && ft_stab) MTIP_HIP_CHECK(c, hipMemsetAsync(c->d_T2, 0, (size_t)c->B * c->G * sizeof(double2), c->stream));
+    for (int s = 0; s < n_steps; ++s) enqueue_step(c, method, ft_stab, betas[s]);
+    return post_launch(c, "mtip_run");
+}
+
+int mtip_fetch_errors(mtip_ctx* c, int64_t first, int64_t n, double* real_err, double* deg2_err) {
+    CTX_CHECK(c);
+    if (first < 0 || n < 0 || first + n > c->n_steps_done) FAIL(c, MTIP_EINVAL, "step range out of bounds");
+    (void)hipSetDevice(c->device);
+    MTIP_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    if (real_err && n)
+        MTIP_HIP_CHECK(c, hipMemcpy(real_err, c->d_err_hist + (size_t)first * c->B, (size_t)n * c->B * sizeof(double), hipMemcpyDeviceToHost));
+    if (deg2_err && n)
+        MTIP_HIP_CHECK(c, hipMemcpy(deg2_err, c->d_deg2_hist + (size_t)first * c->B * (c->L + 1),
+                                    (size_t)n * c->B * (c->L + 1) * sizeof(double), hipMemcpyDeviceToHost));
+    return post_launch(c, "mtip_fetch_errors");
+}
+
+int mtip_run(mtip_ctx* c, int method, int ft_stab, int n_steps, const double* betas, double* real_err, double* deg2_err) {
+    CTX_CHECK(c);
+    const long long first = c->n_steps_done;
+    int r = mtip_run_async(c, method, ft_stab, n_steps, betas);
+    if (r) return r;
+    return mtip_fetch_errors(c, first, n_steps, real_err, (c->deg2_enable ? deg2_err : nullptr));
+}
+
+// ---- state ------------------------------------------------------------------------------------------------
+static int slot_of(mtip_ctx* c, int batch, int which, int* out) {
+    std::vector<int> s(SL_N);
+    MTIP_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    MTIP_HIP_CHECK(c, hipMemcpy(s.data(), c->d_slot + (size_t)batch * SL_N, SL_N * sizeof(int), hipMemcpyDeviceToHost));
+    *out = s[which];
+    return MTIP_OK;
+}
+
+int mtip_set_density(mtip_ctx* c, int batch, const mtip_cdouble* rho) {
+    CTX_CHECK(c);
+    if (batch < 0 || batch >= c->B || !rho) FAIL(c, MTIP_EINVAL, "bad batch / null density");
+    (void)hipSetDevice(c->device);
+    MTIP_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    MTIP_HIP_CHECK(c, hipMemcpy(c->d_T1 + (size_t)batch * c->G, rho, c->G * sizeof(double2), hipMemcpyHostToDevice));
+    return MTIP_OK;
+}
+
+int mtip_init_state(mtip_ctx* c) {
+    CTX_CHECK(c);
+    int r = require_transforms(c);
+    if (r) return r;
+    (void)hipSetDevice(c->device);
+    // reconstruct.py:957-979: F0 = FT(rho0); rho0 <- IFT(F0); history = copies of that pair; best_error = inf
+    std::vector<int> slots((size_t)c->B * SL_N);
+    MTIP_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    MTIP_HIP_CHECK(c, hipMemcpy(slots.data(), c->d_slot, slots.size() * sizeof(int), hipMemcpyDeviceToHost));
+    for (int b = 0; b < c->B; ++b) {
+        slots[b * SL_N + SL_CUR] = 0;
+        slots[b * SL_N + SL_OUT] = 0;      // temporarily: writes below go to slot 0
+        slots[b * SL_N + SL_BEST] = 0;
+        slots[b * SL_N + SL_HAS_ERR] = 0;
+    }
+    MTIP_HIP_CHECK(c, hipMemcpy(c->d_slot, slots.data(), slots.size() * sizeof(int), hipMemcpyHostToDevice));
+    InvEpilogue to_slot;
+    to_slot.out_slot = SL_OUT;
+    ft_pipeline(c, c->d_T1, -1, c->d_Fp, 0, MTIP_PRE_NONE, to_slot, c->d_c[0], c->d_c[1]);
+    ft_pipeline(c, c->d_Fp, SL_CUR, c->d_rho, 1, MTIP_PRE_NONE, to_slot, c->d_c[0], c->d_c[1]);
+    MTIP_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    for (int b = 0; b < c->B; ++b) slots[b * SL_N + SL_OUT] = 1;
+    MTIP_HIP_CHECK(c, hipMemcpy(c->d_slot, slots.data(), slots.size() * sizeof(int), hipMemcpyHostToDevice));
+    std::vector<double> inf(c->B, HUGE_VAL);
+    MTIP_HIP_CHECK(c, hipMemcpy(c->d_best_err, inf.data(), c->B * sizeof(double), hipMemcpyHostToDevice));
+    MTIP_HIP_CHECK(c, hipMemcpy(c->d_last_err, inf.data(), c->B * sizeof(double), hipMemcpyHostToDevice));
+    c->n_steps_done = 0;
+    c->fixed_valid = false;
+    c->state_ready = true;
+    return post_launch(c, "mtip_init_state");
+}
+
+static int get_grid_slot(mtip_ctx* c, const double2* base, int batch, int which, mtip_cdouble* out) {
+    if (batch < 0 || batch >= c->B || !out || which < 0 || which > 1) FAIL(c, MTIP_EINVAL, "bad batch / which / null output");
+    (void)hipSetDevice(c->device);
+    int s = 0;
+    int r = slot_of(c, batch, which == 0 ? SL_CUR : SL_BEST, &s);
+    if (r) return r;
+    MTIP_HIP_CHECK(c, hipMemcpy(out, base + ((size_t)s * c->B + batch) * c->G, c->G * sizeof(double2), hipMemcpyDeviceToHost));
+    return MTIP_OK;
+}
+
+int mtip_get_density(mtip_ctx* c, int batch, int which, mtip_cdouble* rho) {
+    CTX_CHECK(c);
+    return get_grid_slot(c, c->d_rho, batch, which, rho);
+}
+
+int mtip_get_reciprocal_density(mtip_ctx* c, int batch, int which, mtip_cdouble* F) {
+    CTX_CHECK(c);
+    return get_grid_slot(c, c->d_Fp, batch, which, F);
+}
+
+int mtip_get_support(mtip_ctx* c, int batch, int which, uint8_t* support) {
+    CTX_CHECK(c);
+    if (batch < 0 || batch >= c->B || !support || which < 0 || which > 1) FAIL(c, MTIP_EINVAL, "bad batch / which / null output");
+    (void)hipSetDevice(c->device);
+    int s = 0;
+    int r = slot_of(c, batch, which == 0 ? SL_SUP : SL_SUP_BEST, &s);
+    if (r) return r;
+    MTIP_HIP_CHECK(c, hipMemcpy(support, c->d_sup + ((size_t)s * c->B + batch) * c->G, c->G, hipMemcpyDeviceToHost));
+    return MTIP_OK;
+}
+
+int mtip_set_support(mtip_ctx* c, int batch, const uint8_t* support, int enforce) {
+    CTX_CHECK(c);
+    if (batch < 0 || batch >= c->B || !support) FAIL(c, MTIP_EINVAL, "bad batch / null support");
+    (void)hipSetDevice(c->device);
+    std::vector<int> s(SL_N);
+    MTIP_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    MTIP_HIP_CHECK(c, hipMemcpy(s.data(), c->d_slot + (size_t)batch * SL_N, SL_N * sizeof(int), hipMemcpyDeviceToHost));
+    int fs = 0;
+    while (fs == s[SL_SUP] || fs == s[SL_SUP_BEST]) ++fs;
+    // fxs_Projections.py:53-58: effective support = S0 & support when the initial support is enforced
+    std::vector<uint8_t> eff(support, support + c->G);
+    if (enforce) {
+        std::vector<uint8_t> s0(c->G);
+        MTIP_HIP_CHECK(c, hipMemcpy(s0.data(), c->d_S0, c->G, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < c->G; ++i) eff[i] = (eff[i] && s0[i]) ? 1 : 0;
+    }
+    MTIP_HIP_CHECK(c, hipMemcpy(c->d_sup + ((size_t)fs * c->B + batch) * c->G, eff.data(), c->G, hipMemcpyHostToDevice));
+    s[SL_SUP] = fs;
+    s[SL_ENFORCE] = enforce ? 1 : 0;
+    MTIP_HIP_CHECK(c, hipMemcpy(c->d_slot + (size_t)batch * SL_N, s.data(), SL_N * sizeof(int), hipMemcpyHostToDevice));
+    return MTIP_OK;
+}
+
+int mtip_get_unknowns(mtip_ctx* c, int batch, int l, mtip_cdouble* U) {
+    CTX_CHECK(c);
+    if (batch < 0 || batch >= c->B || l < 0 || l > c->L || !U) FAIL(c, MTIP_EINVAL, "bad batch / order / null output");
+    (void)hipSetDevice(c->device);
+    MTIP_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    MTIP_HIP_CHECK(c, hipMemcpy(U, c->d_U + (size_t)batch * c->xtot + c->xoff[l], (size_t)c->kl[l] * (2 * l + 1) * sizeof(double2), hipMemcpyDeviceToHost));
+    return MTIP_OK;
+}
+
+int mtip_get_best_error(mtip_ctx* c, double* best, int64_t* n_steps_done) {
+    CTX_CHECK(c);
+    (void)hipSetDevice(c->device);
+    MTIP_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    if (best) MTIP_HIP_CHECK(c, hipMemcpy(best, c->d_best_err, c->B * sizeof(double), hipMemcpyDeviceToHost));
+    if (n_steps_done) *n_steps_done = c->n_steps_done;
+    return MTIP_OK;
+}
+
+int mtip_select_best(mtip_ctx* c) {
+    CTX_CHECK(c);
+    (void)hipSetDevice(c->device);
+    std::vector<int> slots((size_t)c->B * SL_N);
+    MTIP_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    MTIP_HIP_CHECK(c, hipMemcpy(slots.data(), c->d_slot, slots.size() * sizeof(int), hipMemcpyDeviceToHost));
+    for (int b = 0; b < c->B; ++b) {
+        int* s = &slots[(size_t)b * SL_N];
+        s[SL_CUR] = s[SL_BEST];
+        s[SL_SUP] = s[SL_SUP_BEST];
+        int nxt = 0;
+        while (nxt == s[SL_CUR] || nxt == s[SL_BEST]) ++nxt;
+        s[SL_OUT] = nxt;
+    }
+    MTIP_HIP_CHECK(c, hipMemcpy(c->d_slot, slots.data(), slots.size() * sizeof(int), hipMemcpyHostToDevice));
+    return MTIP_OK;
+}
+
+// ---- shrink wrap (sketch SW, reconstruct.py:598-605) ----------------------------------------------------------
+int mtip_shrinkwrap(mtip_ctx* c, double sigma, double threshold, double error_limit, uint8_t* enforced) {
+    CTX_CHECK(c);
+    int r = require_loop(c);
+    if (r) return r;
+    (void)hipSetDevice(c->device);
+    // G_sigma(q) = sigma sqrt(2 pi) exp(-2 pi^2 sigma^2 q^4)   (mathLibrary.py:616-624, sic: q^4)
+    std::vector<double> q(c->N), gq(c->N);
+    MTIP_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    MTIP_HIP_CHECK(c, hipMemcpy(q.data(), c->d_q, c->N * sizeof(double), hipMemcpyDeviceToHost));
+    const double pi = 3.14159265358979323846;
+    const double a = 1.0 / (2.0 * sigma * sigma);
+    for (int i = 0; i < c->N; ++i) {
+        const double q2 = q[i] * q[i];
+        gq[i] = std::sqrt(pi / a) * std::exp(-pi * pi * (q2 * q2) / a);
+    }
+    double* d_gq = c->d_fixed;                   // reuse: real scratch (only N doubles needed here)
+    // d_fixed may hold the non-FXS amplitudes: invalidate so they are rebuilt when next needed
+    c->fixed_valid = false;
+    MTIP_HIP_CHECK(c, hipMemcpy(d_gq, gq.data(), c->N * sizeof(double), hipMemcpyHostToDevice));
+    InvEpilogue scale, store;
+    scale.mode = EPI_SCALE_SHELL;
+    scale.shell_scale = d_gq;
+    // |rho| -> FT -> * G_sigma
+    ft_pipeline(c, c->d_rho, SL_CUR, c->d_T1, 0, MTIP_PRE_ABS, scale, c->d_c[0], c->d_c[1]);
+    // IFT
+    ft_pipeline(c, c->d_T1, -1, c->d_T2, 1, MTIP_PRE_NONE, store, c->d_c[0], c->d_c[1]);
+    double* tmp = reinterpret_cast<double*>(c->d_T1);
+    launch_sw_clamp(c, c->d_T2, tmp);
+    launch_sw_threshold(c, tmp, threshold, error_limit);
+    r = post_launch(c, "mtip_shrinkwrap");
+    if (r) return r;
+    if (enforced) {
+        std::vector<int> slots((size_t)c->B * SL_N);
+        MTIP_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+        MTIP_HIP_CHECK(c, hipMemcpy(slots.data(), c->d_slot, slots.size() * sizeof(int), hipMemcpyDeviceToHost));
+        for (int b = 0; b < c->B; ++b) enforced[b] = (uint8_t)slots[(size_t)b * SL_N + SL_ENFORCE];
+    }
+    return MTIP_OK;
+}
+
+int mtip_last_deg2_invariant(mtip_ctx* c, int batch, mtip_cdouble* Bl) {
+    CTX_CHECK(c);
+    int r = require_transforms(c);
+    if (r) return r;
+    if (batch < 0 || batch >= c->B || !Bl) FAIL(c, MTIP_EINVAL, "bad batch / null output");
+    (void)hipSetDevice(c->device);
+    const size_t per = (size_t)(c->L + 1) * c->N * c->N;
+    if (!c->d_Bl) {
+        r = dev_alloc(c, &c->d_Bl, (size_t)c->B * per);
+        if (r) return r;
+    }
+    InvEpilogue store;
+    ft_pipeline(c, c->d_rho, SL_CUR, c->d_T1, 0, MTIP_PRE_NONE, store, c->d_c[0], c->d_c[1]);
+    launch_sht_forward(c, c->d_T1, c->d_c[2], MTIP_PRE_SQUARE);
+    launch_deg2(c, c->d_c[2], c->d_Bl);
+    MTIP_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    MTIP_HIP_CHECK(c, hipMemcpy(Bl, c->d_Bl + (size_t)batch * per, per * sizeof(double2), hipMemcpyDeviceToHost));
+    return post_launch(c, "mtip_last_deg2_invariant");
+}
+
+// ---- single operators on host arrays ---------------------------------------------------------------------
+#define H2D(dst, src, n) MTIP_HIP_CHECK(c, hipMemcpy((dst), (src), (n), hipMemcpyHostToDevice))
+#define D2H(dst, src, n) MTIP_HIP_CHECK(c, hipMemcpy((dst), (src), (n), hipMemcpyDeviceToHost))
+#define SYNC() MTIP_HIP_CHECK(c, hipStreamSynchronize(c->stream))
+
+int mtip_op_sht_forward(mtip_ctx* c, const mtip_cdouble* grid, mtip_cdouble* coeff, int prologue) {
+    CTX_CHECK(c);
+    if (!c->have_angular) FAIL(c, MTIP_ESTATE, "mtip_set_angular_grid has not been called");
+    if (!grid || !coeff || prologue < 0 || prologue > 2) FAIL(c, MTIP_EINVAL, "null buffer / bad prologue");
+    (void)hipSetDevice(c->device);
+    SYNC();
+    H2D(c->d_T1, grid, (size_t)c->B * c->G * sizeof(double2));
+    launch_sht_forward(c, c->d_T1, c->d_c[0], prologue);
+    SYNC();
+    D2H(coeff, c->d_c[0], (size_t)c->B * c->C * sizeof(double2));
+    return post_launch(c, "mtip_op_sht_forward");
+}
+
+int mtip_op_sht_inverse(mtip_ctx* c, const mtip_cdouble* coeff, mtip_cdouble* grid) {
+    CTX_CHECK(c);
+    if (!c->have_angular) FAIL(c, MTIP_ESTATE, "mtip_set_angular_grid has not been called");
+    if (!grid || !coeff) FAIL(c, MTIP_EINVAL, "null buffer");
+    (void)hipSetDevice(c->device);
+    SYNC();
+    H2D(c->d_c[0], coeff, (size_t)c->B * c->C * sizeof(double2));
+    InvEpilogue store;
+    launch_sht_inverse(c, c->d_c[0], c->d_T1, store);
+    SYNC();
+    D2H(grid, c->d_T1, (size_t)c->B * c->G * sizeof(double2));
+    return post_launch(c, "mtip_op_sht_inverse");
+}
+
+int mtip_op_hankel(mtip_ctx* c, const mtip_cdouble* in, mtip_cdouble* out, int inverse) {
+    CTX_CHECK(c);
+    if (!c->have_weights) FAIL(c, MTIP_ESTATE, "mtip_set_hankel_weights has not been called");
+    if (!in || !out) FAIL(c, MTIP_EINVAL, "null buffer");
+    (void)hipSetDevice(c->device);
+    SYNC();
+    H2D(c->d_c[0], in, (size_t)c->B * c->C * sizeof(double2));
+    launch_hankel(c, c->d_c[0], c->d_c[1], inverse ? 1 : 0);
+    SYNC();
+    D2H(out, c->d_c[1], (size_t)c->B * c->C * sizeof(double2));
+    return post_launch(c, "mtip_op_hankel");
+}
+
+int mtip_op_fourier_transform(mtip_ctx* c, const mtip_cdouble* in, mtip_cdouble* out, int inverse) {
+    CTX_CHECK(c);
+    int r = require_transforms(c);
+    if (r) return r;
+    if (!in || !out) FAIL(c, MTIP_EINVAL, "null buffer");
+    (void)hipSetDevice(c->device);
+    SYNC();
+    H2D(c->d_T1, in, (size_t)c->B * c->G * sizeof(double2));
+    InvEpilogue store;
+    ft_pipeline(c, c->d_T1, -1, c->d_T2, inverse ? 1 : 0, MTIP_PRE_NONE, store, c->d_c[0], c->d_c[1]);
+    SYNC();
+    D2H(out, c->d_T2, (size_t)c->B * c->G * sizeof(double2));
+    return post_launch(c, "mtip_op_fourier_transform");
+}
+
+int mtip_op_project_coefficients(mtip_ctx* c, const mtip_cdouble* Ilm, mtip_cdouble* out) {
+    CTX_CHECK(c);
+    if (!c->have_radial) FAIL(c, MTIP_ESTATE, "mtip_set_radial_grid has not been called");
+    for (int l = 0; l <= c->L; ++l)
+        if (!c->have_V[l]) FAIL(c, MTIP_ESTATE, "mtip_set_projection_matrix missing for some order");
+    if (!Ilm || !out) FAIL(c, MTIP_EINVAL, "null buffer");
+    (void)hipSetDevice(c->device);
+    SYNC();
+    H2D(c->d_c[2], Ilm, (size_t)c->B * c->C * sizeof(double2));
+    launch_project_coefficients(c, c->d_c[2], c->d_c[3]);
+    SYNC();
+    D2H(out, c->d_c[3], (size_t)c->B * c->C * sizeof(double2));
+    return post_launch(c, "mtip_op_project_coefficients");
+}
+
+int mtip_op_modulus_replacement(mtip_ctx* c, const mtip_cdouble* F, const mtip_cdouble* I_new, mtip_cdouble* F_new) {
+    CTX_CHECK(c);
+    if (!F || !I_new || !F_new) FAIL(c, MTIP_EINVAL, "null buffer");
+    (void)hipSetDevice(c->device);
+    SYNC();
+    H2D(c->d_F, F, (size_t)c->B * c->G * sizeof(double2));
+    H2D(c->d_T1, I_new, (size_t)c->B * c->G * sizeof(double2));
+    launch_modulus_plain(c, c->d_F, c->d_T1, c->d_T2);
+    SYNC();
+    D2H(F_new, c->d_T2, (size_t)c->B * c->G * sizeof(double2));
+    return post_launch(c, "mtip_op_modulus_replacement");
+}
+
+int mtip_op_real_space_update(mtip_ctx* c, const mtip_cdouble* w, const mtip_cdouble* rho_prev, int method, double beta,
+                              mtip_cdouble* rho_new, double* error) {
+    CTX_CHECK(c);
+    if (!c->have_support) FAIL(c, MTIP_ESTATE, "mtip_set_initial_support has not been called");
+    if (!c->have_errw) FAIL(c, MTIP_ESTATE, "mtip_set_error_weights has not been called");
+    if (!w || !rho_prev || !rho_new) FAIL(c, MTIP_EINVAL, "null buffer");
+    if (method < 0 || method > 3) FAIL(c, MTIP_EINVAL, "unknown method");
+    (void)hipSetDevice(c->device);
+    SYNC();
+    H2D(c->d_T1, w, (size_t)c->B * c->G * sizeof(double2));
+    H2D(c->d_T2, rho_prev, (size_t)c->B * c->G * sizeof(double2));
+    launch_real_update(c, c->d_T1, c->d_T2, nullptr, c->d_F, method, beta, 0);
+    launch_finish_step(c, -1);
+    SYNC();
+    D2H(rho_new, c->d_F, (size_t)c->B * c->G * sizeof(double2));
+    if (error) D2H(error, c->d_last_err, c->B * sizeof(double));
+    // d_last_err was used as scratch: restore "no error yet" only if the loop has not started
+    return post_launch(c, "mtip_op_real_space_update");
+}
+
+int mtip_op_deg2_invariants(mtip_ctx* c, const mtip_cdouble* Ilm, mtip_cdouble* Bl) {
+    CTX_CHECK(c);
+    if (!Ilm || !Bl) FAIL(c, MTIP_EINVAL, "null buffer");
+    (void)hipSetDevice(c->device);
+    const size_t per = (size_t)(c->L + 1) * c->N * c->N;
+    if (!c->d_Bl) {
+        int r = dev_alloc(c, &c->d_Bl, (size_t)c->B * per);
+        if (r) return r;
+    }
+    SYNC();
+    H2D(c->d_c[2], Ilm, (size_t)c->B * c->C * sizeof(double2));
+    launch_deg2(c, c->d_c[2], c->d_Bl);
+    SYNC();
+    D2H(Bl, c->d_Bl, (size_t)c->B * per * sizeof(double2));
+    return post_launch(c, "mtip_op_deg2_invariants");
+}
+
+int mtip_op_apply_matrix(mtip_ctx* c, const double* matrix, const double* vects, double* out, int nr, int nc, int nv) {
+    CTX_CHECK(c);
+    if (!matrix || !vects || !out || nr < 1 || nc < 1 || nv < 1) FAIL(c, MTIP_EINVAL, "bad apply_matrix arguments");
+    (void)hipSetDevice(c->device);
+    double *dM = nullptr, *dx = nullptr, *dy = nullptr;
+    int r = dev_alloc(c, &dM, (size_t)nr * nc);
+    if (!r) r = dev_alloc(c, &dx, (size_t)nc * nv);
+    if (!r) r = dev_alloc(c, &dy, (size_t)nr * nv);
+    if (!r) {
+        hipError_t e = hipMemcpy(dM, matrix, (size_t)nr * nc * sizeof(double), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(dx, vects, (size_t)nc * nv * sizeof(double), hipMemcpyHostToDevice);
+        if (e == hipSuccess) {
+            launch_apply_matrix(c, dM, dx, dy, nr, nc, nv);
+            e = hipStreamSynchronize(c->stream);
+        }
+        if (e == hipSuccess) e = hipMemcpy(out, dy, (size_t)nr * nv * sizeof(double), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) {
+            c->err = std::string("apply_matrix: ") + hipGetErrorString(e);
+            r = MTIP_EHIP;
+        }
+    }
+    if (dM) (void)hipFree(dM);
+    if (dx) (void)hipFree(dx);
+    if (dy) (void)hipFree(dy);
+    return r ? r : post_launch(c, "mtip_op_apply_matrix");
+}
+
+// ---- timing ---------------------------------------------------------------------------------------------
+int mtip_profile(mtip_ctx* c, int enable) {
+    CTX_CHECK(c);
+    c->prof = enable ? 1 : 0;
+    return MTIP_OK;
+}
+
+int mtip_profile_get(mtip_ctx* c, const char* name, double* total_ms, int64_t* launches) {
+    CTX_CHECK(c);
+    if (!name) return MTIP_EINVAL;
+    auto it = c->prof_data.find(name);
+    if (total_ms) *total_ms = it == c->prof_data.end() ? 0.0 : it->second.ms;
+    if (launches) *launches = it == c->prof_data.end() ? 0 : it->second.n;
+    return MTIP_OK;
+}
+
+int mtip_profile_reset(mtip_ctx* c) {
+    CTX_CHECK(c);
+    c->prof_data.clear();
+    return MTIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,177 @@
+// Internal declarations of libmtip_hip.so (gfx950 only).  Public ABI: include/mtip_hip.h
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <map>
+#include <string>
+#include <vector>
+#include "../../include/mtip_hip.h"
+
+typedef double v4f64 __attribute__((vector_size(32)));   // accumulator of v_mfma_f64_16x16x4_f64
+
+// ---- complex helpers (complex128 = double2, interleaved like numpy) ----------------------------
+__device__ __forceinline__ double2 cmul(double2 a, double2 b) {
+    return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ double2 cmulc(double2 a, double2 b) {   // a * conj(b)
+    return make_double2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
+}
+__device__ __forceinline__ double2 cadd(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ double2 csub(double2 a, double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ double2 cscale(double2 a, double s) { return make_double2(a.x * s, a.y * s); }
+__device__ __forceinline__ double cabs2(double2 a) { return a.x * a.x + a.y * a.y; }
+__device__ __forceinline__ int isqrt_lm(int lm) {   // l of index l(l+1)+m, exact integer version
+    int l = (int)sqrt((double)lm);
+    while (l * l > lm) --l;
+    while ((l + 1) * (l + 1) <= lm) ++l;
+    return l;
+}
+// multiply by (-i)^l (sign=-1) or (+i)^l (sign=+1)
+__device__ __forceinline__ double2 cmul_ipow(double2 a, int l, int sign) {
+    int r = l & 3;
+    if (sign < 0) r = (4 - r) & 3;              // (-i)^l = i^(-l)
+    switch (r) {
+        case 0: return a;
+        case 1: return make_double2(-a.y, a.x);   // * i
+        case 2: return make_double2(-a.x, -a.y);
+        default: return make_double2(a.y, -a.x);  // * -i
+    }
+}
+
+// ---- per-restart slot table (device ints), see DESIGN.md "state" ---------------------------------
+enum { SL_CUR = 0, SL_OUT = 1, SL_BEST = 2, SL_SUP = 3, SL_SUP_BEST = 4, SL_ENFORCE = 5, SL_HAS_ERR = 6, SL_N = 8 };
+
+// real-space constraint flags (mtip_set_real_constraints)
+enum { RC_SUPPORT = 1, RC_VALUE_LO = 2, RC_VALUE_HI = 4, RC_LIMIT_IMAG = 8 };
+
+struct RealParams {
+    uint32_t flags, hio_flags;
+    double lo, hi, imag_thr;
+};
+
+// epilogues of the inverse SHT (grid-side fused elementwise stages)
+enum { EPI_STORE = 0, EPI_MODULUS = 1, EPI_SCALE_SHELL = 2, EPI_MODULUS_FIXED = 3, EPI_REAL_UPDATE = 4 };
+
+struct ProfEntry { double ms = 0; long long n = 0; };
+
+struct mtip_ctx {
+    mtip_cfg cfg{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    int N = 0, L = 0, nt = 0, np = 0, B = 0, nlm = 0, nm = 0, Np = 0;
+    size_t G = 0, C = 0;
+    // tables
+    double *d_cost = nullptr, *d_gw = nullptr, *d_P = nullptr, *d_r = nullptr, *d_q = nullptr;
+    int* d_poff = nullptr;
+    double2* d_tw = nullptr;
+    double* d_W = nullptr;
+    double fwd_scale = 0, inv_scale = 0;
+    bool have_angular = false, have_radial = false, have_weights = false, have_support = false, have_errw = false;
+    // projection data
+    std::vector<int> kl, used, voff, xoff, uoff;     // host copies
+    int *d_kl = nullptr, *d_used = nullptr, *d_voff = nullptr, *d_xoff = nullptr, *d_uoff = nullptr;
+    int vtot = 0, xtot = 0, utot = 0;                 // per-restart element counts
+    double2* d_V = nullptr;                           // concatenated V_l, (Nq, k_l) row-major each
+    uint8_t* d_rmask = nullptr;                       // (L+1, Nq)
+    std::vector<char> have_V;
+    double n_particles = 1.0;
+    // deg2 metric
+    int deg2_enable = 0;
+    double2* d_Bref = nullptr;                        // (L+1, Nq, Nq) masked reference B_l
+    double* d_Bnorm = nullptr;                        // (L+1)
+    bool bref_dirty = true;
+    // real-space constraints and error metric
+    RealParams rp{RC_SUPPORT | RC_VALUE_LO, RC_SUPPORT | RC_VALUE_LO, 0.0, 0.0, 0.0};
+    uint8_t *d_S0 = nullptr, *d_sup = nullptr;        // (G), (3, B, G)
+    double *d_err_wr = nullptr, *d_err_wt = nullptr;
+    int err_use_mask = 1;
+    // state
+    double2 *d_rho = nullptr, *d_Fp = nullptr;        // (3, B, G) each
+    int* d_slot = nullptr;                            // (B, SL_N)
+    double *d_best_err = nullptr, *d_last_err = nullptr;   // (B)
+    double* d_err_hist = nullptr;                     // (cap, B)
+    double* d_deg2_hist = nullptr;                    // (cap, B, L+1)
+    long long err_cap = 0, n_steps_done = 0;
+    bool state_ready = false, fixed_valid = false;
+    // work buffers
+    double2 *d_F = nullptr, *d_T1 = nullptr, *d_T2 = nullptr;   // grids (B, G)
+    double* d_fixed = nullptr;                        // real grid (B, G)
+    double2* d_g = nullptr;                           // (B, Nq, nt, 2L+1)
+    double2* d_c[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // coefficient arrays (B, C)
+    double2 *d_X = nullptr, *d_Vr = nullptr, *d_U = nullptr;   // projection workspaces
+    double* d_partial = nullptr;                      // (B, nblk, 2) error partial sums
+    int n_partial_blocks = 0;
+    double* d_minmax = nullptr;                       // (B, nblk, 2)
+    double2* d_Bl = nullptr;                          // (B, L+1, Nq, Nq) scratch (lazy)
+    // host staging
+    void* h_stage = nullptr;
+    // profiling
+    int prof = 0;
+    std::map<std::string, ProfEntry> prof_data;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+// ---- launchers (defined next to their kernels) ------------------------------------------------------
+// SHT
+// in_slot >= 0: grid is a (3,B,G) slot array read through slot[b][in_slot]
+void launch_sht_forward(mtip_ctx* c, const double2* grid, double2* coeff, int prologue, int in_slot = -1);
+struct InvEpilogue {
+    int mode = EPI_STORE;
+    const double2* F = nullptr;        // EPI_MODULUS*: reciprocal density to rescale
+    const double* fixed = nullptr;     // EPI_MODULUS_FIXED
+    const double* shell_scale = nullptr;   // EPI_SCALE_SHELL (Nq)
+    int out_slot = -1;                 // >= 0: grid is a (3,B,G) slot array written through slot[b][out_slot]
+};
+void launch_sht_inverse(mtip_ctx* c, const double2* coeff, double2* grid, const InvEpilogue& epi);
+void build_legendre_tables(mtip_ctx* c, const double* cos_theta);
+// Hankel
+void launch_hankel(mtip_ctx* c, const double2* in, double2* out, int inverse);
+void launch_coeff_diff(mtip_ctx* c, const double2* a, const double2* b, double2* out);
+// reciprocal projection
+void launch_project_coefficients(mtip_ctx* c, const double2* Ilm, double2* out);
+void launch_deg2(mtip_ctx* c, const double2* Ilm, double2* Bl);
+void launch_deg2_metric(mtip_ctx* c, const double2* Ilm, double* out /*(B, L+1)*/);
+// elementwise / reductions
+// rho_p = IFT(F') (B,G); prev/out: slot arrays (3,B,G) when use_slots else plain (B,G); rho_rt may be null
+void launch_real_update(mtip_ctx* c, const double2* rho_p, const double2* prev, const double2* rho_rt, double2* out,
+                        int method, double beta, int use_slots);
+void launch_finish_step(mtip_ctx* c, long long step_index);
+void launch_abs_to_fixed(mtip_ctx* c);
+void launch_modulus_plain(mtip_ctx* c, const double2* F, const double2* Inew, double2* out);
+void launch_modulus_fixed_slots(mtip_ctx* c, const double2* F);
+void launch_copy_to_slot(mtip_ctx* c, const double2* src, double2* dst_slots, int which);
+void launch_sw_clamp(mtip_ctx* c, const double2* conv, double* tmp_real);
+void launch_sw_threshold(mtip_ctx* c, const double* tmp_real, double threshold, double error_limit);
+void launch_apply_matrix(mtip_ctx* c, const double* M, const double* x, double* y, int nr, int nc, int nv);
+
+// ---- small utilities ---------------------------------------------------------------------------------
+#define MTIP_HIP_CHECK(c, call)                                                              \
+    do {                                                                                     \
+        hipError_t e__ = (call);                                                             \
+        if (e__ != hipSuccess) {                                                             \
+            (c)->err = std::string(#call) + ": " + hipGetErrorString(e__);                   \
+            return MTIP_EHIP;                                                                \
+        }                                                                                    \
+    } while (0)
+
+struct ProfScope {
+    mtip_ctx* c;
+    const char* name;
+    ProfScope(mtip_ctx* c_, const char* n) : c(c_), name(n) {
+        if (c->prof) (void)hipEventRecord(c->ev0, c->stream);
+    }
+    ~ProfScope() {
+        if (c->prof) {
+            (void)hipEventRecord(c->ev1, c->stream);
+            (void)hipEventSynchronize(c->ev1);
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
+            auto& e = c->prof_data[name];
+            e.ms += ms;
+            e.n += 1;
+        }
+    }
+};
+
+static inline int div_up(long long a, long long b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,295 @@
+"""Device engine: a thin Python object around one ``mtip_ctx`` (one GPU, one stream, ``n_batch`` restarts).
+
+Does the reference's one-off host setup (``hostsetup``), uploads it through the C ABI and exposes the loop
+primitives (`run`, `shrinkwrap`, getters) plus the single operators used by ``operators.py`` and the tests.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib, hostsetup as hs
+from .settings import reciprocity_coefficient, resolve
+
+METHOD_ID = {'HIO': 0, 'ER': 1, 'HIO_non_FXS': 2, 'ER_non_FXS': 3}
+
+
+class Engine:
+    def __init__(self, settings=None, data=None, n_batch=1, device=0, fused=True, lib_path=None,
+                 n_radial=None, l_max=None, max_q=None):
+        """settings: resolved (or override) settings dict; data: invariants dict (may be None for a
+        transforms-only engine, then ``max_q`` must be given)."""
+        self.lib = _lib.load(lib_path)
+        opt = resolve(settings)
+        self.opt = opt
+        g = opt['grid']
+        self.N = int(n_radial if n_radial is not None else g['n_radial_points'])
+        self.L = int(l_max if l_max is not None else g['max_order'])
+        self.kappa = float(reciprocity_coefficient(opt['fourier_transform']))
+        self.mode = opt['fourier_transform']['type']
+        if max_q is None:
+            max_q = g['max_q']
+            if not isinstance(max_q, float):                        # reconstruct.py:258-261
+                if data is None:
+                    raise ValueError('max_q is needed when no invariants are given')
+                max_q = float(np.max(data['data_radial_points']))
+        self.max_q = float(max_q)
+        self.n_theta, self.n_phi = hs.angular_grid_size(self.L, g.get('n_theta', 0), g.get('n_phi', 0))
+        self.B = int(n_batch)
+        self.shape = (self.N, self.n_theta, self.n_phi)
+        self.nlm = (self.L + 1) ** 2
+        self.fused = bool(fused)
+        if self.lib.mtip_device_count() <= 0:
+            raise _lib.MtipError('no HIP device visible: the MTIP engine needs an MI355X (no CPU fallback)')
+        cfg = _lib.MtipCfg(self.N, self.L, self.n_theta, self.n_phi, self.B, 0 if self.mode == 'midpoint' else 1,
+                           1 if fused else 0, 0)
+        self.ctx = self.lib.mtip_create(C.byref(cfg), int(device))
+        if not self.ctx:
+            raise _lib.MtipError('mtip_create: ' + self.lib.mtip_last_error(None).decode())
+        # ---- transforms
+        self.cos_theta, self.gauss_w, self.theta, self.phi = hs.gauss_grid(self.n_theta, self.n_phi)
+        self._ck(self.lib.mtip_set_angular_grid(self.ctx, _lib.ptr(self.cos_theta), _lib.ptr(self.gauss_w)))
+        self.rs, self.qs = hs.radial_grids(self.max_q, self.N, self.kappa, self.mode)
+        self._ck(self.lib.mtip_set_radial_grid(self.ctx, _lib.ptr(self.rs), _lib.ptr(self.qs)))
+        self.r_max = float(np.max(self.rs))                          # reconstruct.py:329
+        self.raw_weights = hs.hankel_raw_weights(self.L, self.N, self.kappa, self.mode)
+        fs, ivs = hs.hankel_scales(self.r_max, self.N, self.kappa)
+        self._ck(self.lib.mtip_set_hankel_weights(self.ctx, _lib.ptr(self.raw_weights), fs, ivs))
+        self.int_wr, self.int_wt = hs.integrator_weights(self.rs, self.n_theta)
+        self.default_sigma = np.pi / np.max(self.qs)                 # fxs_Projections.py:189-193
+        self.rsetup = None
+        if data is not None:
+            self._setup_projections(data)
+
+    # ------------------------------------------------------------------ setup
+    def _ck(self, rc):
+        if rc != 0:
+            raise _lib.MtipError(f'libmtip_hip error {rc}: ' + self.lib.mtip_last_error(self.ctx).decode())
+
+    def _setup_projections(self, data):
+        opt = self.opt
+        ropt = opt['projections']['reciprocal']
+        rs_ = hs.ReciprocalSetup(self.qs, data, self.L, ropt)
+        self.rsetup = rs_
+        used_ids = set(rs_.used_orders.values())
+        for l in range(self.L + 1):
+            if l in used_ids:
+                V = _lib.as_c128(rs_.projection_matrices[l])
+                mask = _lib.as_u8(rs_.radial_mask[l])
+                self._ck(self.lib.mtip_set_projection_matrix(self.ctx, l, _lib.ptr(V), V.shape[1], _lib.ptr(mask), 1))
+            else:
+                self._ck(self.lib.mtip_set_projection_matrix(self.ctx, l, None, 1, None, 0))
+        self._ck(self.lib.mtip_set_number_of_particles(self.ctx, rs_.number_of_particles))
+        popt = opt['projections']['real']['projections']
+        considered = opt['projections']['real']['HIO'].get('considered_projections', ['all'])
+        flags, lo, hi, thr, hio = hs.real_constraint_flags(popt, considered)
+        self._ck(self.lib.mtip_set_real_constraints(self.ctx, flags, lo, hi, thr, hio))
+        auto = None
+        if popt['support']['initial_support']['type'] == 'auto_correlation':
+            auto = self.autocorrelation_guess()
+        self.initial_support = hs.initial_support(self.rs, self.shape, popt, opt['particle_radius'], auto)
+        s0 = _lib.as_u8(self.initial_support)
+        self._ck(self.lib.mtip_set_initial_support(self.ctx, _lib.ptr(s0)))
+        em = opt['main_loop']['error']['methods']
+        inside = em['real'].get('l2_projection_diff', {}).get('inside_initial_support', False)
+        gen = opt.get('general', {})
+        wr, wt, use_mask = hs.error_weights(self.rs, self.n_theta, self.shape, inside, gen.get('cache_aware', True),
+                                            gen.get('L2_cache', 512))
+        self._ck(self.lib.mtip_set_error_weights(self.ctx, _lib.ptr(_lib.as_f64(wr)), _lib.ptr(_lib.as_f64(wt)), int(use_mask)))
+        self.deg2_enabled = 'deg2_invariant_l2_diff' in em['reciprocal']['calculate']
+        self._ck(self.lib.mtip_set_deg2_metric(self.ctx, int(self.deg2_enabled)))
+
+    def autocorrelation_guess(self):
+        """reconstruct.py:400-420: ift(icht(V_l padded)).real"""
+        c = np.zeros((self.B, self.N, self.nlm), complex)
+        for l, p in enumerate(self.rsetup.full_projection_matrices):
+            c[:, :, l * l:l * l + p.shape[1]] = p[None]
+        return self.fourier_transform(self.sht_inverse(c), inverse=True)[0].real
+
+    def close(self):
+        if getattr(self, 'ctx', None):
+            self.lib.mtip_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ batch helpers
+    def _bgrid(self, a):
+        a = _lib.as_c128(a)
+        if a.shape == self.shape:
+            a = np.broadcast_to(a, (self.B,) + self.shape)
+        assert a.shape == (self.B,) + self.shape, (a.shape, self.shape)
+        return np.ascontiguousarray(a)
+
+    def _bcoef(self, a):
+        a = _lib.as_c128(a)
+        if a.shape == (self.N, self.nlm):
+            a = np.broadcast_to(a, (self.B, self.N, self.nlm))
+        assert a.shape == (self.B, self.N, self.nlm), a.shape
+        return np.ascontiguousarray(a)
+
+    # ------------------------------------------------------------------ single operators (host arrays)
+    def sht_forward(self, grid, prologue=0):
+        g = self._bgrid(grid)
+        out = np.empty((self.B, self.N, self.nlm), complex)
+        self._ck(self.lib.mtip_op_sht_forward(self.ctx, _lib.ptr(g), _lib.ptr(out), prologue))
+        return out
+
+    def sht_inverse(self, coeff):
+        c = self._bcoef(coeff)
+        out = np.empty((self.B,) + self.shape, complex)
+        self._ck(self.lib.mtip_op_sht_inverse(self.ctx, _lib.ptr(c), _lib.ptr(out)))
+        return out
+
+    def hankel(self, coeff, inverse=False):
+        c = self._bcoef(coeff)
+        out = np.empty_like(c)
+        self._ck(self.lib.mtip_op_hankel(self.ctx, _lib.ptr(c), _lib.ptr(out), int(inverse)))
+        return out
+
+    def fourier_transform(self, grid, inverse=False):
+        g = self._bgrid(grid)
+        out = np.empty_like(g)
+        self._ck(self.lib.mtip_op_fourier_transform(self.ctx, _lib.ptr(g), _lib.ptr(out), int(inverse)))
+        return out
+
+    def project_coefficients(self, Ilm):
+        c = self._bcoef(Ilm)
+        out = np.empty_like(c)
+        self._ck(self.lib.mtip_op_project_coefficients(self.ctx, _lib.ptr(c), _lib.ptr(out)))
+        return out
+
+    def modulus_replacement(self, F, I_new):
+        f, i = self._bgrid(F), self._bgrid(I_new)
+        out = np.empty_like(f)
+        self._ck(self.lib.mtip_op_modulus_replacement(self.ctx, _lib.ptr(f), _lib.ptr(i), _lib.ptr(out)))
+        return out
+
+    def real_space_update(self, w, rho_prev, method, beta):
+        w_, p_ = self._bgrid(w), self._bgrid(rho_prev)
+        out = np.empty_like(w_)
+        err = np.empty(self.B)
+        self._ck(self.lib.mtip_op_real_space_update(self.ctx, _lib.ptr(w_), _lib.ptr(p_), METHOD_ID[method], float(beta),
+                                                    _lib.ptr(out), _lib.ptr(err)))
+        return out, err
+
+    def deg2_invariants(self, Ilm):
+        c = self._bcoef(Ilm)
+        out = np.empty((self.B, self.L + 1, self.N, self.N), complex)
+        self._ck(self.lib.mtip_op_deg2_invariants(self.ctx, _lib.ptr(c), _lib.ptr(out)))
+        return out
+
+    def apply_matrix(self, matrix, vects):
+        m, v = _lib.as_f64(matrix), _lib.as_f64(vects)
+        squeeze = v.ndim == 1
+        if squeeze:
+            v = np.ascontiguousarray(v[:, None])
+        out = np.empty((m.shape[0], v.shape[1]))
+        self._ck(self.lib.mtip_op_apply_matrix(self.ctx, _lib.ptr(m), _lib.ptr(v), _lib.ptr(out), m.shape[0], m.shape[1], v.shape[1]))
+        return out[:, 0] if squeeze else out
+
+    # ------------------------------------------------------------------ state and loop
+    def set_density(self, batch, rho):
+        r = _lib.as_c128(rho)
+        assert r.shape == self.shape
+        self._ck(self.lib.mtip_set_density(self.ctx, batch, _lib.ptr(r)))
+
+    def init_state(self):
+        self._ck(self.lib.mtip_init_state(self.ctx))
+
+    def density(self, batch, best=False):
+        out = np.empty(self.shape, complex)
+        self._ck(self.lib.mtip_get_density(self.ctx, batch, int(best), _lib.ptr(out)))
+        return out
+
+    def reciprocal_density(self, batch, best=False):
+        out = np.empty(self.shape, complex)
+        self._ck(self.lib.mtip_get_reciprocal_density(self.ctx, batch, int(best), _lib.ptr(out)))
+        return out
+
+    def support(self, batch, best=False):
+        out = np.empty(self.shape, np.uint8)
+        self._ck(self.lib.mtip_get_support(self.ctx, batch, int(best), _lib.ptr(out)))
+        return out.astype(bool)
+
+    def set_support(self, batch, support, enforce_initial_support):
+        s = _lib.as_u8(support)
+        self._ck(self.lib.mtip_set_support(self.ctx, batch, _lib.ptr(s), int(bool(enforce_initial_support))))
+
+    def unknowns(self, batch):
+        out = []
+        for l in range(self.L + 1):
+            k = min(2 * l + 1, self.N)
+            u = np.empty((k, 2 * l + 1), complex)
+            self._ck(self.lib.mtip_get_unknowns(self.ctx, batch, l, _lib.ptr(u)))
+            out.append(u)
+        return tuple(out)
+
+    def best_error(self):
+        out = np.empty(self.B)
+        n = C.c_int64(0)
+        self._ck(self.lib.mtip_get_best_error(self.ctx, _lib.ptr(out), C.byref(n)))
+        return out, int(n.value)
+
+    def select_best(self):
+        self._ck(self.lib.mtip_select_best(self.ctx))
+
+    def run(self, method, ft_stab, betas, fetch=True):
+        betas = _lib.as_f64(np.atleast_1d(betas))
+        n = len(betas)
+        if not fetch:
+            self._ck(self.lib.mtip_run_async(self.ctx, METHOD_ID[method], int(bool(ft_stab)), n, _lib.ptr(betas)))
+            return None, None
+        err = np.empty((n, self.B))
+        deg2 = np.empty((n, self.B, self.L + 1)) if self.deg2_enabled else None
+        self._ck(self.lib.mtip_run(self.ctx, METHOD_ID[method], int(bool(ft_stab)), n, _lib.ptr(betas), _lib.ptr(err), _lib.ptr(deg2)))
+        return err, deg2
+
+    def fetch_errors(self, first, n):
+        err = np.empty((n, self.B))
+        deg2 = np.empty((n, self.B, self.L + 1)) if self.deg2_enabled else None
+        self._ck(self.lib.mtip_fetch_errors(self.ctx, first, n, _lib.ptr(err), _lib.ptr(deg2)))
+        return err, deg2
+
+    def shrinkwrap(self, sigma, threshold, error_limit):
+        enforced = np.empty(self.B, np.uint8)
+        self._ck(self.lib.mtip_shrinkwrap(self.ctx, float(sigma), float(threshold), float(error_limit), _lib.ptr(enforced)))
+        return enforced.astype(bool)
+
+    def last_deg2_invariant(self, batch):
+        out = np.empty((self.L + 1, self.N, self.N), complex)
+        self._ck(self.lib.mtip_last_deg2_invariant(self.ctx, batch, _lib.ptr(out)))
+        return out
+
+    def synchronize(self):
+        self._ck(self.lib.mtip_synchronize(self.ctx))
+
+    # ------------------------------------------------------------------ profiling
+    def profile(self, enable=True):
+        self._ck(self.lib.mtip_profile(self.ctx, int(enable)))
+        self._ck(self.lib.mtip_profile_reset(self.ctx))
+
+    def profile_get(self, name):
+        ms, n = C.c_double(0), C.c_int64(0)
+        self._ck(self.lib.mtip_profile_get(self.ctx, name.encode(), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    # ------------------------------------------------------------------ helpers shared with synthetic.py
+    @property
+    def thetas(self):
+        return self.theta
+
+    @property
+    def phis(self):
+        return self.phi
+
+    def ft(self, grid):
+        """transforms adapter for synthetic.make_invariants (batch element 0)."""
+        return self.fourier_transform(grid)[0]
+
+    def forward_l(self, grid):
+        c = self.sht_forward(grid)[0]
+        return [np.array(c[:, l * l:(l + 1) ** 2]) for l in range(self.L + 1)]

@@ -1,0 +1,290 @@
+"""One-off host-side setup of the MTIP engine (numpy/scipy, exactly where the reference does it on the host).
+
+Each helper mirrors a reference routine (file:line relative to the reference checkout, under xframe/):
+  angular grid        externalLibraries/shtns_plugin.py:94-101, 121-133
+  radial grids        projects/fxs/projectLibrary/ft_grid_pairs.py:282-291 (midpoint), 274-281 (trapz)
+  Hankel weights      projects/fxs/projectLibrary/hankel_transforms.py:399-410, 322-333, 426-452
+  projection matrices projects/fxs/projectLibrary/fxs_Projections.py:471-537, 578-714
+  initial support     fxs_Projections.py:133-155
+  error weights       library/mathLibrary.py:1223-1235 + projects/fxs/projectLibrary/fxs_IO_methods.py:97-151, 287-300
+  ramps               library/mathLibrary.py:1033-1129; reconstruct.py:1212-1258
+  density guess       projects/fxs/reconstruct.py:1115-1174; library/mathLibrary.py:1456-1466
+None of this is on the per-iteration path; the iteration itself runs in libmtip_hip.so.
+"""
+import numpy as np
+from scipy.interpolate import griddata
+from scipy.special import roots_legendre, spherical_jn
+
+
+# ---------------------------------------------------------------------------------------------- grids
+def angular_grid_size(l_max, n_theta=0, n_phi=0, anti_aliazing_degree=2):
+    f_phi = 2 ** (int(np.log2((anti_aliazing_degree + 1) * l_max)) + 1) if l_max > 0 else 4
+    f_theta = f_phi // 2
+    if (not isinstance(n_theta, (int, np.integer))) or isinstance(n_theta, bool) or n_theta == 0:
+        n_theta = f_theta
+    if (not isinstance(n_phi, (int, np.integer))) or isinstance(n_phi, bool) or n_phi == 0:
+        n_phi = f_phi
+    return int(n_theta), int(n_phi)
+
+
+def gauss_grid(n_theta, n_phi):
+    x, w = roots_legendre(n_theta)
+    cos_theta = x[::-1].copy()          # north -> south
+    weights = w[::-1].copy()
+    return cos_theta, weights, np.arccos(cos_theta), 2 * np.pi * np.arange(n_phi) / n_phi
+
+
+def radial_grids(max_q, n, kappa, mode='midpoint'):
+    r_cut = kappa * n / max_q
+    if mode == 'midpoint':
+        dr, dq = r_cut / n, max_q / n
+        return (np.linspace(dr / 2, r_cut - dr / 2, num=n, endpoint=True),
+                np.linspace(dq / 2, max_q - dq / 2, num=n, endpoint=True))
+    if mode in ('trapz', 'Zernike'):
+        return np.linspace(0, r_cut, n), np.linspace(0, max_q, n)
+    raise AssertionError(f'fourier_transform.type {mode!r} is not supported (midpoint, trapz, Zernike)')
+
+
+def hankel_raw_weights(l_max, n, kappa, mode='midpoint'):
+    """real (L+1, Np, N) array indexed [l, p, k] (summation index p, output index k)."""
+    ls = np.arange(l_max + 1)
+    if mode == 'midpoint':
+        ps = np.arange(n) + 0.5
+        ks = np.arange(n) + 0.5
+    else:
+        ps = np.arange(1, n)
+        ks = np.arange(n)
+    arg = ks[None, :] * ps[:, None] * kappa / n
+    return np.ascontiguousarray(ps[None, :, None] ** 2 * spherical_jn(ls[:, None, None], arg[None, :, :]))
+
+
+def hankel_scales(r_max, n, kappa):
+    """(forward, inverse) real prefactors; the (-/+ i)^l phases are applied by the kernel."""
+    q_max = kappa * n / r_max
+    c = np.sqrt(2 / np.pi)
+    return (r_max / n) ** 3 * c, (q_max / n) ** 3 * c
+
+
+# ---------------------------------------------------------------------------------------------- ramps
+def _is_number(v):
+    return np.issubdtype(np.array(v).dtype, np.number)
+
+
+class ExponentialRamp:
+    def __init__(self, start, stop, exponent, stop_argument=1):
+        self.start, self.stop = start, stop
+        exponent = -abs(exponent) if stop < start else abs(exponent)
+        self.exponent = exponent
+        self.A = (start - stop) / (1 - np.exp(exponent * stop_argument))
+        self.B = start - self.A
+
+    def eval(self, x):
+        v = self.A * np.exp(x * self.exponent) + self.B
+        return np.maximum(v, self.stop) if self.start > self.stop else np.minimum(v, self.stop)
+
+    __call__ = eval
+
+
+class LinearRamp:
+    def __init__(self, start, stop=False, slope=False, default_start=False, default_stop=False):
+        self.start = tuple(start) if isinstance(start, (list, tuple)) else (start, 0)
+        self.undefined = False
+        if not _is_number(self.start[0]):
+            if isinstance(default_start, bool) and default_start is False:
+                self.undefined = True
+            else:
+                self.start = (default_start, 0)
+        stop_ok = False
+        if isinstance(stop, (list, tuple)):
+            stop = list(stop)
+            if not _is_number(stop[0]) and _is_number(default_stop):
+                stop[0] = default_stop
+            if _is_number(stop[0]) and _is_number(stop[1]) and stop[1] >= self.start[1]:
+                stop_ok = True
+        slope_ok = not isinstance(slope, bool)
+        self.C = np.nan
+        if self.undefined:
+            return
+        if not stop_ok and not slope_ok:
+            self.A = 0
+        elif stop_ok:
+            self.C = stop[0]
+            self.A = 0 if (stop[1] - self.start[1]) == 0 else (stop[0] - self.start[0]) / (stop[1] - self.start[1])
+            if slope_ok:
+                self.A = slope
+        elif slope == 0:
+            self.A = slope
+        else:
+            self.C = np.sign(slope) * np.inf
+            self.A = slope
+        self.B = self.start[0] - self.A * self.start[1]
+
+    def eval(self, x):
+        if self.undefined:
+            return np.nan
+        v = self.A * x + self.B
+        if self.A < 0:
+            v = max(v, self.C)
+        elif self.A > 0:
+            v = min(v, self.C)
+        return v
+
+    __call__ = eval
+
+
+# ---------------------------------------------------------------------------------------------- reciprocal projection data
+def _regrid(values, old, new, interpolation):
+    return griddata(old[:, None], values, new[:, None], method=interpolation, fill_value=0.0,
+                    rescale=False).reshape(len(new))
+
+
+class ReciprocalSetup:
+    """Everything ``ReciprocalProjection.__init__`` prepares on the host (fxs_Projections.py:471-537)."""
+
+    def __init__(self, qs, data, max_order, opt):
+        q_d = np.asarray(data['data_radial_points'], dtype=float)
+        aint = data['average_intensity']
+        aint = np.asarray(getattr(aint, 'data', aint), dtype=float)
+        self.qs = np.asarray(qs, dtype=float)
+        n = len(self.qs)
+        self.integrated_intensity = (q_d[1] - q_d[0]) * np.sum(aint * q_d ** 2) * 2 * np.sqrt(np.pi)
+        orders = np.arange(max_order + 1)
+        used_ids = np.asarray(opt.get('used_orders', opt['used_order_ids']))
+        self.used_orders = {int(o): int(i) for o, i in zip(orders, used_ids)}
+        self.number_of_particles = float(opt['number_of_particles']['initial'])
+        interp = opt['regrid']['interpolation']
+        dpm = data['data_projection_matrices']
+        self.average_intensity = _regrid(aint, q_d, self.qs, interp)
+        pm = {}
+        for o, oid in self.used_orders.items():
+            m = np.asarray(dpm[oid])
+            if m.ndim < 2:
+                m = m[:, None]
+            pm[oid] = np.stack([_regrid(m[:, c], q_d, self.qs, interp) for c in range(m.shape[1])], axis=1).astype(complex)
+        self.full_projection_matrices = [pm.get(l, np.zeros((n, min(n, 2 * l + 1)), complex)) for l in range(max_order + 1)]
+        # modify_projection_matrices, 679-714
+        proj = {oid: m.copy() for oid, m in pm.items()}
+        if opt.get('odd_orders_to_0', False):
+            for o, oid in self.used_orders.items():
+                if o % 2 == 1:
+                    proj[oid][:] = 0
+        if opt.get('use_averaged_intensity', False) and 0 in self.used_orders:
+            proj[self.used_orders[0]] = (self.average_intensity[:, None] * 2 * np.sqrt(np.pi)).astype(complex)
+        for oid in proj:
+            proj[oid] = proj[oid] * 2
+        self.projection_matrices = proj                     # keyed by order id
+        # radial mask, 578-629
+        data_mask = (self.qs >= q_d.min()) & (self.qs <= q_d.max())
+        mask = np.ones((max_order + 1, n), dtype=bool)
+        mopt = opt.get('q_mask', None)
+        if isinstance(mopt, dict):
+            mtype = mopt['type']
+            if mtype == 'manual' and mopt['manual']['type'] == 'region':
+                lo, hi = mopt['manual']['region']
+                lo_set = not (isinstance(lo, bool) and lo is False)
+                hi_set = not (isinstance(hi, bool) and hi is False)
+                if not lo_set and hi_set:
+                    mask[:] = (self.qs < hi)[None, :]
+                elif lo_set and not hi_set:
+                    mask[:] = (self.qs >= lo)[None, :]
+                elif lo_set and hi_set:
+                    mask[:] = ((self.qs >= lo) & (self.qs < hi))[None, :]
+            elif mtype != 'none':
+                raise NotImplementedError(f'q_mask type {mtype!r}')
+        self.radial_mask = mask & data_mask[None, :]
+        self.max_order = max_order
+
+
+def initial_support(rs, shape, opt, particle_radius, auto_correlation=None):
+    sup = opt['support']['initial_support']
+    r = np.broadcast_to(np.asarray(rs)[:, None, None], shape)
+    if sup['type'] == 'max_radius':
+        return np.ascontiguousarray(r < sup['max_radius'])
+    if sup['type'] == 'auto_correlation':
+        m = auto_correlation >= sup['auto_correlation']['threshold'] * np.max(auto_correlation)
+        m = np.array(m)
+        m[r > particle_radius] = False
+        return m
+    raise AssertionError(f"Initial support type {sup['type']!r} is not known.")
+
+
+def real_constraint_flags(opt, considered):
+    """-> (flags, lo, hi, imag_thr, hio_flags) for mtip_set_real_constraints."""
+    SUP, LO, HI, IM = 1, 2, 4, 8
+    flags, lo, hi, thr = 0, 0.0, 0.0, 0.0
+    bits = {}
+    for key in opt['apply']:
+        if key == 'support':
+            flags |= SUP
+            bits[key] = SUP
+        elif key == 'value_threshold':
+            t = opt['value_threshold'].get('threshold', 0.0)
+            num = [isinstance(v, (float, int)) and not isinstance(v, bool) for v in t]
+            b = 0
+            if num[0]:
+                b |= LO
+                lo = float(t[0])
+            if num[1]:
+                b |= HI
+                hi = float(t[1])
+            flags |= b
+            bits[key] = b
+        elif key == 'limit_imag':
+            flags |= IM
+            thr = float(opt['limit_imag'].get('threshold', 0.0))
+            bits[key] = IM
+        # unknown names (e.g. 'assert_real') have no generator in the reference and are ignored (113-118)
+    if not isinstance(considered, (list, tuple)) or len(considered) == 0 or list(considered) == ['all']:
+        hio = flags
+    else:
+        hio = 0
+        for name in considered:
+            hio |= flags if name == 'all' else bits.get(name, 0)
+    return flags, lo, hi, thr, hio
+
+
+def error_weights(rs, n_theta, shape, inside_initial_support, cache_aware=True, l2_cache_kb=512):
+    """Weights of the l2_projection_diff metric such that E = sum m wr wt |w-P|^2 / sum m wr wt |w|^2.
+
+    Returns (wr, wt, use_initial_support_mask).  Reproduces which variant the reference really runs:
+    the cache-aware routine drops the initial-support mask when the grid fits into L2_cache/2 and then
+    ``square[~True] = 0`` zeroes radial shell N-2 (fxs_IO_methods.py:113-116, 131-151, 203-205)."""
+    rs = np.asarray(rs, dtype=float)
+    n = len(rs)
+    t = np.zeros(n)
+    d = np.diff(rs)
+    t[:-1] += d / 2
+    t[1:] += d / 2
+    wr = t * rs ** 2
+    wt = roots_legendre(n_theta)[1][::-1] * np.pi / n_theta
+    use_mask = bool(inside_initial_support)
+    units = (l2_cache_kb / 2) * 1024 / 16
+    fits = not (np.prod(shape) > units)
+    if cache_aware and fits:
+        use_mask = False
+    if not use_mask:
+        wr = wr.copy()
+        wr[n - 2] = 0.0                # the ~True == -2 quirk
+    return wr, wt, use_mask
+
+
+def bump_density(rs, shape, radius, slope, snr, rng, integrated_intensity, wr_plain, wt):
+    """reconstruct.py:1155-1174 with a seeded generator (the reference seeds from os.urandom)."""
+    amp = 1 + 1 / snr * rng.random(shape)
+    r = np.broadcast_to(np.asarray(rs)[:, None, None], shape)
+    inside = (r > -radius) & (r < radius)
+    env = np.zeros(shape)
+    env[inside] = np.exp(-slope * radius ** 2 / (radius ** 2 - r[inside] ** 2))
+    density = amp * env
+    total_sq = np.einsum('q,t,qtp->', wr_plain, wt, density * density)
+    return (density * np.sqrt(integrated_intensity / total_sq)).astype(complex)
+
+
+def integrator_weights(rs, n_theta):
+    """plain SphericalIntegrator weights: int f = sum wr[q] wt[t] sum_phi f."""
+    rs = np.asarray(rs, dtype=float)
+    t = np.zeros(len(rs))
+    d = np.diff(rs)
+    t[:-1] += d / 2
+    t[1:] += d / 2
+    return t * rs ** 2, roots_legendre(n_theta)[1][::-1] * np.pi / n_theta

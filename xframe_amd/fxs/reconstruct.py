@@ -1,0 +1,292 @@
+"""``fxs reconstruct`` worker on the MI355X engine -- host-side mirror of
+``xframe/projects/fxs/reconstruct.py`` (``ProjectWorker`` 89-209, ``MTIP`` 211-1278).
+
+Same call shape as the reference::
+
+    worker = ProjectWorker(settings, invariants)        # reference: settings.project / db.load('invariants')
+    result, _ = worker.run()                            # object array of per-restart result dicts (1003-1021)
+
+    MTIP.preinit(settings, invariants); m = MTIP(process_factory); m.generate_phasing_loop(); m.phasing_loop()
+
+What differs by design: the reference forks one OS process per restart and round-trips every Hankel
+transform through a GPU daemon (reconstruct.py:141-157, Multiprocessing.py:1033-1117); here all restarts of a
+rank are one batch resident on one GPU and the whole loop runs on the device; the Python side only walks the
+schedule (sub-loops, SW steps, ramps) and collects results.  Restarts are sharded over ranks / GPUs by
+``parallel.shard_restarts``; there is no collective on the data path.
+"""
+import time
+
+import numpy as np
+
+from . import hostsetup as hs
+from .engine import Engine
+from .operators import RecipeFactory, build_operators
+from .settings import DictNamespace, resolve
+
+
+class MTIP:
+    # set by MTIP.preinit (reference: class attributes filled from settings.project / the database, 241-276)
+    settings = None
+    mtip_data = None
+    preinit_was_called = False
+    loops_str = 'Loops:\n'
+
+    @classmethod
+    def preinit(cls, settings=None, mtip_data=None):
+        cls.settings = resolve(settings)
+        cls.mtip_data = mtip_data
+        cls.dimensions = cls.settings['dimensions']
+        if cls.dimensions != 3:
+            raise NotImplementedError('only dimensions == 3 is on the accelerated path')
+        q = np.asarray(mtip_data['data_radial_points'])
+        cls.data_q_limits = [q.min(), q.max()]
+        cls.data_number_of_radial_points = len(q)
+        loops = cls.settings['main_loop']['sub_loops']
+        s = 'Loops:\n'
+        width = max(len(n) for n in loops['order'])
+        for name in loops['order']:
+            lo = loops.get(name, {})
+            ms = ''
+            for method in lo.get('order', []):
+                mo = lo['methods'].get(method, {})
+                ms += f"{mo['iterations'] if isinstance(mo, dict) else mo}x{method} "
+            s += f"\t{name}:" + ' ' * (width - len(name)) + f"\t {lo.get('iterations', '')}x( {ms})\n"
+        cls.loops_str = s
+        cls.preinit_was_called = True
+
+    def __init__(self, process_factory=None, n_restarts=1, device=0, fused=True, seeds=None, initial_densities=None,
+                 lib_path=None):
+        if not MTIP.preinit_was_called:
+            raise RuntimeError('MTIP.preinit(settings, invariants) must be called first')
+        self.process_factory = process_factory if process_factory is not None else RecipeFactory({})
+        self.opt = MTIP.settings
+        self.n_restarts = int(n_restarts)
+        self.device = device
+        self.fused = fused
+        self.seeds = seeds
+        self.initial_densities = initial_densities
+        self.lib_path = lib_path
+        self.results = {}
+        self.engine = None
+        self.phasing_loop = False
+        self.timing = {}
+
+    # ------------------------------------------------------------------ assembly (reference 1269-1278)
+    def generate_phasing_loop(self):
+        self.engine = Engine(self.opt, MTIP.mtip_data, n_batch=self.n_restarts, device=self.device, fused=self.fused,
+                             lib_path=self.lib_path)
+        self.rprojection = self.engine.rsetup
+        self.process_factory.addOperators(build_operators(self.engine))
+        self.phasing_loop = self._main_loop
+
+    # ------------------------------------------------------------------ ramps (reference 1212-1258)
+    def _sw_ramps(self):
+        e = self.engine
+        sw_opt = self.opt['projections']['real']['shrink_wrap']
+        order = self.opt['main_loop']['sub_loops']['order']
+        sig, thr = [], []
+        for lid in range(len(order)):
+            s = sw_opt['sigmas'][lid] if len(sw_opt['sigmas']) - 1 >= lid else False
+            s = s if isinstance(s, (list, tuple)) else [s]
+            sig.append(hs.LinearRamp(*s, default_start=e.default_sigma, default_stop=e.default_sigma))
+            t = sw_opt['thresholds'][lid] if len(sw_opt['thresholds']) - 1 >= lid else 0.1
+            t = t if isinstance(t, (list, tuple)) else [t]
+            thr.append(hs.LinearRamp(*t))
+        return sig, thr
+
+    def _update_shrink_wrap(self, iteration, loop_number):
+        r = self._sig_ramps[loop_number]
+        if not r.undefined:
+            v = r(iteration)
+            ok = np.issubdtype(np.array(v).dtype, np.number) and not isinstance(v, bool) and v > 0
+            self.sw_sigma = v if ok else self.engine.default_sigma           # fxs_Projections.py:233-243
+        t = self._thr_ramps[loop_number]
+        if not t.undefined:
+            v = t(iteration)
+            self.sw_threshold = 0 if v < 0 else (1 if v >= 1 else v)          # 218-227
+
+    # ------------------------------------------------------------------ initial densities (1115-1174, 957-979)
+    def _initial_density(self, i):
+        if self.initial_densities is not None:
+            return np.asarray(self.initial_densities[i], dtype=complex)
+        dg = self.opt['density_guess']
+        if dg['type'] != 'bump':
+            raise NotImplementedError(f"density_guess.type {dg['type']!r}")
+        seed = None if self.seeds is None else self.seeds[i]
+        rng = np.random.default_rng(seed)       # seed None = OS entropy, like the reference's os.urandom seeding
+        e = self.engine
+        radius = dg['radius']
+        if isinstance(radius, bool):
+            radius = self.opt['particle_radius']
+        if radius < 0:
+            radius = np.max(e.rs)
+        return hs.bump_density(e.rs, e.shape, radius, dg['bump']['slope'], dg['random']['SNR'], rng,
+                               e.rsetup.integrated_intensity, e.int_wr, e.int_wt)
+
+    @staticmethod
+    def _change_to_ft_stab(popt, name, eis_list):
+        """reconstruct.py:836-850 (per-batch decision; all restarts share the schedule)."""
+        if name[-8:] == '_ft_stab' or 'ft_stab' not in popt:
+            return False
+        v = popt['ft_stab']
+        if isinstance(v, bool):
+            return v
+        if v == 'link_to_enforce_initial_support':
+            delay = max(int(popt['link_to_enforce_initial_support']['delay']), 1)
+            if len(eis_list) >= delay:
+                recent = np.array(eis_list[-delay:])            # (delay, B)
+                flags = ~(recent == True).any(axis=0)          # noqa: E712
+                if flags.all() != flags.any():
+                    raise NotImplementedError('restarts of one batch disagree on ft_stab linking')
+                return bool(flags.all())
+        return False
+
+    # ------------------------------------------------------------------ the loop (854-951, 1023-1035)
+    def _main_loop(self, *args, **kwargs):
+        e = self.engine
+        B = self.n_restarts
+        opt = self.opt
+        main_cfg = opt['main_loop']['error']['methods']['main']
+        if list(main_cfg['metrics']['real']) != ['l2_projection_diff'] or list(main_cfg['metrics']['reciprocal']):
+            raise NotImplementedError('main error metric other than real l2_projection_diff')
+        t_setup = time.perf_counter()
+        for b in range(B):
+            e.set_density(b, self._initial_density(b))
+        e.init_state()
+        initial_density = [e.density(b) for b in range(B)]
+        initial_mask = e.initial_support.copy()
+        self._sig_ramps, self._thr_ramps = self._sw_ramps()
+        self.sw_sigma, self.sw_threshold = e.default_sigma, 0.06
+        hio_opt = opt['projections']['real']['HIO']
+        eis_opt = opt['projections']['real']['projections']['support']['enforce_initial_support']
+        limit = eis_opt['if_error_bigger_than'] if eis_opt['apply'] else np.inf
+        loops = opt['main_loop']['sub_loops']
+        eis_list = []
+        iterations = []
+        e.synchronize()
+        t0 = time.perf_counter()
+        n_steps = 0
+        for loop_number, loop_name in enumerate(loops['order']):
+            lo = loops[loop_name]
+            methods = {}
+            for key in lo['order']:
+                mo = lo['methods'][key]
+                methods[key] = ({'iterations': mo.get('iterations', 0), 'options': mo} if isinstance(mo, dict)
+                                else {'iterations': mo, 'options': {}})
+            beta_cfg = hio_opt['beta'][loop_number] if len(hio_opt['beta']) - 1 >= loop_number else [0.5, 0.5, -1 / 700, 1600]
+            ramp = hs.ExponentialRamp(*beta_cfg)
+            if 'SW' in methods:
+                self._update_shrink_wrap(0, loop_number)
+            step = 0
+            sw_step = 0
+            iteration = 0
+            for iteration in range(1, lo['iterations'] + 1):
+                for key in lo['order']:
+                    if key == 'SW':
+                        enforced = e.shrinkwrap(self.sw_sigma, self.sw_threshold, limit)
+                        eis_list.append(enforced)
+                        sw_step += 1
+                        self._update_shrink_wrap(sw_step, loop_number)
+                        continue
+                    if key == 'SW_center':
+                        raise NotImplementedError('SW_center')
+                    repeats = methods[key]['iterations']
+                    ft_stab = self._change_to_ft_stab(methods[key]['options'], key, eis_list)
+                    betas = np.array([ramp.eval(step + i) for i in range(repeats)], dtype=float)
+                    e.run(key, ft_stab, betas, fetch=False)
+                    step += repeats
+                    n_steps += repeats
+            best_err, _ = e.best_error()
+            if np.isfinite(lo.get('best_density_not_in_first_n_iterations', np.inf)):
+                raise NotImplementedError('best_density_not_in_first_n_iterations < inf')
+            iterations.append(iteration)
+        e.synchronize()
+        t1 = time.perf_counter()
+        self.timing = {'loop_seconds': t1 - t0, 'setup_seconds': t0 - t_setup, 'steps_per_restart': n_steps,
+                       'iterations_per_second': n_steps * B / (t1 - t0) if t1 > t0 else float('nan')}
+        return self._generate_output(iterations, initial_density, initial_mask, n_steps)
+
+    # ------------------------------------------------------------------ output dict (980-1022)
+    def _generate_output(self, iterations, initial_density, initial_mask, n_steps):
+        e = self.engine
+        real_err, deg2 = e.fetch_errors(0, n_steps)
+        best_err, _ = e.best_error()
+        masked_pm = []
+        for l in range(e.L + 1):
+            m = np.array(e.rsetup.projection_matrices.get(l, np.zeros((e.N, min(e.N, 2 * l + 1)), complex)))
+            m[~e.rsetup.radial_mask[l]] = 0
+            masked_pm.append(m)
+        r, t, p = np.meshgrid(e.rs, e.theta, e.phi, indexing='ij')
+        real_grid = np.stack((r, t, p), -1)
+        q, t, p = np.meshgrid(e.qs, e.theta, e.phi, indexing='ij')
+        reciprocal_grid = np.stack((q, t, p), -1)
+        out = np.empty(self.n_restarts, dtype=object)
+        for b in range(self.n_restarts):
+            err = {'main': real_err[:, b].copy(),
+                   'real': {'l2_projection_diff': real_err[:, b].copy()},
+                   'reciprocal': ({'deg2_invariant_l2_diff': deg2[:, b].copy()} if deg2 is not None else {})}
+            out[b] = {
+                'real_density': e.density(b, best=True), 'last_real_density': e.density(b),
+                'reciprocal_density': e.reciprocal_density(b, best=True),
+                'last_reciprocal_density': e.reciprocal_density(b),
+                'final_error': float(best_err[b]), 'initial_density': initial_density[b],
+                'initial_support': initial_mask, 'error_dict': err,
+                'support_mask': e.support(b, best=True), 'last_support_mask': e.support(b),
+                'loop_iterations': int(np.sum(iterations) + 1), 'fxs_unknowns': e.unknowns(b),
+                'n_particles': np.full((n_steps, 1), e.rsetup.number_of_particles),
+                'n_particles_gradients': np.array([]), 'n_particles_fraction': np.array([]),
+                'grid_pair': {'real_grid': real_grid, 'reciprocal_grid': reciprocal_grid},
+                'projection_matrices': masked_pm, 'last_deg2_invariant': e.last_deg2_invariant(b)}
+        return out
+
+
+class ProjectWorker:
+    """reconstruct.py:89-209.  ``run()`` returns ``(result, locals())`` like ProjectWorkerInterface.run
+    (xframe/interfaces.py:9-20)."""
+
+    def __init__(self, settings=None, invariants=None, device=0, rank=0, world_size=1, seeds=None, lib_path=None):
+        self.opt = DictNamespace.dict_to_dictnamespace(resolve(settings))
+        MTIP.preinit(self.opt, invariants)
+        self.mtip = MTIP
+        self.process_factory = RecipeFactory({})
+        self.device, self.rank, self.world_size = device, rank, world_size
+        self.seeds = seeds
+        self.lib_path = lib_path
+        self.results = {'stats': {}}
+        if not self.opt['GPU']['use']:
+            raise RuntimeError('GPU.use = False: this worker has no CPU path; use the reference for CPU-only runs')
+
+    def n_restarts_total(self):
+        mp = self.opt['multi_process']
+        n = mp.get('n_parallel_reconstructions', 1)
+        if not mp.get('use', True) or isinstance(n, bool) or n is None:
+            return 1
+        return int(n)
+
+    def run(self):
+        from .parallel import shard_restarts, gather_results
+        start = time.time()
+        total = self.n_restarts_total()
+        mine = shard_restarts(total, self.rank, self.world_size)
+        seeds = None if self.seeds is None else [self.seeds[i] for i in mine]
+        result = np.empty(0, dtype=object)
+        if len(mine):
+            m = MTIP(self.process_factory, n_restarts=len(mine), device=self.device, seeds=seeds, lib_path=self.lib_path)
+            m.generate_phasing_loop()
+            result = m.phasing_loop()
+            self.mtip_instance = m
+        result = gather_results(result, mine, total, self.rank, self.world_size)
+        self.results['MTIP'] = result
+        self.results['stats']['run_time'] = time.time() - start
+        self.post_processing()
+        return result, locals()
+
+    def post_processing(self):
+        """reconstruct.py:160-183: sort restarts by their last main error (rank 0 holds everything)."""
+        res = self.results.get('MTIP')
+        if res is None or len(res) == 0:
+            return
+        errors = [r['error_dict']['main'][-1] for r in res]
+        order = np.argsort(errors)
+        self.results['sorted_ids'] = order
+        self.results['reconstruction_results'] = {str(i): res[i] for i in order}
