@@ -1,0 +1,247 @@
+#!/usr/bin/env python3
+"""MTIP phasing benchmark: iterations/sec at 128 q-shells x L_max = 32 (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+One process per GPU (for N > 1 launched by torch.distributed.run; RANK / LOCAL_RANK / WORLD_SIZE from the
+environment).  Every rank phases `--restarts-per-gpu` independent restarts (BASELINE config 4: 64 restarts
+over 8 GPUs = 8 per GPU) as one device-resident batch; restarts never communicate, so scaling is weak and
+there is no data-path collective -- RCCL is only used for the timing barrier / max-over-ranks and for the
+end-of-run gather of the rotation-invariant B_l (outside the timed region, reported separately).
+
+A "step" = one phasing step (HIO or ER sketch incl. ft_stab, reconstruct.py:576-593) of every restart of the
+batch; the K timed steps walk the tutorial schedule (60 HIO, 1 SW, 40 ER, ...; tutorial.yaml:52-72), shrink
+wrap updates are executed and timed but not counted.  value = N * restarts_per_gpu * K / seconds.
+Inputs (synthetic invariants, initial densities) are resident in HBM before the timed region.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument('--gpus', type=int, default=1)
+    p.add_argument('--steps', type=int, default=200)
+    p.add_argument('--warmup', type=int, default=20)
+    p.add_argument('--restarts-per-gpu', type=int, default=8)
+    p.add_argument('--config', type=int, default=4, help='BASELINE config id (sizes): 1..5')
+    p.add_argument('--exact', action='store_true', help='reference operator order instead of the fused step')
+    p.add_argument('--cpu-seconds', type=float, default=20.0, help='budget of the CPU baseline sample')
+    p.add_argument('--no-cpu-baseline', action='store_true')
+    p.add_argument('--no-roofline', action='store_true')
+    return p.parse_args()
+
+
+def schedule(n_steps):
+    """walk the tutorial schedule: 5 x (60 HIO, SW, 40 ER) + 1 x (SW, 100 ER), repeated, truncated."""
+    out = []
+    blocks = [('HIO', 60), ('SW', 1), ('ER', 40)] * 5 + [('SW', 1), ('ER', 100)]
+    done = 0
+    hio_step = 0
+    while done < n_steps:
+        for kind, n in blocks:
+            if done >= n_steps:
+                break
+            if kind == 'SW':
+                if out:                       # a SW needs an error history; skip a leading one
+                    out.append(('SW', 0))
+                continue
+            k = min(n, n_steps - done)
+            out.append((kind, k))
+            done += k
+    return out
+
+
+def algorithmic_bytes_per_step(N, L, nt, nphi, ft_stab=True):
+    """SURVEY section 8 d / BASELINE.md section 4."""
+    G = N * nt * nphi
+    nlm = (L + 1) ** 2
+    n_grid, n_coef, n_hankel = (12, 17, 3) if ft_stab else (8, 13, 2)
+    return 16 * G * n_grid + G + 16 * N * nlm * n_coef + 8 * N * N * (L + 1) * n_hankel
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    np.seterr(all='ignore')
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X (no CPU fallback)')
+    dev = torch.device('cuda', local_rank)
+
+    from xframe_amd.fxs import hostsetup as hs
+    from xframe_amd.fxs import synthetic as S
+    from xframe_amd.fxs.engine import Engine
+    from xframe_amd.fxs.parallel import average_invariants
+
+    N, L = S._SIZES[a.config]
+    B = a.restarts_per_gpu
+    opt = S.config_overrides(a.config)
+    # ---- synthetic inputs (product path: HIP transforms), identical on every rank
+    t_setup = time.time()
+    eng_d = Engine({'grid': {'n_radial_points': N, 'max_order': L}}, None, n_batch=1, device=local_rank,
+                   max_q=S.data_cutoff(N))
+    data, rho_true = S.make_invariants(eng_d, N, L)
+    eng_d.close()
+    e = Engine(opt, data, n_batch=B, device=local_rank, fused=not a.exact)
+    rho0 = []
+    for b in range(B):
+        gid = rank * B + b                                      # global restart id -> seed 1000 + id
+        rho0.append(hs.bump_density(e.rs, e.shape, S.PARTICLE_RADIUS, 0.3, 2, np.random.default_rng(1000 + gid),
+                                    e.rsetup.integrated_intensity, e.int_wr, e.int_wt))
+        e.set_density(b, rho0[-1])
+    e.init_state()
+    e.synchronize()
+    setup_s = time.time() - t_setup
+    ramp = hs.ExponentialRamp(0.5, 0.4, -1 / 250, 500)
+    limit = 6e-3
+    sw_sigma = hs.LinearRamp(20, [False, 5], -2, default_start=e.default_sigma, default_stop=e.default_sigma)
+
+    def run_schedule(n_steps, start_step=0):
+        step = start_step
+        sw_count = 0
+        for kind, k in schedule(n_steps):
+            if kind == 'SW':
+                e.shrinkwrap(sw_sigma(sw_count), 0.09, limit)
+                sw_count += 1
+                continue
+            betas = np.array([ramp.eval(step + i) for i in range(k)])
+            e.run(kind, True, betas, fetch=False)
+            step += k
+        return step
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        e.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    # ---- warmup, then exactly K timed steps
+    run_schedule(a.warmup)
+    barrier()
+    t0 = time.perf_counter()
+    run_schedule(a.steps, start_step=a.warmup)
+    e.synchronize()
+    torch.cuda.synchronize(dev)
+    t1 = time.perf_counter()
+    if dist is not None:
+        dist.barrier()
+    elapsed = t1 - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    its = world * B * a.steps / elapsed
+    ms_per_step = 1e3 * elapsed / a.steps
+
+    # ---- end-of-run reduce of rotation-invariant summaries (outside the timed region)
+    t_red = time.perf_counter()
+    best_err, n_done = e.best_error()
+    sweeps = e.jacobi_sweeps()
+    bl_sum = np.zeros((L + 1, N, N), complex)
+    for b in range(min(B, 2)):                                  # bounded: download is PCIe bound
+        bl_sum += e.last_deg2_invariant(b)
+    bl_mean = average_invariants(bl_sum, min(B, 2), device=dev if dist is not None else None)
+    reduce_s = time.perf_counter() - t_red
+
+    # ---- roofline of the dominant kernel family (hipEvent timing on the ctx stream)
+    roofline = None
+    fam_ms = {}
+    if not a.no_roofline:
+        e.profile(True)
+        nprof = 6
+        e.run('HIO', True, np.full(nprof, 0.45), fetch=False)
+        e.synchronize()
+        for fam in ('sht_fwd', 'sht_inv', 'hankel', 'proj', 'real_update', 'deg2_metric'):
+            ms, n = e.profile_get(fam)
+            if n:
+                fam_ms[fam] = {'total_ms': ms, 'launches': int(n), 'avg_ms': ms / n}
+        e.profile(False)
+        if fam_ms:
+            dom = max(fam_ms, key=lambda k: fam_ms[k]['total_ms'])
+            G = N * e.n_theta * e.n_phi
+            C = N * (L + 1) ** 2
+            alg = {'sht_fwd': 16 * G * B + 16 * C * B, 'sht_inv': 16 * G * B + 16 * C * B,
+                   'hankel': 2 * 16 * C * B + 8 * N * N * (L + 1),
+                   'proj': 3 * 16 * C * B, 'real_update': (3 * 16 + 1) * G * B}.get(dom, 0)
+            achieved = alg / (fam_ms[dom]['avg_ms'] * 1e-3) / 1e9
+            roofline = {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s',
+                        'frac': achieved / 8000.0, 'traffic': None,
+                        'avg_launch_ms': fam_ms[dom]['avg_ms'], 'algorithmic_bytes_per_launch': alg}
+    step_bytes = algorithmic_bytes_per_step(N, L, e.n_theta, e.n_phi, True)
+    whole_step = {'algorithmic_bytes_per_step_per_restart': step_bytes,
+                  'achieved_GBps_per_gpu': step_bytes * B * a.steps / elapsed / 1e9,
+                  'frac_of_8TBps': step_bytes * B * a.steps / elapsed / 8e12}
+
+    # ---- CPU baseline: the oracle (numpy restatement of the reference algorithm), 1 thread, bounded sample
+    cpu = None
+    if rank == 0 and not a.no_cpu_baseline:
+        try:
+            import threadpoolctl
+            limiter = threadpoolctl.threadpool_limits(1)
+        except Exception:
+            limiter = None
+        from oracle import mtip as OM
+        o_opt = OM.deep_update(OM.default_settings(), S.config_overrides(a.config))
+        t_c0 = time.perf_counter()
+        om = OM.MTIP(o_opt, data)
+        state = om.create_initial_state(rho0[0])
+        rho = state['density_pair_history'][-1][1]
+        t_c1 = time.perf_counter()
+        n_cpu = 0
+        om.beta = 0.45
+        while True:
+            _, rho = om.step('HIO', rho, True)
+            n_cpu += 1
+            if time.perf_counter() - t_c1 > a.cpu_seconds or n_cpu >= 50:
+                break
+        t_c2 = time.perf_counter()
+        cpu = {'value': n_cpu / (t_c2 - t_c1), 'unit': 'MTIP iterations/s', 'cores': 1, 'kind': 'port',
+               'host_cpu_count': os.cpu_count(),
+               'sample': f'{n_cpu} HIO ft_stab steps of 1 restart at {N}x L{L} on the same synthetic invariants and '
+                         f'initial density (oracle/mtip.py, numpy, BLAS pinned to 1 thread as xframe/__init__.py:5-8); '
+                         f'setup {t_c1 - t_c0:.1f}s excluded'}
+        if limiter is not None:
+            limiter.unset() if hasattr(limiter, 'unset') else None
+
+    if rank == 0:
+        line = {
+            'metric': 'MTIP iterations/sec, 128 q-shells x L_max=32',
+            'value': its, 'unit': 'MTIP iterations/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
+            'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f64 (complex128)', 'data': 'synthetic',
+            'config': {'workload': f'BASELINE config {a.config}: {N} shells x L_max={L}, grid {N}x{e.n_theta}x{e.n_phi}, '
+                                   f'{B} restarts per GPU, tutorial schedule (HIO/SW/ER, ft_stab on), '
+                                   f'{"reference-order" if a.exact else "fused"} step',
+                       'restarts_per_gpu': B, 'restarts_total': B * world, 'parallelism': f'restart-sharded x{world}',
+                       'step_mode': 'exact' if a.exact else 'fused'},
+            'roofline': roofline, 'cpu_baseline': cpu, 'whole_step': whole_step, 'kernel_families_ms': fam_ms,
+            'setup_seconds': setup_s, 'final_reduce_seconds': reduce_s,
+            'best_error_rank0': [float(x) for x in best_err], 'steps_done_per_restart': int(n_done),
+            'mean_B0_trace': float(np.trace(bl_mean[0]).real),
+            'jacobi_sweeps_last_step_restart0': [int(x) for x in sweeps[0]],
+        }
+        print(json.dumps(line))
+    e.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

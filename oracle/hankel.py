@@ -64,10 +64,12 @@ def apply_direct(w, coeff, trapz=False):
 
     w: (Np, Nk, L+1) complex; coeff: (..., Nq, nlm) complex -> (..., Nk, nlm)."""
     l_max = w.shape[-1] - 1
-    lidx = l_of_lm(l_max)
-    wl = w[:, :, lidx]                      # (Np, Nk, nlm)
     src = coeff[..., 1:, :] if trapz else coeff
-    return np.einsum('pkj,...pj->...kj', wl, src)
+    out = np.empty(coeff.shape[:-2] + (w.shape[1], coeff.shape[-1]), dtype=complex)
+    for l in range(l_max + 1):              # all j with l(j) = l share the weight matrix w[:, :, l]
+        sl = slice(l * l, (l + 1) ** 2)
+        out[..., sl] = np.einsum('pk,...pj->...kj', w[:, :, l], src[..., sl])
+    return out
 
 
 def apply_ml(w, coeff_list, trapz=False):

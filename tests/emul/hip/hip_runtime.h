@@ -137,6 +137,16 @@ static inline unsigned atomicAdd(unsigned* p, unsigned v) {
 }
 static inline void __threadfence() { std::atomic_thread_fence(std::memory_order_seq_cst); }
 static inline double rsqrt(double x) { return 1.0 / std::sqrt(x); }
+// hardware estimates are only ~single precision: emulate that so the Newton refinement is really exercised
+static inline double emul_trunc_mantissa(double v) {
+    unsigned long long u;
+    std::memcpy(&u, &v, 8);
+    u &= ~((1ull << 29) - 1);
+    std::memcpy(&v, &u, 8);
+    return v;
+}
+static inline double __builtin_amdgcn_rsq(double x) { return emul_trunc_mantissa(1.0 / std::sqrt(x)); }
+static inline double __builtin_amdgcn_rcp(double x) { return emul_trunc_mantissa(1.0 / x); }
 static inline double fmin_(double a, double b) { return a < b ? a : b; }
 using std::fma;
 using std::sqrt;

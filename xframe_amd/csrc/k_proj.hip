@@ -13,6 +13,7 @@
 #define JAC_TG 8            // threads cooperating on one column pair
 #define JAC_MAX_SWEEPS 40
 #define JAC_TOL 1e-14
+#define JAC_DEFLATE 1e-15   // columns below this fraction of the largest column are numerical zeros
 
 // X_l[c][r] = sum_q q^2 V_l[q][c] conj(I_l[q][r])      (= conj(A_l[c][r]))
 __global__ void __launch_bounds__(256) k_proj_X(const double2* __restrict__ Ilm, double2* __restrict__ X,
@@ -162,6 +163,246 @@ __global__ void __launch_bounds__(256) k_polar_jacobi(double2* __restrict__ Xall
     }
 }
 
+// ---- LDS-resident variant -------------------------------------------------------------------------------
+// X (k columns x n rows) and V_r (k x k) live in LDS, both column-major with an odd column length so that
+// the 8 lanes of a pair-group (consecutive rows) and different groups (different columns) spread over the
+// banks.  One barrier per tournament round.  Warm start: the caller passes X' = X V_r_prev together with
+// V_r_prev (the right singular vectors move little between phasing steps), so 1-3 sweeps suffice; the
+// sweep loop stops early when the largest relative off-diagonal of a sweep predicts (quadratic
+// convergence) that the next one would be below tolerance.  Output: Pn = W Sigma^-1 (overwrites X) and V_r.
+#define JL_MAX_THREADS 512
+#define JL_EARLY 1e-8
+
+// 1/sqrt(x) to full double precision from the hardware estimate (two Newton steps); the rotation only needs
+// cs^2 + sn^2 = 1 and |em| = 1 to rounding, not a correctly rounded quotient.
+__device__ __forceinline__ double fast_rsqrt(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    y = y * (1.5 - 0.5 * x * y * y);
+    y = y * (1.5 - 0.5 * x * y * y);
+    return y;
+}
+__device__ __forceinline__ double fast_rcp(double x) {
+    double y = __builtin_amdgcn_rcp(x);
+    y = y * (2.0 - x * y);
+    y = y * (2.0 - x * y);
+    return y;
+}
+
+// MAXR = rows of a column handled by one lane of a pair-group (ceil(n / JAC_TG) <= MAXR); the two columns of
+// the pair are cached in registers between the Gram reduction and the rotation.
+template <int MAXR>
+__global__ void __launch_bounds__(JL_MAX_THREADS) k_polar_jacobi_lds(const double2* __restrict__ Xin_all,
+                                                                    double2* __restrict__ Pn_all,
+                                                                    double2* __restrict__ Vr_all, const int* __restrict__ kl,
+                                                                    const int* __restrict__ active,
+                                                                    const int* __restrict__ xoff, const int* __restrict__ roff,
+                                                                    int xtot, int rtot, int L, int warm, double tabs2,
+                                                                    int* __restrict__ sweeps_out) {
+    HIP_DYNAMIC_SHARED(double2, sm)
+    __shared__ double s_gmax[JL_MAX_THREADS / JAC_TG];
+    __shared__ double s_isig[128];
+    __shared__ int s_continue;
+    const int l = L - (int)blockIdx.x;                      // heavy orders first
+    const int b = blockIdx.y;
+    if (!active[l]) return;                                // uniform per block
+    const int k = kl[l], n = 2 * l + 1;
+    const int ns = n | 1, ks = k | 1;                      // odd column strides
+    double2* Xs = sm;
+    double2* Vs = sm + (size_t)k * ns;
+    const double2* Xin = Xin_all + (size_t)b * xtot + xoff[l];
+    double2* Pn = Pn_all + (size_t)b * xtot + xoff[l];
+    double2* Vr = Vr_all + (size_t)b * rtot + roff[l];
+    const int tid = threadIdx.x;
+    for (int e = tid; e < k * n; e += blockDim.x) {
+        const int cc = e / n, r = e - cc * n;
+        Xs[(size_t)cc * ns + r] = Xin[e];
+    }
+    for (int e = tid; e < k * k; e += blockDim.x) {
+        const int cc = e / k, i = e - cc * k;
+        Vs[(size_t)cc * ks + i] = warm ? Vr[e] : make_double2(cc == i ? 1.0 : 0.0, 0.0);
+    }
+    __syncthreads();
+    const int Cp = k + (k & 1);
+    const int rounds = Cp - 1;
+    const int pairs = Cp / 2;
+    const int ngroups = blockDim.x / JAC_TG;
+    const int group = tid / JAC_TG, t = tid - group * JAC_TG;
+    const int per_group = (pairs + ngroups - 1) / ngroups;
+    double S = 0.0;
+    if (k > 1) {
+        for (int sweep = 0; sweep < JAC_MAX_SWEEPS; ++sweep) {
+            // Deflation: a column that has shrunk below eps * (largest column) is a numerical zero -- it only
+            // carries rounding noise of the big columns.  X = I_l^+ D^2 V_l is numerically rank deficient once
+            // the density has a support (singular value ratios < 1e-17), and without this the noise columns
+            // keep the relative criterion busy for ~10 extra sweeps.  Their contribution to V_l U_l is
+            // O(eps) (their left vectors get sigma = 0 -> Pn = 0).
+            double Sl = 0.0;
+            for (int cc0 = 0; cc0 < k; cc0 += ngroups) {
+                const int cc = cc0 + group;
+                double s2 = 0.0;
+                if (cc < k)
+                    for (int row = t; row < n; row += JAC_TG) s2 += cabs2(Xs[(size_t)cc * ns + row]);
+                for (int o = JAC_TG / 2; o > 0; o >>= 1) s2 += __shfl_xor(s2, o, JAC_TG);
+                if (cc < k && t == 0) s_isig[cc] = s2;
+                Sl = fmax(Sl, s2);
+            }
+            if (t == 0) s_gmax[group] = Sl;
+            __syncthreads();
+            S = 0.0;
+            for (int g = 0; g < ngroups; ++g) S = fmax(S, s_gmax[g]);
+            for (int cc0 = 0; cc0 < k; cc0 += ngroups) {
+                const int cc = cc0 + group;
+                if (cc < k && s_isig[cc] <= (JAC_DEFLATE * JAC_DEFLATE) * S && s_isig[cc] > 0.0)
+                    for (int row = t; row < n; row += JAC_TG) Xs[(size_t)cc * ns + row] = make_double2(0.0, 0.0);
+            }
+            __syncthreads();
+            double gmax = 0.0;                                 // largest g2/(alpha beta) seen by this group
+            for (int r = 0; r < rounds; ++r) {
+                for (int it = 0; it < per_group; ++it) {
+                    const int pi = group + it * ngroups;
+                    int ci = 0, cj = 0;
+                    bool valid = pi < pairs;
+                    if (valid) {
+                        jacobi_pair(r, pi, Cp, &ci, &cj);
+                        valid = (ci < k) && (cj < k);
+                    }
+                    double2* xi = Xs + (size_t)ci * ns;
+                    double2* xj = Xs + (size_t)cj * ns;
+                    double2 ra[MAXR], rb[MAXR];
+                    double alpha = 0.0, beta = 0.0, gr = 0.0, gi = 0.0;
+#pragma unroll
+                    for (int u = 0; u < MAXR; ++u) {
+                        const int row = t + u * JAC_TG;
+                        double2 a = make_double2(0.0, 0.0), c2 = make_double2(0.0, 0.0);
+                        if (valid && row < n) {
+                            a = xi[row];
+                            c2 = xj[row];
+                        }
+                        ra[u] = a;
+                        rb[u] = c2;
+                        alpha += cabs2(a);
+                        beta += cabs2(c2);
+                        gr += a.x * c2.x + a.y * c2.y;     // conj(a) * c2
+                        gi += a.x * c2.y - a.y * c2.x;
+                    }
+                    for (int o = JAC_TG / 2; o > 0; o >>= 1) {
+                        alpha += __shfl_xor(alpha, o, JAC_TG);
+                        beta += __shfl_xor(beta, o, JAC_TG);
+                        gr += __shfl_xor(gr, o, JAC_TG);
+                        gi += __shfl_xor(gi, o, JAC_TG);
+                    }
+                    const double g2 = gr * gr + gi * gi;
+                    const double ab = alpha * beta;
+                    if (valid && g2 > (JAC_TOL * JAC_TOL) * ab && g2 > tabs2 * fmax(alpha, beta) * S && g2 > 0.0) {
+                        gmax = fmax(gmax, g2 * fast_rcp(ab));
+                        const double inv_g = fast_rsqrt(g2);
+                        const double zeta = 0.5 * (beta - alpha) * inv_g;
+                        const double z1 = 1.0 + zeta * zeta;
+                        const double rt = z1 * fast_rsqrt(z1);               // sqrt(1 + zeta^2)
+                        const double tt = (zeta >= 0.0 ? 1.0 : -1.0) * fast_rcp(fabs(zeta) + rt);
+                        const double cs = fast_rsqrt(1.0 + tt * tt);
+                        const double sn = cs * tt;
+                        const double2 em = make_double2(gr * inv_g, -gi * inv_g);   // conj(gamma)/|gamma|
+#pragma unroll
+                        for (int u = 0; u < MAXR; ++u) {
+                            const int row = t + u * JAC_TG;
+                            if (row < n) {
+                                const double2 a = ra[u];
+                                const double2 bj = cmul(em, rb[u]);
+                                xi[row] = make_double2(cs * a.x - sn * bj.x, cs * a.y - sn * bj.y);
+                                xj[row] = make_double2(sn * a.x + cs * bj.x, sn * a.y + cs * bj.y);
+                            }
+                        }
+                        double2* vi = Vs + (size_t)ci * ks;
+                        double2* vj = Vs + (size_t)cj * ks;
+#pragma unroll
+                        for (int u = 0; u < MAXR; ++u) {
+                            const int row = t + u * JAC_TG;
+                            if (row < k) {
+                                const double2 a = vi[row];
+                                const double2 bj = cmul(em, vj[row]);
+                                vi[row] = make_double2(cs * a.x - sn * bj.x, cs * a.y - sn * bj.y);
+                                vj[row] = make_double2(sn * a.x + cs * bj.x, sn * a.y + cs * bj.y);
+                            }
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+            if (t == 0) s_gmax[group] = gmax;
+            __syncthreads();
+            if (tid == 0) {
+                double m = 0.0;
+                for (int g = 0; g < ngroups; ++g) m = fmax(m, s_gmax[g]);
+                // m = max (|gamma|^2 / alpha beta); rotations happened iff m > 0. Quadratic convergence:
+                // the next sweep would see ~ m^2, so stop when sqrt(m) < JL_EARLY.
+                s_continue = (m > JL_EARLY * JL_EARLY) ? 1 : 0;
+                sweeps_out[b * (L + 1) + l] = sweep + 1;
+            }
+            __syncthreads();
+            const int cont = s_continue;
+            __syncthreads();
+            if (!cont) break;
+        }
+    }
+    // sigma_c and the normalised columns Pn = W Sigma^-1
+    for (int cc0 = 0; cc0 < k; cc0 += ngroups) {           // uniform trip count: the shuffles are wave collectives
+        const int cc = cc0 + group;
+        double s2 = 0.0;
+        if (cc < k) {
+            const double2* wc = Xs + (size_t)cc * ns;
+            for (int row = t; row < n; row += JAC_TG) s2 += cabs2(wc[row]);
+        }
+        for (int o = JAC_TG / 2; o > 0; o >>= 1) s2 += __shfl_xor(s2, o, JAC_TG);
+        if (cc < k && t == 0) s_isig[cc] = s2 > 1e-300 ? 1.0 / sqrt(s2) : 0.0;
+    }
+    __syncthreads();
+    for (int e = tid; e < k * n; e += blockDim.x) {
+        const int cc = e / n, r = e - cc * n;
+        Pn[e] = cscale(Xs[(size_t)cc * ns + r], s_isig[cc]);
+    }
+    for (int e = tid; e < k * k; e += blockDim.x) {
+        const int cc = e / k, i = e - cc * k;
+        Vr[e] = Vs[(size_t)cc * ks + i];
+    }
+}
+
+// warm start: X'[c][r] = sum_j X[j][r] Vr[j][c]   (all column-major: X[j*n+r], Vr[c*k+j])
+__global__ void __launch_bounds__(256) k_proj_warm(const double2* __restrict__ Xall, const double2* __restrict__ Vrall,
+                                                   double2* __restrict__ Xw_all, const int* __restrict__ kl,
+                                                   const int* __restrict__ active, const int* __restrict__ xoff,
+                                                   const int* __restrict__ roff, int xtot, int rtot) {
+    const int l = blockIdx.y, b = blockIdx.z;
+    if (!active[l]) return;
+    const int k = kl[l], n = 2 * l + 1;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= k * n) return;
+    const int cc = e / n, r = e - cc * n;
+    const double2* X = Xall + (size_t)b * xtot + xoff[l] + r;
+    const double2* v = Vrall + (size_t)b * rtot + roff[l] + (size_t)cc * k;
+    double2 acc = make_double2(0.0, 0.0);
+    for (int j = 0; j < k; ++j) acc = cadd(acc, cmul(X[(size_t)j * n], v[j]));
+    Xw_all[(size_t)b * xtot + xoff[l] + e] = acc;
+}
+
+// U[i][j] = sum_c Vr[i][c] conj(Pn[j][c])        (U row-major k x n)
+__global__ void __launch_bounds__(256) k_proj_U(const double2* __restrict__ Pn_all, const double2* __restrict__ Vrall,
+                                                double2* __restrict__ Uall, const int* __restrict__ kl,
+                                                const int* __restrict__ active, const int* __restrict__ xoff,
+                                                const int* __restrict__ roff, int xtot, int rtot) {
+    const int l = blockIdx.y, b = blockIdx.z;
+    if (!active[l]) return;
+    const int k = kl[l], n = 2 * l + 1;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= k * n) return;
+    const int i = e / n, j = e - i * n;
+    const double2* Pn = Pn_all + (size_t)b * xtot + xoff[l] + j;
+    const double2* v = Vrall + (size_t)b * rtot + roff[l] + i;
+    double2 acc = make_double2(0.0, 0.0);
+    for (int cc = 0; cc < k; ++cc) acc = cadd(acc, cmulc(v[(size_t)cc * k], Pn[(size_t)cc * n]));
+    Uall[(size_t)b * xtot + xoff[l] + e] = acc;
+}
+
 // I'_l = mask ? V_l U_l : I_l  (+ the l = 0 rules)
 __global__ void __launch_bounds__(256) k_proj_apply(const double2* __restrict__ Ilm, double2* __restrict__ out,
                                                     const double2* __restrict__ V, const double2* __restrict__ Uall,
@@ -197,14 +438,50 @@ __global__ void __launch_bounds__(256) k_proj_apply(const double2* __restrict__ 
 
 void launch_project_coefficients(mtip_ctx* c, const double2* Ilm, double2* out) {
     ProfScope ps(c, "proj");
-    int max_kn = 1;
-    for (int l = 0; l <= c->L; ++l) max_kn = std::max(max_kn, c->kl[l] * (2 * l + 1));
-    hipLaunchKernelGGL(k_proj_X, dim3((unsigned)div_up(max_kn, 256), (unsigned)(c->L + 1), (unsigned)c->B), dim3(256), 0,
-                       c->stream, Ilm, c->d_X, (const double2*)c->d_V, (const double*)c->d_q, (const int*)c->d_kl,
-                       (const int*)c->d_used, (const int*)c->d_voff, (const int*)c->d_xoff, c->N, c->L, c->xtot);
-    hipLaunchKernelGGL(k_polar_jacobi, dim3((unsigned)(c->L + 1), (unsigned)c->B), dim3(256), 0, c->stream, c->d_X,
-                       c->d_Vr, c->d_U, (const int*)c->d_kl, (const int*)c->d_used, (const int*)c->d_xoff,
-                       (const int*)c->d_uoff, c->xtot, c->utot);
+    int max_kn = 1, kmax = 1, nmax = 1;
+    for (int l = 0; l <= c->L; ++l) {
+        if (!c->active[l]) continue;
+        max_kn = std::max(max_kn, c->kl[l] * (2 * l + 1));
+        kmax = std::max(kmax, c->kl[l]);
+        nmax = std::max(nmax, 2 * l + 1);
+    }
+    const dim3 gmat((unsigned)div_up(max_kn, 256), (unsigned)(c->L + 1), (unsigned)c->B);
+    hipLaunchKernelGGL(k_proj_X, gmat, dim3(256), 0, c->stream, Ilm, c->d_X, (const double2*)c->d_V,
+                       (const double*)c->d_q, (const int*)c->d_kl, (const int*)c->d_active, (const int*)c->d_voff,
+                       (const int*)c->d_xoff, c->N, c->L, c->xtot);
+    const size_t lds = ((size_t)kmax * (nmax | 1) + (size_t)kmax * (kmax | 1)) * sizeof(double2);
+    if (lds <= 150 * 1024) {
+        // cold start every 64 calls bounds the accumulated rounding drift of the carried V_r
+        const int warm = (c->vr_valid && (c->proj_calls % 64) != 0) ? 1 : 0;
+        const double2* src = c->d_X;
+        if (warm) {
+            hipLaunchKernelGGL(k_proj_warm, gmat, dim3(256), 0, c->stream, (const double2*)c->d_X, (const double2*)c->d_Vr,
+                               c->d_U, (const int*)c->d_kl, (const int*)c->d_active, (const int*)c->d_xoff,
+                               (const int*)c->d_uoff, c->xtot, c->utot);
+            src = c->d_U;
+        }
+        const int pairs_max = (kmax + 1) / 2;
+        int threads = ((pairs_max * JAC_TG + 63) / 64) * 64;
+        threads = std::min(std::max(threads, 64), JL_MAX_THREADS);
+        const dim3 gj((unsigned)(c->L + 1), (unsigned)c->B);
+        if (nmax <= 9 * JAC_TG)
+            hipLaunchKernelGGL(k_polar_jacobi_lds<9>, gj, dim3(threads), lds, c->stream, src, c->d_X, c->d_Vr,
+                               (const int*)c->d_kl, (const int*)c->d_active, (const int*)c->d_xoff, (const int*)c->d_uoff,
+                               c->xtot, c->utot, c->L, warm, c->polar_abs_tol * c->polar_abs_tol, c->d_sweeps);
+        else
+            hipLaunchKernelGGL(k_polar_jacobi_lds<16>, gj, dim3(threads), lds, c->stream, src, c->d_X, c->d_Vr,
+                               (const int*)c->d_kl, (const int*)c->d_active, (const int*)c->d_xoff, (const int*)c->d_uoff,
+                               c->xtot, c->utot, c->L, warm, c->polar_abs_tol * c->polar_abs_tol, c->d_sweeps);
+        hipLaunchKernelGGL(k_proj_U, gmat, dim3(256), 0, c->stream, (const double2*)c->d_X, (const double2*)c->d_Vr, c->d_U,
+                           (const int*)c->d_kl, (const int*)c->d_active, (const int*)c->d_xoff, (const int*)c->d_uoff,
+                           c->xtot, c->utot);
+        c->vr_valid = true;
+        c->proj_calls += 1;
+    } else {
+        hipLaunchKernelGGL(k_polar_jacobi, dim3((unsigned)(c->L + 1), (unsigned)c->B), dim3(256), 0, c->stream, c->d_X,
+                           c->d_Vr, c->d_U, (const int*)c->d_kl, (const int*)c->d_active, (const int*)c->d_xoff,
+                           (const int*)c->d_uoff, c->xtot, c->utot);
+    }
     const long long total = (long long)c->B * c->N * c->nlm;
     hipLaunchKernelGGL(k_proj_apply, dim3((unsigned)div_up(total, 256)), dim3(256), 0, c->stream, Ilm, out,
                        (const double2*)c->d_V, (const double2*)c->d_U, (const uint8_t*)c->d_rmask, (const int*)c->d_kl,

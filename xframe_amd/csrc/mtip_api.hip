@@ -4,6 +4,7 @@
 #include "mtip_internal.h"
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 static std::string g_create_error;
@@ -52,7 +53,7 @@ void mtip_destroy(mtip_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    void* ptrs[] = {c->d_cost, c->d_gw, c->d_P, c->d_r, c->d_q, c->d_poff, c->d_tw, c->d_W, c->d_kl, c->d_used, c->d_voff,
+    void* ptrs[] = {c->d_cost, c->d_gw, c->d_P, c->d_r, c->d_q, c->d_poff, c->d_tw, c->d_W, c->d_kl, c->d_used, c->d_active, c->d_sweeps, c->d_voff,
                     c->d_xoff, c->d_uoff, c->d_V, c->d_rmask, c->d_Bref, c->d_Bnorm, c->d_S0, c->d_sup, c->d_err_wr,
                     c->d_err_wt, c->d_rho, c->d_Fp, c->d_slot, c->d_best_err, c->d_last_err, c->d_err_hist,
                     c->d_deg2_hist, c->d_F, c->d_T1, c->d_T2, c->d_fixed, c->d_g, c->d_c[0], c->d_c[1], c->d_c[2],
@@ -101,6 +102,7 @@ mtip_ctx* mtip_create(const mtip_cfg* cfg, int device) {
     c->nlm = (c->L + 1) * (c->L + 1);
     c->nm = 2 * c->L + 1;
     c->Np = cfg->hankel_trapz ? c->N - 1 : c->N;
+    if (const char* e = std::getenv("MTIP_POLAR_ABS_TOL")) c->polar_abs_tol = std::atof(e);
     c->G = (size_t)c->N * c->nt * c->np;
     c->C = (size_t)c->N * c->nlm;
     const int L = c->L, N = c->N, B = c->B;
@@ -120,6 +122,7 @@ mtip_ctx* mtip_create(const mtip_cfg* cfg, int device) {
     // projection layout
     c->kl.assign(L + 1, 0);
     c->used.assign(L + 1, 0);
+    c->active.assign(L + 1, 0);
     c->voff.assign(L + 2, 0);
     c->xoff.assign(L + 2, 0);
     c->uoff.assign(L + 2, 0);
@@ -136,6 +139,8 @@ mtip_ctx* mtip_create(const mtip_cfg* cfg, int device) {
     c->utot = c->uoff[L + 1];
     A(dev_alloc(c, &c->d_kl, L + 1));
     A(dev_alloc(c, &c->d_used, L + 1));
+    A(dev_alloc(c, &c->d_active, L + 1));
+    A(dev_alloc(c, &c->d_sweeps, (size_t)B * (L + 1)));
     A(dev_alloc(c, &c->d_voff, L + 2));
     A(dev_alloc(c, &c->d_xoff, L + 2));
     A(dev_alloc(c, &c->d_uoff, L + 2));
@@ -177,6 +182,11 @@ mtip_ctx* mtip_create(const mtip_cfg* cfg, int device) {
     (void)hipMemcpy(c->d_xoff, c->xoff.data(), (L + 2) * sizeof(int), hipMemcpyHostToDevice);
     (void)hipMemcpy(c->d_uoff, c->uoff.data(), (L + 2) * sizeof(int), hipMemcpyHostToDevice);
     (void)hipMemset(c->d_used, 0, (L + 1) * sizeof(int));
+    (void)hipMemset(c->d_active, 0, (L + 1) * sizeof(int));
+    (void)hipMemset(c->d_sweeps, 0, (size_t)B * (L + 1) * sizeof(int));
+    (void)hipMemset(c->d_U, 0, (size_t)B * c->xtot * sizeof(double2));
+    (void)hipMemset(c->d_X, 0, (size_t)B * c->xtot * sizeof(double2));
+    (void)hipMemset(c->d_Vr, 0, (size_t)B * c->utot * sizeof(double2));
     (void)hipMemset(c->d_V, 0, (size_t)c->vtot * sizeof(double2));
     (void)hipMemset(c->d_rmask, 0, (size_t)(L + 1) * N);
     (void)hipMemset(c->d_sup, 1, (size_t)3 * B * c->G);
@@ -258,7 +268,13 @@ int mtip_set_projection_matrix(mtip_ctx* c, int l, const mtip_cdouble* V, int k_
     MTIP_HIP_CHECK(c, hipMemcpy(c->d_V + c->voff[l], tmp.data(), tmp.size() * sizeof(double2), hipMemcpyHostToDevice));
     if (radial_mask) MTIP_HIP_CHECK(c, hipMemcpy(c->d_rmask + (size_t)l * c->N, radial_mask, c->N, hipMemcpyHostToDevice));
     c->used[l] = used ? 1 : 0;
+    bool nonzero = false;
+    for (const double2& v : tmp) nonzero = nonzero || v.x != 0.0 || v.y != 0.0;
+    c->active[l] = (used && nonzero) ? 1 : 0;          // V_l == 0 (odd_orders_to_0): U_l stays 0, nothing to solve
+    c->vr_valid = false;
     MTIP_HIP_CHECK(c, hipMemcpy(c->d_used, c->used.data(), (c->L + 1) * sizeof(int), hipMemcpyHostToDevice));
+    MTIP_HIP_CHECK(c, hipMemcpy(c->d_active, c->active.data(), (c->L + 1) * sizeof(int), hipMemcpyHostToDevice));
+    MTIP_HIP_CHECK(c, hipMemset(c->d_U, 0, (size_t)c->B * c->xtot * sizeof(double2)));
     c->have_V[l] = 1;
     c->bref_dirty = true;
     return MTIP_OK;
@@ -855,6 +871,15 @@ int mtip_profile_get(mtip_ctx* c, const char* name, double* total_ms, int64_t* l
     auto it = c->prof_data.find(name);
     if (total_ms) *total_ms = it == c->prof_data.end() ? 0.0 : it->second.ms;
     if (launches) *launches = it == c->prof_data.end() ? 0 : it->second.n;
+    return MTIP_OK;
+}
+
+int mtip_debug_jacobi_sweeps(mtip_ctx* c, int32_t* out) {
+    CTX_CHECK(c);
+    if (!out) return MTIP_EINVAL;
+    (void)hipSetDevice(c->device);
+    MTIP_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    MTIP_HIP_CHECK(c, hipMemcpy(out, c->d_sweeps, (size_t)c->B * (c->L + 1) * sizeof(int), hipMemcpyDeviceToHost));
     return MTIP_OK;
 }
 

@@ -69,7 +69,12 @@ struct mtip_ctx {
     double fwd_scale = 0, inv_scale = 0;
     bool have_angular = false, have_radial = false, have_weights = false, have_support = false, have_errw = false;
     // projection data
-    std::vector<int> kl, used, voff, xoff, uoff;     // host copies
+    std::vector<int> kl, used, active, voff, xoff, uoff;     // host copies (active = used and V_l != 0)
+    int* d_active = nullptr;
+    int* d_sweeps = nullptr;                          // (B, L+1) Jacobi sweeps of the last projection (diagnostic)
+    bool vr_valid = false;                            // d_Vr holds right singular vectors of the previous call
+    long long proj_calls = 0;
+    double polar_abs_tol = 0.0;                       // 0 = purely relative Jacobi criterion (env MTIP_POLAR_ABS_TOL)
     int *d_kl = nullptr, *d_used = nullptr, *d_voff = nullptr, *d_xoff = nullptr, *d_uoff = nullptr;
     int vtot = 0, xtot = 0, utot = 0;                 // per-restart element counts
     double2* d_V = nullptr;                           // concatenated V_l, (Nq, k_l) row-major each

@@ -68,6 +68,7 @@ _SIGNATURES = {
     'mtip_profile': (C.c_int, [c_void, C.c_int]),
     'mtip_profile_get': (C.c_int, [c_void, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     'mtip_profile_reset': (C.c_int, [c_void]),
+    'mtip_debug_jacobi_sweeps': (C.c_int, [c_void, c_void]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

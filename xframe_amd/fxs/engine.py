@@ -277,6 +277,11 @@ class Engine:
         self._ck(self.lib.mtip_profile_get(self.ctx, name.encode(), C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+    def jacobi_sweeps(self):
+        out = np.zeros((self.B, self.L + 1), np.int32)
+        self._ck(self.lib.mtip_debug_jacobi_sweeps(self.ctx, _lib.ptr(out)))
+        return out
+
     # ------------------------------------------------------------------ helpers shared with synthetic.py
     @property
     def thetas(self):
