@@ -5,12 +5,14 @@
 
 One process per GPU (for N > 1 launched by torch.distributed.run; RANK / LOCAL_RANK / WORLD_SIZE from the
 environment).  Every rank phases `--restarts-per-gpu` independent restarts (BASELINE config 4: 64 restarts
-over 8 GPUs = 8 per GPU) as one device-resident batch; restarts never communicate, so scaling is weak and
-there is no data-path collective -- RCCL is only used for the timing barrier / max-over-ranks and for the
-end-of-run gather of the rotation-invariant B_l (outside the timed region, reported separately).
+over 8 GPUs = 8 per GPU), device resident; restarts never communicate, so scaling is weak and there is no
+data-path collective -- RCCL is only used for the timing barrier / max-over-ranks and for the end-of-run
+reduce of the rotation-invariant B_l (outside the timed region, reported separately).
+The restarts of a rank are split over `--streams` engines (one mtip_ctx + HIP stream each) so that the
+latency-bound polar-factor kernel of one group overlaps the bandwidth-bound transforms of the others.
 
 A "step" = one phasing step (HIO or ER sketch incl. ft_stab, reconstruct.py:576-593) of every restart of the
-batch; the K timed steps walk the tutorial schedule (60 HIO, 1 SW, 40 ER, ...; tutorial.yaml:52-72), shrink
+rank; the K timed steps walk the tutorial schedule (60 HIO, 1 SW, 40 ER, ...; tutorial.yaml:52-72), shrink
 wrap updates are executed and timed but not counted.  value = N * restarts_per_gpu * K / seconds.
 Inputs (synthetic invariants, initial densities) are resident in HBM before the timed region.
 """
@@ -32,6 +34,7 @@ def parse():
     p.add_argument('--steps', type=int, default=200)
     p.add_argument('--warmup', type=int, default=20)
     p.add_argument('--restarts-per-gpu', type=int, default=8)
+    p.add_argument('--streams', type=int, default=2, help='engines (HIP streams) the restarts of a rank are split over')
     p.add_argument('--config', type=int, default=4, help='BASELINE config id (sizes): 1..5')
     p.add_argument('--exact', action='store_true', help='reference operator order instead of the fused step')
     p.add_argument('--cpu-seconds', type=float, default=20.0, help='budget of the CPU baseline sample')
@@ -45,7 +48,6 @@ def schedule(n_steps):
     out = []
     blocks = [('HIO', 60), ('SW', 1), ('ER', 40)] * 5 + [('SW', 1), ('ER', 100)]
     done = 0
-    hio_step = 0
     while done < n_steps:
         for kind, n in blocks:
             if done >= n_steps:
@@ -92,6 +94,7 @@ def main():
 
     N, L = S._SIZES[a.config]
     B = a.restarts_per_gpu
+    n_eng = max(1, min(a.streams, B))
     opt = S.config_overrides(a.config)
     # ---- synthetic inputs (product path: HIP transforms), identical on every rank
     t_setup = time.time()
@@ -99,46 +102,58 @@ def main():
                    max_q=S.data_cutoff(N))
     data, rho_true = S.make_invariants(eng_d, N, L)
     eng_d.close()
-    e = Engine(opt, data, n_batch=B, device=local_rank, fused=not a.exact)
+    sizes = [B // n_eng + (1 if i < B % n_eng else 0) for i in range(n_eng)]
+    engines = [Engine(opt, data, n_batch=nb, device=local_rank, fused=not a.exact) for nb in sizes]
+    e0 = engines[0]
     rho0 = []
-    for b in range(B):
-        gid = rank * B + b                                      # global restart id -> seed 1000 + id
-        rho0.append(hs.bump_density(e.rs, e.shape, S.PARTICLE_RADIUS, 0.3, 2, np.random.default_rng(1000 + gid),
-                                    e.rsetup.integrated_intensity, e.int_wr, e.int_wt))
-        e.set_density(b, rho0[-1])
-    e.init_state()
-    e.synchronize()
+    gid = rank * B
+    for e in engines:
+        for b in range(e.B):                                    # global restart id -> seed 1000 + id
+            rho0.append(hs.bump_density(e.rs, e.shape, S.PARTICLE_RADIUS, 0.3, 2, np.random.default_rng(1000 + gid),
+                                        e.rsetup.integrated_intensity, e.int_wr, e.int_wt))
+            e.set_density(b, rho0[-1])
+            gid += 1
+        e.init_state()
+    for e in engines:
+        e.synchronize()
     setup_s = time.time() - t_setup
     ramp = hs.ExponentialRamp(0.5, 0.4, -1 / 250, 500)
     limit = 6e-3
-    sw_sigma = hs.LinearRamp(20, [False, 5], -2, default_start=e.default_sigma, default_stop=e.default_sigma)
+    sw_sigma = hs.LinearRamp(20, [False, 5], -2, default_start=e0.default_sigma, default_stop=e0.default_sigma)
+    CHUNK = 10                                                  # steps enqueued per engine before switching
 
     def run_schedule(n_steps, start_step=0):
         step = start_step
         sw_count = 0
         for kind, k in schedule(n_steps):
             if kind == 'SW':
-                e.shrinkwrap(sw_sigma(sw_count), 0.09, limit)
+                for e in engines:
+                    e.shrinkwrap(sw_sigma(sw_count), 0.09, limit)
                 sw_count += 1
                 continue
-            betas = np.array([ramp.eval(step + i) for i in range(k)])
-            e.run(kind, True, betas, fetch=False)
+            done = 0
+            while done < k:
+                c = min(CHUNK, k - done)
+                betas = np.array([ramp.eval(step + done + i) for i in range(c)])
+                for e in engines:
+                    e.run(kind, True, betas, fetch=False)
+                done += c
             step += k
         return step
 
-    def barrier():
+    def sync_all():
+        for e in engines:
+            e.synchronize()
         torch.cuda.synchronize(dev)
-        e.synchronize()
-        if dist is not None:
-            dist.barrier()
 
     # ---- warmup, then exactly K timed steps
     run_schedule(a.warmup)
-    barrier()
+    sync_all()
+    if dist is not None:
+        dist.barrier()
     t0 = time.perf_counter()
     run_schedule(a.steps, start_step=a.warmup)
-    e.synchronize()
-    torch.cuda.synchronize(dev)
+    sync_all()
     t1 = time.perf_counter()
     if dist is not None:
         dist.barrier()
@@ -152,39 +167,45 @@ def main():
 
     # ---- end-of-run reduce of rotation-invariant summaries (outside the timed region)
     t_red = time.perf_counter()
-    best_err, n_done = e.best_error()
-    sweeps = e.jacobi_sweeps()
+    best_err = np.concatenate([e.best_error()[0] for e in engines])
+    n_done = e0.best_error()[1]
+    sweeps = e0.jacobi_sweeps()
     bl_sum = np.zeros((L + 1, N, N), complex)
-    for b in range(min(B, 2)):                                  # bounded: download is PCIe bound
-        bl_sum += e.last_deg2_invariant(b)
-    bl_mean = average_invariants(bl_sum, min(B, 2), device=dev if dist is not None else None)
+    n_bl = 0
+    for e in engines[:2]:                                       # bounded sample: the download is PCIe bound
+        bl_sum += e.last_deg2_invariant(0)
+        n_bl += 1
+    bl_mean = average_invariants(bl_sum, n_bl, device=dev if dist is not None else None)
     reduce_s = time.perf_counter() - t_red
 
-    # ---- roofline of the dominant kernel family (hipEvent timing on the ctx stream)
+    # ---- roofline of the dominant kernel family (hipEvent timing on the ctx stream, one engine, alone on the GPU)
     roofline = None
     fam_ms = {}
+    Bp = e0.B
     if not a.no_roofline:
-        e.profile(True)
-        nprof = 6
-        e.run('HIO', True, np.full(nprof, 0.45), fetch=False)
-        e.synchronize()
+        sync_all()
+        e0.profile(True)
+        e0.run('HIO', True, np.full(6, 0.45), fetch=False)
+        e0.synchronize()
         for fam in ('sht_fwd', 'sht_inv', 'hankel', 'proj', 'real_update', 'deg2_metric'):
-            ms, n = e.profile_get(fam)
+            ms, n = e0.profile_get(fam)
             if n:
                 fam_ms[fam] = {'total_ms': ms, 'launches': int(n), 'avg_ms': ms / n}
-        e.profile(False)
+        e0.profile(False)
         if fam_ms:
-            dom = max(fam_ms, key=lambda k: fam_ms[k]['total_ms'])
-            G = N * e.n_theta * e.n_phi
+            G = N * e0.n_theta * e0.n_phi
             C = N * (L + 1) ** 2
-            alg = {'sht_fwd': 16 * G * B + 16 * C * B, 'sht_inv': 16 * G * B + 16 * C * B,
-                   'hankel': 2 * 16 * C * B + 8 * N * N * (L + 1),
-                   'proj': 3 * 16 * C * B, 'real_update': (3 * 16 + 1) * G * B}.get(dom, 0)
-            achieved = alg / (fam_ms[dom]['avg_ms'] * 1e-3) / 1e9
+            alg = {'sht_fwd': 16 * G * Bp + 16 * C * Bp, 'sht_inv': 16 * G * Bp + 16 * C * Bp,
+                   'hankel': 2 * 16 * C * Bp + 8 * N * N * (L + 1), 'real_update': (3 * 16 + 2) * G * Bp}
+            hbm = {k: v for k, v in fam_ms.items() if k in alg}
+            dom = max(hbm, key=lambda k: hbm[k]['total_ms'])
+            achieved = alg[dom] / (fam_ms[dom]['avg_ms'] * 1e-3) / 1e9
             roofline = {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s',
-                        'frac': achieved / 8000.0, 'traffic': None,
-                        'avg_launch_ms': fam_ms[dom]['avg_ms'], 'algorithmic_bytes_per_launch': alg}
-    step_bytes = algorithmic_bytes_per_step(N, L, e.n_theta, e.n_phi, True)
+                        'frac': achieved / 8000.0, 'traffic': None, 'avg_launch_ms': fam_ms[dom]['avg_ms'],
+                        'algorithmic_bytes_per_launch': alg[dom], 'restarts_per_launch': Bp,
+                        'note': 'dominant HBM-bound kernel family; the latency-bound polar-factor kernel (proj) is '
+                                'listed in kernel_families_ms'}
+    step_bytes = algorithmic_bytes_per_step(N, L, e0.n_theta, e0.n_phi, True)
     whole_step = {'algorithmic_bytes_per_step_per_restart': step_bytes,
                   'achieved_GBps_per_gpu': step_bytes * B * a.steps / elapsed / 1e9,
                   'frac_of_8TBps': step_bytes * B * a.steps / elapsed / 8e12}
@@ -192,11 +213,12 @@ def main():
     # ---- CPU baseline: the oracle (numpy restatement of the reference algorithm), 1 thread, bounded sample
     cpu = None
     if rank == 0 and not a.no_cpu_baseline:
+        limiter = None
         try:
             import threadpoolctl
             limiter = threadpoolctl.threadpool_limits(1)
         except Exception:
-            limiter = None
+            pass
         from oracle import mtip as OM
         o_opt = OM.deep_update(OM.default_settings(), S.config_overrides(a.config))
         t_c0 = time.perf_counter()
@@ -209,7 +231,7 @@ def main():
         while True:
             _, rho = om.step('HIO', rho, True)
             n_cpu += 1
-            if time.perf_counter() - t_c1 > a.cpu_seconds or n_cpu >= 50:
+            if time.perf_counter() - t_c1 > a.cpu_seconds or n_cpu >= 200:
                 break
         t_c2 = time.perf_counter()
         cpu = {'value': n_cpu / (t_c2 - t_c1), 'unit': 'MTIP iterations/s', 'cores': 1, 'kind': 'port',
@@ -217,8 +239,7 @@ def main():
                'sample': f'{n_cpu} HIO ft_stab steps of 1 restart at {N}x L{L} on the same synthetic invariants and '
                          f'initial density (oracle/mtip.py, numpy, BLAS pinned to 1 thread as xframe/__init__.py:5-8); '
                          f'setup {t_c1 - t_c0:.1f}s excluded'}
-        if limiter is not None:
-            limiter.unset() if hasattr(limiter, 'unset') else None
+        del limiter
 
     if rank == 0:
         line = {
@@ -226,11 +247,11 @@ def main():
             'value': its, 'unit': 'MTIP iterations/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
             'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f64 (complex128)', 'data': 'synthetic',
-            'config': {'workload': f'BASELINE config {a.config}: {N} shells x L_max={L}, grid {N}x{e.n_theta}x{e.n_phi}, '
-                                   f'{B} restarts per GPU, tutorial schedule (HIO/SW/ER, ft_stab on), '
+            'config': {'workload': f'BASELINE config {a.config}: {N} shells x L_max={L}, grid {N}x{e0.n_theta}x{e0.n_phi}, '
+                                   f'{B} restarts per GPU on {n_eng} streams, tutorial schedule (HIO/SW/ER, ft_stab on), '
                                    f'{"reference-order" if a.exact else "fused"} step',
-                       'restarts_per_gpu': B, 'restarts_total': B * world, 'parallelism': f'restart-sharded x{world}',
-                       'step_mode': 'exact' if a.exact else 'fused'},
+                       'restarts_per_gpu': B, 'restarts_total': B * world, 'streams_per_gpu': n_eng,
+                       'parallelism': f'restart-sharded x{world}', 'step_mode': 'exact' if a.exact else 'fused'},
             'roofline': roofline, 'cpu_baseline': cpu, 'whole_step': whole_step, 'kernel_families_ms': fam_ms,
             'setup_seconds': setup_s, 'final_reduce_seconds': reduce_s,
             'best_error_rank0': [float(x) for x in best_err], 'steps_done_per_restart': int(n_done),
@@ -238,7 +259,8 @@ def main():
             'jacobi_sweeps_last_step_restart0': [int(x) for x in sweeps[0]],
         }
         print(json.dumps(line))
-    e.close()
+    for e in engines:
+        e.close()
     if dist is not None:
         dist.destroy_process_group()
 

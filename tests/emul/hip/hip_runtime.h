@@ -122,6 +122,24 @@ static inline emul_v4f64 __builtin_amdgcn_mfma_f64_16x16x4f64(double a, double b
     return d;
 }
 
+// DPP lane permutations used by the kernels: quad_perm (ctrl < 0x100), row_mirror 0x140, row_half_mirror 0x141
+static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int, int, bool) {
+    (void)old;
+    const int l = emul::lane();
+    int from;
+    if (ctrl < 0x100) from = (l & ~3) | ((ctrl >> (2 * (l & 3))) & 3);
+    else if (ctrl == 0x141) from = (l & ~7) | (7 - (l & 7));
+    else if (ctrl == 0x140) from = (l & ~15) | (15 - (l & 15));
+    else { std::fprintf(stderr, "emul: unsupported dpp ctrl 0x%x\n", ctrl); std::abort(); }
+    return __shfl(src, from, 64);
+}
+static inline int __double2loint(double v) { long long u; std::memcpy(&u, &v, 8); return (int)(u & 0xffffffffll); }
+static inline int __double2hiint(double v) { long long u; std::memcpy(&u, &v, 8); return (int)(u >> 32); }
+static inline double __hiloint2double(int hi, int lo) {
+    unsigned long long u = ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
+    double v; std::memcpy(&v, &u, 8); return v;
+}
+
 static std::mutex emul_atomic_mutex;
 static inline double atomicAdd(double* p, double v) {
     std::lock_guard<std::mutex> g(emul_atomic_mutex);
@@ -153,6 +171,8 @@ using std::sqrt;
 using std::fabs;
 using std::fmax;
 using std::fmin;
+using std::min;
+using std::max;
 
 // ---- runtime API ----------------------------------------------------------------------------
 static inline const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "hipSuccess" : "emul error"; }

@@ -188,8 +188,26 @@ __device__ __forceinline__ double fast_rcp(double x) {
     return y;
 }
 
-// MAXR = rows of a column handled by one lane of a pair-group (ceil(n / JAC_TG) <= MAXR); the two columns of
-// the pair are cached in registers between the Gram reduction and the rotation.
+// sum over the 8 lanes of a pair-group with DPP moves (3 VALU ops per stage instead of two ds_bpermute each):
+// xor 1 = quad_perm [1,0,3,2], xor 2 = quad_perm [2,3,0,1], then row_half_mirror (lane i <-> 7-i) crosses quads.
+template <int CTRL>
+__device__ __forceinline__ double dpp_add(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const int lo2 = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
+    const int hi2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+    return v + __hiloint2double(hi2, lo2);
+}
+__device__ __forceinline__ double group8_sum(double v) {
+    v = dpp_add<0xB1>(v);
+    v = dpp_add<0x4E>(v);
+    v = dpp_add<0x141>(v);
+    return v;
+}
+
+// MAXR = upper bound of the rows of a column handled by one lane of a pair-group (ceil(n / 8) <= MAXR).  Columns
+// are zero padded to a multiple of 8 rows in LDS, so the row loops need no per-lane predicate; the two columns of
+// the pair stay in registers between the Gram reduction and the rotation.  For odd k the tournament pair that
+// contains the dummy player is skipped, so ceil(k/2) <= 32 pair-groups (one wave per SIMD at k <= 65) suffice.
 template <int MAXR>
 __global__ void __launch_bounds__(JL_MAX_THREADS) k_polar_jacobi_lds(const double2* __restrict__ Xin_all,
                                                                     double2* __restrict__ Pn_all,
@@ -206,25 +224,29 @@ __global__ void __launch_bounds__(JL_MAX_THREADS) k_polar_jacobi_lds(const doubl
     const int b = blockIdx.y;
     if (!active[l]) return;                                // uniform per block
     const int k = kl[l], n = 2 * l + 1;
-    const int ns = n | 1, ks = k | 1;                      // odd column strides
+    const int nr = (n + JAC_TG - 1) / JAC_TG, kr = (k + JAC_TG - 1) / JAC_TG;   // rows per lane
+    const int ns = nr * JAC_TG + 1, ks = kr * JAC_TG + 1;  // padded, odd column strides
     double2* Xs = sm;
     double2* Vs = sm + (size_t)k * ns;
     const double2* Xin = Xin_all + (size_t)b * xtot + xoff[l];
     double2* Pn = Pn_all + (size_t)b * xtot + xoff[l];
     double2* Vr = Vr_all + (size_t)b * rtot + roff[l];
     const int tid = threadIdx.x;
-    for (int e = tid; e < k * n; e += blockDim.x) {
-        const int cc = e / n, r = e - cc * n;
-        Xs[(size_t)cc * ns + r] = Xin[e];
+    for (int e = tid; e < k * ns; e += blockDim.x) {
+        const int cc = e / ns, r = e - cc * ns;
+        Xs[e] = r < n ? Xin[(size_t)cc * n + r] : make_double2(0.0, 0.0);
     }
-    for (int e = tid; e < k * k; e += blockDim.x) {
-        const int cc = e / k, i = e - cc * k;
-        Vs[(size_t)cc * ks + i] = warm ? Vr[e] : make_double2(cc == i ? 1.0 : 0.0, 0.0);
+    for (int e = tid; e < k * ks; e += blockDim.x) {
+        const int cc = e / ks, i = e - cc * ks;
+        double2 v = make_double2(0.0, 0.0);
+        if (i < k) v = warm ? Vr[(size_t)cc * k + i] : make_double2(cc == i ? 1.0 : 0.0, 0.0);
+        Vs[e] = v;
     }
     __syncthreads();
     const int Cp = k + (k & 1);
     const int rounds = Cp - 1;
-    const int pairs = Cp / 2;
+    const int skip = k & 1;                                 // odd k: pair 0 of every round holds the dummy player
+    const int pairs = Cp / 2 - skip;
     const int ngroups = blockDim.x / JAC_TG;
     const int group = tid / JAC_TG, t = tid - group * JAC_TG;
     const int per_group = (pairs + ngroups - 1) / ngroups;
@@ -241,8 +263,8 @@ __global__ void __launch_bounds__(JL_MAX_THREADS) k_polar_jacobi_lds(const doubl
                 const int cc = cc0 + group;
                 double s2 = 0.0;
                 if (cc < k)
-                    for (int row = t; row < n; row += JAC_TG) s2 += cabs2(Xs[(size_t)cc * ns + row]);
-                for (int o = JAC_TG / 2; o > 0; o >>= 1) s2 += __shfl_xor(s2, o, JAC_TG);
+                    for (int u = 0; u < nr; ++u) s2 += cabs2(Xs[(size_t)cc * ns + t + u * JAC_TG]);
+                s2 = group8_sum(s2);
                 if (cc < k && t == 0) s_isig[cc] = s2;
                 Sl = fmax(Sl, s2);
             }
@@ -253,7 +275,7 @@ __global__ void __launch_bounds__(JL_MAX_THREADS) k_polar_jacobi_lds(const doubl
             for (int cc0 = 0; cc0 < k; cc0 += ngroups) {
                 const int cc = cc0 + group;
                 if (cc < k && s_isig[cc] <= (JAC_DEFLATE * JAC_DEFLATE) * S && s_isig[cc] > 0.0)
-                    for (int row = t; row < n; row += JAC_TG) Xs[(size_t)cc * ns + row] = make_double2(0.0, 0.0);
+                    for (int u = 0; u < nr; ++u) Xs[(size_t)cc * ns + t + u * JAC_TG] = make_double2(0.0, 0.0);
             }
             __syncthreads();
             double gmax = 0.0;                                 // largest g2/(alpha beta) seen by this group
@@ -263,34 +285,29 @@ __global__ void __launch_bounds__(JL_MAX_THREADS) k_polar_jacobi_lds(const doubl
                     int ci = 0, cj = 0;
                     bool valid = pi < pairs;
                     if (valid) {
-                        jacobi_pair(r, pi, Cp, &ci, &cj);
+                        jacobi_pair(r, pi + skip, Cp, &ci, &cj);
                         valid = (ci < k) && (cj < k);
                     }
-                    double2* xi = Xs + (size_t)ci * ns;
-                    double2* xj = Xs + (size_t)cj * ns;
+                    double2* xi = Xs + (size_t)ci * ns + t;
+                    double2* xj = Xs + (size_t)cj * ns + t;
                     double2 ra[MAXR], rb[MAXR];
                     double alpha = 0.0, beta = 0.0, gr = 0.0, gi = 0.0;
 #pragma unroll
                     for (int u = 0; u < MAXR; ++u) {
-                        const int row = t + u * JAC_TG;
-                        double2 a = make_double2(0.0, 0.0), c2 = make_double2(0.0, 0.0);
-                        if (valid && row < n) {
-                            a = xi[row];
-                            c2 = xj[row];
+                        if (u < nr) {                            // block-uniform
+                            const double2 a = xi[u * JAC_TG], c2 = xj[u * JAC_TG];
+                            ra[u] = a;
+                            rb[u] = c2;
+                            alpha += cabs2(a);
+                            beta += cabs2(c2);
+                            gr += a.x * c2.x + a.y * c2.y;     // conj(a) * c2
+                            gi += a.x * c2.y - a.y * c2.x;
                         }
-                        ra[u] = a;
-                        rb[u] = c2;
-                        alpha += cabs2(a);
-                        beta += cabs2(c2);
-                        gr += a.x * c2.x + a.y * c2.y;     // conj(a) * c2
-                        gi += a.x * c2.y - a.y * c2.x;
                     }
-                    for (int o = JAC_TG / 2; o > 0; o >>= 1) {
-                        alpha += __shfl_xor(alpha, o, JAC_TG);
-                        beta += __shfl_xor(beta, o, JAC_TG);
-                        gr += __shfl_xor(gr, o, JAC_TG);
-                        gi += __shfl_xor(gi, o, JAC_TG);
-                    }
+                    alpha = group8_sum(alpha);
+                    beta = group8_sum(beta);
+                    gr = group8_sum(gr);
+                    gi = group8_sum(gi);
                     const double g2 = gr * gr + gi * gi;
                     const double ab = alpha * beta;
                     if (valid && g2 > (JAC_TOL * JAC_TOL) * ab && g2 > tabs2 * fmax(alpha, beta) * S && g2 > 0.0) {
@@ -305,24 +322,22 @@ __global__ void __launch_bounds__(JL_MAX_THREADS) k_polar_jacobi_lds(const doubl
                         const double2 em = make_double2(gr * inv_g, -gi * inv_g);   // conj(gamma)/|gamma|
 #pragma unroll
                         for (int u = 0; u < MAXR; ++u) {
-                            const int row = t + u * JAC_TG;
-                            if (row < n) {
+                            if (u < nr) {
                                 const double2 a = ra[u];
                                 const double2 bj = cmul(em, rb[u]);
-                                xi[row] = make_double2(cs * a.x - sn * bj.x, cs * a.y - sn * bj.y);
-                                xj[row] = make_double2(sn * a.x + cs * bj.x, sn * a.y + cs * bj.y);
+                                xi[u * JAC_TG] = make_double2(cs * a.x - sn * bj.x, cs * a.y - sn * bj.y);
+                                xj[u * JAC_TG] = make_double2(sn * a.x + cs * bj.x, sn * a.y + cs * bj.y);
                             }
                         }
-                        double2* vi = Vs + (size_t)ci * ks;
-                        double2* vj = Vs + (size_t)cj * ks;
+                        double2* vi = Vs + (size_t)ci * ks + t;
+                        double2* vj = Vs + (size_t)cj * ks + t;
 #pragma unroll
                         for (int u = 0; u < MAXR; ++u) {
-                            const int row = t + u * JAC_TG;
-                            if (row < k) {
-                                const double2 a = vi[row];
-                                const double2 bj = cmul(em, vj[row]);
-                                vi[row] = make_double2(cs * a.x - sn * bj.x, cs * a.y - sn * bj.y);
-                                vj[row] = make_double2(sn * a.x + cs * bj.x, sn * a.y + cs * bj.y);
+                            if (u < kr) {
+                                const double2 a = vi[u * JAC_TG];
+                                const double2 bj = cmul(em, vj[u * JAC_TG]);
+                                vi[u * JAC_TG] = make_double2(cs * a.x - sn * bj.x, cs * a.y - sn * bj.y);
+                                vj[u * JAC_TG] = make_double2(sn * a.x + cs * bj.x, sn * a.y + cs * bj.y);
                             }
                         }
                     }
@@ -346,14 +361,12 @@ __global__ void __launch_bounds__(JL_MAX_THREADS) k_polar_jacobi_lds(const doubl
         }
     }
     // sigma_c and the normalised columns Pn = W Sigma^-1
-    for (int cc0 = 0; cc0 < k; cc0 += ngroups) {           // uniform trip count: the shuffles are wave collectives
+    for (int cc0 = 0; cc0 < k; cc0 += ngroups) {           // uniform trip count: DPP sums need the whole group
         const int cc = cc0 + group;
         double s2 = 0.0;
-        if (cc < k) {
-            const double2* wc = Xs + (size_t)cc * ns;
-            for (int row = t; row < n; row += JAC_TG) s2 += cabs2(wc[row]);
-        }
-        for (int o = JAC_TG / 2; o > 0; o >>= 1) s2 += __shfl_xor(s2, o, JAC_TG);
+        if (cc < k)
+            for (int u = 0; u < nr; ++u) s2 += cabs2(Xs[(size_t)cc * ns + t + u * JAC_TG]);
+        s2 = group8_sum(s2);
         if (cc < k && t == 0) s_isig[cc] = s2 > 1e-300 ? 1.0 / sqrt(s2) : 0.0;
     }
     __syncthreads();
@@ -449,8 +462,8 @@ void launch_project_coefficients(mtip_ctx* c, const double2* Ilm, double2* out) 
     hipLaunchKernelGGL(k_proj_X, gmat, dim3(256), 0, c->stream, Ilm, c->d_X, (const double2*)c->d_V,
                        (const double*)c->d_q, (const int*)c->d_kl, (const int*)c->d_active, (const int*)c->d_voff,
                        (const int*)c->d_xoff, c->N, c->L, c->xtot);
-    const size_t lds = ((size_t)kmax * (nmax | 1) + (size_t)kmax * (kmax | 1)) * sizeof(double2);
-    if (lds <= 150 * 1024) {
+    const size_t lds = ((size_t)kmax * (((nmax + 7) / 8) * 8 + 1) + (size_t)kmax * (((kmax + 7) / 8) * 8 + 1)) * sizeof(double2);
+    if (lds <= 158 * 1024) {
         // cold start every 64 calls bounds the accumulated rounding drift of the carried V_r
         const int warm = (c->vr_valid && (c->proj_calls % 64) != 0) ? 1 : 0;
         const double2* src = c->d_X;
@@ -460,7 +473,7 @@ void launch_project_coefficients(mtip_ctx* c, const double2* Ilm, double2* out) 
                                (const int*)c->d_uoff, c->xtot, c->utot);
             src = c->d_U;
         }
-        const int pairs_max = (kmax + 1) / 2;
+        const int pairs_max = kmax / 2;                         // valid pairs per round (odd k: dummy pair skipped)
         int threads = ((pairs_max * JAC_TG + 63) / 64) * 64;
         threads = std::min(std::max(threads, 64), JL_MAX_THREADS);
         const dim3 gj((unsigned)(c->L + 1), (unsigned)c->B);

@@ -40,6 +40,20 @@ void build_legendre_tables(mtip_ctx* c, const double* cos_theta) {
     }
     (void)hipMemcpy(c->d_P, P.data(), P.size() * sizeof(double), hipMemcpyHostToDevice);
     (void)hipMemcpy(c->d_poff, poff.data(), poff.size() * sizeof(int), hipMemcpyHostToDevice);
+    // theta-major copy of the northern half + (l,m) lookup for the fused kernels (k_sht_fused.hip)
+    if (c->d_PT != nullptr) {
+        const int nth = nt / 2;
+        std::vector<double> PT((size_t)nth * rows);
+        std::vector<int> lmtab(rows);
+        for (int m = 0; m <= L; ++m)
+            for (int l = m; l <= L; ++l) {
+                const size_t idx = (size_t)poff[m] + l - m;
+                lmtab[idx] = l | (m << 8);
+                for (int t = 0; t < nth; ++t) PT[(size_t)t * rows + idx] = P[idx * nt + t];
+            }
+        (void)hipMemcpy(c->d_PT, PT.data(), PT.size() * sizeof(double), hipMemcpyHostToDevice);
+        (void)hipMemcpy(c->d_lmtab, lmtab.data(), lmtab.size() * sizeof(int), hipMemcpyHostToDevice);
+    }
     // twiddles exp(-2 pi i j / n_phi), j < n_phi/2
     std::vector<double2> tw(c->np / 2);
     for (int j = 0; j < c->np / 2; ++j) {
@@ -249,6 +263,10 @@ static void fft_launch_dims(const mtip_ctx* c, long long nrows, dim3* grid, dim3
 
 void launch_sht_forward(mtip_ctx* c, const double2* grid, double2* coeff, int prologue, int in_slot) {
     ProfScope ps(c, "sht_fwd");
+    if (sht_fused_supported(c)) {
+        launch_sht_forward_fused(c, grid, coeff, prologue, in_slot);
+        return;
+    }
     const long long nrows = (long long)c->B * c->N * c->nt;
     dim3 gr, bl;
     size_t sm;
@@ -268,6 +286,10 @@ void launch_sht_forward(mtip_ctx* c, const double2* grid, double2* coeff, int pr
 
 void launch_sht_inverse(mtip_ctx* c, const double2* coeff, double2* grid, const InvEpilogue& epi) {
     ProfScope ps(c, "sht_inv");
+    if (sht_fused_supported(c)) {
+        launch_sht_inverse_fused(c, coeff, grid, epi);
+        return;
+    }
     const long long nrows = (long long)c->B * c->N * c->nt;
     const long long total = nrows * c->nm;
     hipLaunchKernelGGL(k_leg_inv, dim3((unsigned)div_up(total, 256)), dim3(256), 0, c->stream, coeff, c->d_g,

@@ -64,8 +64,15 @@ struct mtip_ctx {
     // tables
     double *d_cost = nullptr, *d_gw = nullptr, *d_P = nullptr, *d_r = nullptr, *d_q = nullptr;
     int* d_poff = nullptr;
+    double* d_PT = nullptr;                           // (nt/2, npairs) theta-major Legendre table (fused SHT)
+    int* d_lmtab = nullptr;                           // (npairs) l | m << 8
+    int npairs = 0;
+    bool sht_unfused = false;                         // env MTIP_SHT_UNFUSED=1: two-kernel SHT (A/B testing)
     double2* d_tw = nullptr;
     double* d_W = nullptr;
+    void* d_htiles = nullptr;                         // HankelTile list of the MFMA kernel
+    int n_htiles = 0;
+    bool hankel_simple = false;                       // env MTIP_HANKEL_SIMPLE=1: one-thread-per-output kernel
     double fwd_scale = 0, inv_scale = 0;
     bool have_angular = false, have_radial = false, have_weights = false, have_support = false, have_errw = false;
     // projection data
@@ -130,8 +137,12 @@ struct InvEpilogue {
 };
 void launch_sht_inverse(mtip_ctx* c, const double2* coeff, double2* grid, const InvEpilogue& epi);
 void build_legendre_tables(mtip_ctx* c, const double* cos_theta);
+bool sht_fused_supported(const mtip_ctx* c);
+void launch_sht_forward_fused(mtip_ctx* c, const double2* grid, double2* coeff, int prologue, int in_slot);
+void launch_sht_inverse_fused(mtip_ctx* c, const double2* coeff, double2* grid, const InvEpilogue& epi);
 // Hankel
 void launch_hankel(mtip_ctx* c, const double2* in, double2* out, int inverse);
+int build_hankel_tiles(mtip_ctx* c);
 void launch_coeff_diff(mtip_ctx* c, const double2* a, const double2* b, double2* out);
 // reciprocal projection
 void launch_project_coefficients(mtip_ctx* c, const double2* Ilm, double2* out);
