@@ -61,6 +61,14 @@ void build_legendre_tables(mtip_ctx* c, const double* cos_theta) {
         tw[j] = make_double2(std::cos(a), std::sin(a));
     }
     (void)hipMemcpy(c->d_tw, tw.data(), tw.size() * sizeof(double2), hipMemcpyHostToDevice);
+    if (c->d_twN != nullptr) {                       // full-circle table for the register FFT kernels
+        std::vector<double2> twn(c->np);
+        for (int j = 0; j < c->np; ++j) {
+            const double a = -2.0 * pi * j / c->np;
+            twn[j] = make_double2(std::cos(a), std::sin(a));
+        }
+        (void)hipMemcpy(c->d_twN, twn.data(), twn.size() * sizeof(double2), hipMemcpyHostToDevice);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -263,6 +271,10 @@ static void fft_launch_dims(const mtip_ctx* c, long long nrows, dim3* grid, dim3
 
 void launch_sht_forward(mtip_ctx* c, const double2* grid, double2* coeff, int prologue, int in_slot) {
     ProfScope ps(c, "sht_fwd");
+    if (sht_reg_supported(c)) {
+        launch_sht_forward_reg(c, grid, coeff, prologue, in_slot);
+        return;
+    }
     if (sht_fused_supported(c)) {
         launch_sht_forward_fused(c, grid, coeff, prologue, in_slot);
         return;
@@ -286,6 +298,10 @@ void launch_sht_forward(mtip_ctx* c, const double2* grid, double2* coeff, int pr
 
 void launch_sht_inverse(mtip_ctx* c, const double2* coeff, double2* grid, const InvEpilogue& epi) {
     ProfScope ps(c, "sht_inv");
+    if (sht_reg_supported(c)) {
+        launch_sht_inverse_reg(c, coeff, grid, epi);
+        return;
+    }
     if (sht_fused_supported(c)) {
         launch_sht_inverse_fused(c, coeff, grid, epi);
         return;

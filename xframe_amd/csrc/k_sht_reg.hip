@@ -1,0 +1,407 @@
+// Spherical-harmonic transforms with register-resident FFTs (row a4 of SURVEY section 8), one workgroup per shell.
+//
+// The phi-FFT of length N = R1 * R2 (16 = 4x4, 32 = 4x8, 64 = 8x8, 128 = 8x16, 256 = 16x16) is done as two
+// rounds of small FFTs held entirely in registers with ONE transpose through LDS in between (Cooley-Tukey
+// n = R2 n1 + n2, k = k1 + R1 k2), instead of log2(N) LDS round trips + barriers per row:
+//   forward  thread (pair j, n2): loads x[R2 n1 + n2] of row theta_j and of its mirror row (coalesced), folds them
+//            into even/odd parts (FFT is linear, so the mirror fold happens before the transform), two R1-point
+//            FFTs, twiddle w_N^(n2 k1), store to LDS;   thread (row, k1): R2-point FFT, keeps |m| <= L, scales
+//            by the Gauss weight and writes the (theta, m) panel to LDS;   then every thread accumulates its
+//            (l, m >= 0) coefficients in registers:  c_lm += P_lm(theta_j) * E/O[j][m]  (table PT, L2 resident).
+//   inverse  Legendre synthesis of a block of thetas (+ mirrors) into LDS, R2-point inverse FFTs over k2, twiddle,
+//            LDS transpose, R1-point inverse FFTs, fused epilogue, coalesced stores.
+// ~4 barriers per 32 (forward) / 16 (inverse) grid rows; ~5x fewer instructions than the LDS Stockham variant
+// (k_sht_fused.hip), which stays as the fallback for other n_phi.
+#include "mtip_internal.h"
+
+#define SR_THREADS 256
+
+// exp(-2 pi i j / 16), j = 0..7
+__device__ __forceinline__ double2 tw16(int j) {
+    const double c1 = 0.92387953251128673848, s1 = 0.38268343236508978178, h = 0.70710678118654752440;
+    switch (j) {
+        case 0: return make_double2(1.0, 0.0);
+        case 1: return make_double2(c1, -s1);
+        case 2: return make_double2(h, -h);
+        case 3: return make_double2(s1, -c1);
+        case 4: return make_double2(0.0, -1.0);
+        case 5: return make_double2(-s1, -c1);
+        case 6: return make_double2(-h, -h);
+        default: return make_double2(-c1, -s1);
+    }
+}
+
+// in-register FFT of R points (natural order in and out), decimation in time, fully unrolled
+template <int R, bool INV>
+struct SmallFFT {
+    static __device__ __forceinline__ void run(double2 (&v)[R]) {
+        double2 e[R / 2], o[R / 2];
+#pragma unroll
+        for (int i = 0; i < R / 2; ++i) {
+            e[i] = v[2 * i];
+            o[i] = v[2 * i + 1];
+        }
+        SmallFFT<R / 2, INV>::run(e);
+        SmallFFT<R / 2, INV>::run(o);
+#pragma unroll
+        for (int k = 0; k < R / 2; ++k) {
+            const int j = k * (16 / R);
+            double2 t;
+            if (j == 0) {
+                t = o[k];
+            } else if (j == 4) {
+                t = INV ? make_double2(-o[k].y, o[k].x) : make_double2(o[k].y, -o[k].x);   // * (+-i)
+            } else {
+                double2 w = tw16(j);
+                if (INV) w.y = -w.y;
+                t = cmul(o[k], w);
+            }
+            v[k] = cadd(e[k], t);
+            v[k + R / 2] = csub(e[k], t);
+        }
+    }
+};
+template <bool INV>
+struct SmallFFT<1, INV> {
+    static __device__ __forceinline__ void run(double2 (&)[1]) {}
+};
+
+// ------------------------------------------------------------------------------------------------------
+template <int PRE, int R1, int R2, int MAXI>
+__global__ void __launch_bounds__(SR_THREADS) k_sht_fwd_reg(const double2* __restrict__ grid, double2* __restrict__ coeff,
+                                                            const double* __restrict__ PT, const int* __restrict__ lmtab,
+                                                            const double2* __restrict__ twN_g, const double* __restrict__ gw,
+                                                            int nt, int L, int npairs, int RP, double norm,
+                                                            const int* __restrict__ slot, int which, int B, int Nq) {
+    constexpr int N = R1 * R2;
+    constexpr int AS = R2 + 1;                      // padded row of the transpose buffer
+    HIP_DYNAMIC_SHARED(double2, sm)
+    const int nm = 2 * L + 1;
+    const int nlm = (L + 1) * (L + 1);
+    double2* twN = sm;                              // N       exp(-2 pi i j / N)
+    double2* A = twN + N;                           // RP * R1 * AS   (aliased by the (theta, m) panel G: RP * nm)
+    double2* G = A;
+    const int tid = threadIdx.x;
+    const long long shell = blockIdx.x;
+    for (int e = tid; e < N; e += blockDim.x) twN[e] = twN_g[e];
+    long long src_shell = shell;                    // slot-indirect input: (3, B, Nq, ...) pair array
+    if (slot != nullptr) src_shell += (long long)slot[(shell / Nq) * SL_N + which] * B * Nq;
+    const double2* gsrc = grid + (size_t)src_shell * nt * N;
+    int my_l[MAXI], my_m[MAXI];
+    double2 accp[MAXI], accm[MAXI];
+#pragma unroll
+    for (int u = 0; u < MAXI; ++u) {
+        const int idx = tid + u * SR_THREADS;
+        const int lm = idx < npairs ? lmtab[idx] : 0;
+        my_l[u] = lm & 0xff;
+        my_m[u] = lm >> 8;
+        accp[u] = make_double2(0.0, 0.0);
+        accm[u] = make_double2(0.0, 0.0);
+    }
+    const int half = RP >> 1;
+    const int n_pass = nt / RP;
+    __syncthreads();
+    for (int pass = 0; pass < n_pass; ++pass) {
+        // ---- phase 1: fold theta / mirror, R1-point FFTs over n1, twiddle, transpose store
+        if (tid < half * R2) {
+            const int j = tid / R2, n2 = tid - j * R2;
+            const int th = pass * half + j;
+            const double2* rn = gsrc + (size_t)th * N + n2;
+            const double2* rs = gsrc + (size_t)(nt - 1 - th) * N + n2;
+            double2 ev[R1], ov[R1];
+#pragma unroll
+            for (int n1 = 0; n1 < R1; ++n1) {
+                double2 a = rn[R2 * n1];
+                double2 b = rs[R2 * n1];
+                if (PRE == MTIP_PRE_SQUARE) {
+                    a = make_double2(cabs2(a), 0.0);
+                    b = make_double2(cabs2(b), 0.0);
+                } else if (PRE == MTIP_PRE_ABS) {
+                    a = make_double2(sqrt(cabs2(a)), 0.0);
+                    b = make_double2(sqrt(cabs2(b)), 0.0);
+                }
+                ev[n1] = cadd(a, b);
+                ov[n1] = csub(a, b);
+            }
+            SmallFFT<R1, false>::run(ev);
+            SmallFFT<R1, false>::run(ov);
+            double2* ae = A + (size_t)(2 * j) * R1 * AS + n2;
+            double2* ao = ae + (size_t)R1 * AS;
+#pragma unroll
+            for (int k1 = 0; k1 < R1; ++k1) {
+                const double2 w = twN[n2 * k1];
+                ae[k1 * AS] = cmul(ev[k1], w);
+                ao[k1 * AS] = cmul(ov[k1], w);
+            }
+        }
+        __syncthreads();
+        // ---- phase 2: R2-point FFTs over n2; keep |m| <= L
+        double2 uv[R2];
+        const bool act2 = tid < RP * R1;
+        const int r2 = tid / R1, k1 = tid - r2 * R1;
+        if (act2) {
+            const double2* ar = A + (size_t)(r2 * R1 + k1) * AS;
+#pragma unroll
+            for (int n2 = 0; n2 < R2; ++n2) uv[n2] = ar[n2];
+        }
+        __syncthreads();                                // A is dead from here on: G may overwrite it
+        if (act2) {
+            SmallFFT<R2, false>::run(uv);
+            const double sc = gw[pass * half + (r2 >> 1)] * norm;
+            double2* gr = G + (size_t)r2 * nm + L;
+#pragma unroll
+            for (int k2 = 0; k2 < R2; ++k2) {
+                const int k = k1 + R1 * k2;
+                if (k <= L) gr[k] = cscale(uv[k2], sc);
+                else if (k >= N - L) gr[k - N] = cscale(uv[k2], sc);
+            }
+        }
+        __syncthreads();
+        // ---- Legendre accumulation (rows 2j = even part, 2j+1 = odd part of theta pair j)
+#pragma unroll
+        for (int u = 0; u < MAXI; ++u) {
+            const int idx = tid + u * SR_THREADS;
+            if (idx < npairs) {
+                const int l = my_l[u], m = my_m[u];
+                const double2* src = G + (size_t)((l + m) & 1) * nm + L;
+                const double* pt = PT + (size_t)(pass * half) * npairs + idx;
+                double2 ap = accp[u], am = accm[u];
+                for (int j = 0; j < half; ++j) {
+                    const double p = pt[(size_t)j * npairs];
+                    const double2 vp = src[(size_t)(2 * j) * nm + m];
+                    const double2 vm = src[(size_t)(2 * j) * nm - m];
+                    ap.x = fma(p, vp.x, ap.x);
+                    ap.y = fma(p, vp.y, ap.y);
+                    am.x = fma(p, vm.x, am.x);
+                    am.y = fma(p, vm.y, am.y);
+                }
+                accp[u] = ap;
+                accm[u] = am;
+            }
+        }
+        __syncthreads();                                // the next pass rewrites A / G
+    }
+    double2* cdst = coeff + (size_t)shell * nlm;
+#pragma unroll
+    for (int u = 0; u < MAXI; ++u) {
+        const int idx = tid + u * SR_THREADS;
+        if (idx < npairs) {
+            const int l = my_l[u], m = my_m[u];
+            cdst[l * (l + 1) + m] = accp[u];
+            if (m > 0) cdst[l * (l + 1) - m] = (m & 1) ? make_double2(-accm[u].x, -accm[u].y) : accm[u];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+template <int EPI, int R1, int R2>
+__global__ void __launch_bounds__(SR_THREADS) k_sht_inv_reg(const double2* __restrict__ coeff, double2* __restrict__ grid,
+                                                            const double* __restrict__ PT, const int* __restrict__ poff,
+                                                            const double2* __restrict__ twN_g, int nt, int L, int npairs,
+                                                            int RP, int Nq, const double2* __restrict__ Fin,
+                                                            const double* __restrict__ shell_scale,
+                                                            const int* __restrict__ slot, int which, int B) {
+    constexpr int N = R1 * R2;
+    constexpr int AS = R2 + 1;
+    HIP_DYNAMIC_SHARED(double2, sm)
+    const int nm = 2 * L + 1;
+    const int nlm = (L + 1) * (L + 1);
+    double2* twN = sm;                              // N
+    double2* cl = twN + N;                          // nlm
+    double2* Gs = cl + nlm;                         // RP * nm        spectra: row 2j = theta_j, 2j+1 = mirror
+    double2* Bm = Gs + (size_t)RP * nm;             // RP * R1 * AS   transpose buffer
+    const int tid = threadIdx.x;
+    const long long shell = blockIdx.x;
+    const int q = (int)(shell % Nq);
+    const double2* csrc = coeff + (size_t)shell * nlm;
+    for (int e = tid; e < N; e += blockDim.x) twN[e] = twN_g[e];
+    for (int e = tid; e < nlm; e += blockDim.x) cl[e] = csrc[e];
+    long long dst_shell = shell;
+    if (slot != nullptr) dst_shell += (long long)slot[(shell / Nq) * SL_N + which] * B * Nq;
+    double2* gdst = grid + (size_t)dst_shell * nt * N;
+    const double2* fsrc = Fin ? Fin + (size_t)shell * nt * N : nullptr;
+    const int half = RP >> 1;
+    const int n_pass = nt / RP;
+    const int ipt = (L + 2) / 2;                    // items per theta: m pairs (mm, L - mm) of equal total length
+    __syncthreads();
+    for (int pass = 0; pass < n_pass; ++pass) {
+        // ---- Legendre synthesis of `half` thetas and their mirrors
+        for (int item = tid; item < half * ipt; item += blockDim.x) {
+            const int j = item / ipt, mm = item - j * ipt;
+            const int th = pass * half + j;
+            const double* prow = PT + (size_t)th * npairs;
+            double2* g_n = Gs + (size_t)(2 * j) * nm + L;
+            double2* g_s = g_n + nm;
+            for (int side = 0; side < 2; ++side) {
+                const int m = side == 0 ? mm : L - mm;
+                if (side == 1 && m == mm) break;        // middle m of an even L is done once
+                const double* pp = prow + poff[m] - m;
+                double2 ep = make_double2(0.0, 0.0), op = ep, em = ep, om = ep;
+                for (int l = m; l <= L; ++l) {
+                    const double p = pp[l];
+                    const double2 cp = cl[l * (l + 1) + m];
+                    const double2 cm = cl[l * (l + 1) - m];
+                    if ((l - m) & 1) {
+                        op.x = fma(p, cp.x, op.x); op.y = fma(p, cp.y, op.y);
+                        om.x = fma(p, cm.x, om.x); om.y = fma(p, cm.y, om.y);
+                    } else {
+                        ep.x = fma(p, cp.x, ep.x); ep.y = fma(p, cp.y, ep.y);
+                        em.x = fma(p, cm.x, em.x); em.y = fma(p, cm.y, em.y);
+                    }
+                }
+                const double sg = (m & 1) ? -1.0 : 1.0;
+                g_n[m] = cadd(ep, op);
+                g_s[m] = csub(ep, op);
+                if (m > 0) {
+                    g_n[-m] = make_double2(sg * (em.x + om.x), sg * (em.y + om.y));
+                    g_s[-m] = make_double2(sg * (em.x - om.x), sg * (em.y - om.y));
+                }
+            }
+        }
+        __syncthreads();
+        // ---- step 1: inverse R2-point FFTs over k2 of the zero padded spectrum, twiddle, transpose store
+        if (tid < RP * R1) {
+            const int r = tid / R1, k1 = tid - r * R1;
+            const double2* gr = Gs + (size_t)r * nm + L;
+            double2 uv[R2];
+#pragma unroll
+            for (int k2 = 0; k2 < R2; ++k2) {
+                const int k = k1 + R1 * k2;
+                double2 v = make_double2(0.0, 0.0);
+                if (k <= L) v = gr[k];
+                else if (k >= N - L) v = gr[k - N];
+                uv[k2] = v;
+            }
+            SmallFFT<R2, true>::run(uv);
+            double2* br = Bm + (size_t)(r * R1 + k1) * AS;
+#pragma unroll
+            for (int n2 = 0; n2 < R2; ++n2) {
+                double2 w = twN[n2 * k1];
+                w.y = -w.y;
+                br[n2] = cmul(uv[n2], w);
+            }
+        }
+        __syncthreads();
+        // ---- step 2: inverse R1-point FFTs over k1, epilogue, coalesced store
+        if (tid < RP * R2) {
+            const int r = tid / R2, n2 = tid - r * R2;
+            const double2* br = Bm + (size_t)r * R1 * AS + n2;
+            double2 vv[R1];
+#pragma unroll
+            for (int k1 = 0; k1 < R1; ++k1) vv[k1] = br[k1 * AS];
+            SmallFFT<R1, true>::run(vv);
+            const int th = pass * half + (r >> 1);
+            const int row = (r & 1) ? (nt - 1 - th) : th;
+#pragma unroll
+            for (int n1 = 0; n1 < R1; ++n1) {
+                double2 v = vv[n1];
+                const size_t o = (size_t)row * N + R2 * n1 + n2;
+                if (EPI == EPI_MODULUS) {
+                    // project_to_modified_intensity, fxs_Projections.py:899-909
+                    const double2 Fv = fsrc[o];
+                    const double I = cabs2(Fv);
+                    const bool ok = (I >= 0.0) && (v.x >= 0.0);
+                    const double mult = ok ? sqrt(v.x / I) : 0.0;
+                    v = cscale(Fv, mult);
+                } else if (EPI == EPI_SCALE_SHELL) {
+                    v = cscale(v, shell_scale[q]);
+                }
+                gdst[o] = v;
+            }
+        }
+        __syncthreads();                                // Gs / Bm are rewritten by the next pass
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+static bool reg_radices(int np, int* r1, int* r2) {
+    switch (np) {
+        case 16: *r1 = 4; *r2 = 4; return true;
+        case 32: *r1 = 4; *r2 = 8; return true;
+        case 64: *r1 = 8; *r2 = 8; return true;
+        case 128: *r1 = 8; *r2 = 16; return true;
+        case 256: *r1 = 16; *r2 = 16; return true;
+        default: return false;
+    }
+}
+
+static int largest_even_divisor_le(int nt, int cap) {
+    for (int v = std::min(nt, cap) & ~1; v >= 2; v -= 2)
+        if (nt % v == 0) return v;
+    return 0;
+}
+
+bool sht_reg_supported(const mtip_ctx* c) {
+    int r1, r2;
+    if (c->sht_mode < 2 || c->d_PT == nullptr || c->d_twN == nullptr || (c->nt & 1)) return false;
+    if (!reg_radices(c->np, &r1, &r2)) return false;
+    const int rpf = largest_even_divisor_le(c->nt, std::min(2 * SR_THREADS / r2, SR_THREADS / r1));
+    const int rpi = largest_even_divisor_le(c->nt, std::min(SR_THREADS / r2, SR_THREADS / r1));
+    if (rpf < 2 || rpi < 2) return false;
+    const size_t lds_f = ((size_t)c->np + (size_t)rpf * r1 * (r2 + 1)) * sizeof(double2);
+    const size_t lds_i = ((size_t)c->np + c->nlm + (size_t)rpi * c->nm + (size_t)rpi * r1 * (r2 + 1)) * sizeof(double2);
+    return lds_f <= 160 * 1024 && lds_i <= 160 * 1024;
+}
+
+template <int PRE, int R1, int R2>
+static void launch_fwd_r(mtip_ctx* c, const double2* grid, double2* coeff, int in_slot) {
+    const int RP = largest_even_divisor_le(c->nt, std::min(2 * SR_THREADS / R2, SR_THREADS / R1));
+    const size_t smem = ((size_t)c->np + (size_t)RP * R1 * (R2 + 1)) * sizeof(double2);
+    const double norm = 2.0 * 3.14159265358979323846 / c->np;
+    const int* sl = in_slot >= 0 ? c->d_slot : nullptr;
+    const dim3 gr((unsigned)(c->B * c->N)), bl(SR_THREADS);
+    const int per = div_up(c->npairs, SR_THREADS);
+#define FWD_ARGS grid, coeff, (const double*)c->d_PT, (const int*)c->d_lmtab, (const double2*)c->d_twN, (const double*)c->d_gw, \
+                 c->nt, c->L, c->npairs, RP, norm, sl, in_slot, c->B, c->N
+    if (per <= 3) hipLaunchKernelGGL((k_sht_fwd_reg<PRE, R1, R2, 3>), gr, bl, smem, c->stream, FWD_ARGS);
+    else if (per <= 5) hipLaunchKernelGGL((k_sht_fwd_reg<PRE, R1, R2, 5>), gr, bl, smem, c->stream, FWD_ARGS);
+    else hipLaunchKernelGGL((k_sht_fwd_reg<PRE, R1, R2, 9>), gr, bl, smem, c->stream, FWD_ARGS);
+#undef FWD_ARGS
+}
+
+template <int PRE>
+static void launch_fwd_p(mtip_ctx* c, const double2* grid, double2* coeff, int in_slot) {
+    switch (c->np) {
+        case 16: launch_fwd_r<PRE, 4, 4>(c, grid, coeff, in_slot); break;
+        case 32: launch_fwd_r<PRE, 4, 8>(c, grid, coeff, in_slot); break;
+        case 64: launch_fwd_r<PRE, 8, 8>(c, grid, coeff, in_slot); break;
+        case 128: launch_fwd_r<PRE, 8, 16>(c, grid, coeff, in_slot); break;
+        default: launch_fwd_r<PRE, 16, 16>(c, grid, coeff, in_slot); break;
+    }
+}
+
+void launch_sht_forward_reg(mtip_ctx* c, const double2* grid, double2* coeff, int prologue, int in_slot) {
+    if (prologue == MTIP_PRE_SQUARE) launch_fwd_p<MTIP_PRE_SQUARE>(c, grid, coeff, in_slot);
+    else if (prologue == MTIP_PRE_ABS) launch_fwd_p<MTIP_PRE_ABS>(c, grid, coeff, in_slot);
+    else launch_fwd_p<MTIP_PRE_NONE>(c, grid, coeff, in_slot);
+}
+
+template <int EPI, int R1, int R2>
+static void launch_inv_r(mtip_ctx* c, const double2* coeff, double2* grid, const InvEpilogue& epi) {
+    const int RP = largest_even_divisor_le(c->nt, std::min(SR_THREADS / R2, SR_THREADS / R1));
+    const size_t smem = ((size_t)c->np + c->nlm + (size_t)RP * c->nm + (size_t)RP * R1 * (R2 + 1)) * sizeof(double2);
+    const int* sl = epi.out_slot >= 0 ? c->d_slot : nullptr;
+    const dim3 gr((unsigned)(c->B * c->N)), bl(SR_THREADS);
+    hipLaunchKernelGGL((k_sht_inv_reg<EPI, R1, R2>), gr, bl, smem, c->stream, coeff, grid, (const double*)c->d_PT,
+                       (const int*)c->d_poff, (const double2*)c->d_twN, c->nt, c->L, c->npairs, RP, c->N, epi.F,
+                       epi.shell_scale, sl, epi.out_slot, c->B);
+}
+
+template <int EPI>
+static void launch_inv_p(mtip_ctx* c, const double2* coeff, double2* grid, const InvEpilogue& epi) {
+    switch (c->np) {
+        case 16: launch_inv_r<EPI, 4, 4>(c, coeff, grid, epi); break;
+        case 32: launch_inv_r<EPI, 4, 8>(c, coeff, grid, epi); break;
+        case 64: launch_inv_r<EPI, 8, 8>(c, coeff, grid, epi); break;
+        case 128: launch_inv_r<EPI, 8, 16>(c, coeff, grid, epi); break;
+        default: launch_inv_r<EPI, 16, 16>(c, coeff, grid, epi); break;
+    }
+}
+
+void launch_sht_inverse_reg(mtip_ctx* c, const double2* coeff, double2* grid, const InvEpilogue& epi) {
+    switch (epi.mode) {
+        case EPI_MODULUS: launch_inv_p<EPI_MODULUS>(c, coeff, grid, epi); break;
+        case EPI_SCALE_SHELL: launch_inv_p<EPI_SCALE_SHELL>(c, coeff, grid, epi); break;
+        default: launch_inv_p<EPI_STORE>(c, coeff, grid, epi); break;
+    }
+}

@@ -67,7 +67,9 @@ struct mtip_ctx {
     double* d_PT = nullptr;                           // (nt/2, npairs) theta-major Legendre table (fused SHT)
     int* d_lmtab = nullptr;                           // (npairs) l | m << 8
     int npairs = 0;
-    bool sht_unfused = false;                         // env MTIP_SHT_UNFUSED=1: two-kernel SHT (A/B testing)
+    bool sht_unfused = false;                         // MTIP_SHT_MODE=0: two-kernel SHT (A/B testing)
+    int sht_mode = 2;                                 // env MTIP_SHT_MODE: 0 unfused, 1 LDS-Stockham fused, 2 register FFT
+    double2* d_twN = nullptr;                         // exp(-2 pi i j / n_phi), j < n_phi
     double2* d_tw = nullptr;
     double* d_W = nullptr;
     void* d_htiles = nullptr;                         // HankelTile list of the MFMA kernel
@@ -140,6 +142,9 @@ void build_legendre_tables(mtip_ctx* c, const double* cos_theta);
 bool sht_fused_supported(const mtip_ctx* c);
 void launch_sht_forward_fused(mtip_ctx* c, const double2* grid, double2* coeff, int prologue, int in_slot);
 void launch_sht_inverse_fused(mtip_ctx* c, const double2* coeff, double2* grid, const InvEpilogue& epi);
+bool sht_reg_supported(const mtip_ctx* c);
+void launch_sht_forward_reg(mtip_ctx* c, const double2* grid, double2* coeff, int prologue, int in_slot);
+void launch_sht_inverse_reg(mtip_ctx* c, const double2* coeff, double2* grid, const InvEpilogue& epi);
 // Hankel
 void launch_hankel(mtip_ctx* c, const double2* in, double2* out, int inverse);
 int build_hankel_tiles(mtip_ctx* c);
