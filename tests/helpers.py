@@ -38,7 +38,7 @@ def golden_settings(N, L, extra=None):
     o = OM.deep_update(OM.default_settings(), S.config_overrides(1))
     o = OM.deep_update(o, {'grid': {'n_radial_points': N, 'max_order': L},
                            'projections': {'reciprocal': {'used_order_ids': np.arange(L + 1)}},
-                           'GPU': {'use': False}, 'multi_process': {'use': False}})
+                           'GPU': {'use': True}, 'multi_process': {'use': False}})
     if extra:
         o = OM.deep_update(o, extra)
     return o

@@ -1,0 +1,132 @@
+"""Host-side mirror of the reference API (worker schema, operator registry + sketches, GPU-process boundary),
+run on the CPU emulation build of the kernels."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from helpers import data_from_golden, golden_settings, rel_l2
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+EMUL_DIR = os.path.join(HERE, 'emul')
+EMUL_LIB = os.path.join(EMUL_DIR, 'libmtip_emul.so')
+
+
+@pytest.fixture(scope='module')
+def emul_lib():
+    r = subprocess.run(['make', '-C', EMUL_DIR, '-j6'], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    return EMUL_LIB
+
+
+def test_worker_result_schema(emul_lib, golden_mtip16):
+    """The schema the reference's integration test pins (tests/test_fxs_integration.py:388-423)."""
+    from xframe_amd.fxs import reconstruct as R
+    g = golden_mtip16
+    N, L = int(g['N']), int(g['L'])
+    opt = golden_settings(N, L, {'multi_process': {'use': True, 'n_parallel_reconstructions': 2}})
+    main = opt['main_loop']['sub_loops']['main']
+    main['methods']['HIO']['iterations'] = 2
+    main['methods']['ER']['iterations'] = 2
+    main['iterations'] = 2
+    w = R.ProjectWorker(opt, data_from_golden(g, L), seeds=[1, 2], lib_path=emul_lib)
+    result, _ = w.run()
+    assert result.dtype == object and len(result) == 2
+    n_steps = 2 * (2 + 2)
+    shape = (N, 8, 16)
+    for r in result:
+        for key in ('real_density', 'last_real_density', 'reciprocal_density', 'last_reciprocal_density', 'initial_density'):
+            assert r[key].shape == shape and r[key].dtype == np.complex128 and not np.isnan(r[key]).any(), key
+        for key in ('initial_support', 'support_mask', 'last_support_mask'):
+            assert r[key].shape == shape and r[key].dtype == bool, key
+        assert r['error_dict']['main'].shape == (n_steps,)
+        assert r['error_dict']['real']['l2_projection_diff'].shape == (n_steps,)
+        assert len(r['fxs_unknowns']) == L + 1
+        for l, u in enumerate(r['fxs_unknowns']):
+            assert u.shape == (min(2 * l + 1, N), 2 * l + 1) and u.dtype == np.complex128
+        assert r['last_deg2_invariant'].shape == (L + 1, N, N)
+        assert r['loop_iterations'] == 3 and np.isfinite(r['final_error'])
+        assert r['grid_pair']['real_grid'].shape == shape + (3,)
+        assert len(r['projection_matrices']) == L + 1
+        assert r['n_particles'].shape == (n_steps, 1)
+    assert set(w.results['reconstruction_results']) == {'0', '1'}
+    with pytest.raises(RuntimeError):
+        R.ProjectWorker(dict(opt, GPU={'use': False}), data_from_golden(g, L), lib_path=emul_lib)
+
+
+def test_reference_sketch_on_registry(emul_lib, golden_mtip16):
+    """The reference's HIO_ft_stab sketch (reconstruct.py:584-593, MTIP_start 518-528) executed through
+    RecipeFactory on the HIP-backed operators == the device-resident step."""
+    from xframe_amd.fxs.engine import Engine
+    from xframe_amd.fxs.operators import RecipeFactory, build_operators
+    g = golden_mtip16
+    N, L = int(g['N']), int(g['L'])
+    e = Engine(golden_settings(N, L), data_from_golden(g, L), n_batch=1, lib_path=emul_lib, fused=False)
+    f = RecipeFactory({})
+    ops = build_operators(e)
+    f.addOperators(ops)
+    f.addOperators({'save_to_dict': lambda *a: None, 'save_number_of_particles': lambda: None,
+                    'calc_reciprocal_errors': [lambda a, b, c: {}, 3], 'calc_real_errors': [lambda a, b: {}, 2]})
+    mtip_start = [
+        [(0, 0), ['copy', 'square_grid']],
+        [(0, 1, 1), ['id', 'harmonic_transform', 'copy']],
+        [(0, 1, 1, 2), ['id', 'id', 'approximate_unknowns', 'id']],
+        [(0, 1, 2, 1, 3), ['id', 'mtip_projection', 'id', 'id']],
+        [(0, 1, 2, 3), ['id', 'inverse_harmonic_transform', 'id', 'id']],
+        [(0, 0, 3, 1, 2), ['id', 'project_to_modified_intensity', 'save_number_of_particles', 'id']],
+        [(0, 1, 2, 1), ['calc_reciprocal_errors', 'id']],
+        [(1,), ['id']]]
+    f.addOperators({'MTIP_start': f.buildProcessFromSketch(mtip_start)})
+    sketch = [
+        [(1, 1), ['fourier_transform', 'id']],
+        [(0, 0, 0, 1), ['MTIP_start', 'inverse_fourier_transform', 'id']],
+        [(0, 2, 1, 2, 0), ['inverse_fourier_transform', 'diff', 'id', 'id']],
+        [(0, 1, 2, 3), ['add_above_zero_index', 'id', 'id']],
+        [(0, 0, 1, 2), ['copy', 'real_projection', 'id', 'id']],
+        [(0, 1, 2, 0, 1, 3), ['hybrid_input_output', 'calc_real_errors', 'id']],
+        [(2, 0), ['id', 'id']]]
+    proc = f.buildProcessFromSketch(sketch)
+    e.set_density(0, g['rho0'])
+    e.init_state()
+    rho = e.density(0)
+    e.hio_beta = 0.45
+    F_new, rho_new = proc.run(np.zeros_like(rho), np.array(rho))
+    e.run('HIO', True, [0.45])
+    assert rel_l2(F_new, e.reciprocal_density(0)) < 1e-10
+    assert rel_l2(rho_new, e.density(0)) < 1e-10
+    e.close()
+
+
+def test_gpu_process_boundary(emul_lib):
+    """ClProcess / add_gpu_process look-alike: the reference's test_GPU contract gpu_func(vects) == matrix @ vects
+    (tests/test_framework_integration.py:230-400) and the spherical Hankel kernel_dict of
+    hankel_transforms.py:733-759."""
+    from oracle import hankel as OH
+    from xframe_amd.fxs.gpu_process import ClProcess, _GpuProcessManager
+    mgr = _GpuProcessManager()
+    rng = np.random.default_rng(0)
+    nq, nvec = 12, 5
+    matrix = rng.integers(-4, 5, (nq, nq)).astype(float)
+    vects = rng.integers(-4, 5, (nq, nvec)).astype(float)
+    kd = {'kernel': 'apply_matrix', 'name': 'matmul',
+          'functions': ({'name': 'apply_matrix', 'dtypes': (float, float, float, np.int64, np.int64),
+                         'shapes': ((nq, nvec), (nq, nq), (nq, nvec), None, None),
+                         'arg_roles': ('output', 'const_input', 'input', 'const_input', 'const_input'),
+                         'const_inputs': (None, matrix, None, np.int64(nq), np.int64(nvec)),
+                         'global_range': (nq, nvec), 'local_range': None},)}
+    gpu_func = mgr.add_gpu_process(ClProcess(kd), lib_path=emul_lib)
+    assert (gpu_func(vects) == matrix @ vects).all()            # exact on small integers, like the reference test
+    L, kappa = 3, 2.0
+    w = OH.assemble_weights(OH.spherical_mid_weights(L, nq, kappa), 37.0, kappa)
+    nlm = (L + 1) ** 2
+    for key in ('forward', 'inverse'):
+        kdh = {'kernel': '__kernel void apply_weights(...) { /* OpenCL source is ignored */ }', 'name': key + '_hankel',
+               'functions': ({'name': 'apply_weights', 'dtypes': (complex, complex, complex, np.int64, np.int64, np.int64),
+                              'shapes': ((nq, nlm), w[key].shape, (nq, nlm), None, None, None),
+                              'arg_roles': ('output', 'const_input', 'input', 'const_input', 'const_input', 'const_input'),
+                              'const_inputs': (None, w[key], None, np.int64(nq), np.int64(nlm), np.int64(L + 1)),
+                              'global_range': (nq, nlm), 'local_range': None},)}
+        fn = mgr.add_gpu_process(ClProcess(kdh), lib_path=emul_lib)
+        rho = rng.normal(size=(nq, nlm)) + 1j * rng.normal(size=(nq, nlm))
+        assert rel_l2(fn(rho), OH.apply_direct(w[key], rho)) < 1e-12

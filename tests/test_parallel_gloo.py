@@ -1,0 +1,81 @@
+"""N > 1 path on CPU: two gloo ranks shard the restarts, each runs its batch through the worker (on the CPU
+emulation build of the kernels -- there is no GPU here), rank 0 gathers the result dicts; the rotation-invariant
+B_l are all-reduced.  The same code path runs with backend nccl (= RCCL) on the MI355X node."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+EMUL_DIR = os.path.join(HERE, 'emul')
+
+WORKER = r'''
+import os, sys, json
+import numpy as np
+sys.path.insert(0, {root!r}); sys.path.insert(0, {here!r})
+np.seterr(all='ignore')
+import torch.distributed as dist
+from helpers import data_from_golden, golden_settings
+from xframe_amd.fxs import reconstruct as R, parallel as P
+rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+dist.init_process_group('gloo', rank=rank, world_size=world)
+g = np.load(os.path.join({here!r}, 'golden', 'mtip_N16_L4.npz'))
+N, L = int(g['N']), int(g['L'])
+opt = golden_settings(N, L, {{'multi_process': {{'use': True, 'n_parallel_reconstructions': 3}}}})
+main = opt['main_loop']['sub_loops']['main']
+main['methods']['HIO']['iterations'] = 2; main['methods']['ER']['iterations'] = 1; main['iterations'] = 1
+w = R.ProjectWorker(opt, data_from_golden(g, L), rank=rank, world_size=world, seeds=[11, 12, 13],
+                    lib_path=os.path.join({emul!r}, 'libmtip_emul.so'))
+result, _ = w.run()
+mine = P.shard_restarts(3, rank, world)
+own = [result[i] for i in mine] if rank == 0 else list(result)     # rank 0 holds all restarts, others only theirs
+allv = P.gather_scalars(np.array([float(len(mine)), float(rank)]))
+bl_sum = sum(r['last_deg2_invariant'] for r in own)
+mean_bl = P.average_invariants(bl_sum, len(own))
+out = {{'rank': rank, 'n_results': int(len(result)), 'mine': mine,
+       'gathered': allv.tolist(), 'bl_trace': float(np.trace(mean_bl[0]).real),
+       'errs': [float(r['final_error']) for r in result],
+       'sorted': [int(i) for i in w.results.get('sorted_ids', [])]}}
+print('RESULT ' + json.dumps(out), flush=True)
+dist.destroy_process_group()
+'''
+
+
+@pytest.fixture(scope='module')
+def emul_lib():
+    r = subprocess.run(['make', '-C', EMUL_DIR, '-j6'], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_shard_restarts_round_robin():
+    from xframe_amd.fxs.parallel import shard_restarts
+    assert shard_restarts(64, 3, 8) == list(range(3, 64, 8))
+    assert sorted(sum((shard_restarts(10, r, 4) for r in range(4)), [])) == list(range(10))
+    assert shard_restarts(2, 3, 4) == []
+
+
+def test_two_rank_gloo_worker(emul_lib, tmp_path):
+    import json
+    script = tmp_path / 'worker.py'
+    script.write_text(WORKER.format(root=ROOT, here=HERE, emul=EMUL_DIR))
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29571', WORLD_SIZE='2', MTIP_EMUL_THREADS='2')
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True) for r in range(2)]
+    outs = []
+    for p in procs:
+        o, e = p.communicate(timeout=600)
+        assert p.returncode == 0, e[-3000:]
+        outs.append(json.loads([l for l in o.splitlines() if l.startswith('RESULT ')][0][7:]))
+    r0 = [o for o in outs if o['rank'] == 0][0]
+    r1 = [o for o in outs if o['rank'] == 1][0]
+    assert r0['mine'] == [0, 2] and r1['mine'] == [1]
+    assert r0['n_results'] == 3                      # rank 0 holds every restart after the gather
+    assert r0['gathered'] == [[2.0, 0.0], [1.0, 1.0]] == r1['gathered']
+    assert np.isclose(r0['bl_trace'], r1['bl_trace'], rtol=1e-12)       # all-reduced mean B_l identical on both ranks
+    assert len(r0['errs']) == 3 and all(np.isfinite(r0['errs']))
+    assert sorted(r0['sorted']) == [0, 1, 2]
+    assert r0['errs'][r0['sorted'][0]] == min(r0['errs'])
+    assert r1['n_results'] == 1
