@@ -44,13 +44,17 @@ __global__ void __launch_bounds__(256) k_proj_X(const double2* __restrict__ Ilm,
 
 // tournament pairing of round r: players 0..Cp-1 (Cp even), pair index pi in [0, Cp/2)
 __device__ __forceinline__ void jacobi_pair(int r, int pi, int Cp, int* a, int* b) {
-    const int M = Cp - 1;
+    const int M = Cp - 1;                 // 0 <= r < M, 0 <= pi <= M/2: one conditional subtract replaces the modulo
     if (pi == 0) {
-        *a = r % M;
+        *a = r;
         *b = M;
     } else {
-        *a = (r + pi) % M;
-        *b = (r - pi + M) % M;
+        int x = r + pi;
+        if (x >= M) x -= M;
+        int y = r - pi + M;
+        if (y >= M) y -= M;
+        *a = x;
+        *b = y;
     }
 }
 
