@@ -122,6 +122,8 @@ def main():
     sw_sigma = hs.LinearRamp(20, [False, 5], -2, default_start=e0.default_sigma, default_stop=e0.default_sigma)
     CHUNK = 10                                                  # steps enqueued per engine before switching
 
+    host = {'enqueue_s': 0.0}
+
     def run_schedule(n_steps, start_step=0):
         step = start_step
         sw_count = 0
@@ -135,8 +137,10 @@ def main():
             while done < k:
                 c = min(CHUNK, k - done)
                 betas = np.array([ramp.eval(step + done + i) for i in range(c)])
+                th = time.perf_counter()
                 for e in engines:
                     e.run(kind, True, betas, fetch=False)
+                host['enqueue_s'] += time.perf_counter() - th
                 done += c
             step += k
         return step
@@ -151,6 +155,7 @@ def main():
     sync_all()
     if dist is not None:
         dist.barrier()
+    host['enqueue_s'] = 0.0
     t0 = time.perf_counter()
     run_schedule(a.steps, start_step=a.warmup)
     sync_all()
@@ -254,6 +259,7 @@ def main():
                        'parallelism': f'restart-sharded x{world}', 'step_mode': 'exact' if a.exact else 'fused'},
             'roofline': roofline, 'cpu_baseline': cpu, 'whole_step': whole_step, 'kernel_families_ms': fam_ms,
             'setup_seconds': setup_s, 'final_reduce_seconds': reduce_s,
+            'host_enqueue_ms_per_step': 1e3 * host['enqueue_s'] / max(a.steps, 1),
             'best_error_rank0': [float(x) for x in best_err], 'steps_done_per_restart': int(n_done),
             'mean_B0_trace': float(np.trace(bl_mean[0]).real),
             'jacobi_sweeps_last_step_restart0': [int(x) for x in sweeps[0]],

@@ -161,7 +161,8 @@ int mtip_op_apply_matrix(mtip_ctx* ctx, const double* matrix, const double* vect
 int mtip_profile(mtip_ctx* ctx, int enable);
 int mtip_profile_get(mtip_ctx* ctx, const char* name, double* total_ms, int64_t* launches);
 int mtip_profile_reset(mtip_ctx* ctx);
-/* diagnostic: Jacobi sweeps used by the last polar-factor solve, (n_batch, L+1) int32 */
+/* diagnostic of the last polar-factor solve, (n_batch, L+1) int32: bits 0-7 Jacobi sweeps used, bits 8+ the
+ * number of columns of X_l that were still non-zero (not deflated) in the final sweep */
 int mtip_debug_jacobi_sweeps(mtip_ctx* ctx, int32_t* out);
 
 #ifdef __cplusplus

@@ -26,7 +26,8 @@ def run(kind, n):
         step += 1
         if i in (0, 1, 2, 5, 10, 20, n - 1):
             sw = e.jacobi_sweeps()[0][::2]
-            print(kind, step, 'err %.3e' % err[0, 0], 'ms %.2f' % (dt * 1e3), 'sweeps(even l)', list(sw))
+            print(kind, step, 'err %.3e' % err[0, 0], 'ms %.2f' % (dt * 1e3), 'sweeps(even l)', [int(x) for x in sw],
+                  'active cols', [int(x) for x in e.jacobi_active_columns()[0][::2]])
 run('HIO', 60)
 print('SW', e.shrinkwrap(20.0, 0.09, 6e-3))
 run('ER', 40)

@@ -201,35 +201,164 @@ __device__ __forceinline__ double dpp_add(double v) {
     const int hi2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
     return v + __hiloint2double(hi2, lo2);
 }
-__device__ __forceinline__ double group8_sum(double v) {
+template <int TG>
+__device__ __forceinline__ double group_sum(double v) {
     v = dpp_add<0xB1>(v);
     v = dpp_add<0x4E>(v);
     v = dpp_add<0x141>(v);
+    if (TG == 16) v = dpp_add<0x140>(v);                   // row_mirror (lane i <-> 15-i) joins the two halves
     return v;
+}
+
+// Rotation parameters of one column pair from its Gram entries (alpha, beta, gamma = gr + i gi): returns false
+// when the pair is already orthogonal to tolerance.
+__device__ __forceinline__ bool jl_params(double alpha, double beta, double gr, double gi, bool valid, double tabs2,
+                                          double S, double& gmax, double& cs, double& sn, double2& em) {
+    const double g2 = gr * gr + gi * gi;
+    const double ab = alpha * beta;
+    if (!(valid && g2 > (JAC_TOL * JAC_TOL) * ab && g2 > tabs2 * fmax(alpha, beta) * S && g2 > 0.0)) return false;
+    gmax = fmax(gmax, g2 * fast_rcp(ab));
+    const double inv_g = fast_rsqrt(g2);
+    const double zeta = 0.5 * (beta - alpha) * inv_g;
+    const double z1 = 1.0 + zeta * zeta;
+    const double rt = z1 * fast_rsqrt(z1);               // sqrt(1 + zeta^2)
+    const double tt = (zeta >= 0.0 ? 1.0 : -1.0) * fast_rcp(fabs(zeta) + rt);
+    cs = fast_rsqrt(1.0 + tt * tt);
+    sn = cs * tt;
+    em = make_double2(gr * inv_g, -gi * inv_g);          // conj(gamma)/|gamma|
+    return true;
+}
+
+// One column pair of a tournament round, NR row slots per lane for X and for V_r, no branches inside the row
+// loops: only the last slot can fall outside the column (xl_ok / vl_ok), its loads are issued anyway (the
+// address stays inside the LDS allocation) and zeroed by a select, its stores are predicated.  The V_r loads
+// are issued before the rotation parameters are known so that their latency hides behind that arithmetic.
+template <int NR, int TG>
+__device__ __forceinline__ void jl_pair(double2* xi, double2* xj, double2* vi, double2* vj, bool xl_ok, bool vl_ok,
+                                        bool valid, double tabs2, double S, double& gmax) {
+    double2 ra[NR], rb[NR], va[NR], vb[NR];
+#pragma unroll
+    for (int u = 0; u < NR; ++u) {
+        ra[u] = xi[u * TG];
+        rb[u] = xj[u * TG];
+    }
+#pragma unroll
+    for (int u = 0; u < NR; ++u) {
+        va[u] = vi[u * TG];
+        vb[u] = vj[u * TG];
+    }
+    if (!xl_ok) {
+        ra[NR - 1] = make_double2(0.0, 0.0);
+        rb[NR - 1] = make_double2(0.0, 0.0);
+    }
+    double alpha = 0.0, beta = 0.0, gr = 0.0, gi = 0.0;
+#pragma unroll
+    for (int u = 0; u < NR; ++u) {
+        const double2 a = ra[u], c2 = rb[u];
+        alpha += cabs2(a);
+        beta += cabs2(c2);
+        gr += a.x * c2.x + a.y * c2.y;                     // conj(a) * c2
+        gi += a.x * c2.y - a.y * c2.x;
+    }
+    alpha = group_sum<TG>(alpha);
+    beta = group_sum<TG>(beta);
+    gr = group_sum<TG>(gr);
+    gi = group_sum<TG>(gi);
+    double cs, sn;
+    double2 em;
+    if (!jl_params(alpha, beta, gr, gi, valid, tabs2, S, gmax, cs, sn, em)) return;
+#pragma unroll
+    for (int u = 0; u < NR; ++u) {
+        const double2 a = ra[u];
+        const double2 bj = cmul(em, rb[u]);
+        if (u < NR - 1 || xl_ok) {
+            xi[u * TG] = make_double2(cs * a.x - sn * bj.x, cs * a.y - sn * bj.y);
+            xj[u * TG] = make_double2(sn * a.x + cs * bj.x, sn * a.y + cs * bj.y);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < NR; ++u) {
+        const double2 a = va[u];
+        const double2 bj = cmul(em, vb[u]);
+        if (u < NR - 1 || vl_ok) {
+            vi[u * TG] = make_double2(cs * a.x - sn * bj.x, cs * a.y - sn * bj.y);
+            vj[u * TG] = make_double2(sn * a.x + cs * bj.x, sn * a.y + cs * bj.y);
+        }
+    }
+}
+
+// same with run-time row counts (k_l != 2l+1, or more row slots than the specialised bodies cover)
+template <int MAXR, int TG>
+__device__ __forceinline__ void jl_pair_generic(double2* xi, double2* xj, double2* vi, double2* vj, int nr, int kr, int n,
+                                                int k, int pad, int t, bool valid, double tabs2, double S, double& gmax) {
+    double2 ra[MAXR], rb[MAXR];
+    double alpha = 0.0, beta = 0.0, gr = 0.0, gi = 0.0;
+#pragma unroll
+    for (int u = 0; u < MAXR; ++u) {
+        ra[u] = make_double2(0.0, 0.0);
+        rb[u] = make_double2(0.0, 0.0);
+        if (u < nr && (pad || t + u * TG < n)) {
+            const double2 a = xi[u * TG], c2 = xj[u * TG];
+            ra[u] = a;
+            rb[u] = c2;
+            alpha += cabs2(a);
+            beta += cabs2(c2);
+            gr += a.x * c2.x + a.y * c2.y;
+            gi += a.x * c2.y - a.y * c2.x;
+        }
+    }
+    alpha = group_sum<TG>(alpha);
+    beta = group_sum<TG>(beta);
+    gr = group_sum<TG>(gr);
+    gi = group_sum<TG>(gi);
+    double cs, sn;
+    double2 em;
+    if (!jl_params(alpha, beta, gr, gi, valid, tabs2, S, gmax, cs, sn, em)) return;
+#pragma unroll
+    for (int u = 0; u < MAXR; ++u) {
+        if (u < nr && (pad || t + u * TG < n)) {
+            const double2 a = ra[u];
+            const double2 bj = cmul(em, rb[u]);
+            xi[u * TG] = make_double2(cs * a.x - sn * bj.x, cs * a.y - sn * bj.y);
+            xj[u * TG] = make_double2(sn * a.x + cs * bj.x, sn * a.y + cs * bj.y);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < MAXR; ++u) {
+        if (u < kr && (pad || t + u * TG < k)) {
+            const double2 a = vi[u * TG];
+            const double2 bj = cmul(em, vj[u * TG]);
+            vi[u * TG] = make_double2(cs * a.x - sn * bj.x, cs * a.y - sn * bj.y);
+            vj[u * TG] = make_double2(sn * a.x + cs * bj.x, sn * a.y + cs * bj.y);
+        }
+    }
 }
 
 // MAXR = upper bound of the rows of a column handled by one lane of a pair-group (ceil(n / 8) <= MAXR).  Columns
 // are zero padded to a multiple of 8 rows in LDS, so the row loops need no per-lane predicate; the two columns of
 // the pair stay in registers between the Gram reduction and the rotation.  For odd k the tournament pair that
 // contains the dummy player is skipped, so ceil(k/2) <= 32 pair-groups (one wave per SIMD at k <= 65) suffice.
-template <int MAXR>
+template <int MAXR, int TG>
 __global__ void __launch_bounds__(JL_MAX_THREADS) k_polar_jacobi_lds(const double2* __restrict__ Xin_all,
                                                                     double2* __restrict__ Pn_all,
                                                                     double2* __restrict__ Vr_all, const int* __restrict__ kl,
                                                                     const int* __restrict__ active,
                                                                     const int* __restrict__ xoff, const int* __restrict__ roff,
                                                                     int xtot, int rtot, int L, int warm, double tabs2,
-                                                                    int* __restrict__ sweeps_out) {
+                                                                    int* __restrict__ sweeps_out, int pad) {
     HIP_DYNAMIC_SHARED(double2, sm)
-    __shared__ double s_gmax[JL_MAX_THREADS / JAC_TG];
+    __shared__ double s_gmax[JL_MAX_THREADS / 8];
     __shared__ double s_isig[128];
     __shared__ int s_continue;
+    __shared__ int s_perm[128];
+    __shared__ int s_keff;
     const int l = L - (int)blockIdx.x;                      // heavy orders first
     const int b = blockIdx.y;
     if (!active[l]) return;                                // uniform per block
     const int k = kl[l], n = 2 * l + 1;
-    const int nr = (n + JAC_TG - 1) / JAC_TG, kr = (k + JAC_TG - 1) / JAC_TG;   // rows per lane
-    const int ns = nr * JAC_TG + 1, ks = kr * JAC_TG + 1;  // padded, odd column strides
+    const int nr = (n + TG - 1) / TG, kr = (k + TG - 1) / TG;   // rows per lane
+    // column strides: odd; padded to whole lane-groups of rows when LDS allows (pad), else row predicates
+    const int ns = pad ? nr * TG + 1 : (n | 1), ks = pad ? kr * TG + 1 : (k | 1);
     double2* Xs = sm;
     double2* Vs = sm + (size_t)k * ns;
     const double2* Xin = Xin_all + (size_t)b * xtot + xoff[l];
@@ -247,13 +376,8 @@ __global__ void __launch_bounds__(JL_MAX_THREADS) k_polar_jacobi_lds(const doubl
         Vs[e] = v;
     }
     __syncthreads();
-    const int Cp = k + (k & 1);
-    const int rounds = Cp - 1;
-    const int skip = k & 1;                                 // odd k: pair 0 of every round holds the dummy player
-    const int pairs = Cp / 2 - skip;
-    const int ngroups = blockDim.x / JAC_TG;
-    const int group = tid / JAC_TG, t = tid - group * JAC_TG;
-    const int per_group = (pairs + ngroups - 1) / ngroups;
+    const int ngroups = blockDim.x / TG;
+    const int group = tid / TG, t = tid - group * TG;
     double S = 0.0;
     if (k > 1) {
         for (int sweep = 0; sweep < JAC_MAX_SWEEPS; ++sweep) {
@@ -267,8 +391,9 @@ __global__ void __launch_bounds__(JL_MAX_THREADS) k_polar_jacobi_lds(const doubl
                 const int cc = cc0 + group;
                 double s2 = 0.0;
                 if (cc < k)
-                    for (int u = 0; u < nr; ++u) s2 += cabs2(Xs[(size_t)cc * ns + t + u * JAC_TG]);
-                s2 = group8_sum(s2);
+                    for (int u = 0; u < nr; ++u)
+                        if (pad || t + u * TG < n) s2 += cabs2(Xs[(size_t)cc * ns + t + u * TG]);
+                s2 = group_sum<TG>(s2);
                 if (cc < k && t == 0) s_isig[cc] = s2;
                 Sl = fmax(Sl, s2);
             }
@@ -279,9 +404,24 @@ __global__ void __launch_bounds__(JL_MAX_THREADS) k_polar_jacobi_lds(const doubl
             for (int cc0 = 0; cc0 < k; cc0 += ngroups) {
                 const int cc = cc0 + group;
                 if (cc < k && s_isig[cc] <= (JAC_DEFLATE * JAC_DEFLATE) * S && s_isig[cc] > 0.0)
-                    for (int u = 0; u < nr; ++u) Xs[(size_t)cc * ns + t + u * JAC_TG] = make_double2(0.0, 0.0);
+                    for (int u = 0; u < nr; ++u)
+                        if (pad || t + u * TG < n) Xs[(size_t)cc * ns + t + u * TG] = make_double2(0.0, 0.0);
+            }
+            // Compaction: the tournament only runs over the columns that are still non-zero (numerical rank of X;
+            // about half of 2l+1 once the density has a support), through the index list s_perm.
+            if (tid == 0) {
+                int ne = 0;
+                for (int cc = 0; cc < k; ++cc)
+                    if (s_isig[cc] > (JAC_DEFLATE * JAC_DEFLATE) * S) s_perm[ne++] = cc;
+                s_keff = ne;
             }
             __syncthreads();
+            const int ke = s_keff;
+            const int Cp = ke + (ke & 1);
+            const int rounds = Cp - 1;
+            const int skip = ke & 1;                           // odd count: pair 0 of every round holds the dummy player
+            const int pairs = Cp / 2 - skip;
+            const int per_group = (pairs + ngroups - 1) / ngroups;
             double gmax = 0.0;                                 // largest g2/(alpha beta) seen by this group
             for (int r = 0; r < rounds; ++r) {
                 for (int it = 0; it < per_group; ++it) {
@@ -290,61 +430,40 @@ __global__ void __launch_bounds__(JL_MAX_THREADS) k_polar_jacobi_lds(const doubl
                     bool valid = pi < pairs;
                     if (valid) {
                         jacobi_pair(r, pi + skip, Cp, &ci, &cj);
-                        valid = (ci < k) && (cj < k);
+                        valid = (ci < ke) && (cj < ke);
+                        ci = valid ? s_perm[ci] : 0;
+                        cj = valid ? s_perm[cj] : 0;
                     }
                     double2* xi = Xs + (size_t)ci * ns + t;
                     double2* xj = Xs + (size_t)cj * ns + t;
-                    double2 ra[MAXR], rb[MAXR];
-                    double alpha = 0.0, beta = 0.0, gr = 0.0, gi = 0.0;
-#pragma unroll
-                    for (int u = 0; u < MAXR; ++u) {
-                        if (u < nr) {                            // block-uniform
-                            const double2 a = xi[u * JAC_TG], c2 = xj[u * JAC_TG];
-                            ra[u] = a;
-                            rb[u] = c2;
-                            alpha += cabs2(a);
-                            beta += cabs2(c2);
-                            gr += a.x * c2.x + a.y * c2.y;     // conj(a) * c2
-                            gi += a.x * c2.y - a.y * c2.x;
+                    double2* vi = Vs + (size_t)ci * ks + t;
+                    double2* vj = Vs + (size_t)cj * ks + t;
+                    // last row slot of this lane: inside the column?  (all earlier slots always are)
+                    const bool xl_ok = pad || t + (nr - 1) * TG < n, vl_ok = pad || t + (kr - 1) * TG < k;
+                    // block-uniform dispatch to a branch-free body with compile-time row counts
+                    bool done = false;
+                    if (nr == kr) {
+                        done = true;
+                        switch (nr) {
+                        case 1: jl_pair<1, TG>(xi, xj, vi, vj, xl_ok, vl_ok, valid, tabs2, S, gmax); break;
+                        case 2: jl_pair<2, TG>(xi, xj, vi, vj, xl_ok, vl_ok, valid, tabs2, S, gmax); break;
+                        case 3: jl_pair<3, TG>(xi, xj, vi, vj, xl_ok, vl_ok, valid, tabs2, S, gmax); break;
+                        case 4: jl_pair<4, TG>(xi, xj, vi, vj, xl_ok, vl_ok, valid, tabs2, S, gmax); break;
+                        case 5: jl_pair<5, TG>(xi, xj, vi, vj, xl_ok, vl_ok, valid, tabs2, S, gmax); break;
+                        default: done = false;
                         }
-                    }
-                    alpha = group8_sum(alpha);
-                    beta = group8_sum(beta);
-                    gr = group8_sum(gr);
-                    gi = group8_sum(gi);
-                    const double g2 = gr * gr + gi * gi;
-                    const double ab = alpha * beta;
-                    if (valid && g2 > (JAC_TOL * JAC_TOL) * ab && g2 > tabs2 * fmax(alpha, beta) * S && g2 > 0.0) {
-                        gmax = fmax(gmax, g2 * fast_rcp(ab));
-                        const double inv_g = fast_rsqrt(g2);
-                        const double zeta = 0.5 * (beta - alpha) * inv_g;
-                        const double z1 = 1.0 + zeta * zeta;
-                        const double rt = z1 * fast_rsqrt(z1);               // sqrt(1 + zeta^2)
-                        const double tt = (zeta >= 0.0 ? 1.0 : -1.0) * fast_rcp(fabs(zeta) + rt);
-                        const double cs = fast_rsqrt(1.0 + tt * tt);
-                        const double sn = cs * tt;
-                        const double2 em = make_double2(gr * inv_g, -gi * inv_g);   // conj(gamma)/|gamma|
-#pragma unroll
-                        for (int u = 0; u < MAXR; ++u) {
-                            if (u < nr) {
-                                const double2 a = ra[u];
-                                const double2 bj = cmul(em, rb[u]);
-                                xi[u * JAC_TG] = make_double2(cs * a.x - sn * bj.x, cs * a.y - sn * bj.y);
-                                xj[u * JAC_TG] = make_double2(sn * a.x + cs * bj.x, sn * a.y + cs * bj.y);
-                            }
-                        }
-                        double2* vi = Vs + (size_t)ci * ks + t;
-                        double2* vj = Vs + (size_t)cj * ks + t;
-#pragma unroll
-                        for (int u = 0; u < MAXR; ++u) {
-                            if (u < kr) {
-                                const double2 a = vi[u * JAC_TG];
-                                const double2 bj = cmul(em, vj[u * JAC_TG]);
-                                vi[u * JAC_TG] = make_double2(cs * a.x - sn * bj.x, cs * a.y - sn * bj.y);
-                                vj[u * JAC_TG] = make_double2(sn * a.x + cs * bj.x, sn * a.y + cs * bj.y);
+                        if (MAXR > 5 && !done) {
+                            done = true;
+                            switch (nr) {
+                            case 6: jl_pair<(MAXR > 5 ? 6 : 1), TG>(xi, xj, vi, vj, xl_ok, vl_ok, valid, tabs2, S, gmax); break;
+                            case 7: jl_pair<(MAXR > 5 ? 7 : 1), TG>(xi, xj, vi, vj, xl_ok, vl_ok, valid, tabs2, S, gmax); break;
+                            case 8: jl_pair<(MAXR > 5 ? 8 : 1), TG>(xi, xj, vi, vj, xl_ok, vl_ok, valid, tabs2, S, gmax); break;
+                            case 9: jl_pair<(MAXR > 5 ? 9 : 1), TG>(xi, xj, vi, vj, xl_ok, vl_ok, valid, tabs2, S, gmax); break;
+                            default: done = false;
                             }
                         }
                     }
+                    if (!done) jl_pair_generic<MAXR, TG>(xi, xj, vi, vj, nr, kr, n, k, pad, t, valid, tabs2, S, gmax);
                 }
                 __syncthreads();
             }
@@ -356,7 +475,7 @@ __global__ void __launch_bounds__(JL_MAX_THREADS) k_polar_jacobi_lds(const doubl
                 // m = max (|gamma|^2 / alpha beta); rotations happened iff m > 0. Quadratic convergence:
                 // the next sweep would see ~ m^2, so stop when sqrt(m) < JL_EARLY.
                 s_continue = (m > JL_EARLY * JL_EARLY) ? 1 : 0;
-                sweeps_out[b * (L + 1) + l] = sweep + 1;
+                sweeps_out[b * (L + 1) + l] = (sweep + 1) | (ke << 8);
             }
             __syncthreads();
             const int cont = s_continue;
@@ -369,8 +488,9 @@ __global__ void __launch_bounds__(JL_MAX_THREADS) k_polar_jacobi_lds(const doubl
         const int cc = cc0 + group;
         double s2 = 0.0;
         if (cc < k)
-            for (int u = 0; u < nr; ++u) s2 += cabs2(Xs[(size_t)cc * ns + t + u * JAC_TG]);
-        s2 = group8_sum(s2);
+            for (int u = 0; u < nr; ++u)
+                if (pad || t + u * TG < n) s2 += cabs2(Xs[(size_t)cc * ns + t + u * TG]);
+        s2 = group_sum<TG>(s2);
         if (cc < k && t == 0) s_isig[cc] = s2 > 1e-300 ? 1.0 / sqrt(s2) : 0.0;
     }
     __syncthreads();
@@ -466,7 +586,7 @@ void launch_project_coefficients(mtip_ctx* c, const double2* Ilm, double2* out) 
     hipLaunchKernelGGL(k_proj_X, gmat, dim3(256), 0, c->stream, Ilm, c->d_X, (const double2*)c->d_V,
                        (const double*)c->d_q, (const int*)c->d_kl, (const int*)c->d_active, (const int*)c->d_voff,
                        (const int*)c->d_xoff, c->N, c->L, c->xtot);
-    const size_t lds = ((size_t)kmax * (((nmax + 7) / 8) * 8 + 1) + (size_t)kmax * (((kmax + 7) / 8) * 8 + 1)) * sizeof(double2);
+    const size_t lds = ((size_t)kmax * (nmax | 1) + (size_t)kmax * (kmax | 1)) * sizeof(double2);   // unpadded minimum
     if (lds <= 158 * 1024) {
         // cold start every 64 calls bounds the accumulated rounding drift of the carried V_r
         const int warm = (c->vr_valid && (c->proj_calls % 64) != 0) ? 1 : 0;
@@ -478,17 +598,23 @@ void launch_project_coefficients(mtip_ctx* c, const double2* Ilm, double2* out) 
             src = c->d_U;
         }
         const int pairs_max = kmax / 2;                         // valid pairs per round (odd k: dummy pair skipped)
-        int threads = ((pairs_max * JAC_TG + 63) / 64) * 64;
+        // 16 lanes per pair (two waves per SIMD at k = 65: one wave's rotation parameters overlap the other's
+        // row updates) when all pairs of a round still fit one workgroup, else 8
+        const int tg = (c->jac_tg == 16 && pairs_max * 16 <= JL_MAX_THREADS && nmax <= 5 * 16) ? 16 : 8;
+        const size_t lds_pad = ((size_t)kmax * (div_up(nmax, tg) * tg + 1) + (size_t)kmax * (div_up(kmax, tg) * tg + 1)) * sizeof(double2);
+        const int pad = lds_pad <= 158 * 1024 ? 1 : 0;
+        const size_t lds_use = (pad ? lds_pad : ((size_t)kmax * (nmax | 1) + (size_t)kmax * (kmax | 1)) * sizeof(double2)) + 16 * sizeof(double2);
+        int threads = ((pairs_max * tg + 63) / 64) * 64;
         threads = std::min(std::max(threads, 64), JL_MAX_THREADS);
         const dim3 gj((unsigned)(c->L + 1), (unsigned)c->B);
-        if (nmax <= 9 * JAC_TG)
-            hipLaunchKernelGGL(k_polar_jacobi_lds<9>, gj, dim3(threads), lds, c->stream, src, c->d_X, c->d_Vr,
-                               (const int*)c->d_kl, (const int*)c->d_active, (const int*)c->d_xoff, (const int*)c->d_uoff,
-                               c->xtot, c->utot, c->L, warm, c->polar_abs_tol * c->polar_abs_tol, c->d_sweeps);
-        else
-            hipLaunchKernelGGL(k_polar_jacobi_lds<16>, gj, dim3(threads), lds, c->stream, src, c->d_X, c->d_Vr,
-                               (const int*)c->d_kl, (const int*)c->d_active, (const int*)c->d_xoff, (const int*)c->d_uoff,
-                               c->xtot, c->utot, c->L, warm, c->polar_abs_tol * c->polar_abs_tol, c->d_sweeps);
+#define JL_LAUNCH(MAXR, TG)                                                                                              \
+    hipLaunchKernelGGL((k_polar_jacobi_lds<MAXR, TG>), gj, dim3(threads), lds_use, c->stream, src, c->d_X, c->d_Vr,     \
+                       (const int*)c->d_kl, (const int*)c->d_active, (const int*)c->d_xoff, (const int*)c->d_uoff,      \
+                       c->xtot, c->utot, c->L, warm, c->polar_abs_tol * c->polar_abs_tol, c->d_sweeps, pad)
+        if (tg == 16) JL_LAUNCH(5, 16);
+        else if (nmax <= 9 * 8) JL_LAUNCH(9, 8);
+        else JL_LAUNCH(16, 8);
+#undef JL_LAUNCH
         hipLaunchKernelGGL(k_proj_U, gmat, dim3(256), 0, c->stream, (const double2*)c->d_X, (const double2*)c->d_Vr, c->d_U,
                            (const int*)c->d_kl, (const int*)c->d_active, (const int*)c->d_xoff, (const int*)c->d_uoff,
                            c->xtot, c->utot);

@@ -119,6 +119,7 @@ mtip_ctx* mtip_create(const mtip_cfg* cfg, int device) {
     A(dev_alloc(c, &c->d_PT, (size_t)(c->nt / 2 + 1) * c->npairs));
     A(dev_alloc(c, &c->d_lmtab, c->npairs));
     if (const char* e = std::getenv("MTIP_HANKEL_SIMPLE")) c->hankel_simple = std::atoi(e) != 0;
+    if (const char* e = std::getenv("MTIP_JAC_TG")) c->jac_tg = std::atoi(e) == 8 ? 8 : 16;
     if (rc == MTIP_OK) rc = build_hankel_tiles(c);
     A(dev_alloc(c, &c->d_twN, c->np));
     if (const char* e = std::getenv("MTIP_SHT_MODE")) c->sht_mode = std::atoi(e);

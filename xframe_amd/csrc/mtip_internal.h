@@ -74,6 +74,7 @@ struct mtip_ctx {
     double* d_W = nullptr;
     void* d_htiles = nullptr;                         // HankelTile list of the MFMA kernel
     int n_htiles = 0;
+    int jac_tg = 16;                                  // env MTIP_JAC_TG=8|16: lanes per Jacobi column pair
     bool hankel_simple = false;                       // env MTIP_HANKEL_SIMPLE=1: one-thread-per-output kernel
     double fwd_scale = 0, inv_scale = 0;
     bool have_angular = false, have_radial = false, have_weights = false, have_support = false, have_errw = false;

@@ -280,7 +280,13 @@ class Engine:
     def jacobi_sweeps(self):
         out = np.zeros((self.B, self.L + 1), np.int32)
         self._ck(self.lib.mtip_debug_jacobi_sweeps(self.ctx, _lib.ptr(out)))
-        return out
+        return out & 0xff
+
+    def jacobi_active_columns(self):
+        """columns of X_l the last polar-factor call still rotated in its final sweep (numerical rank estimate)"""
+        out = np.zeros((self.B, self.L + 1), np.int32)
+        self._ck(self.lib.mtip_debug_jacobi_sweeps(self.ctx, _lib.ptr(out)))
+        return out >> 8
 
     # ------------------------------------------------------------------ helpers shared with synthetic.py
     @property
