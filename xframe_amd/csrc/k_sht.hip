@@ -15,6 +15,7 @@ void build_legendre_tables(mtip_ctx* c, const double* cos_theta) {
     for (int m = 0; m <= L + 1; ++m) poff[m] = m * (L + 1) - m * (m - 1) / 2;
     const size_t rows = (size_t)(L + 1) * (L + 2) / 2;
     std::vector<double> P(rows * nt);
+    std::vector<double2> AB(rows, make_double2(0.0, 0.0));   // P_lm = a_lm (x P_l-1,m - b_lm P_l-2,m), l >= m + 2
     const double pi = 3.14159265358979323846;
     for (int t = 0; t < nt; ++t) {
         const double x = cos_theta[t];
@@ -32,6 +33,7 @@ void build_legendre_tables(mtip_ctx* c, const double* cos_theta) {
                     const double b = std::sqrt((((double)l - 1.0) * (l - 1.0) - (double)m * m) / (4.0 * (l - 1.0) * (l - 1.0) - 1.0));
                     const double p = a * (x * p1 - b * p2);
                     P[(size_t)(poff[m] + l - m) * nt + t] = p;
+                    AB[(size_t)poff[m] + l - m] = make_double2(a, b);
                     p2 = p1;
                     p1 = p;
                 }
@@ -40,6 +42,7 @@ void build_legendre_tables(mtip_ctx* c, const double* cos_theta) {
     }
     (void)hipMemcpy(c->d_P, P.data(), P.size() * sizeof(double), hipMemcpyHostToDevice);
     (void)hipMemcpy(c->d_poff, poff.data(), poff.size() * sizeof(int), hipMemcpyHostToDevice);
+    if (c->d_AB != nullptr) (void)hipMemcpy(c->d_AB, AB.data(), AB.size() * sizeof(double2), hipMemcpyHostToDevice);
     // theta-major copy of the northern half + (l,m) lookup for the fused kernels (k_sht_fused.hip)
     if (c->d_PT != nullptr) {
         const int nth = nt / 2;

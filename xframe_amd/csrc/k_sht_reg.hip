@@ -314,6 +314,182 @@ __global__ void __launch_bounds__(SR_THREADS) k_sht_inv_reg(const double2* __res
 }
 
 // ------------------------------------------------------------------------------------------------------
+// Inverse transform, "wide" variant: the Legendre synthesis of ALL thetas of the shell happens once, with the
+// wave as the unit of work -- lanes 0-31 = 32 northern thetas for +m, lanes 32-63 = the same thetas for -m, so
+// a wave has one m (uniform trip count, no divergence) and the coefficient c_l,+-m is an LDS broadcast.  Each
+// lane runs the three-term recurrence P_lm = a_lm (x P_l-1,m - b_lm P_l-2,m) for its theta in registers
+// ("LDS-staged Legendre recursion": a_lm, b_lm sit in LDS, the two start values P_mm, P_m+1,m come from the
+// table and are prefetched one item ahead), so the synthesis loop touches no global memory.  Even and odd l-m
+// accumulate separately (north = E + O, south = E - O).  Items (m, theta chunk) are dealt to the waves in
+// snake order of decreasing length, which balances them to within one column.  Then the spectra of all rows
+// sit in LDS and the two register-FFT steps run over RP rows per pass as in k_sht_inv_reg.  One 512-thread
+// workgroup per shell and CU (LDS: n_theta (2L+1) spectra + transpose buffer, 147 KB at 64 x 128, L = 32).
+#define SW_THREADS 512
+template <int EPI, int R1, int R2>
+__global__ void __launch_bounds__(SW_THREADS) k_sht_inv_wide(const double2* __restrict__ coeff, double2* __restrict__ grid,
+                                                             const double* __restrict__ P, const int* __restrict__ poff,
+                                                             const double2* __restrict__ AB, const double* __restrict__ cost,
+                                                             int npairs, const double2* __restrict__ twN_g, int nt, int L,
+                                                             int RP, int Nq, const double2* __restrict__ Fin,
+                                                             const double* __restrict__ shell_scale,
+                                                             const int* __restrict__ slot, int which, int B) {
+    constexpr int N = R1 * R2;
+    constexpr int AS = R2 + 1;
+    HIP_DYNAMIC_SHARED(double2, sm)
+    const int nm = 2 * L + 1;
+    const int nlm = (L + 1) * (L + 1);
+    double2* twN = sm;                              // N
+    double2* Gs = twN + N;                          // nt * nm        spectra: row 2j = theta_j, 2j+1 = its mirror
+    double2* ABs = Gs + (size_t)nt * nm;            // npairs         recurrence coefficients
+    double2* cl = ABs + npairs;                     // nlm            (Legendre phase)
+    double2* Bm = cl;                               // RP * R1 * AS   transpose buffer (FFT passes; reuses cl)
+    const int tid = threadIdx.x;
+    const long long shell = blockIdx.x;
+    const int q = (int)(shell % Nq);
+    const double2* csrc = coeff + (size_t)shell * nlm;
+    // Legendre work items (m, chunk of 32 thetas), dealt to the waves in snake order of decreasing length
+    const int wave = tid >> 6, lane = tid & 63, nw = blockDim.x >> 6;
+    const int nth = nt >> 1;
+    const int jj = lane & 31, sgn = lane >> 5;
+    const int n_chunks = (nth + 31) >> 5;
+    const int n_items = (L + 1) * n_chunks;
+    // start values P_mm, P_m+1,m of the first item: in flight while the tables are staged
+    double pmm_n = 0.0, pm1_n = 0.0;
+    {
+        const int i = wave;
+        if (i < n_items) {
+            const int m = i / n_chunks, ch = i - m * n_chunks;
+            const int j = ch * 32 + jj;
+            const int jc = j < nth ? j : nth - 1;
+            const double* pcol = P + (size_t)poff[m] * nt + jc;
+            pmm_n = pcol[0];
+            pm1_n = m < L ? pcol[nt] : 0.0;
+        }
+    }
+    for (int e = tid; e < N; e += blockDim.x) twN[e] = twN_g[e];
+    for (int e = tid; e < npairs; e += blockDim.x) ABs[e] = AB[e];
+    for (int e = tid; e < nlm; e += blockDim.x) cl[e] = csrc[e];
+    long long dst_shell = shell;
+    if (slot != nullptr) dst_shell += (long long)slot[(shell / Nq) * SL_N + which] * B * Nq;
+    double2* gdst = grid + (size_t)dst_shell * nt * N;
+    const double2* fsrc = Fin ? Fin + (size_t)shell * nt * N : nullptr;
+    __syncthreads();
+    // ---- Legendre synthesis of every row: P_lm(theta) by the three-term recurrence in l (registers only)
+    for (int kk = 0;; ++kk) {
+        const int i = kk * nw + ((kk & 1) ? nw - 1 - wave : wave);
+        if (i >= n_items) break;
+        const int m = i / n_chunks, ch = i - m * n_chunks;
+        const int j = ch * 32 + jj;
+        const bool act = (j < nth) && !(sgn == 1 && m == 0);
+        const int jc = j < nth ? j : nth - 1;
+        const double x = cost[jc];
+        double p2 = pmm_n, p1 = pm1_n;
+        {   // prefetch the start values of this wave's next item
+            const int i2 = (kk + 1) * nw + (((kk + 1) & 1) ? nw - 1 - wave : wave);
+            if (i2 < n_items) {
+                const int m2 = i2 / n_chunks, ch2 = i2 - m2 * n_chunks;
+                const int j2 = ch2 * 32 + jj;
+                const int jc2 = j2 < nth ? j2 : nth - 1;
+                const double* pcol = P + (size_t)poff[m2] * nt + jc2;
+                pmm_n = pcol[0];
+                pm1_n = m2 < L ? pcol[nt] : 0.0;
+            }
+        }
+        const int ms = sgn ? -m : m;
+        const double2* cc = cl + ms;
+        const double2* abm = ABs + poff[m] - m;              // abm[l]
+        double2 E, O = make_double2(0.0, 0.0);
+        {
+            const double2 ce = cc[m * (m + 1)];
+            E = make_double2(p2 * ce.x, p2 * ce.y);
+        }
+        if (m < L) {
+            const double2 co = cc[(m + 1) * (m + 2)];
+            O = make_double2(p1 * co.x, p1 * co.y);
+        }
+        int l = m + 2;
+        for (; l + 1 <= L; l += 2) {
+            const double2 ab0 = abm[l], ab1 = abm[l + 1];
+            const double2 ce = cc[l * (l + 1)], co = cc[(l + 1) * (l + 2)];
+            const double pa = ab0.x * (x * p1 - ab0.y * p2);
+            const double pb = ab1.x * (x * pa - ab1.y * p1);
+            E.x = fma(pa, ce.x, E.x); E.y = fma(pa, ce.y, E.y);
+            O.x = fma(pb, co.x, O.x); O.y = fma(pb, co.y, O.y);
+            p2 = pa;
+            p1 = pb;
+        }
+        if (l <= L) {
+            const double2 ab0 = abm[l];
+            const double2 ce = cc[l * (l + 1)];
+            const double pa = ab0.x * (x * p1 - ab0.y * p2);
+            E.x = fma(pa, ce.x, E.x); E.y = fma(pa, ce.y, E.y);
+        }
+        if (act) {
+            const double sg = (sgn && (m & 1)) ? -1.0 : 1.0;       // Y_l,-m = (-1)^m conj(Y_lm)
+            double2* g_n = Gs + (size_t)(2 * j) * nm + L + ms;
+            g_n[0] = make_double2(sg * (E.x + O.x), sg * (E.y + O.y));
+            g_n[nm] = make_double2(sg * (E.x - O.x), sg * (E.y - O.y));
+        }
+    }
+    __syncthreads();
+    const int n_pass = nt / RP;
+    for (int pass = 0; pass < n_pass; ++pass) {
+        // ---- step 1: inverse R2-point FFTs over k2 of the zero padded spectrum, twiddle, transpose store
+        if (tid < RP * R1) {
+            const int r = tid / R1, k1 = tid - r * R1;
+            const double2* gr = Gs + (size_t)(pass * RP + r) * nm + L;
+            double2 uv[R2];
+#pragma unroll
+            for (int k2 = 0; k2 < R2; ++k2) {
+                const int k = k1 + R1 * k2;
+                double2 v = make_double2(0.0, 0.0);
+                if (k <= L) v = gr[k];
+                else if (k >= N - L) v = gr[k - N];
+                uv[k2] = v;
+            }
+            SmallFFT<R2, true>::run(uv);
+            double2* br = Bm + (size_t)(r * R1 + k1) * AS;
+#pragma unroll
+            for (int n2 = 0; n2 < R2; ++n2) {
+                double2 w = twN[n2 * k1];
+                w.y = -w.y;
+                br[n2] = cmul(uv[n2], w);
+            }
+        }
+        __syncthreads();
+        // ---- step 2: inverse R1-point FFTs over k1, epilogue, coalesced store
+        if (tid < RP * R2) {
+            const int r = tid / R2, n2 = tid - r * R2;
+            const double2* br = Bm + (size_t)r * R1 * AS + n2;
+            double2 vv[R1];
+#pragma unroll
+            for (int k1 = 0; k1 < R1; ++k1) vv[k1] = br[k1 * AS];
+            SmallFFT<R1, true>::run(vv);
+            const int rr = pass * RP + r;
+            const int th = rr >> 1;
+            const int row = (rr & 1) ? (nt - 1 - th) : th;
+#pragma unroll
+            for (int n1 = 0; n1 < R1; ++n1) {
+                double2 v = vv[n1];
+                const size_t o = (size_t)row * N + R2 * n1 + n2;
+                if (EPI == EPI_MODULUS) {
+                    // project_to_modified_intensity, fxs_Projections.py:899-909
+                    const double2 Fv = fsrc[o];
+                    const double I = cabs2(Fv);
+                    const bool ok = (I >= 0.0) && (v.x >= 0.0);
+                    const double mult = ok ? sqrt(v.x / I) : 0.0;
+                    v = cscale(Fv, mult);
+                } else if (EPI == EPI_SCALE_SHELL) {
+                    v = cscale(v, shell_scale[q]);
+                }
+                gdst[o] = v;
+            }
+        }
+        __syncthreads();                                // Bm is rewritten by the next pass
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
 static bool reg_radices(int np, int* r1, int* r2) {
     switch (np) {
         case 16: *r1 = 4; *r2 = 4; return true;
@@ -376,8 +552,24 @@ void launch_sht_forward_reg(mtip_ctx* c, const double2* grid, double2* coeff, in
     else launch_fwd_p<MTIP_PRE_NONE>(c, grid, coeff, in_slot);
 }
 
+static size_t wide_lds(const mtip_ctx* c, int r1, int r2, int* rp_out) {
+    const int rp = largest_even_divisor_le(c->nt, std::min(SW_THREADS / r2, SW_THREADS / r1));
+    if (rp_out) *rp_out = rp;
+    if (rp < 2) return (size_t)1 << 40;
+    return ((size_t)c->np + (size_t)c->nt * c->nm + c->npairs + std::max((size_t)c->nlm, (size_t)rp * r1 * (r2 + 1))) * sizeof(double2);
+}
+
 template <int EPI, int R1, int R2>
 static void launch_inv_r(mtip_ctx* c, const double2* coeff, double2* grid, const InvEpilogue& epi) {
+    int rpw = 0;
+    const size_t lds_w = wide_lds(c, R1, R2, &rpw);
+    if (c->sht_wide && c->d_AB != nullptr && lds_w <= 158 * 1024) {
+        const int* slw = epi.out_slot >= 0 ? c->d_slot : nullptr;
+        hipLaunchKernelGGL((k_sht_inv_wide<EPI, R1, R2>), dim3((unsigned)(c->B * c->N)), dim3(SW_THREADS), lds_w, c->stream,
+                           coeff, grid, (const double*)c->d_P, (const int*)c->d_poff, (const double2*)c->d_AB,
+                           (const double*)c->d_cost, c->npairs, (const double2*)c->d_twN, c->nt, c->L, rpw, c->N, epi.F, epi.shell_scale, slw, epi.out_slot, c->B);
+        return;
+    }
     const int RP = largest_even_divisor_le(c->nt, std::min(SR_THREADS / R2, SR_THREADS / R1));
     const size_t smem = ((size_t)c->np + c->nlm + (size_t)RP * c->nm + (size_t)RP * R1 * (R2 + 1)) * sizeof(double2);
     const int* sl = epi.out_slot >= 0 ? c->d_slot : nullptr;

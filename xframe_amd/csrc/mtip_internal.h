@@ -64,6 +64,7 @@ struct mtip_ctx {
     // tables
     double *d_cost = nullptr, *d_gw = nullptr, *d_P = nullptr, *d_r = nullptr, *d_q = nullptr;
     int* d_poff = nullptr;
+    double2* d_AB = nullptr;                          // (npairs) three-term recurrence coefficients (a_lm, b_lm), (l,m)-major
     double* d_PT = nullptr;                           // (nt/2, npairs) theta-major Legendre table (fused SHT)
     int* d_lmtab = nullptr;                           // (npairs) l | m << 8
     int npairs = 0;
@@ -74,6 +75,7 @@ struct mtip_ctx {
     double* d_W = nullptr;
     void* d_htiles = nullptr;                         // HankelTile list of the MFMA kernel
     int n_htiles = 0;
+    bool sht_wide = true;                             // env MTIP_SHT_WIDE=0: pass-wise inverse Legendre synthesis
     int jac_tg = 16;                                  // env MTIP_JAC_TG=8|16: lanes per Jacobi column pair
     bool hankel_simple = false;                       // env MTIP_HANKEL_SIMPLE=1: one-thread-per-output kernel
     double fwd_scale = 0, inv_scale = 0;
