@@ -69,15 +69,18 @@ void launch_coeff_diff(mtip_ctx* c, const double2* a, const double2* b, double2*
 // (batch, m, re/im) axes flattened into columns (B (4l+2) of them, tiled by 16 without waste when B is a
 // multiple of 8).  v_mfma_f64_16x16x4_f64: lane j holds A[i = j&15][kk = j>>4] = W_l[p0+kk][k0+i] (16 lanes read
 // 128 contiguous bytes), B[kk = j>>4][col = j&15] = X[p0+kk][col0+col] (8 consecutive complex numbers), and
-// D reg r = D[(j>>4) + 4r][j&15].  One wave owns one 16-column tile and up to 8 row tiles (128 output shells),
-// so the X fragment is loaded once per k-step and reused by 8 MFMAs; W_l streams through L1/L2 (131 KB per
-// order at Nq = 128, shared by all column tiles).  Next k-step's fragments are prefetched into registers
-// while the current MFMAs run.  The (-/+ i)^l * scale prefactor is applied in the epilogue: multiplying by
+// D reg r = D[(j>>4) + 4r][j&15].  W_l streams through L1/L2 (131 KB per order at Nq = 128, shared by all
+// column tiles).  The (-/+ i)^l * scale prefactor is applied in the epilogue: multiplying by
 // +-i swaps the re/im columns, i.e. neighbouring lanes (shfl_xor 1).
-#define HK_MT 8
+#define HK_MT 2           // 16-row output tiles per wave
+#define HK_PF 4           // k-steps (of 4 shells) whose fragments are in flight together
 
 struct HankelTile { int l, cflat0; };
 
+// One wave = one 16-column tile x HK_MT row tiles.  With HK_MT = 2 a 128-shell transform is spread over 4 waves per
+// column tile (17 waves per CU at 8 restarts, L = 32): the kernel is bound by the latency of the W_l / panel
+// fragment loads (L2 hits), so it wants many waves and HK_PF k-steps of loads in flight (double buffered in
+// registers) rather than long per-wave MFMA chains.
 __global__ void __launch_bounds__(256) k_hankel_mfma(const double* __restrict__ in, double* __restrict__ out,
                                                      const double* __restrict__ W, const HankelTile* __restrict__ tiles,
                                                      int n_tiles, int N, int Np, int L, int B, int poffs, double scale,
@@ -85,7 +88,7 @@ __global__ void __launch_bounds__(256) k_hankel_mfma(const double* __restrict__ 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int tile = blockIdx.x * 4 + wave;
     if (tile >= n_tiles) return;                                  // uniform per wave
-    const int mg = blockIdx.y;                                    // row group of 8 x 16 output shells
+    const int mg = blockIdx.y;                                    // row group of HK_MT x 16 output shells
     const HankelTile tinfo = tiles[tile];
     const int l = tinfo.l;
     const int ncl = 4 * l + 2;                                    // doubles per (batch, shell) of this order
@@ -103,32 +106,33 @@ __global__ void __launch_bounds__(256) k_hankel_mfma(const double* __restrict__ 
 #pragma unroll
     for (int t = 0; t < HK_MT; ++t) acc[t] = v4f64{0.0, 0.0, 0.0, 0.0};
     const int n_steps = (Np + 3) / 4;
-    double a_cur[HK_MT], a_nxt[HK_MT], b_cur, b_nxt;
-    // prologue: fragments of step 0
-    {
-        const int p = kk;
-        const bool p_ok = p < Np;
-        b_cur = (p_ok && col_ok) ? in[col_off + (size_t)(p + poffs) * nlm2] : 0.0;
+    double a_cur[HK_PF][HK_MT], a_nxt[HK_PF][HK_MT], b_cur[HK_PF], b_nxt[HK_PF];
+    bool k_ok[HK_MT];
 #pragma unroll
-        for (int t = 0; t < HK_MT; ++t) {
-            const int k = k_base + t * 16 + li;
-            a_cur[t] = (p_ok && k < N) ? Wl[(size_t)p * N + k] : 0.0;
+    for (int t = 0; t < HK_MT; ++t) k_ok[t] = k_base + t * 16 + li < N;
+    auto load_group = [&](int s0, double (&af)[HK_PF][HK_MT], double (&bf)[HK_PF]) {
+#pragma unroll
+        for (int u = 0; u < HK_PF; ++u) {
+            const int p = (s0 + u) * 4 + kk;
+            const bool p_ok = p < Np;
+            bf[u] = (p_ok && col_ok) ? in[col_off + (size_t)(p + poffs) * nlm2] : 0.0;
+#pragma unroll
+            for (int t = 0; t < HK_MT; ++t) af[u][t] = (p_ok && k_ok[t]) ? Wl[(size_t)p * N + k_base + t * 16 + li] : 0.0;
         }
-    }
-    for (int s = 0; s < n_steps; ++s) {
-        const int p = (s + 1) * 4 + kk;
-        const bool p_ok = (s + 1 < n_steps) && (p < Np);
-        b_nxt = (p_ok && col_ok) ? in[col_off + (size_t)(p + poffs) * nlm2] : 0.0;
+    };
+    load_group(0, a_cur, b_cur);
+    for (int s0 = 0; s0 < n_steps; s0 += HK_PF) {
+        load_group(s0 + HK_PF, a_nxt, b_nxt);                      // beyond the last step: p >= Np, loads nothing
 #pragma unroll
-        for (int t = 0; t < HK_MT; ++t) {
-            const int k = k_base + t * 16 + li;
-            a_nxt[t] = (p_ok && k < N) ? Wl[(size_t)p * N + k] : 0.0;
+        for (int u = 0; u < HK_PF; ++u)
+#pragma unroll
+            for (int t = 0; t < HK_MT; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_cur[u][t], b_cur[u], acc[t], 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < HK_PF; ++u) {
+            b_cur[u] = b_nxt[u];
+#pragma unroll
+            for (int t = 0; t < HK_MT; ++t) a_cur[u][t] = a_nxt[u][t];
         }
-#pragma unroll
-        for (int t = 0; t < HK_MT; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_cur[t], b_cur, acc[t], 0, 0, 0);
-        b_cur = b_nxt;
-#pragma unroll
-        for (int t = 0; t < HK_MT; ++t) a_cur[t] = a_nxt[t];
     }
     // epilogue: * scale * (-/+ i)^l, store
     int r = l & 3;
