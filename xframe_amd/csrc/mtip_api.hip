@@ -109,6 +109,10 @@ mtip_ctx* mtip_create(const mtip_cfg* cfg, int device) {
     int rc = MTIP_OK;
     auto A = [&](int r) { if (rc == MTIP_OK) rc = r; };
     if (hipStreamCreate(&c->stream) != hipSuccess) A(MTIP_EHIP);
+    {
+        int ncu = 0;
+        if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0) c->n_cu = ncu;
+    }
     (void)hipEventCreate(&c->ev0);
     (void)hipEventCreate(&c->ev1);
     A(dev_alloc(c, &c->d_cost, c->nt));

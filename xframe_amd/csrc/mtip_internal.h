@@ -75,6 +75,7 @@ struct mtip_ctx {
     double* d_W = nullptr;
     void* d_htiles = nullptr;                         // HankelTile list of the MFMA kernel
     int n_htiles = 0;
+    int n_cu = 256;                                   // compute units of the device (persistent-grid sizing)
     bool sht_wide = true;                             // env MTIP_SHT_WIDE=0: pass-wise inverse Legendre synthesis
     int jac_tg = 16;                                  // env MTIP_JAC_TG=8|16: lanes per Jacobi column pair
     bool hankel_simple = false;                       // env MTIP_HANKEL_SIMPLE=1: one-thread-per-output kernel
