@@ -1,0 +1,31 @@
+"""Per-kernel HBM traffic from two rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE, collected separately as the
+TCC slots require).  Units: both counters are in KiB; on gfx950 FETCH_SIZE tallies 128-byte read requests at 64 bytes,
+so wide coalesced reads are doubled (MI355X_MICROARCH.md, HBM section) -- printed raw and corrected.
+usage: pmc_summary.py <fetch_dir> <write_dir>"""
+import csv, glob, sys
+from collections import defaultdict
+
+
+def per_kernel(d, counter):
+    f = glob.glob(d + "/*/*counter_collection.csv")[0]
+    acc = defaultdict(lambda: [0.0, 0])
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] != counter:
+            continue
+        a = acc[r["Kernel_Name"]]
+        a[0] += float(r["Counter_Value"])
+        a[1] += 1
+    return acc
+
+
+fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
+write = per_kernel(sys.argv[2], "WRITE_SIZE")
+rows = []
+for k in fetch:
+    fk = fetch[k][0] / fetch[k][1] * 1024
+    wk = write[k][0] / write[k][1] * 1024 if k in write else 0.0
+    rows.append((2 * fk + wk, k, fetch[k][1], fk, wk))
+rows.sort(reverse=True)
+print("%-52s %6s %12s %12s %12s %12s" % ("kernel", "calls", "fetch_raw_MB", "fetch_x2_MB", "write_MB", "hbm_MB"))
+for tot, k, n, fk, wk in rows[:24]:
+    print("%-52s %6d %12.2f %12.2f %12.2f %12.2f" % (k[:52], n, fk / 1e6, 2 * fk / 1e6, wk / 1e6, tot / 1e6))

@@ -122,7 +122,7 @@ static inline emul_v4f64 __builtin_amdgcn_mfma_f64_16x16x4f64(double a, double b
     return d;
 }
 
-// DPP lane permutations used by the kernels: quad_perm (ctrl < 0x100), row_mirror 0x140, row_half_mirror 0x141
+// DPP lane permutations used by the kernels: quad_perm (ctrl < 0x100), row_mirror 0x140, row_half_mirror 0x141, row_ror:n 0x120+n
 static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int, int, bool) {
     (void)old;
     const int l = emul::lane();
@@ -130,6 +130,7 @@ static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int, i
     if (ctrl < 0x100) from = (l & ~3) | ((ctrl >> (2 * (l & 3))) & 3);
     else if (ctrl == 0x141) from = (l & ~7) | (7 - (l & 7));
     else if (ctrl == 0x140) from = (l & ~15) | (15 - (l & 15));
+    else if (ctrl > 0x120 && ctrl <= 0x12F) from = (l & ~15) | ((l - (ctrl - 0x120)) & 15);   // row_ror:n
     else { std::fprintf(stderr, "emul: unsupported dpp ctrl 0x%x\n", ctrl); std::abort(); }
     return __shfl(src, from, 64);
 }

@@ -210,23 +210,75 @@ __device__ __forceinline__ double group_sum(double v) {
     return v;
 }
 
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const int lo2 = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
+    const int hi2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi2, lo2);
+}
+
+// Sums of FOUR values over the 16 lanes of a pair-group at once ("transposed" reduction): after the xor-1 step a lane
+// carries two of the four partial sums, after the xor-2 step one, the steps across quads (row_ror 4, 8 keep lane & 3)
+// finish that one sum, and four quad broadcasts hand every lane all four totals: 35 VALU ops instead of 68 for
+// four independent butterflies.
+template <int TG>
+__device__ __forceinline__ void group_sum4(double& v0, double& v1, double& v2, double& v3) {
+    if (TG != 16) {
+        v0 = group_sum<TG>(v0);
+        v1 = group_sum<TG>(v1);
+        v2 = group_sum<TG>(v2);
+        v3 = group_sum<TG>(v3);
+        return;
+    }
+    const int lane = threadIdx.x;
+    const bool p = (lane & 1) != 0, p2 = (lane & 2) != 0;
+    // xor 1: odd lanes keep (v2, v3), even lanes keep (v0, v1); the other two go to the neighbour
+    const double s0 = p ? v0 : v2, s1 = p ? v1 : v3;
+    double u0 = p ? v2 : v0, u1 = p ? v3 : v1;
+    u0 += dpp_mov<0xB1>(s0);
+    u1 += dpp_mov<0xB1>(s1);
+    // xor 2: lanes with bit 1 keep u1, the others u0
+    const double s = p2 ? u0 : u1;
+    double w = p2 ? u1 : u0;
+    w += dpp_mov<0x4E>(s);
+    // across the four quads of the group
+    w += dpp_mov<0x124>(w);
+    w += dpp_mov<0x128>(w);
+    // lane & 3 = p + 2 p2 holds value 2 p + p2:  quad lane 0 -> v0, 2 -> v1, 1 -> v2, 3 -> v3
+    v0 = dpp_mov<0x00>(w);
+    v1 = dpp_mov<0xAA>(w);
+    v2 = dpp_mov<0x55>(w);
+    v3 = dpp_mov<0xFF>(w);
+}
+
 // Rotation parameters of one column pair from its Gram entries (alpha, beta, gamma = gr + i gi): returns false
 // when the pair is already orthogonal to tolerance.
 __device__ __forceinline__ bool jl_params(double alpha, double beta, double gr, double gi, bool valid, double tabs2,
-                                          double S, double& gmax, double& cs, double& sn, double2& em) {
+                                          double S, bool& big, double& cs, double2& w) {
     const double g2 = gr * gr + gi * gi;
     const double ab = alpha * beta;
     if (!(valid && g2 > (JAC_TOL * JAC_TOL) * ab && g2 > tabs2 * fmax(alpha, beta) * S && g2 > 0.0)) return false;
-    gmax = fmax(gmax, g2 * fast_rcp(ab));
-    const double inv_g = fast_rsqrt(g2);
-    const double zeta = 0.5 * (beta - alpha) * inv_g;
-    const double z1 = 1.0 + zeta * zeta;
-    const double rt = z1 * fast_rsqrt(z1);               // sqrt(1 + zeta^2)
-    const double tt = (zeta >= 0.0 ? 1.0 : -1.0) * fast_rcp(fabs(zeta) + rt);
-    cs = fast_rsqrt(1.0 + tt * tt);
-    sn = cs * tt;
-    em = make_double2(gr * inv_g, -gi * inv_g);          // conj(gamma)/|gamma|
+    big = big || (g2 > (JL_EARLY * JL_EARLY) * ab);
+    // smaller-angle rotation [a b] <- [a b] [[c, conj(w)], [-w, c]] that annihilates gamma = a^+ b:  with
+    // d = (beta - alpha)/2, h = sqrt(d^2 + |gamma|^2):  c^2 = (1 + |d|/h)/2,  w = s e = sign(d) conj(gamma) / (2 h c).
+    // Only two reciprocal square roots, no division and no |gamma| (the phase e and the sine never appear alone).
+    const double d = 0.5 * (beta - alpha);
+    const double ih = fast_rsqrt(fma(d, d, g2));
+    const double c2 = fma(0.5 * fabs(d), ih, 0.5);
+    const double rc = fast_rsqrt(c2);
+    cs = c2 * rc;
+    const double kappa = (d >= 0.0 ? 0.5 : -0.5) * ih * rc;
+    w = make_double2(kappa * gr, -kappa * gi);
     return true;
+}
+
+// [a b] <- [a b] [[c, conj(w)], [-w, c]]:  a' = c a - w b,  b' = conj(w) a + c b
+__device__ __forceinline__ void jl_rotate(double cs, double2 w, double2 a, double2 b, double2& an, double2& bn) {
+    an.x = fma(w.y, b.y, fma(-w.x, b.x, cs * a.x));
+    an.y = fma(-w.y, b.x, fma(-w.x, b.y, cs * a.y));
+    bn.x = fma(w.y, a.y, fma(w.x, a.x, cs * b.x));
+    bn.y = fma(-w.y, a.x, fma(w.x, a.y, cs * b.y));
 }
 
 // One column pair of a tournament round, NR row slots per lane for X and for V_r, no branches inside the row
@@ -235,17 +287,12 @@ __device__ __forceinline__ bool jl_params(double alpha, double beta, double gr, 
 // are issued before the rotation parameters are known so that their latency hides behind that arithmetic.
 template <int NR, int TG>
 __device__ __forceinline__ void jl_pair(double2* xi, double2* xj, double2* vi, double2* vj, bool xl_ok, bool vl_ok,
-                                        bool valid, double tabs2, double S, double& gmax) {
+                                        bool valid, double tabs2, double S, bool& big) {
     double2 ra[NR], rb[NR], va[NR], vb[NR];
 #pragma unroll
     for (int u = 0; u < NR; ++u) {
         ra[u] = xi[u * TG];
         rb[u] = xj[u * TG];
-    }
-#pragma unroll
-    for (int u = 0; u < NR; ++u) {
-        va[u] = vi[u * TG];
-        vb[u] = vj[u * TG];
     }
     if (!xl_ok) {
         ra[NR - 1] = make_double2(0.0, 0.0);
@@ -260,29 +307,31 @@ __device__ __forceinline__ void jl_pair(double2* xi, double2* xj, double2* vi, d
         gr += a.x * c2.x + a.y * c2.y;                     // conj(a) * c2
         gi += a.x * c2.y - a.y * c2.x;
     }
-    alpha = group_sum<TG>(alpha);
-    beta = group_sum<TG>(beta);
-    gr = group_sum<TG>(gr);
-    gi = group_sum<TG>(gi);
-    double cs, sn;
-    double2 em;
-    if (!jl_params(alpha, beta, gr, gi, valid, tabs2, S, gmax, cs, sn, em)) return;
+    group_sum4<TG>(alpha, beta, gr, gi);
+    double cs;
+    double2 w;
+    if (!jl_params(alpha, beta, gr, gi, valid, tabs2, S, big, cs, w)) return;
 #pragma unroll
     for (int u = 0; u < NR; ++u) {
-        const double2 a = ra[u];
-        const double2 bj = cmul(em, rb[u]);
+        va[u] = vi[u * TG];
+        vb[u] = vj[u * TG];
+    }
+#pragma unroll
+    for (int u = 0; u < NR; ++u) {
+        double2 an, bn;
+        jl_rotate(cs, w, ra[u], rb[u], an, bn);
         if (u < NR - 1 || xl_ok) {
-            xi[u * TG] = make_double2(cs * a.x - sn * bj.x, cs * a.y - sn * bj.y);
-            xj[u * TG] = make_double2(sn * a.x + cs * bj.x, sn * a.y + cs * bj.y);
+            xi[u * TG] = an;
+            xj[u * TG] = bn;
         }
     }
 #pragma unroll
     for (int u = 0; u < NR; ++u) {
-        const double2 a = va[u];
-        const double2 bj = cmul(em, vb[u]);
+        double2 an, bn;
+        jl_rotate(cs, w, va[u], vb[u], an, bn);
         if (u < NR - 1 || vl_ok) {
-            vi[u * TG] = make_double2(cs * a.x - sn * bj.x, cs * a.y - sn * bj.y);
-            vj[u * TG] = make_double2(sn * a.x + cs * bj.x, sn * a.y + cs * bj.y);
+            vi[u * TG] = an;
+            vj[u * TG] = bn;
         }
     }
 }
@@ -290,7 +339,7 @@ __device__ __forceinline__ void jl_pair(double2* xi, double2* xj, double2* vi, d
 // same with run-time row counts (k_l != 2l+1, or more row slots than the specialised bodies cover)
 template <int MAXR, int TG>
 __device__ __forceinline__ void jl_pair_generic(double2* xi, double2* xj, double2* vi, double2* vj, int nr, int kr, int n,
-                                                int k, int pad, int t, bool valid, double tabs2, double S, double& gmax) {
+                                                int k, int pad, int t, bool valid, double tabs2, double S, bool& big) {
     double2 ra[MAXR], rb[MAXR];
     double alpha = 0.0, beta = 0.0, gr = 0.0, gi = 0.0;
 #pragma unroll
@@ -307,29 +356,26 @@ __device__ __forceinline__ void jl_pair_generic(double2* xi, double2* xj, double
             gi += a.x * c2.y - a.y * c2.x;
         }
     }
-    alpha = group_sum<TG>(alpha);
-    beta = group_sum<TG>(beta);
-    gr = group_sum<TG>(gr);
-    gi = group_sum<TG>(gi);
-    double cs, sn;
-    double2 em;
-    if (!jl_params(alpha, beta, gr, gi, valid, tabs2, S, gmax, cs, sn, em)) return;
+    group_sum4<TG>(alpha, beta, gr, gi);
+    double cs;
+    double2 w;
+    if (!jl_params(alpha, beta, gr, gi, valid, tabs2, S, big, cs, w)) return;
 #pragma unroll
     for (int u = 0; u < MAXR; ++u) {
         if (u < nr && (pad || t + u * TG < n)) {
-            const double2 a = ra[u];
-            const double2 bj = cmul(em, rb[u]);
-            xi[u * TG] = make_double2(cs * a.x - sn * bj.x, cs * a.y - sn * bj.y);
-            xj[u * TG] = make_double2(sn * a.x + cs * bj.x, sn * a.y + cs * bj.y);
+            double2 an, bn;
+            jl_rotate(cs, w, ra[u], rb[u], an, bn);
+            xi[u * TG] = an;
+            xj[u * TG] = bn;
         }
     }
 #pragma unroll
     for (int u = 0; u < MAXR; ++u) {
         if (u < kr && (pad || t + u * TG < k)) {
-            const double2 a = vi[u * TG];
-            const double2 bj = cmul(em, vj[u * TG]);
-            vi[u * TG] = make_double2(cs * a.x - sn * bj.x, cs * a.y - sn * bj.y);
-            vj[u * TG] = make_double2(sn * a.x + cs * bj.x, sn * a.y + cs * bj.y);
+            double2 an, bn;
+            jl_rotate(cs, w, vi[u * TG], vj[u * TG], an, bn);
+            vi[u * TG] = an;
+            vj[u * TG] = bn;
         }
     }
 }
@@ -422,7 +468,7 @@ __global__ void __launch_bounds__(JL_MAX_THREADS) k_polar_jacobi_lds(const doubl
             const int skip = ke & 1;                           // odd count: pair 0 of every round holds the dummy player
             const int pairs = Cp / 2 - skip;
             const int per_group = (pairs + ngroups - 1) / ngroups;
-            double gmax = 0.0;                                 // largest g2/(alpha beta) seen by this group
+            bool big = false;                                  // some pair of this group was above the early-exit level
             for (int r = 0; r < rounds; ++r) {
                 for (int it = 0; it < per_group; ++it) {
                     const int pi = group + it * ngroups;
@@ -445,36 +491,36 @@ __global__ void __launch_bounds__(JL_MAX_THREADS) k_polar_jacobi_lds(const doubl
                     if (nr == kr) {
                         done = true;
                         switch (nr) {
-                        case 1: jl_pair<1, TG>(xi, xj, vi, vj, xl_ok, vl_ok, valid, tabs2, S, gmax); break;
-                        case 2: jl_pair<2, TG>(xi, xj, vi, vj, xl_ok, vl_ok, valid, tabs2, S, gmax); break;
-                        case 3: jl_pair<3, TG>(xi, xj, vi, vj, xl_ok, vl_ok, valid, tabs2, S, gmax); break;
-                        case 4: jl_pair<4, TG>(xi, xj, vi, vj, xl_ok, vl_ok, valid, tabs2, S, gmax); break;
-                        case 5: jl_pair<5, TG>(xi, xj, vi, vj, xl_ok, vl_ok, valid, tabs2, S, gmax); break;
+                        case 1: jl_pair<1, TG>(xi, xj, vi, vj, xl_ok, vl_ok, valid, tabs2, S, big); break;
+                        case 2: jl_pair<2, TG>(xi, xj, vi, vj, xl_ok, vl_ok, valid, tabs2, S, big); break;
+                        case 3: jl_pair<3, TG>(xi, xj, vi, vj, xl_ok, vl_ok, valid, tabs2, S, big); break;
+                        case 4: jl_pair<4, TG>(xi, xj, vi, vj, xl_ok, vl_ok, valid, tabs2, S, big); break;
+                        case 5: jl_pair<5, TG>(xi, xj, vi, vj, xl_ok, vl_ok, valid, tabs2, S, big); break;
                         default: done = false;
                         }
                         if (MAXR > 5 && !done) {
                             done = true;
                             switch (nr) {
-                            case 6: jl_pair<(MAXR > 5 ? 6 : 1), TG>(xi, xj, vi, vj, xl_ok, vl_ok, valid, tabs2, S, gmax); break;
-                            case 7: jl_pair<(MAXR > 5 ? 7 : 1), TG>(xi, xj, vi, vj, xl_ok, vl_ok, valid, tabs2, S, gmax); break;
-                            case 8: jl_pair<(MAXR > 5 ? 8 : 1), TG>(xi, xj, vi, vj, xl_ok, vl_ok, valid, tabs2, S, gmax); break;
-                            case 9: jl_pair<(MAXR > 5 ? 9 : 1), TG>(xi, xj, vi, vj, xl_ok, vl_ok, valid, tabs2, S, gmax); break;
+                            case 6: jl_pair<(MAXR > 5 ? 6 : 1), TG>(xi, xj, vi, vj, xl_ok, vl_ok, valid, tabs2, S, big); break;
+                            case 7: jl_pair<(MAXR > 5 ? 7 : 1), TG>(xi, xj, vi, vj, xl_ok, vl_ok, valid, tabs2, S, big); break;
+                            case 8: jl_pair<(MAXR > 5 ? 8 : 1), TG>(xi, xj, vi, vj, xl_ok, vl_ok, valid, tabs2, S, big); break;
+                            case 9: jl_pair<(MAXR > 5 ? 9 : 1), TG>(xi, xj, vi, vj, xl_ok, vl_ok, valid, tabs2, S, big); break;
                             default: done = false;
                             }
                         }
                     }
-                    if (!done) jl_pair_generic<MAXR, TG>(xi, xj, vi, vj, nr, kr, n, k, pad, t, valid, tabs2, S, gmax);
+                    if (!done) jl_pair_generic<MAXR, TG>(xi, xj, vi, vj, nr, kr, n, k, pad, t, valid, tabs2, S, big);
                 }
                 __syncthreads();
             }
-            if (t == 0) s_gmax[group] = gmax;
+            if (t == 0) s_gmax[group] = big ? 1.0 : 0.0;
             __syncthreads();
             if (tid == 0) {
                 double m = 0.0;
                 for (int g = 0; g < ngroups; ++g) m = fmax(m, s_gmax[g]);
-                // m = max (|gamma|^2 / alpha beta); rotations happened iff m > 0. Quadratic convergence:
-                // the next sweep would see ~ m^2, so stop when sqrt(m) < JL_EARLY.
-                s_continue = (m > JL_EARLY * JL_EARLY) ? 1 : 0;
+                // quadratic convergence: a sweep whose largest |gamma|/sqrt(alpha beta) stayed below JL_EARLY leaves
+                // ~JL_EARLY^2 behind, so stop unless some pair was above that level
+                s_continue = (m > 0.0) ? 1 : 0;
                 sweeps_out[b * (L + 1) + l] = (sweep + 1) | (ke << 8);
             }
             __syncthreads();
