@@ -174,7 +174,7 @@ __global__ void __launch_bounds__(256) k_polar_jacobi(double2* __restrict__ Xall
 // V_r_prev (the right singular vectors move little between phasing steps), so 1-3 sweeps suffice; the
 // sweep loop stops early when the largest relative off-diagonal of a sweep predicts (quadratic
 // convergence) that the next one would be below tolerance.  Output: Pn = W Sigma^-1 (overwrites X) and V_r.
-#define JL_MAX_THREADS 512
+#define JL_MAX_THREADS 576
 #define JL_EARLY 1e-8
 
 // 1/sqrt(x) to full double precision from the hardware estimate (two Newton steps); the rotation only needs
@@ -380,6 +380,102 @@ __device__ __forceinline__ void jl_pair_generic(double2* xi, double2* xj, double
     }
 }
 
+// ---- resident-column ordering ------------------------------------------------------------------------------
+// The tournament round is bound by LDS traffic (every column of X and V_r read and written once per round, all
+// waves in step because of the barrier).  With the divide-and-conquer ordering below a pair-group keeps ONE column
+// (X and V_r rows, NR + NR registers per lane) resident in registers over a whole phase and only the other column
+// ("mover") goes through LDS: a set of columns is split into halves A, B; for |A| rounds group i pairs resident
+// A_i with mover B_((i + r) mod |A|); then A and B are solved recursively side by side on disjoint groups (the
+// groups of A keep their residents).  Every pair meets once per sweep, ceil(k/2) groups are busy, and the LDS
+// traffic per round halves.  The schedule (which resident / mover each group takes in each round, and when a
+// resident must be written back because another group needs it next) is precomputed on the host for every
+// column count (build_jacobi_schedule) and verified there.
+#define JS_ACTIVE (1 << 17)
+#define JS_WB (1 << 16)
+
+template <int NR, int TG>
+__device__ __forceinline__ void jl_sweep_resident(double2* Xs, double2* Vs, int ns, int ks, int t, int group,
+                                                  const int* __restrict__ tab, int n_rounds, int ps, const int* s_perm,
+                                                  bool xl_ok, bool vl_ok, double tabs2, double S, bool& big) {
+    double2 rx[NR], rv[NR];
+#pragma unroll
+    for (int u = 0; u < NR; ++u) rx[u] = rv[u] = make_double2(0.0, 0.0);
+    int cur = -1;                                            // compact index of the resident column
+    bool dirty = false;
+    int e_next = (group < ps && n_rounds > 0) ? tab[group] : 0;
+    for (int r = 0; r < n_rounds; ++r) {
+        const int e = e_next;
+        if (r + 1 < n_rounds && group < ps) e_next = tab[(size_t)(r + 1) * ps + group];   // in flight during the round
+        // (the wave-level reductions run for every group, active or not: uniform control flow around DPP)
+        const bool act = (e & JS_ACTIVE) != 0;
+        const int res = act ? (e & 255) : 0, mov = act ? ((e >> 8) & 255) : 0;
+        double2* xh = Xs + (size_t)s_perm[res] * ns + t;
+        double2* vh = Vs + (size_t)s_perm[res] * ks + t;
+        double2* xm = Xs + (size_t)s_perm[mov] * ns + t;
+        double2* vm = Vs + (size_t)s_perm[mov] * ks + t;
+        double2 mx[NR], mv[NR];
+#pragma unroll
+        for (int u = 0; u < NR; ++u) mx[u] = make_double2(0.0, 0.0);
+        if (act) {
+#pragma unroll
+            for (int u = 0; u < NR; ++u) mx[u] = xm[u * TG];
+            if (res != cur) {
+#pragma unroll
+                for (int u = 0; u < NR; ++u) {
+                    rx[u] = xh[u * TG];
+                    rv[u] = vh[u * TG];
+                }
+                if (!xl_ok) rx[NR - 1] = make_double2(0.0, 0.0);
+                cur = res;
+                dirty = false;
+            }
+            if (!xl_ok) mx[NR - 1] = make_double2(0.0, 0.0);
+        }
+        double alpha = 0.0, beta = 0.0, gr = 0.0, gi = 0.0;
+#pragma unroll
+        for (int u = 0; u < NR; ++u) {
+            const double2 a = rx[u], c2 = mx[u];
+            alpha += cabs2(a);
+            beta += cabs2(c2);
+            gr += a.x * c2.x + a.y * c2.y;                     // conj(a) * c2
+            gi += a.x * c2.y - a.y * c2.x;
+        }
+        group_sum4<TG>(alpha, beta, gr, gi);
+        double cs;
+        double2 w;
+        if (jl_params(alpha, beta, gr, gi, act, tabs2, S, big, cs, w)) {
+#pragma unroll
+            for (int u = 0; u < NR; ++u) mv[u] = vm[u * TG];
+#pragma unroll
+            for (int u = 0; u < NR; ++u) {
+                double2 an, bn;
+                jl_rotate(cs, w, rx[u], mx[u], an, bn);
+                rx[u] = an;
+                if (u < NR - 1 || xl_ok) xm[u * TG] = bn;
+            }
+#pragma unroll
+            for (int u = 0; u < NR; ++u) {
+                double2 an, bn;
+                jl_rotate(cs, w, rv[u], mv[u], an, bn);
+                rv[u] = an;
+                if (u < NR - 1 || vl_ok) vm[u * TG] = bn;
+            }
+            dirty = true;
+        }
+        if (act && (e & JS_WB)) {                              // someone else takes this column next round
+            if (dirty) {
+#pragma unroll
+                for (int u = 0; u < NR; ++u) {
+                    if (u < NR - 1 || xl_ok) xh[u * TG] = rx[u];
+                    if (u < NR - 1 || vl_ok) vh[u * TG] = rv[u];
+                }
+            }
+            cur = -1;
+        }
+        __syncthreads();
+    }
+}
+
 // MAXR = upper bound of the rows of a column handled by one lane of a pair-group (ceil(n / 8) <= MAXR).  Columns
 // are zero padded to a multiple of 8 rows in LDS, so the row loops need no per-lane predicate; the two columns of
 // the pair stay in registers between the Gram reduction and the rotation.  For odd k the tournament pair that
@@ -391,7 +487,10 @@ __global__ void __launch_bounds__(JL_MAX_THREADS) k_polar_jacobi_lds(const doubl
                                                                     const int* __restrict__ active,
                                                                     const int* __restrict__ xoff, const int* __restrict__ roff,
                                                                     int xtot, int rtot, int L, int warm, double tabs2,
-                                                                    int* __restrict__ sweeps_out, int pad) {
+                                                                    int* __restrict__ sweeps_out, int pad,
+                                                                    const int* __restrict__ sched,
+                                                                    const int* __restrict__ sched_off,
+                                                                    const int* __restrict__ sched_rounds, int sched_ps) {
     HIP_DYNAMIC_SHARED(double2, sm)
     __shared__ double s_gmax[JL_MAX_THREADS / 8];
     __shared__ double s_isig[128];
@@ -469,7 +568,21 @@ __global__ void __launch_bounds__(JL_MAX_THREADS) k_polar_jacobi_lds(const doubl
             const int pairs = Cp / 2 - skip;
             const int per_group = (pairs + ngroups - 1) / ngroups;
             bool big = false;                                  // some pair of this group was above the early-exit level
-            for (int r = 0; r < rounds; ++r) {
+            // resident-column ordering when it applies (16-lane groups, equal row counts, enough groups)
+            const bool resident = TG == 16 && sched != nullptr && nr == kr && nr <= 5 && sched_ps <= ngroups;
+            if (resident) {
+                const bool xl_ok = pad || t + (nr - 1) * TG < n, vl_ok = pad || t + (kr - 1) * TG < k;
+                const int* tab = sched + sched_off[ke];
+                const int nrd = sched_rounds[ke];
+                switch (nr) {
+                case 1: jl_sweep_resident<1, TG>(Xs, Vs, ns, ks, t, group, tab, nrd, sched_ps, s_perm, xl_ok, vl_ok, tabs2, S, big); break;
+                case 2: jl_sweep_resident<2, TG>(Xs, Vs, ns, ks, t, group, tab, nrd, sched_ps, s_perm, xl_ok, vl_ok, tabs2, S, big); break;
+                case 3: jl_sweep_resident<3, TG>(Xs, Vs, ns, ks, t, group, tab, nrd, sched_ps, s_perm, xl_ok, vl_ok, tabs2, S, big); break;
+                case 4: jl_sweep_resident<4, TG>(Xs, Vs, ns, ks, t, group, tab, nrd, sched_ps, s_perm, xl_ok, vl_ok, tabs2, S, big); break;
+                default: jl_sweep_resident<5, TG>(Xs, Vs, ns, ks, t, group, tab, nrd, sched_ps, s_perm, xl_ok, vl_ok, tabs2, S, big); break;
+                }
+            }
+            for (int r = 0; r < (resident ? 0 : rounds); ++r) {
                 for (int it = 0; it < per_group; ++it) {
                     const int pi = group + it * ngroups;
                     int ci = 0, cj = 0;
@@ -619,6 +732,97 @@ __global__ void __launch_bounds__(256) k_proj_apply(const double2* __restrict__ 
     out[idx] = v;
 }
 
+// Divide-and-conquer pairing schedule for every column count 2..kmax (see jl_sweep_resident).  Entry
+// [off[ke] + round * ps + group] = resident | mover << 8 | JS_WB | JS_ACTIVE (compact column indices).
+// pair-groups a set of s columns needs (a set of 3 idles one group in its cross phase, so this can exceed ceil(s/2))
+static int js_groups(int s) {
+    if (s < 2) return 0;
+    const int a = (s + 1) / 2;
+    return std::max(a, js_groups(a) + js_groups(s - a));
+}
+
+static void js_build(const std::vector<int>& cols, int g0, int round0, int ps, std::vector<std::vector<int>>& rounds) {
+    const int s = (int)cols.size();
+    if (s < 2) return;
+    const int a = (s + 1) / 2, b = s - a;
+    if ((int)rounds.size() < round0 + a) rounds.resize(round0 + a, std::vector<int>(ps, 0));
+    for (int r = 0; r < a; ++r)
+        for (int i = 0; i < a; ++i) {
+            const int j = (i + r) % a;
+            if (j < b) rounds[round0 + r][g0 + i] = cols[i] | (cols[a + j] << 8) | JS_ACTIVE;
+        }
+    js_build(std::vector<int>(cols.begin(), cols.begin() + a), g0, round0 + a, ps, rounds);
+    js_build(std::vector<int>(cols.begin() + a, cols.end()), g0 + js_groups(a), round0 + a, ps, rounds);
+}
+
+int build_jacobi_schedule(mtip_ctx* c, int kmax) {
+    if (c->d_jsched != nullptr && c->jsched_kmax >= kmax) return MTIP_OK;
+    int ps = 1;
+    for (int ke = 2; ke <= kmax; ++ke) ps = std::max(ps, js_groups(ke));
+    std::vector<int> all, off(kmax + 1, 0), nrd(kmax + 1, 0);
+    for (int ke = 2; ke <= kmax; ++ke) {
+        std::vector<int> cols(ke);
+        for (int i = 0; i < ke; ++i) cols[i] = i;
+        std::vector<std::vector<int>> rounds;
+        js_build(cols, 0, 0, ps, rounds);
+        // verification: no column twice in a round, every pair exactly once per sweep
+        std::vector<char> met((size_t)ke * ke, 0);
+        for (size_t r = 0; r < rounds.size(); ++r) {
+            std::vector<char> used(ke, 0);
+            for (int g = 0; g < ps; ++g) {
+                const int e = rounds[r][g];
+                if (!(e & JS_ACTIVE)) continue;
+                const int x = e & 255, y = (e >> 8) & 255;
+                if (x >= ke || y >= ke || x == y || used[x] || used[y] || met[(size_t)x * ke + y]) return MTIP_EINVAL;
+                used[x] = used[y] = 1;
+                met[(size_t)x * ke + y] = met[(size_t)y * ke + x] = 1;
+            }
+        }
+        for (int x = 0; x < ke; ++x)
+            for (int y = 0; y < ke; ++y)
+                if (x != y && !met[(size_t)x * ke + y]) return MTIP_EINVAL;
+        // write-back flag: the group does not keep this resident in its next active round, or the column is used by
+        // anybody (this group as mover included) before that
+        for (size_t r = 0; r < rounds.size(); ++r)
+            for (int g = 0; g < ps; ++g) {
+                int& e = rounds[r][g];
+                if (!(e & JS_ACTIVE)) continue;
+                const int res = e & 255;
+                bool keep = false;
+                for (size_t r2 = r + 1; r2 < rounds.size(); ++r2) {
+                    bool elsewhere = false;
+                    for (int g2 = 0; g2 < ps; ++g2) {
+                        const int e2 = rounds[r2][g2];
+                        if (!(e2 & JS_ACTIVE)) continue;
+                        const int x = e2 & 255, y = (e2 >> 8) & 255;
+                        if (y == res || (x == res && g2 != g)) elsewhere = true;
+                    }
+                    if (elsewhere) break;
+                    const int e2 = rounds[r2][g];
+                    if (e2 & JS_ACTIVE) {
+                        keep = (e2 & 255) == res;
+                        break;
+                    }
+                }
+                if (!keep) e |= JS_WB;
+            }
+        off[ke] = (int)all.size();
+        nrd[ke] = (int)rounds.size();
+        for (auto& rd : rounds) all.insert(all.end(), rd.begin(), rd.end());
+    }
+    if (all.empty()) all.push_back(0);
+    if (c->d_jsched) { (void)hipFree(c->d_jsched); (void)hipFree(c->d_jsched_off); (void)hipFree(c->d_jsched_rounds); }
+    if (hipMalloc((void**)&c->d_jsched, all.size() * sizeof(int)) != hipSuccess) return MTIP_ENOMEM;
+    if (hipMalloc((void**)&c->d_jsched_off, off.size() * sizeof(int)) != hipSuccess) return MTIP_ENOMEM;
+    if (hipMalloc((void**)&c->d_jsched_rounds, nrd.size() * sizeof(int)) != hipSuccess) return MTIP_ENOMEM;
+    (void)hipMemcpy(c->d_jsched, all.data(), all.size() * sizeof(int), hipMemcpyHostToDevice);
+    (void)hipMemcpy(c->d_jsched_off, off.data(), off.size() * sizeof(int), hipMemcpyHostToDevice);
+    (void)hipMemcpy(c->d_jsched_rounds, nrd.data(), nrd.size() * sizeof(int), hipMemcpyHostToDevice);
+    c->jsched_kmax = kmax;
+    c->jsched_ps = ps;
+    return MTIP_OK;
+}
+
 void launch_project_coefficients(mtip_ctx* c, const double2* Ilm, double2* out) {
     ProfScope ps(c, "proj");
     int max_kn = 1, kmax = 1, nmax = 1;
@@ -650,13 +854,17 @@ void launch_project_coefficients(mtip_ctx* c, const double2* Ilm, double2* out) 
         const size_t lds_pad = ((size_t)kmax * (div_up(nmax, tg) * tg + 1) + (size_t)kmax * (div_up(kmax, tg) * tg + 1)) * sizeof(double2);
         const int pad = lds_pad <= 158 * 1024 ? 1 : 0;
         const size_t lds_use = (pad ? lds_pad : ((size_t)kmax * (nmax | 1) + (size_t)kmax * (kmax | 1)) * sizeof(double2)) + 16 * sizeof(double2);
-        int threads = ((pairs_max * tg + 63) / 64) * 64;
+        const bool use_sched = tg == 16 && c->jac_resident && kmax <= 255 && build_jacobi_schedule(c, kmax) == MTIP_OK &&
+                               c->jsched_ps * 16 <= JL_MAX_THREADS;
+        int threads = (((use_sched ? c->jsched_ps : pairs_max) * tg + 63) / 64) * 64;
         threads = std::min(std::max(threads, 64), JL_MAX_THREADS);
         const dim3 gj((unsigned)(c->L + 1), (unsigned)c->B);
 #define JL_LAUNCH(MAXR, TG)                                                                                              \
     hipLaunchKernelGGL((k_polar_jacobi_lds<MAXR, TG>), gj, dim3(threads), lds_use, c->stream, src, c->d_X, c->d_Vr,     \
                        (const int*)c->d_kl, (const int*)c->d_active, (const int*)c->d_xoff, (const int*)c->d_uoff,      \
-                       c->xtot, c->utot, c->L, warm, c->polar_abs_tol * c->polar_abs_tol, c->d_sweeps, pad)
+                       c->xtot, c->utot, c->L, warm, c->polar_abs_tol * c->polar_abs_tol, c->d_sweeps, pad,             \
+                       use_sched ? (const int*)c->d_jsched : (const int*)nullptr, (const int*)c->d_jsched_off,          \
+                       (const int*)c->d_jsched_rounds, c->jsched_ps)
         if (tg == 16) JL_LAUNCH(5, 16);
         else if (nmax <= 9 * 8) JL_LAUNCH(9, 8);
         else JL_LAUNCH(16, 8);
