@@ -384,10 +384,10 @@ __device__ __forceinline__ void jl_pair_generic(double2* xi, double2* xj, double
 // The tournament round is bound by LDS traffic (every column of X and V_r read and written once per round, all
 // waves in step because of the barrier).  With the divide-and-conquer ordering below a pair-group keeps ONE column
 // (X and V_r rows, NR + NR registers per lane) resident in registers over a whole phase and only the other column
-// ("mover") goes through LDS: a set of columns is split into halves A, B; for |A| rounds group i pairs resident
-// A_i with mover B_((i + r) mod |A|); then A and B are solved recursively side by side on disjoint groups (the
-// groups of A keep their residents).  Every pair meets once per sweep, ceil(k/2) groups are busy, and the LDS
-// traffic per round halves.  The schedule (which resident / mover each group takes in each round, and when a
+// ("mover") goes through LDS: a set of columns is split into halves A (floor) and B (ceil); for |B| rounds group
+// i pairs resident A_i with mover B_((i + r) mod |B|); then A and B are solved recursively side by side on
+// disjoint groups (the groups of A keep their residents).  Every pair meets once per sweep, floor(k/2) groups
+// (32 = 8 waves, two per SIMD, at k = 65) are busy in every round, and the LDS traffic per round halves.  The schedule (which resident / mover each group takes in each round, and when a
 // resident must be written back because another group needs it next) is precomputed on the host for every
 // column count (build_jacobi_schedule) and verified there.
 #define JS_ACTIVE (1 << 17)
@@ -734,25 +734,24 @@ __global__ void __launch_bounds__(256) k_proj_apply(const double2* __restrict__ 
 
 // Divide-and-conquer pairing schedule for every column count 2..kmax (see jl_sweep_resident).  Entry
 // [off[ke] + round * ps + group] = resident | mover << 8 | JS_WB | JS_ACTIVE (compact column indices).
-// pair-groups a set of s columns needs (a set of 3 idles one group in its cross phase, so this can exceed ceil(s/2))
+// pair-groups a set of s columns needs: residents = the smaller half
 static int js_groups(int s) {
     if (s < 2) return 0;
-    const int a = (s + 1) / 2;
+    const int a = s / 2;
     return std::max(a, js_groups(a) + js_groups(s - a));
 }
 
+// cols -> halves A (floor(s/2) residents, one group each) and B (movers); |B| rounds: group i takes B_((i + r) mod |B|),
+// so every group is busy in every round; then A and B side by side on disjoint groups (A's groups keep residents)
 static void js_build(const std::vector<int>& cols, int g0, int round0, int ps, std::vector<std::vector<int>>& rounds) {
     const int s = (int)cols.size();
     if (s < 2) return;
-    const int a = (s + 1) / 2, b = s - a;
-    if ((int)rounds.size() < round0 + a) rounds.resize(round0 + a, std::vector<int>(ps, 0));
-    for (int r = 0; r < a; ++r)
-        for (int i = 0; i < a; ++i) {
-            const int j = (i + r) % a;
-            if (j < b) rounds[round0 + r][g0 + i] = cols[i] | (cols[a + j] << 8) | JS_ACTIVE;
-        }
-    js_build(std::vector<int>(cols.begin(), cols.begin() + a), g0, round0 + a, ps, rounds);
-    js_build(std::vector<int>(cols.begin() + a, cols.end()), g0 + js_groups(a), round0 + a, ps, rounds);
+    const int a = s / 2, b = s - a;
+    if ((int)rounds.size() < round0 + b) rounds.resize(round0 + b, std::vector<int>(ps, 0));
+    for (int r = 0; r < b; ++r)
+        for (int i = 0; i < a; ++i) rounds[round0 + r][g0 + i] = cols[i] | (cols[a + (i + r) % b] << 8) | JS_ACTIVE;
+    js_build(std::vector<int>(cols.begin(), cols.begin() + a), g0, round0 + b, ps, rounds);
+    js_build(std::vector<int>(cols.begin() + a, cols.end()), g0 + js_groups(a), round0 + b, ps, rounds);
 }
 
 int build_jacobi_schedule(mtip_ctx* c, int kmax) {
