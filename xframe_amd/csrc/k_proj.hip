@@ -402,17 +402,20 @@ __device__ __forceinline__ void jl_sweep_resident(double2* Xs, double2* Vs, int 
     for (int u = 0; u < NR; ++u) rx[u] = rv[u] = make_double2(0.0, 0.0);
     int cur = -1;                                            // compact index of the resident column
     bool dirty = false;
+    // table entry and physical columns (through s_perm) of a round are resolved during the previous round
     int e_next = (group < ps && n_rounds > 0) ? tab[group] : 0;
+    int pr_next = s_perm[(e_next & JS_ACTIVE) ? (e_next & 255) : 0], pm_next = s_perm[(e_next & JS_ACTIVE) ? ((e_next >> 8) & 255) : 0];
     for (int r = 0; r < n_rounds; ++r) {
         const int e = e_next;
+        const int pr = pr_next, pm = pm_next;
         if (r + 1 < n_rounds && group < ps) e_next = tab[(size_t)(r + 1) * ps + group];   // in flight during the round
         // (the wave-level reductions run for every group, active or not: uniform control flow around DPP)
         const bool act = (e & JS_ACTIVE) != 0;
-        const int res = act ? (e & 255) : 0, mov = act ? ((e >> 8) & 255) : 0;
-        double2* xh = Xs + (size_t)s_perm[res] * ns + t;
-        double2* vh = Vs + (size_t)s_perm[res] * ks + t;
-        double2* xm = Xs + (size_t)s_perm[mov] * ns + t;
-        double2* vm = Vs + (size_t)s_perm[mov] * ks + t;
+        const int res = act ? (e & 255) : 0;
+        double2* xh = Xs + (size_t)pr * ns + t;
+        double2* vh = Vs + (size_t)pr * ks + t;
+        double2* xm = Xs + (size_t)pm * ns + t;
+        double2* vm = Vs + (size_t)pm * ks + t;
         double2 mx[NR], mv[NR];
 #pragma unroll
         for (int u = 0; u < NR; ++u) mx[u] = make_double2(0.0, 0.0);
@@ -472,6 +475,8 @@ __device__ __forceinline__ void jl_sweep_resident(double2* Xs, double2* Vs, int 
             }
             cur = -1;
         }
+        pr_next = s_perm[(e_next & JS_ACTIVE) ? (e_next & 255) : 0];
+        pm_next = s_perm[(e_next & JS_ACTIVE) ? ((e_next >> 8) & 255) : 0];
         __syncthreads();
     }
 }
