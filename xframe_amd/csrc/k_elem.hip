@@ -56,34 +56,8 @@ __global__ void __launch_bounds__(256) k_real_update(RealUpdateArgs a) {
                 w = cadd(w, d);
             }
             const bool S = sup[i] != 0;
-            double2 P = w;
-            uint32_t viol = 0;
-            if (a.rp.flags & RC_SUPPORT) {
-                if (!S) {
-                    P = make_double2(0.0, 0.0);
-                    viol |= RC_SUPPORT;
-                }
-            }
-            if ((a.rp.flags & RC_VALUE_LO) && (a.rp.flags & RC_VALUE_HI)) {
-                if (P.x < a.rp.lo) { P.x = a.rp.lo; viol |= RC_VALUE_LO; }
-                if (P.x > a.rp.hi) { P.x = a.rp.hi; viol |= RC_VALUE_LO; }
-            } else if (a.rp.flags & RC_VALUE_LO) {
-                if (P.x < a.rp.lo) { P.x = a.rp.lo; viol |= RC_VALUE_LO; }
-            } else if (a.rp.flags & RC_VALUE_HI) {
-                if (P.x > a.rp.hi) { P.x = a.rp.hi; viol |= RC_VALUE_LO; }
-            }
-            if (a.rp.flags & RC_LIMIT_IMAG) {
-                if (fabs(P.y) >= a.rp.imag_thr) { P.y = 0.0; viol |= RC_LIMIT_IMAG; }
-            }
-            double2 nw = P;
-            if (a.method == MTIP_HIO || a.method == MTIP_HIO_NON_FXS) {
-                uint32_t hm = a.rp.hio_flags;
-                if (hm & (RC_VALUE_LO | RC_VALUE_HI)) hm |= RC_VALUE_LO;      // both bounds share one mask
-                if (viol & hm) {
-                    nw.x = pv.x - a.beta * (w.x - P.x);
-                    nw.y = pv.y - a.beta * (w.y - P.y);
-                }
-            }
+            double2 P;
+            const double2 nw = real_update_point(a.rp, a.method, a.beta, w, pv, S, P);
             out[i] = nw;
             const bool em = a.err_use_mask ? (a.S0[i] != 0) : true;
             if (em) {
@@ -187,10 +161,10 @@ void launch_real_update(mtip_ctx* c, const double2* rho_p, const double2* prev, 
     launch_real_update_impl(c, a);
 }
 
-void launch_finish_step(mtip_ctx* c, long long step_index) {
+void launch_finish_step(mtip_ctx* c, long long step_index, int nblk) {
     double* hist = step_index >= 0 ? c->d_err_hist + (size_t)step_index * c->B : c->d_last_err;
     hipLaunchKernelGGL(k_finish_step, dim3((unsigned)c->B), dim3(256), 0, c->stream, (const double*)c->d_partial,
-                       c->n_partial_blocks, c->d_slot, c->d_best_err, c->d_last_err, hist, c->B, step_index >= 0 ? 1 : 0);
+                       nblk > 0 ? nblk : c->n_partial_blocks, c->d_slot, c->d_best_err, c->d_last_err, hist, c->B, step_index >= 0 ? 1 : 0);
 }
 
 // ---- non-FXS variants: fixed = |F'_latest|  (reconstruct.py:899-902), F' = F sqrt(fixed/|F|^2) -------

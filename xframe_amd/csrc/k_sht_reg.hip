@@ -332,7 +332,8 @@ __global__ void __launch_bounds__(SW_THREADS) k_sht_inv_wide(const double2* __re
                                                              int npairs, const double2* __restrict__ twN_g, int nt, int L,
                                                              int RP, int Nq, const double2* __restrict__ Fin,
                                                              const double* __restrict__ shell_scale,
-                                                             const int* __restrict__ slot, int which, int B) {
+                                                             const int* __restrict__ slot, int which, int B,
+                                                             const double2* __restrict__ coeff_sub, RealEpi re) {
     constexpr int N = R1 * R2;
     constexpr int AS = R2 + 1;
     HIP_DYNAMIC_SHARED(double2, sm)
@@ -368,11 +369,30 @@ __global__ void __launch_bounds__(SW_THREADS) k_sht_inv_wide(const double2* __re
     }
     for (int e = tid; e < N; e += blockDim.x) twN[e] = twN_g[e];
     for (int e = tid; e < npairs; e += blockDim.x) ABs[e] = AB[e];
-    for (int e = tid; e < nlm; e += blockDim.x) cl[e] = csrc[e];
+    if (coeff_sub != nullptr && q > 0) {                    // ft_stab: IFT(F') - IFT(F) on shells > 0 (misk.py:326-329)
+        const double2* ssrc = coeff_sub + (size_t)shell * nlm;
+        for (int e = tid; e < nlm; e += blockDim.x) cl[e] = csub(csrc[e], ssrc[e]);
+    } else {
+        for (int e = tid; e < nlm; e += blockDim.x) cl[e] = csrc[e];
+    }
     long long dst_shell = shell;
-    if (slot != nullptr) dst_shell += (long long)slot[(shell / Nq) * SL_N + which] * B * Nq;
+    if (slot != nullptr && which >= 0) dst_shell += (long long)slot[(shell / Nq) * SL_N + which] * B * Nq;
     double2* gdst = grid + (size_t)dst_shell * nt * N;
     const double2* fsrc = Fin ? Fin + (size_t)shell * nt * N : nullptr;
+    // EPI_REAL_UPDATE: previous / new density and support of this shell through the slot table
+    const double2* rprev = nullptr;
+    const uint8_t* rsup = nullptr;
+    const uint8_t* rS0 = nullptr;
+    double err_num = 0.0, err_den = 0.0;
+    if (EPI == EPI_REAL_UPDATE) {
+        const int bb = (int)(shell / Nq);
+        const int* sl = slot + bb * SL_N;
+        const size_t gsh = (size_t)nt * N;
+        rprev = re.prev + ((size_t)sl[SL_CUR] * B * Nq + shell) * gsh;
+        gdst = re.out + ((size_t)sl[SL_OUT] * B * Nq + shell) * gsh;
+        rsup = re.sup + ((size_t)sl[SL_SUP] * B * Nq + shell) * gsh;
+        rS0 = re.S0 + (size_t)q * gsh;
+    }
     __syncthreads();
     // ---- Legendre synthesis of every row: P_lm(theta) by the three-term recurrence in l (registers only)
     for (int kk = 0;; ++kk) {
@@ -434,6 +454,25 @@ __global__ void __launch_bounds__(SW_THREADS) k_sht_inv_wide(const double2* __re
     __syncthreads();
     const int n_pass = nt / RP;
     for (int pass = 0; pass < n_pass; ++pass) {
+        // epilogue operands of this thread's step-2 outputs: requested now, they arrive behind step 1
+        double2 pre[(EPI == EPI_MODULUS || EPI == EPI_REAL_UPDATE) ? R1 : 1];
+        uint8_t pre_s[EPI == EPI_REAL_UPDATE ? R1 : 1], pre_0[EPI == EPI_REAL_UPDATE ? R1 : 1];
+        if ((EPI == EPI_MODULUS || EPI == EPI_REAL_UPDATE) && tid < RP * R2) {
+            const int r = tid / R2, n2 = tid - r * R2;
+            const int rr = pass * RP + r;
+            const int th = rr >> 1;
+            const int row = (rr & 1) ? (nt - 1 - th) : th;
+#pragma unroll
+            for (int n1 = 0; n1 < R1; ++n1) {
+                const size_t o = (size_t)row * N + R2 * n1 + n2;
+                if (EPI == EPI_MODULUS) pre[n1] = fsrc[o];
+                if (EPI == EPI_REAL_UPDATE) {
+                    pre[n1] = rprev[o];
+                    pre_s[n1] = rsup[o];
+                    pre_0[n1] = re.err_use_mask ? rS0[o] : (uint8_t)1;
+                }
+            }
+        }
         // ---- step 1: inverse R2-point FFTs over k2 of the zero padded spectrum, twiddle, transpose store
         if (tid < RP * R1) {
             const int r = tid / R1, k1 = tid - r * R1;
@@ -474,18 +513,51 @@ __global__ void __launch_bounds__(SW_THREADS) k_sht_inv_wide(const double2* __re
                 const size_t o = (size_t)row * N + R2 * n1 + n2;
                 if (EPI == EPI_MODULUS) {
                     // project_to_modified_intensity, fxs_Projections.py:899-909
-                    const double2 Fv = fsrc[o];
+                    const double2 Fv = pre[n1];
                     const double I = cabs2(Fv);
                     const bool ok = (I >= 0.0) && (v.x >= 0.0);
                     const double mult = ok ? sqrt(v.x / I) : 0.0;
                     v = cscale(Fv, mult);
                 } else if (EPI == EPI_SCALE_SHELL) {
                     v = cscale(v, shell_scale[q]);
+                } else if (EPI == EPI_REAL_UPDATE) {
+                    const double2 pv = pre[n1];
+                    const double2 w = (re.add_prev && q > 0) ? cadd(v, pv) : v;
+                    double2 P;
+                    v = real_update_point(re.rp, re.method, re.beta, w, pv, pre_s[n1] != 0, P);
+                    if (pre_0[n1] != 0) {                            // l2_projection_diff, fxs_IO_methods.py:97-128
+                        const double wg = re.wr[q] * re.wt[row];
+                        const double dx = w.x - P.x, dy = w.y - P.y;
+                        err_num = fma(wg, dx * dx + dy * dy, err_num);
+                        err_den = fma(wg, w.x * w.x + w.y * w.y, err_den);
+                    }
                 }
                 gdst[o] = v;
             }
         }
         __syncthreads();                                // Bm is rewritten by the next pass
+    }
+    if (EPI == EPI_REAL_UPDATE) {
+        // per-shell error partial sums in a fixed order (bitwise reproducible): wave butterflies, then the waves
+        for (int o = 32; o > 0; o >>= 1) {
+            err_num += __shfl_xor(err_num, o, 64);
+            err_den += __shfl_xor(err_den, o, 64);
+        }
+        double* red = reinterpret_cast<double*>(Bm);
+        if ((tid & 63) == 0) {
+            red[2 * (tid >> 6)] = err_num;
+            red[2 * (tid >> 6) + 1] = err_den;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double sn = 0.0, sd = 0.0;
+            for (int wv = 0; wv < (int)(blockDim.x >> 6); ++wv) {
+                sn += red[2 * wv];
+                sd += red[2 * wv + 1];
+            }
+            re.partial[(size_t)shell * 2] = sn;
+            re.partial[(size_t)shell * 2 + 1] = sd;
+        }
     }
 }
 
@@ -506,6 +578,8 @@ static int largest_even_divisor_le(int nt, int cap) {
         if (nt % v == 0) return v;
     return 0;
 }
+
+bool sht_inverse_fuses_real_update(const mtip_ctx* c);
 
 bool sht_reg_supported(const mtip_ctx* c) {
     int r1, r2;
@@ -564,10 +638,10 @@ static void launch_inv_r(mtip_ctx* c, const double2* coeff, double2* grid, const
     int rpw = 0;
     const size_t lds_w = wide_lds(c, R1, R2, &rpw);
     if (c->sht_wide && c->d_AB != nullptr && lds_w <= 158 * 1024) {
-        const int* slw = epi.out_slot >= 0 ? c->d_slot : nullptr;
+        const int* slw = (epi.out_slot >= 0 || EPI == EPI_REAL_UPDATE) ? c->d_slot : nullptr;
         hipLaunchKernelGGL((k_sht_inv_wide<EPI, R1, R2>), dim3((unsigned)(c->B * c->N)), dim3(SW_THREADS), lds_w, c->stream,
                            coeff, grid, (const double*)c->d_P, (const int*)c->d_poff, (const double2*)c->d_AB,
-                           (const double*)c->d_cost, c->npairs, (const double2*)c->d_twN, c->nt, c->L, rpw, c->N, epi.F, epi.shell_scale, slw, epi.out_slot, c->B);
+                           (const double*)c->d_cost, c->npairs, (const double2*)c->d_twN, c->nt, c->L, rpw, c->N, epi.F, epi.shell_scale, slw, epi.out_slot, c->B, epi.coeff_sub, epi.real);
         return;
     }
     const int RP = largest_even_divisor_le(c->nt, std::min(SR_THREADS / R2, SR_THREADS / R1));
@@ -594,6 +668,15 @@ void launch_sht_inverse_reg(mtip_ctx* c, const double2* coeff, double2* grid, co
     switch (epi.mode) {
         case EPI_MODULUS: launch_inv_p<EPI_MODULUS>(c, coeff, grid, epi); break;
         case EPI_SCALE_SHELL: launch_inv_p<EPI_SCALE_SHELL>(c, coeff, grid, epi); break;
+        case EPI_REAL_UPDATE: launch_inv_p<EPI_REAL_UPDATE>(c, coeff, grid, epi); break;
         default: launch_inv_p<EPI_STORE>(c, coeff, grid, epi); break;
     }
+}
+
+// the fused real-space epilogue and the on-load coefficient difference exist in the wide inverse kernel only
+bool sht_inverse_fuses_real_update(const mtip_ctx* c) {
+    int r1, r2;
+    if (!sht_reg_supported(c) || !c->sht_wide || c->d_AB == nullptr || !c->fuse_real_update) return false;
+    if (!reg_radices(c->np, &r1, &r2)) return false;
+    return wide_lds(c, r1, r2, nullptr) <= 158 * 1024;
 }

@@ -124,6 +124,7 @@ mtip_ctx* mtip_create(const mtip_cfg* cfg, int device) {
     A(dev_alloc(c, &c->d_AB, (size_t)c->npairs));
     A(dev_alloc(c, &c->d_lmtab, c->npairs));
     if (const char* e = std::getenv("MTIP_HANKEL_SIMPLE")) c->hankel_simple = std::atoi(e) != 0;
+    if (const char* e = std::getenv("MTIP_FUSE_REAL")) c->fuse_real_update = std::atoi(e) != 0;
     if (const char* e = std::getenv("MTIP_SHT_WIDE")) c->sht_wide = std::atoi(e) != 0;
     if (const char* e = std::getenv("MTIP_JAC_RESIDENT")) c->jac_resident = std::atoi(e) != 0;
     if (const char* e = std::getenv("MTIP_JAC_TG")) c->jac_tg = std::atoi(e) == 8 ? 8 : 16;
@@ -186,7 +187,7 @@ mtip_ctx* mtip_create(const mtip_cfg* cfg, int device) {
     A(dev_alloc(c, &c->d_Vr, (size_t)B * c->utot));
     A(dev_alloc(c, &c->d_U, (size_t)B * c->xtot));
     c->n_partial_blocks = div_up((long long)c->G, 256 * 4);
-    A(dev_alloc(c, &c->d_partial, (size_t)B * c->n_partial_blocks * 2));
+    A(dev_alloc(c, &c->d_partial, (size_t)B * std::max(c->n_partial_blocks, N) * 2));
     A(dev_alloc(c, &c->d_minmax, (size_t)B * c->n_partial_blocks * 2));
     if (rc != MTIP_OK) {
         g_create_error = c->err.empty() ? "allocation failed" : c->err;
@@ -453,6 +454,29 @@ static void enqueue_step(mtip_ctx* c, int method, int ft_stab, double beta) {
     if (c->cfg.fused && ft_stab) {
         // rho'' = rho + IFT(F' - F) on shells > 0, IFT(F') on shell 0, using SHT(F) == Hankel(SHT(rho)) = cc[1]
         launch_hankel(c, cc[1], cc[0], 1);
+        if (sht_inverse_fuses_real_update(c)) {
+            // coefficient difference on load, constraints + HIO/ER + error sums in the epilogue: the density of
+            // this step is written once and nothing else of grid size moves
+            InvEpilogue ru;
+            ru.mode = EPI_REAL_UPDATE;
+            ru.coeff_sub = cc[0];
+            ru.real.prev = c->d_rho;
+            ru.real.out = c->d_rho;
+            ru.real.sup = c->d_sup;
+            ru.real.S0 = c->d_S0;
+            ru.real.wr = c->d_err_wr;
+            ru.real.wt = c->d_err_wt;
+            ru.real.partial = c->d_partial;
+            ru.real.rp = c->rp;
+            ru.real.method = method;
+            ru.real.err_use_mask = c->err_use_mask;
+            ru.real.add_prev = 1;
+            ru.real.beta = beta;
+            launch_sht_inverse(c, cc[5], nullptr, ru);
+            launch_finish_step(c, c->n_steps_done, c->N);
+            c->n_steps_done += 1;
+            return;
+        }
         launch_coeff_diff(c, cc[5], cc[0], cc[4]);
         launch_sht_inverse(c, cc[4], c->d_T1, store);
         // prev enters twice: as the add-back (rho_rt = 0 path) -- handled by passing a zero round trip

@@ -49,6 +49,59 @@ struct RealParams {
     double lo, hi, imag_thr;
 };
 
+// One grid point of the real-space stage: P = real_projection(w) (support, value bounds, imaginary-part limit;
+// fxs_Projections.py:72-130), new density = P (error reduction) or prev - beta (w - P) where a constraint counted
+// by the HIO mask was violated (fxs_IO_methods.py:40-64).  Returns the new density, P through P_out.
+__device__ __forceinline__ double2 real_update_point(const RealParams& rp, int method, double beta, double2 w, double2 pv,
+                                                     bool S, double2& P_out) {
+    double2 P = w;
+    uint32_t viol = 0;
+    if (rp.flags & RC_SUPPORT) {
+        if (!S) {
+            P = make_double2(0.0, 0.0);
+            viol |= RC_SUPPORT;
+        }
+    }
+    if ((rp.flags & RC_VALUE_LO) && (rp.flags & RC_VALUE_HI)) {
+        if (P.x < rp.lo) { P.x = rp.lo; viol |= RC_VALUE_LO; }
+        if (P.x > rp.hi) { P.x = rp.hi; viol |= RC_VALUE_LO; }
+    } else if (rp.flags & RC_VALUE_LO) {
+        if (P.x < rp.lo) { P.x = rp.lo; viol |= RC_VALUE_LO; }
+    } else if (rp.flags & RC_VALUE_HI) {
+        if (P.x > rp.hi) { P.x = rp.hi; viol |= RC_VALUE_LO; }
+    }
+    if (rp.flags & RC_LIMIT_IMAG) {
+        if (fabs(P.y) >= rp.imag_thr) { P.y = 0.0; viol |= RC_LIMIT_IMAG; }
+    }
+    double2 nw = P;
+    if (method == MTIP_HIO || method == MTIP_HIO_NON_FXS) {
+        uint32_t hm = rp.hio_flags;
+        if (hm & (RC_VALUE_LO | RC_VALUE_HI)) hm |= RC_VALUE_LO;      // both bounds share one mask
+        if (viol & hm) {
+            nw.x = pv.x - beta * (w.x - P.x);
+            nw.y = pv.y - beta * (w.y - P.y);
+        }
+    }
+    P_out = P;
+    return nw;
+}
+
+// real-space stage fused into the last inverse SHT of a step (EPI_REAL_UPDATE): w = iSHT value (+ previous density on
+// shells > 0: the ft_stab add-back), densities and support read / written through the slot table, error partial
+// sums per shell
+struct RealEpi {
+    const double2* prev = nullptr;     // slot base (3,B,G)
+    double2* out = nullptr;            // slot base (3,B,G)
+    const uint8_t* sup = nullptr;      // support slot base (3,B,G)
+    const uint8_t* S0 = nullptr;       // (G)
+    const double* wr = nullptr;        // (Nq) radial error weights
+    const double* wt = nullptr;        // (nt) polar error weights
+    double* partial = nullptr;         // (B, Nq, 2)
+    RealParams rp{};
+    int method = 0, err_use_mask = 0, add_prev = 0;
+    double beta = 0.0;
+};
+
 // epilogues of the inverse SHT (grid-side fused elementwise stages)
 enum { EPI_STORE = 0, EPI_MODULUS = 1, EPI_SCALE_SHELL = 2, EPI_MODULUS_FIXED = 3, EPI_REAL_UPDATE = 4 };
 
@@ -76,6 +129,7 @@ struct mtip_ctx {
     void* d_htiles = nullptr;                         // HankelTile list of the MFMA kernel
     int n_htiles = 0;
     int n_cu = 256;                                   // compute units of the device (persistent-grid sizing)
+    bool fuse_real_update = true;                     // env MTIP_FUSE_REAL=0: separate coefficient-difference / real-space kernels
     bool sht_wide = true;                             // env MTIP_SHT_WIDE=0: pass-wise inverse Legendre synthesis
     bool jac_resident = true;                         // env MTIP_JAC_RESIDENT=0: round-robin ordering, both columns via LDS
     int *d_jsched = nullptr, *d_jsched_off = nullptr, *d_jsched_rounds = nullptr;   // resident-column pairing schedule
@@ -142,6 +196,8 @@ struct InvEpilogue {
     const double2* F = nullptr;        // EPI_MODULUS*: reciprocal density to rescale
     const double* fixed = nullptr;     // EPI_MODULUS_FIXED
     const double* shell_scale = nullptr;   // EPI_SCALE_SHELL (Nq)
+    const double2* coeff_sub = nullptr;    // coefficients to subtract on shells > 0 before the synthesis (ft_stab)
+    RealEpi real;                          // EPI_REAL_UPDATE
     int out_slot = -1;                 // >= 0: grid is a (3,B,G) slot array written through slot[b][out_slot]
 };
 void launch_sht_inverse(mtip_ctx* c, const double2* coeff, double2* grid, const InvEpilogue& epi);
@@ -150,6 +206,7 @@ bool sht_fused_supported(const mtip_ctx* c);
 void launch_sht_forward_fused(mtip_ctx* c, const double2* grid, double2* coeff, int prologue, int in_slot);
 void launch_sht_inverse_fused(mtip_ctx* c, const double2* coeff, double2* grid, const InvEpilogue& epi);
 bool sht_reg_supported(const mtip_ctx* c);
+bool sht_inverse_fuses_real_update(const mtip_ctx* c);    // EPI_REAL_UPDATE / coeff_sub available (wide inverse kernel)
 void launch_sht_forward_reg(mtip_ctx* c, const double2* grid, double2* coeff, int prologue, int in_slot);
 void launch_sht_inverse_reg(mtip_ctx* c, const double2* coeff, double2* grid, const InvEpilogue& epi);
 // Hankel
@@ -164,7 +221,7 @@ void launch_deg2_metric(mtip_ctx* c, const double2* Ilm, double* out /*(B, L+1)*
 // rho_p = IFT(F') (B,G); prev/out: slot arrays (3,B,G) when use_slots else plain (B,G); rho_rt may be null
 void launch_real_update(mtip_ctx* c, const double2* rho_p, const double2* prev, const double2* rho_rt, double2* out,
                         int method, double beta, int use_slots);
-void launch_finish_step(mtip_ctx* c, long long step_index);
+void launch_finish_step(mtip_ctx* c, long long step_index, int nblk = 0);   // nblk partial sums per restart (0: grid blocks)
 void launch_abs_to_fixed(mtip_ctx* c);
 void launch_modulus_plain(mtip_ctx* c, const double2* F, const double2* Inew, double2* out);
 void launch_modulus_fixed_slots(mtip_ctx* c, const double2* F);
