@@ -15,33 +15,6 @@
 #define JAC_TOL 1e-14
 #define JAC_DEFLATE 1e-15   // columns below this fraction of the largest column are numerical zeros
 
-// X_l[c][r] = sum_q q^2 V_l[q][c] conj(I_l[q][r])      (= conj(A_l[c][r]))
-__global__ void __launch_bounds__(256) k_proj_X(const double2* __restrict__ Ilm, double2* __restrict__ X,
-                                                const double2* __restrict__ V, const double* __restrict__ qv,
-                                                const int* __restrict__ kl, const int* __restrict__ used,
-                                                const int* __restrict__ voff, const int* __restrict__ xoff,
-                                                int N, int L, int xtot) {
-    const int l = blockIdx.y, b = blockIdx.z;
-    if (!used[l]) return;
-    const int k = kl[l], n = 2 * l + 1;
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= k * n) return;
-    const int nlm = (L + 1) * (L + 1);
-    const int cidx = e / n, r = e - cidx * n;
-    const double2* Vl = V + voff[l] + cidx;
-    const double2* Il = Ilm + (size_t)b * N * nlm + l * l + r;
-    double2 acc = make_double2(0.0, 0.0);
-    for (int q = 0; q < N; ++q) {
-        const double q2 = qv[q] * qv[q];
-        const double2 v = Vl[(size_t)q * k];
-        const double2 iv = Il[(size_t)q * nlm];
-        const double2 p = cmulc(v, iv);
-        acc.x = fma(q2, p.x, acc.x);
-        acc.y = fma(q2, p.y, acc.y);
-    }
-    X[(size_t)b * xtot + xoff[l] + (size_t)cidx * n + r] = acc;
-}
-
 // tournament pairing of round r: players 0..Cp-1 (Cp even), pair index pi in [0, Cp/2)
 __device__ __forceinline__ void jacobi_pair(int r, int pi, int Cp, int* a, int* b) {
     const int M = Cp - 1;                 // 0 <= r < M, 0 <= pi <= M/2: one conditional subtract replaces the modulo
@@ -668,73 +641,204 @@ __global__ void __launch_bounds__(JL_MAX_THREADS) k_polar_jacobi_lds(const doubl
     }
 }
 
-// warm start: X'[c][r] = sum_j X[j][r] Vr[j][c]   (all column-major: X[j*n+r], Vr[c*k+j])
-__global__ void __launch_bounds__(256) k_proj_warm(const double2* __restrict__ Xall, const double2* __restrict__ Vrall,
-                                                   double2* __restrict__ Xw_all, const int* __restrict__ kl,
-                                                   const int* __restrict__ active, const int* __restrict__ xoff,
-                                                   const int* __restrict__ roff, int xtot, int rtot) {
-    const int l = blockIdx.y, b = blockIdx.z;
-    if (!active[l]) return;
-    const int k = kl[l], n = 2 * l + 1;
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= k * n) return;
-    const int cc = e / n, r = e - cc * n;
-    const double2* X = Xall + (size_t)b * xtot + xoff[l] + r;
-    const double2* v = Vrall + (size_t)b * rtot + roff[l] + (size_t)cc * k;
-    double2 acc = make_double2(0.0, 0.0);
-    for (int j = 0; j < k; ++j) acc = cadd(acc, cmul(X[(size_t)j * n], v[j]));
-    Xw_all[(size_t)b * xtot + xoff[l] + e] = acc;
-}
+// ---- register-tiled complex GEMMs around the polar factor ----------------------------------------------------
+// The four products of the projection (X_l = I_l^+ D^2 V_l, the warm start X_l V_r, U_l = V_r Pn^+ and
+// I'_l = V_l U_l) are small batched complex GEMMs (<= 128 x 65 x 65 per (restart, l)), 285 MFLOP per call in all:
+// they have to be spread over the whole chip (one (restart, l = 32) product alone is 14 us of one CU's FP64 peak) and
+// must not re-read their operands per output element (32 bytes per complex FMA from L2 otherwise).  Tile = 33 x 33
+// outputs (2l+1 <= 65 -> two tiles, 1.5 % padding), 11 x 11 threads with 3 x 3 outputs each, inner extent in chunks
+// of 16 through LDS, the next chunk's operands in flight in registers while the current one is multiplied.
+#define PG_T 11                 // threads per tile edge
+#define PG_R 3                  // outputs per thread and edge
+#define PG_TM (PG_T * PG_R)     // tile edge (33)
+#define PG_TK 8
+#define PG_THREADS 128
+#define PG_LD ((PG_TM * PG_TK + PG_THREADS - 1) / PG_THREADS)    // staged elements per thread and operand (5)
 
-// U[i][j] = sum_c Vr[i][c] conj(Pn[j][c])        (U row-major k x n)
-__global__ void __launch_bounds__(256) k_proj_U(const double2* __restrict__ Pn_all, const double2* __restrict__ Vrall,
-                                                double2* __restrict__ Uall, const int* __restrict__ kl,
-                                                const int* __restrict__ active, const int* __restrict__ xoff,
-                                                const int* __restrict__ roff, int xtot, int rtot) {
-    const int l = blockIdx.y, b = blockIdx.z;
-    if (!active[l]) return;
-    const int k = kl[l], n = 2 * l + 1;
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= k * n) return;
-    const int i = e / n, j = e - i * n;
-    const double2* Pn = Pn_all + (size_t)b * xtot + xoff[l] + j;
-    const double2* v = Vrall + (size_t)b * rtot + roff[l] + i;
-    double2 acc = make_double2(0.0, 0.0);
-    for (int cc = 0; cc < k; ++cc) acc = cadd(acc, cmulc(v[(size_t)cc * k], Pn[(size_t)cc * n]));
-    Uall[(size_t)b * xtot + xoff[l] + e] = acc;
-}
+struct ProjGemmArgs {
+    const double2* Ilm;
+    const double2* V;
+    const double2* X;           // d_X: X_l, later Pn
+    const double2* Xw;          // d_U: warm-start buffer, later U
+    const double2* Vr;
+    double2* dst;
+    const double* q;
+    const uint8_t* rmask;
+    const int *kl, *active, *used, *voff, *xoff, *uoff;
+    int N, L, xtot, utot, nlm;
+    double inv_sqrt_np;
+};
 
-// I'_l = mask ? V_l U_l : I_l  (+ the l = 0 rules)
-__global__ void __launch_bounds__(256) k_proj_apply(const double2* __restrict__ Ilm, double2* __restrict__ out,
-                                                    const double2* __restrict__ V, const double2* __restrict__ Uall,
-                                                    const uint8_t* __restrict__ rmask, const int* __restrict__ kl,
-                                                    const int* __restrict__ used, const int* __restrict__ voff,
-                                                    const int* __restrict__ xoff, int N, int L, int xtot,
-                                                    double inv_sqrt_np, long long total) {
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= total) return;
-    const int nlm = (L + 1) * (L + 1);
-    const int lm = (int)(idx % nlm);
-    const long long bq = idx / nlm;
-    const int q = (int)(bq % N);
-    const long long b = bq / N;
-    const int l = isqrt_lm(lm);
-    const int j = lm - l * l;
-    double2 v = Ilm[idx];
-    if (used[l] && rmask[(size_t)l * N + q]) {
-        const int k = kl[l], n = 2 * l + 1;
-        const double2* Vl = V + voff[l] + (size_t)q * k;
-        if (l == 0) {
-            v = Vl[0];                                   // fxs_Projections.py:840
-        } else {
-            const double2* U = Uall + (size_t)b * xtot + xoff[l] + j;
-            double2 acc = make_double2(0.0, 0.0);
-            for (int i = 0; i < k; ++i) acc = cadd(acc, cmul(Vl[i], U[(size_t)i * n]));
-            v = acc;
+enum { PG_X = 0, PG_WARM = 1, PG_U = 2, PG_APPLY = 3 };
+
+// operand views of one (restart, l) product: element (i, j) at base[i * si + j * sj], optionally conjugated
+struct PgView {
+    const double2* base;
+    int si, sj;
+};
+
+template <int OP>
+struct ProjGemm {
+    static constexpr bool A_M_FAST = (OP != PG_APPLY);      // memory-contiguous index of the A operand: m (else k)
+    static constexpr bool B_N_FAST = (OP != PG_WARM);
+    static constexpr bool A_CONJ = (OP == PG_X), B_CONJ = (OP == PG_U);
+    // dims and operand views (A: rows m, columns kk;  B: rows kk, columns nn) for order l of restart b
+    static __device__ __forceinline__ void setup(const ProjGemmArgs& a, int b, int l, int& M, int& Nn, int& K, PgView& A,
+                                                 PgView& Bv) {
+        const int k = a.kl[l], n = 2 * l + 1;
+        if (OP == PG_X) {                                   // conj(I_l[q][r]) q^2  x  V_l[q][c]
+            M = n; Nn = k; K = a.N;
+            A = PgView{a.Ilm + (size_t)b * a.N * a.nlm + l * l, 1, a.nlm};
+            Bv = PgView{a.V + a.voff[l], k, 1};
+        } else if (OP == PG_WARM) {                         // X[j][r]  x  Vr[c][j]
+            M = n; Nn = k; K = k;
+            A = PgView{a.X + (size_t)b * a.xtot + a.xoff[l], 1, n};
+            Bv = PgView{a.Vr + (size_t)b * a.utot + a.uoff[l], 1, k};
+        } else if (OP == PG_U) {                            // Vr[c][i]  x  conj(Pn[c][j])
+            M = k; Nn = n; K = k;
+            A = PgView{a.Vr + (size_t)b * a.utot + a.uoff[l], 1, k};
+            Bv = PgView{a.X + (size_t)b * a.xtot + a.xoff[l], n, 1};
+        } else {                                            // V_l[q][i]  x  U[i][j]
+            M = a.N; Nn = n; K = k;
+            A = PgView{a.V + a.voff[l], k, 1};
+            Bv = PgView{a.Xw + (size_t)b * a.xtot + a.xoff[l], n, 1};
         }
     }
-    if (l == 0 && used[0]) v = cscale(v, inv_sqrt_np);     // fxs_Projections.py:870
-    out[idx] = v;
+    static __device__ __forceinline__ void store(const ProjGemmArgs& a, int b, int l, int k, int n, int xo, int m, int nn,
+                                                 double2 acc) {
+        if (OP == PG_X || OP == PG_WARM) {                  // column-major n x k
+            a.dst[(size_t)b * a.xtot + xo + (size_t)nn * n + m] = acc;
+        } else if (OP == PG_U) {                            // row-major k x n
+            a.dst[(size_t)b * a.xtot + xo + (size_t)m * n + nn] = acc;
+        } else {                                            // I'_l[q = m][j = nn]: mask ? V_l U_l : I_l (+ l = 0 rules)
+            const size_t idx = ((size_t)b * a.N + m) * a.nlm + l * l + nn;
+            double2 v = a.Ilm[idx];
+            if (a.used[l] && a.rmask[(size_t)l * a.N + m]) v = (l == 0) ? a.V[a.voff[0] + (size_t)m * k] : acc;   // fxs_Projections.py:840
+            if (l == 0 && a.used[0]) v = cscale(v, a.inv_sqrt_np);                                                 // fxs_Projections.py:870
+            a.dst[idx] = v;
+        }
+    }
+    static __device__ __forceinline__ bool has_product(const ProjGemmArgs& a, int l) {
+        if (OP == PG_APPLY) return a.used[l] && l > 0;
+        return a.active[l] != 0;
+    }
+};
+
+template <int OP>
+__global__ void __launch_bounds__(PG_THREADS) k_proj_gemm(ProjGemmArgs a) {
+    typedef ProjGemm<OP> G;
+    constexpr int LD = PG_TM + 1;
+    __shared__ double2 As[2][PG_TK][LD];
+    __shared__ double2 Bs[2][PG_TK][LD];
+    const int l = blockIdx.y, b = blockIdx.z;
+    const bool prod = G::has_product(a, l);
+    if (!prod && OP != PG_APPLY) return;
+    int M, Nn, K;
+    PgView A, Bv;
+    G::setup(a, b, l, M, Nn, K, A, Bv);
+    const int k = a.kl[l], n = 2 * l + 1, xo = a.xoff[l];
+    const int tn = (Nn + PG_TM - 1) / PG_TM;
+    const int tile_m = blockIdx.x / tn, tile_n = blockIdx.x - tile_m * tn;
+    const int m0 = tile_m * PG_TM, n0 = tile_n * PG_TM;
+    if (m0 >= M) return;                                     // block-uniform
+    const int tid = threadIdx.x;
+    const int ty = tid / PG_T, tx = tid - ty * PG_T;
+    const bool worker = tid < PG_T * PG_T;
+    double2 acc[PG_R][PG_R];
+#pragma unroll
+    for (int i = 0; i < PG_R; ++i)
+#pragma unroll
+        for (int j = 0; j < PG_R; ++j) acc[i][j] = make_double2(0.0, 0.0);
+    if (prod) {
+        // staging slots of this thread: element e = tid + u * PG_THREADS of the PG_TM x PG_TK operand chunks
+        int am[PG_LD], ak[PG_LD], bn[PG_LD], bk[PG_LD];
+#pragma unroll
+        for (int u = 0; u < PG_LD; ++u) {
+            const int e = tid + u * PG_THREADS;
+            if (G::A_M_FAST) { ak[u] = e / PG_TM; am[u] = e - ak[u] * PG_TM; }
+            else { am[u] = e / PG_TK; ak[u] = e - am[u] * PG_TK; }
+            if (G::B_N_FAST) { bk[u] = e / PG_TM; bn[u] = e - bk[u] * PG_TM; }
+            else { bn[u] = e / PG_TK; bk[u] = e - bn[u] * PG_TK; }
+            if (e >= PG_TM * PG_TK) { am[u] = PG_TM; bn[u] = PG_TM; ak[u] = 0; bk[u] = 0; }    // no such slot
+        }
+        double2 ra[PG_LD], rb[PG_LD];
+        auto request = [&](int k0) {
+#pragma unroll
+            for (int u = 0; u < PG_LD; ++u) {
+                ra[u] = make_double2(0.0, 0.0);
+                rb[u] = make_double2(0.0, 0.0);
+                if (am[u] < PG_TM && m0 + am[u] < M && k0 + ak[u] < K) {
+                    double2 v = A.base[(size_t)(m0 + am[u]) * A.si + (size_t)(k0 + ak[u]) * A.sj];
+                    if (OP == PG_X) {
+                        const double qq = a.q[k0 + ak[u]];
+                        v = make_double2(qq * qq * v.x, -qq * qq * v.y);
+                    }
+                    ra[u] = v;
+                }
+                if (bn[u] < PG_TM && n0 + bn[u] < Nn && k0 + bk[u] < K) {
+                    double2 v = Bv.base[(size_t)(k0 + bk[u]) * Bv.si + (size_t)(n0 + bn[u]) * Bv.sj];
+                    if (G::B_CONJ) v.y = -v.y;
+                    rb[u] = v;
+                }
+            }
+        };
+        auto deposit = [&](int buf) {
+#pragma unroll
+            for (int u = 0; u < PG_LD; ++u) {
+                if (am[u] < PG_TM) {
+                    As[buf][ak[u]][am[u]] = ra[u];
+                    Bs[buf][bk[u]][bn[u]] = rb[u];
+                }
+            }
+        };
+        request(0);
+        deposit(0);
+        __syncthreads();
+        int buf = 0;
+        for (int k0 = 0; k0 < K; k0 += PG_TK) {
+            const bool more = k0 + PG_TK < K;
+            if (more) request(k0 + PG_TK);                    // in flight during the multiply
+            if (worker) {
+#pragma unroll
+                for (int kk = 0; kk < PG_TK; ++kk) {
+                    double2 av[PG_R], bv[PG_R];
+#pragma unroll
+                    for (int i = 0; i < PG_R; ++i) {
+                        av[i] = As[buf][kk][ty * PG_R + i];
+                        bv[i] = Bs[buf][kk][tx * PG_R + i];
+                    }
+#pragma unroll
+                    for (int i = 0; i < PG_R; ++i)
+#pragma unroll
+                        for (int j = 0; j < PG_R; ++j) {
+                            acc[i][j].x = fma(av[i].x, bv[j].x, acc[i][j].x);
+                            acc[i][j].x = fma(-av[i].y, bv[j].y, acc[i][j].x);
+                            acc[i][j].y = fma(av[i].x, bv[j].y, acc[i][j].y);
+                            acc[i][j].y = fma(av[i].y, bv[j].x, acc[i][j].y);
+                        }
+                }
+            }
+            if (more) deposit(buf ^ 1);
+            __syncthreads();
+            buf ^= 1;
+        }
+    }
+    if (worker) {
+#pragma unroll
+        for (int i = 0; i < PG_R; ++i)
+#pragma unroll
+            for (int j = 0; j < PG_R; ++j) {
+                const int mm = m0 + ty * PG_R + i, nn = n0 + tx * PG_R + j;
+                if (mm < M && nn < Nn) G::store(a, b, l, k, n, xo, mm, nn, acc[i][j]);
+            }
+    }
+}
+
+template <int OP>
+static void launch_proj_gemm(mtip_ctx* c, const ProjGemmArgs& a, int max_m, int max_n) {
+    const int tiles = div_up(max_m, PG_TM) * div_up(max_n, PG_TM);
+    hipLaunchKernelGGL(k_proj_gemm<OP>, dim3((unsigned)tiles, (unsigned)(c->L + 1), (unsigned)c->B), dim3(PG_THREADS), 0,
+                       c->stream, a);
 }
 
 // Divide-and-conquer pairing schedule for every column count 2..kmax (see jl_sweep_resident).  Entry
@@ -836,19 +940,21 @@ void launch_project_coefficients(mtip_ctx* c, const double2* Ilm, double2* out) 
         kmax = std::max(kmax, c->kl[l]);
         nmax = std::max(nmax, 2 * l + 1);
     }
-    const dim3 gmat((unsigned)div_up(max_kn, 256), (unsigned)(c->L + 1), (unsigned)c->B);
-    hipLaunchKernelGGL(k_proj_X, gmat, dim3(256), 0, c->stream, Ilm, c->d_X, (const double2*)c->d_V,
-                       (const double*)c->d_q, (const int*)c->d_kl, (const int*)c->d_active, (const int*)c->d_voff,
-                       (const int*)c->d_xoff, c->N, c->L, c->xtot);
+    ProjGemmArgs ga;
+    ga.Ilm = Ilm; ga.V = c->d_V; ga.X = c->d_X; ga.Xw = c->d_U; ga.Vr = c->d_Vr; ga.dst = c->d_X;
+    ga.q = c->d_q; ga.rmask = c->d_rmask; ga.kl = c->d_kl; ga.active = c->d_active; ga.used = c->d_used;
+    ga.voff = c->d_voff; ga.xoff = c->d_xoff; ga.uoff = c->d_uoff;
+    ga.N = c->N; ga.L = c->L; ga.xtot = c->xtot; ga.utot = c->utot; ga.nlm = c->nlm;
+    ga.inv_sqrt_np = 1.0 / std::sqrt(c->n_particles);
+    launch_proj_gemm<PG_X>(c, ga, nmax, kmax);
     const size_t lds = ((size_t)kmax * (nmax | 1) + (size_t)kmax * (kmax | 1)) * sizeof(double2);   // unpadded minimum
     if (lds <= 158 * 1024) {
         // cold start every 64 calls bounds the accumulated rounding drift of the carried V_r
         const int warm = (c->vr_valid && (c->proj_calls % 64) != 0) ? 1 : 0;
         const double2* src = c->d_X;
         if (warm) {
-            hipLaunchKernelGGL(k_proj_warm, gmat, dim3(256), 0, c->stream, (const double2*)c->d_X, (const double2*)c->d_Vr,
-                               c->d_U, (const int*)c->d_kl, (const int*)c->d_active, (const int*)c->d_xoff,
-                               (const int*)c->d_uoff, c->xtot, c->utot);
+            ga.dst = c->d_U;
+            launch_proj_gemm<PG_WARM>(c, ga, nmax, kmax);
             src = c->d_U;
         }
         const int pairs_max = kmax / 2;                         // valid pairs per round (odd k: dummy pair skipped)
@@ -873,9 +979,8 @@ void launch_project_coefficients(mtip_ctx* c, const double2* Ilm, double2* out) 
         else if (nmax <= 9 * 8) JL_LAUNCH(9, 8);
         else JL_LAUNCH(16, 8);
 #undef JL_LAUNCH
-        hipLaunchKernelGGL(k_proj_U, gmat, dim3(256), 0, c->stream, (const double2*)c->d_X, (const double2*)c->d_Vr, c->d_U,
-                           (const int*)c->d_kl, (const int*)c->d_active, (const int*)c->d_xoff, (const int*)c->d_uoff,
-                           c->xtot, c->utot);
+        ga.dst = c->d_U;
+        launch_proj_gemm<PG_U>(c, ga, kmax, nmax);
         c->vr_valid = true;
         c->proj_calls += 1;
     } else {
@@ -883,11 +988,8 @@ void launch_project_coefficients(mtip_ctx* c, const double2* Ilm, double2* out) 
                            c->d_Vr, c->d_U, (const int*)c->d_kl, (const int*)c->d_active, (const int*)c->d_xoff,
                            (const int*)c->d_uoff, c->xtot, c->utot);
     }
-    const long long total = (long long)c->B * c->N * c->nlm;
-    hipLaunchKernelGGL(k_proj_apply, dim3((unsigned)div_up(total, 256)), dim3(256), 0, c->stream, Ilm, out,
-                       (const double2*)c->d_V, (const double2*)c->d_U, (const uint8_t*)c->d_rmask, (const int*)c->d_kl,
-                       (const int*)c->d_used, (const int*)c->d_voff, (const int*)c->d_xoff, c->N, c->L, c->xtot,
-                       1.0 / std::sqrt(c->n_particles), total);
+    ga.dst = out;
+    launch_proj_gemm<PG_APPLY>(c, ga, c->N, 2 * c->L + 1);     // every order is written (unused ones copied)
 }
 
 // ---- B_l = I_l I_l^+ ------------------------------------------------------------------------------
