@@ -122,7 +122,7 @@ def main():
     sw_sigma = hs.LinearRamp(20, [False, 5], -2, default_start=e0.default_sigma, default_stop=e0.default_sigma)
     CHUNK = 10                                                  # steps enqueued per engine before switching
 
-    host = {'enqueue_s': 0.0}
+    host = {'enqueue_s': 0.0, 'profile': False, 'chunks': 0}
 
     def run_schedule(n_steps, start_step=0):
         step = start_step
@@ -138,6 +138,11 @@ def main():
                 c = min(CHUNK, k - done)
                 betas = np.array([ramp.eval(step + done + i) for i in range(c)])
                 th = time.perf_counter()
+                # family timers (hipEvent brackets on engine 0's stream) on for one chunk in four of the timed region:
+                # recording them costs ~5 % when always on
+                if host['profile']:
+                    engines[0].lib.mtip_profile(engines[0].ctx, 1 if host['chunks'] % 4 == 0 else 0)
+                    host['chunks'] += 1
                 for e in engines:
                     e.run(kind, True, betas, fetch=False)
                 host['enqueue_s'] += time.perf_counter() - th
@@ -156,6 +161,9 @@ def main():
     if dist is not None:
         dist.barrier()
     host['enqueue_s'] = 0.0
+    if not a.no_roofline:
+        e0.profile(True)                                        # resets the timers
+        host['profile'] = True
     t0 = time.perf_counter()
     run_schedule(a.steps, start_step=a.warmup)
     sync_all()
@@ -183,16 +191,13 @@ def main():
     bl_mean = average_invariants(bl_sum, n_bl, device=dev if dist is not None else None)
     reduce_s = time.perf_counter() - t_red
 
-    # ---- roofline of the dominant kernel family (hipEvent timing on the ctx stream, one engine, alone on the GPU)
+    # ---- roofline of the dominant kernel family: hipEvent brackets on engine 0's stream, recorded over the timed
+    #      region itself (asynchronous event pairs, resolved after the final synchronisation)
     roofline = None
     fam_ms = {}
     Bp = e0.B
     if not a.no_roofline:
-        sync_all()
-        e0.profile(True)
-        e0.run('HIO', True, np.full(6, 0.45), fetch=False)
-        e0.synchronize()
-        for fam in ('sht_fwd', 'sht_inv', 'hankel', 'proj', 'real_update', 'deg2_metric'):
+        for fam in ('sht_fwd', 'sht_inv', 'sht_inv_modulus', 'sht_inv_real', 'hankel', 'proj', 'real_update', 'deg2_metric'):
             ms, n = e0.profile_get(fam)
             if n:
                 fam_ms[fam] = {'total_ms': ms, 'launches': int(n), 'avg_ms': ms / n}
@@ -200,16 +205,33 @@ def main():
         if fam_ms:
             G = N * e0.n_theta * e0.n_phi
             C = N * (L + 1) ** 2
-            alg = {'sht_fwd': 16 * G * Bp + 16 * C * Bp, 'sht_inv': 16 * G * Bp + 16 * C * Bp,
-                   'hankel': 2 * 16 * C * Bp + 8 * N * N * (L + 1), 'real_update': (3 * 16 + 2) * G * Bp}
+            # algorithmic bytes per launch (SURVEY section 8 d: 16 B per grid point / coefficient moved once,
+            # 1 B per mask byte), Bp restarts per launch
+            alg = {'sht_fwd': (16 * G + 16 * C) * Bp,                       # grid in, coefficients out
+                   'sht_inv': (16 * C + 16 * G) * Bp,                       # coefficients in, grid out
+                   'sht_inv_modulus': (16 * C + 2 * 16 * G) * Bp,           # + F in  (F' = F sqrt(I'/I) epilogue)
+                   'sht_inv_real': (2 * 16 * C + 2 * 16 * G + 2 * G) * Bp,  # two coefficient sets, rho in/out, 2 masks
+                   'hankel': 2 * 16 * C * Bp + 8 * N * N * (L + 1),
+                   'real_update': (3 * 16 + 2) * G * Bp}
             hbm = {k: v for k, v in fam_ms.items() if k in alg}
             dom = max(hbm, key=lambda k: hbm[k]['total_ms'])
             achieved = alg[dom] / (fam_ms[dom]['avg_ms'] * 1e-3) / 1e9
+            traffic = None
+            try:                                                        # PMC pass of the same command, committed
+                with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'pmc_traffic.json')) as f:
+                    pmc = json.load(f)
+                if pmc.get('restarts_per_launch') == Bp and pmc.get('config') == a.config:
+                    traffic = pmc['hbm_bytes_per_launch'].get(dom)
+            except (OSError, ValueError, KeyError):
+                traffic = None
             roofline = {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s',
-                        'frac': achieved / 8000.0, 'traffic': None, 'avg_launch_ms': fam_ms[dom]['avg_ms'],
+                        'frac': achieved / 8000.0, 'traffic': traffic, 'avg_launch_ms': fam_ms[dom]['avg_ms'],
                         'algorithmic_bytes_per_launch': alg[dom], 'restarts_per_launch': Bp,
-                        'note': 'dominant HBM-bound kernel family; the latency-bound polar-factor kernel (proj) is '
-                                'listed in kernel_families_ms'}
+                        'families_GBps': {k: alg[k] / (fam_ms[k]['avg_ms'] * 1e-3) / 1e9 for k in hbm},
+                        'note': 'dominant HBM-bound kernel family, timed with hipEvents over the timed region on the '
+                                'stream of engine 0; the polar-factor kernel (inside proj, LDS/latency bound in one CU '
+                                'per matrix) is listed in kernel_families_ms; traffic = FETCH_SIZE x 2 + WRITE_SIZE '
+                                'of profiles/pmc_traffic.json when it was collected at this batch size'}
     step_bytes = algorithmic_bytes_per_step(N, L, e0.n_theta, e0.n_phi, True)
     whole_step = {'algorithmic_bytes_per_step_per_restart': step_bytes,
                   'achieved_GBps_per_gpu': step_bytes * B * a.steps / elapsed / 1e9,

@@ -1,7 +1,7 @@
 """Per-kernel HBM traffic from two rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE, collected separately as the
 TCC slots require).  Units: both counters are in KiB; on gfx950 FETCH_SIZE tallies 128-byte read requests at 64 bytes,
 so wide coalesced reads are doubled (MI355X_MICROARCH.md, HBM section) -- printed raw and corrected.
-usage: pmc_summary.py <fetch_dir> <write_dir>"""
+usage: pmc_summary.py <fetch_dir> <write_dir> [out.json restarts_per_launch config]"""
 import csv, glob, sys
 from collections import defaultdict
 
@@ -29,3 +29,22 @@ rows.sort(reverse=True)
 print("%-52s %6s %12s %12s %12s %12s" % ("kernel", "calls", "fetch_raw_MB", "fetch_x2_MB", "write_MB", "hbm_MB"))
 for tot, k, n, fk, wk in rows[:24]:
     print("%-52s %6d %12.2f %12.2f %12.2f %12.2f" % (k[:52], n, fk / 1e6, 2 * fk / 1e6, wk / 1e6, tot / 1e6))
+
+if len(sys.argv) > 3:
+    import json
+    fam_of = [("k_sht_fwd_reg", "sht_fwd"), ("k_sht_inv_wide<0", "sht_inv"), ("k_sht_inv_wide<1", "sht_inv_modulus"),
+              ("k_sht_inv_wide<4", "sht_inv_real"), ("k_hankel", "hankel"), ("k_real_update", "real_update")]
+    fam = defaultdict(lambda: [0.0, 0])
+    for k in fetch:
+        for pat, name in fam_of:
+            if pat in k:
+                wb = write[k][0] * 1024 if k in write else 0.0
+                # per-launch mean of (2 x FETCH_SIZE + WRITE_SIZE), weighting the variants of a family by their calls
+                fam[name][0] += 2 * fetch[k][0] * 1024 + wb * fetch[k][1] / max(write[k][1], 1) if k in write else 2 * fetch[k][0] * 1024
+                fam[name][1] += fetch[k][1]
+    out = {"restarts_per_launch": int(sys.argv[4]), "config": int(sys.argv[5]),
+           "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of bench.py; KiB units; FETCH_SIZE doubled (gfx950 "
+                     "tallies 128-byte read requests at 64 bytes); Infinity-Cache hits are included in FETCH_SIZE",
+           "hbm_bytes_per_launch": {k: v[0] / v[1] for k, v in fam.items()}}
+    json.dump(out, open(sys.argv[3], "w"), indent=1)
+    print(json.dumps(out["hbm_bytes_per_launch"], indent=1))

@@ -300,7 +300,8 @@ void launch_sht_forward(mtip_ctx* c, const double2* grid, double2* coeff, int pr
 }
 
 void launch_sht_inverse(mtip_ctx* c, const double2* coeff, double2* grid, const InvEpilogue& epi) {
-    ProfScope ps(c, "sht_inv");
+    // timer families by epilogue: they move different amounts of data
+    ProfScope ps(c, epi.mode == EPI_REAL_UPDATE ? "sht_inv_real" : (epi.mode == EPI_MODULUS || epi.mode == EPI_MODULUS_FIXED) ? "sht_inv_modulus" : "sht_inv");
     if (sht_reg_supported(c)) {
         launch_sht_inverse_reg(c, coeff, grid, epi);
         return;

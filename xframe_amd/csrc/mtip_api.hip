@@ -60,6 +60,7 @@ void mtip_destroy(mtip_ctx* c) {
                     c->d_c[3], c->d_c[4], c->d_c[5], c->d_X, c->d_Vr, c->d_U, c->d_partial, c->d_minmax, c->d_Bl};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
+    for (hipEvent_t e : c->prof_events) (void)hipEventDestroy(e);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -901,13 +902,14 @@ int mtip_op_apply_matrix(mtip_ctx* c, const double* matrix, const double* vects,
 // ---- timing ---------------------------------------------------------------------------------------------
 int mtip_profile(mtip_ctx* c, int enable) {
     CTX_CHECK(c);
-    c->prof = enable ? 1 : 0;
+    c->prof = enable ? 1 : 0;                // pending brackets are resolved by mtip_profile_get / _reset
     return MTIP_OK;
 }
 
 int mtip_profile_get(mtip_ctx* c, const char* name, double* total_ms, int64_t* launches) {
     CTX_CHECK(c);
     if (!name) return MTIP_EINVAL;
+    prof_flush(c);
     auto it = c->prof_data.find(name);
     if (total_ms) *total_ms = it == c->prof_data.end() ? 0.0 : it->second.ms;
     if (launches) *launches = it == c->prof_data.end() ? 0 : it->second.n;
@@ -925,8 +927,28 @@ int mtip_debug_jacobi_sweeps(mtip_ctx* c, int32_t* out) {
 
 int mtip_profile_reset(mtip_ctx* c) {
     CTX_CHECK(c);
+    prof_flush(c);
     c->prof_data.clear();
     return MTIP_OK;
 }
 
 }  // extern "C"
+
+void prof_flush(mtip_ctx* c) {
+    if (c->prof_pending.empty()) {
+        c->prof_next = 0;
+        return;
+    }
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (auto& p : c->prof_pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, c->prof_events[p.second], c->prof_events[p.second + 1]) == hipSuccess) {
+            auto& e = c->prof_data[p.first];
+            e.ms += ms;
+            e.n += 1;
+        }
+    }
+    c->prof_pending.clear();
+    c->prof_next = 0;
+}

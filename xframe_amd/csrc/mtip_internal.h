@@ -184,6 +184,10 @@ struct mtip_ctx {
     // profiling
     int prof = 0;
     std::map<std::string, ProfEntry> prof_data;
+    // asynchronous family timers: event pairs recorded on the ctx stream, resolved when the numbers are read
+    std::vector<hipEvent_t> prof_events;
+    std::vector<std::pair<const char*, int>> prof_pending;   // (family, index of the first event of the pair)
+    int prof_next = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
 
@@ -240,22 +244,30 @@ void launch_apply_matrix(mtip_ctx* c, const double* M, const double* x, double* 
         }                                                                                    \
     } while (0)
 
+void prof_flush(mtip_ctx* c);       // mtip_api.hip: synchronise the stream and fold the pending event pairs into prof_data
+
+// hipEvent bracket of one kernel family launch.  Nothing waits here: the pair is resolved by prof_flush (called when
+// the numbers are read, or when 4096 pairs are pending), so the brackets can stay on during a timed run.
 struct ProfScope {
     mtip_ctx* c;
     const char* name;
+    int idx = -1;
     ProfScope(mtip_ctx* c_, const char* n) : c(c_), name(n) {
-        if (c->prof) (void)hipEventRecord(c->ev0, c->stream);
+        if (!c->prof) return;
+        if (c->prof_next + 2 > 8192) prof_flush(c);
+        while ((int)c->prof_events.size() < c->prof_next + 2) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) return;
+            c->prof_events.push_back(e);
+        }
+        idx = c->prof_next;
+        c->prof_next += 2;
+        (void)hipEventRecord(c->prof_events[idx], c->stream);
     }
     ~ProfScope() {
-        if (c->prof) {
-            (void)hipEventRecord(c->ev1, c->stream);
-            (void)hipEventSynchronize(c->ev1);
-            float ms = 0.f;
-            (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
-            auto& e = c->prof_data[name];
-            e.ms += ms;
-            e.n += 1;
-        }
+        if (idx < 0) return;
+        (void)hipEventRecord(c->prof_events[idx + 1], c->stream);
+        c->prof_pending.emplace_back(name, idx);
     }
 };
 
