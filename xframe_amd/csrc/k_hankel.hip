@@ -155,7 +155,147 @@ __global__ void __launch_bounds__(256) k_hankel_mfma(const double* __restrict__ 
     }
 }
 
+// ---- workgroup-tiled variant ---------------------------------------------------------------------------------
+// k_hankel_mfma above re-reads the panel once per row group and W_l once per column tile (PMC: 3.3 x the algorithmic
+// bytes), and what bounds these kernels is the rate at which a CU can pull bytes when every CU pulls (~11 B/clk,
+// L2 hits included).  Here a 512-thread workgroup owns 80 columns x all (<= 128) output shells of one order -- 218
+// workgroups at 8 restarts, L = 32: one per CU, all resident, W_l read once per 80 columns and the panel once.  Per
+// chunk of 16 input shells W_l[16][Nq] and the panel [16][80] are staged in LDS with coalesced loads (operands of the
+// next two chunks in flight in registers); wave w multiplies row tile w with the five column tiles (one A and five B
+// fragments from LDS per k-step).  LDS row strides = 16 doubles mod 32, so the two input shells a half-wave reads
+// land on disjoint banks.
+#define HT_CT 5                     // 16-column MFMA tiles per workgroup
+#define HT_COLS (16 * HT_CT)
+#define HT_KC 16                    // input shells per chunk (4 MFMA k-steps)
+#define HT_ROWS 128                 // output shells per workgroup (8 row tiles = 8 waves)
+#define HT_WS (HT_ROWS + 16)        // LDS row strides (doubles)
+#define HT_XS (HT_COLS + 16)
+#define HT_THREADS 512
+#define HT_NW (HT_KC * HT_ROWS / HT_THREADS)                       // W doubles per thread and chunk (4)
+#define HT_NX ((HT_KC * HT_COLS + HT_THREADS - 1) / HT_THREADS)    // panel doubles per thread and chunk (3)
+
+struct HankelTile32 { int l, cflat0; };
+
+__global__ void __launch_bounds__(HT_THREADS) k_hankel_tile(const double* __restrict__ in, double* __restrict__ out,
+                                                            const double* __restrict__ W,
+                                                            const HankelTile32* __restrict__ tiles, int N, int Np, int L,
+                                                            int B, int poffs, double scale, int sign) {
+    __shared__ double Ws[2][HT_KC][HT_WS];
+    __shared__ double Xs[2][HT_KC][HT_XS];
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const HankelTile32 tinfo = tiles[blockIdx.x];
+    const int l = tinfo.l;
+    const int k_base = blockIdx.y * HT_ROWS;                      // row block (Nq > 128)
+    const int ncl = 4 * l + 2;                                    // doubles per (batch, shell) of this order
+    const int nlm2 = 2 * (L + 1) * (L + 1);                       // doubles per (batch, shell)
+    const double* Wl = W + (size_t)l * Np * N;
+    // ---- staging roles: W chunk = 16 x 128 doubles (row tid / 32, 4 consecutive columns),
+    //      panel chunk = 16 x 80 doubles, element e = tid + j * 512 -> (row e / 80, column e % 80)
+    const int wrow = tid >> 5, wcol = (tid & 31) * 4;
+    int xrow[HT_NX], xc[HT_NX];
+    size_t xoff[HT_NX];
+    bool xok[HT_NX];
+#pragma unroll
+    for (int j = 0; j < HT_NX; ++j) {
+        const int e = tid + j * HT_THREADS;
+        xrow[j] = e / HT_COLS;
+        xc[j] = e - xrow[j] * HT_COLS;
+        const int cflat = tinfo.cflat0 + xc[j];
+        xok[j] = xrow[j] < HT_KC && cflat < B * ncl;
+        const int b = xok[j] ? cflat / ncl : 0;
+        const int within = xok[j] ? cflat - b * ncl : 0;
+        xoff[j] = (size_t)b * N * nlm2 + 2 * (size_t)l * l + within;
+    }
+    // two register sets: the operands of the next TWO chunks are in flight while one is multiplied
+    double rw0[HT_NW], rx0[HT_NX], rw1[HT_NW], rx1[HT_NX];
+    auto request = [&](int p0, double (&rw)[HT_NW], double (&rx)[HT_NX]) {
+        const int p = p0 + wrow;
+        const bool p_ok = p < Np;
+        const double* wr = Wl + (size_t)(p_ok ? p : 0) * N + k_base + wcol;
+#pragma unroll
+        for (int j = 0; j < HT_NW; ++j) rw[j] = (p_ok && k_base + wcol + j < N) ? wr[j] : 0.0;
+#pragma unroll
+        for (int j = 0; j < HT_NX; ++j)
+            rx[j] = (xok[j] && p0 + xrow[j] < Np) ? in[xoff[j] + (size_t)(p0 + xrow[j] + poffs) * nlm2] : 0.0;
+    };
+    auto deposit = [&](int buf, const double (&rw)[HT_NW], const double (&rx)[HT_NX]) {
+#pragma unroll
+        for (int j = 0; j < HT_NW; ++j) Ws[buf][wrow][wcol + j] = rw[j];
+#pragma unroll
+        for (int j = 0; j < HT_NX; ++j)
+            if (xrow[j] < HT_KC) Xs[buf][xrow[j]][xc[j]] = rx[j];
+    };
+    // ---- MFMA roles: wave = row tile, all HT_CT column tiles
+    const int li = lane & 15, kk = lane >> 4;
+    v4f64 acc[HT_CT];
+#pragma unroll
+    for (int t = 0; t < HT_CT; ++t) acc[t] = v4f64{0.0, 0.0, 0.0, 0.0};
+    auto multiply = [&](int buf) {
+#pragma unroll
+        for (int s = 0; s < HT_KC / 4; ++s) {
+            const double af = Ws[buf][4 * s + kk][wave * 16 + li];
+#pragma unroll
+            for (int t = 0; t < HT_CT; ++t) {
+                const double bf = Xs[buf][4 * s + kk][16 * t + li];
+                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(af, bf, acc[t], 0, 0, 0);
+            }
+        }
+    };
+    const int n_chunks = (Np + HT_KC - 1) / HT_KC;
+    request(0, rw0, rx0);
+    deposit(0, rw0, rx0);
+    if (n_chunks > 1) request(HT_KC, rw1, rx1);
+    if (n_chunks > 2) request(2 * HT_KC, rw0, rx0);
+    __syncthreads();
+    for (int i = 0; i < n_chunks; i += 2) {
+        // chunk i from buffer 0; chunk i+1 (set 1) goes to buffer 1; then set 1 asks for chunk i+3
+        multiply(0);
+        if (i + 1 < n_chunks) deposit(1, rw1, rx1);
+        __syncthreads();
+        if (i + 3 < n_chunks) request((i + 3) * HT_KC, rw1, rx1);
+        if (i + 1 >= n_chunks) break;
+        // chunk i+1 from buffer 1; chunk i+2 (set 0) goes to buffer 0; then set 0 asks for chunk i+4
+        multiply(1);
+        if (i + 2 < n_chunks) deposit(0, rw0, rx0);
+        __syncthreads();
+        if (i + 4 < n_chunks) request((i + 4) * HT_KC, rw0, rx0);
+    }
+    // epilogue: * scale * (-/+ i)^l, store
+    int r = l & 3;
+    if (sign < 0) r = (4 - r) & 3;
+    const bool is_im = (li & 1) != 0;
+#pragma unroll
+    for (int t = 0; t < HT_CT; ++t) {
+        const int cflat = tinfo.cflat0 + 16 * t + li;
+        const bool col_ok = cflat < B * ncl;
+        const int b = col_ok ? cflat / ncl : 0;
+        const int within = col_ok ? cflat - b * ncl : 0;
+        const size_t col_off = (size_t)b * N * nlm2 + 2 * (size_t)l * l + within;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            double v = acc[t][j] * scale;
+            const double partner = __shfl_xor(v, 1, 64);
+            double o;
+            if (r == 0) o = v;
+            else if (r == 2) o = -v;
+            else if (r == 1) o = is_im ? partner : -partner;       // * i : (a+bi) i = -b + a i
+            else o = is_im ? -partner : partner;                   // * -i: (a+bi)(-i) = b - a i
+            const int k = k_base + wave * 16 + kk + 4 * j;
+            if (col_ok && k < N) out[col_off + (size_t)k * nlm2] = o;
+        }
+    }
+}
+
 void launch_hankel_mfma(mtip_ctx* c, const double2* in, double2* out, int inverse) {
+    if (c->d_htiles32 != nullptr && !c->hankel_wave_tiles) {
+        const dim3 grid((unsigned)c->n_htiles32, (unsigned)div_up(c->N, HT_ROWS));
+        hipLaunchKernelGGL(k_hankel_tile, grid, dim3(HT_THREADS), 0, c->stream, reinterpret_cast<const double*>(in),
+                           reinterpret_cast<double*>(out), (const double*)c->d_W, (const HankelTile32*)c->d_htiles32, c->N,
+                           c->Np, c->L, c->B, c->cfg.hankel_trapz ? 1 : 0, inverse ? c->inv_scale : c->fwd_scale,
+                           inverse ? +1 : -1);
+        return;
+    }
     const int n_tiles = c->n_htiles;
     const dim3 grid((unsigned)div_up(n_tiles, 4), (unsigned)div_up(c->N, HK_MT * 16));
     hipLaunchKernelGGL(k_hankel_mfma, grid, dim3(256), 0, c->stream, reinterpret_cast<const double*>(in),
@@ -173,5 +313,13 @@ int build_hankel_tiles(mtip_ctx* c) {
     c->n_htiles = (int)t.size();
     if (hipMalloc((void**)&c->d_htiles, t.size() * sizeof(HankelTile)) != hipSuccess) return MTIP_ENOMEM;
     (void)hipMemcpy(c->d_htiles, t.data(), t.size() * sizeof(HankelTile), hipMemcpyHostToDevice);
+    std::vector<HankelTile32> t32;
+    for (int l = c->L; l >= 0; --l) {                       // heavy orders first
+        const int ncols = c->B * (4 * l + 2);
+        for (int c0 = 0; c0 < ncols; c0 += HT_COLS) t32.push_back(HankelTile32{l, c0});
+    }
+    c->n_htiles32 = (int)t32.size();
+    if (hipMalloc((void**)&c->d_htiles32, t32.size() * sizeof(HankelTile32)) != hipSuccess) return MTIP_ENOMEM;
+    (void)hipMemcpy(c->d_htiles32, t32.data(), t32.size() * sizeof(HankelTile32), hipMemcpyHostToDevice);
     return MTIP_OK;
 }
