@@ -164,22 +164,23 @@ __global__ void __launch_bounds__(256) k_hankel_mfma(const double* __restrict__ 
 // next two chunks in flight in registers); wave w multiplies row tile w with the five column tiles (one A and five B
 // fragments from LDS per k-step).  LDS row strides = 16 doubles mod 32, so the two input shells a half-wave reads
 // land on disjoint banks.
-#define HT_CT 5                     // 16-column MFMA tiles per workgroup
-#define HT_COLS (16 * HT_CT)
+#define HT_CT_MAX 5                 // 16-column MFMA tiles per workgroup: template parameter CT in {1, 2, 3, 5}
 #define HT_KC 16                    // input shells per chunk (4 MFMA k-steps)
 #define HT_ROWS 128                 // output shells per workgroup (8 row tiles = 8 waves)
 #define HT_WS (HT_ROWS + 16)        // LDS row strides (doubles)
-#define HT_XS (HT_COLS + 16)
 #define HT_THREADS 512
 #define HT_NW (HT_KC * HT_ROWS / HT_THREADS)                       // W doubles per thread and chunk (4)
-#define HT_NX ((HT_KC * HT_COLS + HT_THREADS - 1) / HT_THREADS)    // panel doubles per thread and chunk (3)
 
 struct HankelTile32 { int l, cflat0; };
 
+template <int HT_CT>
 __global__ void __launch_bounds__(HT_THREADS) k_hankel_tile(const double* __restrict__ in, double* __restrict__ out,
                                                             const double* __restrict__ W,
                                                             const HankelTile32* __restrict__ tiles, int N, int Np, int L,
                                                             int B, int poffs, double scale, int sign) {
+    constexpr int HT_COLS = 16 * HT_CT;
+    constexpr int HT_XS = HT_COLS + 16;
+    constexpr int HT_NX = (HT_KC * HT_COLS + HT_THREADS - 1) / HT_THREADS;    // panel doubles per thread and chunk
     __shared__ double Ws[2][HT_KC][HT_WS];
     __shared__ double Xs[2][HT_KC][HT_XS];
     const int tid = threadIdx.x;
@@ -290,10 +291,18 @@ __global__ void __launch_bounds__(HT_THREADS) k_hankel_tile(const double* __rest
 void launch_hankel_mfma(mtip_ctx* c, const double2* in, double2* out, int inverse) {
     if (c->d_htiles32 != nullptr && !c->hankel_wave_tiles) {
         const dim3 grid((unsigned)c->n_htiles32, (unsigned)div_up(c->N, HT_ROWS));
-        hipLaunchKernelGGL(k_hankel_tile, grid, dim3(HT_THREADS), 0, c->stream, reinterpret_cast<const double*>(in),
-                           reinterpret_cast<double*>(out), (const double*)c->d_W, (const HankelTile32*)c->d_htiles32, c->N,
-                           c->Np, c->L, c->B, c->cfg.hankel_trapz ? 1 : 0, inverse ? c->inv_scale : c->fwd_scale,
-                           inverse ? +1 : -1);
+#define HT_LAUNCH(CT)                                                                                                   \
+    hipLaunchKernelGGL(k_hankel_tile<CT>, grid, dim3(HT_THREADS), 0, c->stream, reinterpret_cast<const double*>(in),    \
+                       reinterpret_cast<double*>(out), (const double*)c->d_W, (const HankelTile32*)c->d_htiles32, c->N, \
+                       c->Np, c->L, c->B, c->cfg.hankel_trapz ? 1 : 0, inverse ? c->inv_scale : c->fwd_scale,           \
+                       inverse ? +1 : -1)
+        switch (c->htile_ct) {
+            case 1: HT_LAUNCH(1); break;
+            case 2: HT_LAUNCH(2); break;
+            case 3: HT_LAUNCH(3); break;
+            default: HT_LAUNCH(5); break;
+        }
+#undef HT_LAUNCH
         return;
     }
     const int n_tiles = c->n_htiles;
@@ -313,10 +322,17 @@ int build_hankel_tiles(mtip_ctx* c) {
     c->n_htiles = (int)t.size();
     if (hipMalloc((void**)&c->d_htiles, t.size() * sizeof(HankelTile)) != hipSuccess) return MTIP_ENOMEM;
     (void)hipMemcpy(c->d_htiles, t.data(), t.size() * sizeof(HankelTile), hipMemcpyHostToDevice);
+    // widest workgroup tile that still gives (about) one workgroup per CU: W_l is re-read once per tile
     std::vector<HankelTile32> t32;
-    for (int l = c->L; l >= 0; --l) {                       // heavy orders first
-        const int ncols = c->B * (4 * l + 2);
-        for (int c0 = 0; c0 < ncols; c0 += HT_COLS) t32.push_back(HankelTile32{l, c0});
+    const int cts[4] = {5, 3, 2, 1};
+    for (int ci = 0; ci < 4; ++ci) {
+        t32.clear();
+        c->htile_ct = cts[ci];
+        for (int l = c->L; l >= 0; --l) {                   // heavy orders first
+            const int ncols = c->B * (4 * l + 2);
+            for (int c0 = 0; c0 < ncols; c0 += 16 * cts[ci]) t32.push_back(HankelTile32{l, c0});
+        }
+        if ((int)t32.size() * div_up(c->N, HT_ROWS) * 5 >= c->n_cu * 4) break;
     }
     c->n_htiles32 = (int)t32.size();
     if (hipMalloc((void**)&c->d_htiles32, t32.size() * sizeof(HankelTile32)) != hipSuccess) return MTIP_ENOMEM;

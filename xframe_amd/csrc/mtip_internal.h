@@ -137,7 +137,7 @@ struct mtip_ctx {
     int jac_tg = 16;                                  // env MTIP_JAC_TG=8|16: lanes per Jacobi column pair
     bool hankel_wave_tiles = false;                   // env MTIP_HANKEL_WAVE_TILES=1: per-wave tiles straight from L2 (k_hankel_mfma)
     void* d_htiles32 = nullptr;                       // workgroup tiles (order, first column) of k_hankel_tile
-    int n_htiles32 = 0;
+    int n_htiles32 = 0, htile_ct = 5;                 // 16-column MFMA tiles per workgroup
     bool hankel_simple = false;                       // env MTIP_HANKEL_SIMPLE=1: one-thread-per-output kernel
     double fwd_scale = 0, inv_scale = 0;
     bool have_angular = false, have_radial = false, have_weights = false, have_support = false, have_errw = false;
