@@ -24,6 +24,9 @@ import time
 
 import numpy as np
 
+# HIP maps streams onto 4 hardware queues by default (one is taken by the null stream): give every engine its own
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -34,7 +37,7 @@ def parse():
     p.add_argument('--steps', type=int, default=200)
     p.add_argument('--warmup', type=int, default=20)
     p.add_argument('--restarts-per-gpu', type=int, default=8)
-    p.add_argument('--streams', type=int, default=2, help='engines (HIP streams) the restarts of a rank are split over')
+    p.add_argument('--streams', type=int, default=3, help='engines (HIP streams) the restarts of a rank are split over')
     p.add_argument('--config', type=int, default=4, help='BASELINE config id (sizes): 1..5')
     p.add_argument('--exact', action='store_true', help='reference operator order instead of the fused step')
     p.add_argument('--cpu-seconds', type=float, default=20.0, help='budget of the CPU baseline sample')

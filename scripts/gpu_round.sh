@@ -10,7 +10,8 @@ export TMPDIR=/tmp
 python scripts/kernel_stats.py gpurun_out/$tag/stats > gpurun_out/$tag/kernel_stats.txt; cat gpurun_out/$tag/kernel_stats.txt
 ( cd /tmp && cd $GRAFT_REPO_ROOT && rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/$tag/pmc_fetch -- python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-roofline > /dev/null 2>&1 )
 ( cd /tmp && cd $GRAFT_REPO_ROOT && rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/$tag/pmc_write -- python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-roofline > /dev/null 2>&1 )
-python scripts/pmc_summary.py gpurun_out/$tag/pmc_fetch gpurun_out/$tag/pmc_write gpurun_out/$tag/pmc_traffic.json 4 4 > gpurun_out/$tag/pmc_summary.txt 2>&1; cat gpurun_out/$tag/pmc_summary.txt
+BP=$(python -c "import json; print(json.loads(open('gpurun_out/$tag/bench_default.json').read().strip().splitlines()[-1])['roofline']['restarts_per_launch'])")
+python scripts/pmc_summary.py gpurun_out/$tag/pmc_fetch gpurun_out/$tag/pmc_write gpurun_out/$tag/pmc_traffic.json $BP 4 > gpurun_out/$tag/pmc_summary.txt 2>&1; cat gpurun_out/$tag/pmc_summary.txt
 python - <<PY
 import json
 for f in ("bench_default", "bench_noprof", "bench_rocprof"):
