@@ -36,6 +36,8 @@ struct Worker {
     unsigned char* smem = nullptr;
 };
 
+static thread_local long long idle_yields = 0;
+
 static void yield_to_scheduler() {
     Worker* w = W;
     swapcontext(&w->fibers[w->current].ctx, &w->sched);
@@ -47,6 +49,7 @@ void block_barrier() {
     if (++w->arrived == w->live) {
         w->arrived = 0;
         ++w->gen;
+        idle_yields = 0;
         return;
     }
     f.wait_gen = w->gen;
@@ -70,9 +73,32 @@ void wave_barrier() {
 
 WaveBuf& wave_buf() { return W->w_buf[W->current / WAVE]; }
 
+// spin waits: the fiber stays runnable; a block in which nothing but yields happens for a long time is livelocked
+void fiber_yield() {
+    if (++idle_yields > 200000000ll) {
+        std::fprintf(stderr, "emul: LIVELOCK: threads spin in s_sleep waits and nothing else makes progress\n");
+        std::abort();
+    }
+    yield_to_scheduler();
+}
+
+int wave_all(int pred) {
+    Worker* w = W;
+    const int me = w->current, wv = me / WAVE;
+    w->w_buf[wv].i[me % WAVE] = pred ? 1 : 0;
+    wave_barrier();
+    w = W;
+    int all = 1;
+    for (int l = wv * WAVE; l < (wv + 1) * WAVE && l < w->n; ++l)
+        if (w->fibers[l].state != DONE && !w->w_buf[wv].i[l % WAVE]) all = 0;
+    wave_barrier();
+    return all;
+}
+
 static void fiber_main() {
     Worker* w = W;
     (*w->body)();
+    idle_yields = 0;
     w = W;
     Fiber& f = w->fibers[w->current];
     f.state = DONE;

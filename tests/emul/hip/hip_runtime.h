@@ -35,6 +35,7 @@ struct dim3 {
 struct double2 { double x, y; };
 static inline double2 make_double2(double x, double y) { return double2{x, y}; }
 struct int2 { int x, y; };
+static inline int2 make_int2(int x, int y) { return int2{x, y}; }
 
 typedef int hipError_t;
 typedef void* hipStream_t;
@@ -59,6 +60,8 @@ void launch(dim3 grid, dim3 block, size_t smem, const std::function<void()>& bod
 void block_barrier();
 void wave_barrier();
 WaveBuf& wave_buf();
+void fiber_yield();                 // s_sleep inside a spin wait: let the other threads of the block run
+int wave_all(int pred);             // wave vote over the lanes that are still running
 inline int lane() { return t_linear % WAVE; }
 inline int wave() { return t_linear / WAVE; }
 }  // namespace emul
@@ -155,6 +158,9 @@ static inline unsigned atomicAdd(unsigned* p, unsigned v) {
     unsigned o = *p; *p = o + v; return o;
 }
 static inline void __threadfence() { std::atomic_thread_fence(std::memory_order_seq_cst); }
+static inline void __threadfence_block() { std::atomic_thread_fence(std::memory_order_seq_cst); }
+static inline void __builtin_amdgcn_s_sleep(int) { emul::fiber_yield(); }
+static inline int __all(int pred) { return emul::wave_all(pred); }
 static inline double rsqrt(double x) { return 1.0 / std::sqrt(x); }
 // hardware estimates are only ~single precision: emulate that so the Newton refinement is really exercised
 static inline double emul_trunc_mantissa(double v) {
