@@ -55,6 +55,42 @@ def test_worker_result_schema(emul_lib, golden_mtip16):
         R.ProjectWorker(dict(opt, GPU={'use': False}), data_from_golden(g, L), lib_path=emul_lib)
 
 
+def test_jacobi_pairing_schedule_is_a_valid_sweep(emul_lib):
+    """The resident-column ordering of the polar-factor kernel is generated and verified on the host for every column
+    count (every pair once per sweep, no column twice in a round); a failing verification would silently fall back
+    to the round-robin ordering, so check it here for all sizes the kernel accepts."""
+    from xframe_amd.fxs.engine import Engine
+    e = Engine({'grid': {'n_radial_points': 4, 'max_order': 2}}, None, n_batch=1, max_q=1.0, lib_path=emul_lib)
+    assert e.lib.mtip_debug_check_jacobi_schedule(e.ctx, 127) == 0
+    assert e.lib.mtip_debug_check_jacobi_schedule(e.ctx, 1) != 0
+    e.close()
+
+
+def test_worker_restart_groups_match_single_engine(emul_lib, golden_mtip16):
+    """GPU.n_gpu_workers > 1 splits the restarts of a rank into concurrently driven engines (host threads, one HIP stream
+    each); restarts are independent, so every restart must come out exactly as from one engine holding them all."""
+    from xframe_amd.fxs import reconstruct as R
+    g = golden_mtip16
+    N, L = int(g['N']), int(g['L'])
+    outs = []
+    for workers in (1, 2):
+        opt = golden_settings(N, L, {'multi_process': {'use': True, 'n_parallel_reconstructions': 4},
+                                     'GPU': {'use': True, 'n_gpu_workers': workers}})
+        main = opt['main_loop']['sub_loops']['main']
+        main['methods']['HIO']['iterations'] = 2
+        main['methods']['ER']['iterations'] = 1
+        main['iterations'] = 1
+        w = R.ProjectWorker(opt, data_from_golden(g, L), seeds=[11, 12, 13, 14], lib_path=emul_lib)
+        result, _ = w.run()
+        assert len(result) == 4
+        assert len(getattr(w, 'mtip_instances')) == workers
+        outs.append(result)
+    for a, b in zip(*outs):
+        assert np.array_equal(a['initial_density'], b['initial_density'])
+        assert np.array_equal(a['real_density'], b['real_density'])
+        assert np.array_equal(a['error_dict']['main'], b['error_dict']['main'])
+
+
 def test_reference_sketch_on_registry(emul_lib, golden_mtip16):
     """The reference's HIO_ft_stab sketch (reconstruct.py:584-593, MTIP_start 518-528) executed through
     RecipeFactory on the HIP-backed operators == the device-resident step."""

@@ -926,6 +926,16 @@ int mtip_debug_jacobi_sweeps(mtip_ctx* c, int32_t* out) {
     return MTIP_OK;
 }
 
+int mtip_debug_check_jacobi_schedule(mtip_ctx* c, int k_max) {
+    CTX_CHECK(c);
+    if (k_max < 2 || k_max > 127) FAIL(c, MTIP_EINVAL, "k_max must be in [2, 127]");
+    (void)hipSetDevice(c->device);
+    MTIP_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    const int r = build_jacobi_schedule(c, k_max);
+    if (r != MTIP_OK) FAIL(c, r, "pairing schedule failed its verification");
+    return MTIP_OK;
+}
+
 int mtip_profile_reset(mtip_ctx* c) {
     CTX_CHECK(c);
     prof_flush(c);

@@ -9,6 +9,10 @@ import os
 
 import numpy as np
 
+# HIP maps streams onto 4 hardware queues by default (one is the null stream's): with up to 3 engines per GPU give every
+# engine its own queue.  Only effective if set before the HIP runtime initialises; harmless otherwise.
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(os.path.dirname(_HERE), 'csrc', 'libmtip_hip.so')
 
@@ -69,6 +73,7 @@ _SIGNATURES = {
     'mtip_profile_get': (C.c_int, [c_void, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     'mtip_profile_reset': (C.c_int, [c_void]),
     'mtip_debug_jacobi_sweeps': (C.c_int, [c_void, c_void]),
+    'mtip_debug_check_jacobi_schedule': (C.c_int, [c_void, C.c_int]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

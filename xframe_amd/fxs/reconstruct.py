@@ -271,10 +271,34 @@ class ProjectWorker:
         seeds = None if self.seeds is None else [self.seeds[i] for i in mine]
         result = np.empty(0, dtype=object)
         if len(mine):
-            m = MTIP(self.process_factory, n_restarts=len(mine), device=self.device, seeds=seeds, lib_path=self.lib_path)
-            m.generate_phasing_loop()
-            result = m.phasing_loop()
-            self.mtip_instance = m
+            # GPU.n_gpu_workers (reference: number of GPU daemon processes, reconstruct.py:104) = restart groups that run
+            # concurrently on this GPU, each with its own engine / HIP stream, driven from its own host thread.  The
+            # per-restart chain of a step is serial (the polar-factor kernel alone is half of it and fills half of the
+            # CUs), so 2-3 groups overlap it with the streaming kernels of the others; more than 3 serialise on the
+            # hardware queues.
+            n_eng = int(self.opt['GPU'].get('n_gpu_workers', 1) or 1)
+            n_eng = max(1, min(n_eng, 3, len(mine) // 2))
+            groups = [list(range(g, len(mine), n_eng)) for g in range(n_eng)]
+
+            def run_group(local_ids):
+                gseeds = None if seeds is None else [seeds[i] for i in local_ids]
+                m = MTIP(self.process_factory, n_restarts=len(local_ids), device=self.device, seeds=gseeds,
+                         lib_path=self.lib_path)
+                m.generate_phasing_loop()
+                return m, m.phasing_loop()
+
+            if n_eng == 1:
+                outs = [run_group(groups[0])]
+            else:
+                from concurrent.futures import ThreadPoolExecutor
+                with ThreadPoolExecutor(n_eng) as pool:             # ctypes calls release the GIL
+                    outs = list(pool.map(run_group, groups))
+            result = np.empty(len(mine), dtype=object)
+            for local_ids, (m, res) in zip(groups, outs):
+                for j, i in enumerate(local_ids):
+                    result[i] = res[j]
+            self.mtip_instance = outs[0][0]
+            self.mtip_instances = [m for m, _ in outs]
         result = gather_results(result, mine, total, self.rank, self.world_size)
         self.results['MTIP'] = result
         self.results['stats']['run_time'] = time.time() - start
