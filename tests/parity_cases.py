@@ -236,6 +236,47 @@ def synthetic_problem(cfg, lib_path=None, N=None, L=None):
     return data, rho
 
 
+def check_config_trajectory_vs_oracle(cfg, lib_path=None, fused=True, n_hio=10, n_er=10):
+    """BASELINE config sizes the oracle still walks in seconds (config 2: 64 x L16): n_hio HIO + SW + n_er ER ft_stab
+    steps of the product worker against the oracle's phasing loop on the same synthetic invariants and the same seeded
+    initial density.  This is the size at which the wide inverse SHT (n_phi = 64), the 16-lane resident-column Jacobi
+    (3 row slots) and the workgroup-tiled Hankel kernel run as they do in the benchmark."""
+    import xframe_amd.fxs.hostsetup as hs
+    data, _ = synthetic_problem(cfg, lib_path)
+    N, L = S._SIZES[cfg]
+    opt = S.config_overrides(cfg)
+    opt = OM.deep_update(OM.default_settings(), opt)
+    opt = OM.deep_update(opt, {'main_loop': {'error': {'methods': {'reciprocal': {
+        'calculate': ['deg2_invariant_l2_diff'], 'deg2_invariant_l2_diff': {'order': 2}}}}}})
+    loops = opt['main_loop']['sub_loops']
+    name = loops['order'][0]
+    loops['order'] = [name]
+    main = loops[name]
+    main['order'] = ['HIO', 'SW', 'ER'] if 'SW' in main['methods'] else ['HIO', 'ER']
+    main['methods']['HIO']['iterations'] = n_hio
+    main['methods']['ER']['iterations'] = n_er
+    main['iterations'] = 1
+    e = Engine(opt, data, n_batch=1, lib_path=lib_path)
+    rho0 = hs.bump_density(e.rs, e.shape, S.PARTICLE_RADIUS, 0.3, 2, np.random.default_rng(1000),
+                           e.rsetup.integrated_intensity, e.int_wr, e.int_wt)
+    e.close()
+    ref = OM.MTIP(opt, data).phasing_loop(rho0=rho0)
+    R.MTIP.preinit(opt, data)
+    m = R.MTIP(n_restarts=2, initial_densities=[rho0, rho0], lib_path=lib_path, fused=fused)
+    m.generate_phasing_loop()
+    res = m.phasing_loop()
+    for r in res:
+        assert np.allclose(r['error_dict']['main'], ref['error_dict']['main'], rtol=1e-6)
+        assert np.allclose(r['error_dict']['reciprocal']['deg2_invariant_l2_diff'],
+                           ref['error_dict']['reciprocal']['deg2_invariant_l2_diff'], rtol=1e-5)
+        for k in ('real_density', 'last_real_density', 'reciprocal_density', 'last_reciprocal_density'):
+            assert rel_l2(r[k], ref[k]) < TOL_TRAJ, k
+        assert rel_l2(r['last_deg2_invariant'], ref['last_deg2_invariant']) < TOL_TRAJ
+        assert (r['support_mask'] != ref['support_mask']).mean() < 1e-5
+    m.engine.close()
+    return ref['error_dict']['main']
+
+
 def check_full_size_properties(cfg, lib_path=None, n_steps=12):
     """At BASELINE sizes the oracle is too slow for step-by-step comparison: check size-independent properties.
     * FT round trip of a band-limited density, SHT(iSHT(c)) == c

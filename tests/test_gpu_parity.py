@@ -52,6 +52,17 @@ def test_trajectory_golden_cfg1(golden_cfg1, fused):
     PC.check_trajectory_golden(golden_cfg1, None, fused, n_restarts=1)
 
 
+@pytest.mark.parametrize('fused', [False, True])
+def test_config2_trajectory_vs_oracle(fused):
+    """64 x L16 (BASELINE config 2 size): 20 steps + shrink-wrap against the oracle, both step orders."""
+    PC.check_config_trajectory_vs_oracle(2, fused=fused)
+
+
+def test_config3_short_trajectory_vs_oracle():
+    """128 x L32 (the benchmark size): 10 HIO + shrink-wrap + 10 ER ft_stab steps against the oracle."""
+    PC.check_config_trajectory_vs_oracle(3, fused=True, n_hio=10, n_er=10)
+
+
 def test_config2_properties():
     PC.check_full_size_properties(2)
 
