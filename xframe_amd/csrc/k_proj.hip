@@ -724,23 +724,26 @@ struct ProjGemm {
     }
 };
 
+// The grid is the compact list of (order, tile) pairs that exist (host-built, `tiles`): a dense
+// (max tiles) x (L+1) x B grid is mostly workgroups that return at once, and dispatching them costs more than the
+// products (measured: 1056 workgroups of 8 waves start over 34 us).
 template <int OP>
-__global__ void __launch_bounds__(PG_THREADS) k_proj_gemm(ProjGemmArgs a) {
+__global__ void __launch_bounds__(PG_THREADS) k_proj_gemm(ProjGemmArgs a, const int* __restrict__ tiles) {
     typedef ProjGemm<OP> G;
     constexpr int LD = PG_TM + 1;
     __shared__ double2 As[2][PG_TK][LD];
     __shared__ double2 Bs[2][PG_TK][LD];
-    const int l = blockIdx.y, b = blockIdx.z;
+    const int tinfo = tiles[blockIdx.x];
+    const int l = tinfo & 255, tile_m = (tinfo >> 8) & 255, tile_n = tinfo >> 16;
+    const int b = blockIdx.y;
     const bool prod = G::has_product(a, l);
     if (!prod && OP != PG_APPLY) return;
     int M, Nn, K;
     PgView A, Bv;
     G::setup(a, b, l, M, Nn, K, A, Bv);
     const int k = a.kl[l], n = 2 * l + 1, xo = a.xoff[l];
-    const int tn = (Nn + PG_TM - 1) / PG_TM;
-    const int tile_m = blockIdx.x / tn, tile_n = blockIdx.x - tile_m * tn;
     const int m0 = tile_m * PG_TM, n0 = tile_n * PG_TM;
-    if (m0 >= M) return;                                     // block-uniform
+    if (m0 >= M || n0 >= Nn) return;                         // block-uniform
     const int tid = threadIdx.x;
     const int ty = tid / PG_T, tx = tid - ty * PG_T;
     const bool worker = tid < PG_T * PG_T;
@@ -834,11 +837,33 @@ __global__ void __launch_bounds__(PG_THREADS) k_proj_gemm(ProjGemmArgs a) {
     }
 }
 
+// tile lists of the four products (order | tile_m << 8 | tile_n << 16), heavy orders first
+static int build_proj_tiles(mtip_ctx* c) {
+    if (c->d_pg_tiles[0] != nullptr) return MTIP_OK;
+    for (int op = 0; op < 4; ++op) {
+        std::vector<int> t;
+        for (int l = c->L; l >= 0; --l) {
+            const int k = c->kl[l], n = 2 * l + 1;
+            int M, Nn;
+            if (op == PG_X || op == PG_WARM) { M = n; Nn = k; }
+            else if (op == PG_U) { M = k; Nn = n; }
+            else { M = c->N; Nn = n; }
+            if (op != PG_APPLY && !c->active[l]) continue;      // PG_APPLY writes every order (unused ones are copied)
+            for (int tm = 0; tm < div_up(M, PG_TM); ++tm)
+                for (int tn = 0; tn < div_up(Nn, PG_TM); ++tn) t.push_back(l | (tm << 8) | (tn << 16));
+        }
+        if (t.empty()) t.push_back(0);
+        c->n_pg_tiles[op] = (int)t.size();
+        if (hipMalloc((void**)&c->d_pg_tiles[op], t.size() * sizeof(int)) != hipSuccess) return MTIP_ENOMEM;
+        (void)hipMemcpy(c->d_pg_tiles[op], t.data(), t.size() * sizeof(int), hipMemcpyHostToDevice);
+    }
+    return MTIP_OK;
+}
+
 template <int OP>
-static void launch_proj_gemm(mtip_ctx* c, const ProjGemmArgs& a, int max_m, int max_n) {
-    const int tiles = div_up(max_m, PG_TM) * div_up(max_n, PG_TM);
-    hipLaunchKernelGGL(k_proj_gemm<OP>, dim3((unsigned)tiles, (unsigned)(c->L + 1), (unsigned)c->B), dim3(PG_THREADS), 0,
-                       c->stream, a);
+static void launch_proj_gemm(mtip_ctx* c, const ProjGemmArgs& a) {
+    hipLaunchKernelGGL(k_proj_gemm<OP>, dim3((unsigned)c->n_pg_tiles[OP], (unsigned)c->B), dim3(PG_THREADS), 0, c->stream, a,
+                       (const int*)c->d_pg_tiles[OP]);
 }
 
 // Divide-and-conquer pairing schedule for every column count 2..kmax (see jl_sweep_resident).  Entry
@@ -946,7 +971,8 @@ void launch_project_coefficients(mtip_ctx* c, const double2* Ilm, double2* out) 
     ga.voff = c->d_voff; ga.xoff = c->d_xoff; ga.uoff = c->d_uoff;
     ga.N = c->N; ga.L = c->L; ga.xtot = c->xtot; ga.utot = c->utot; ga.nlm = c->nlm;
     ga.inv_sqrt_np = 1.0 / std::sqrt(c->n_particles);
-    launch_proj_gemm<PG_X>(c, ga, nmax, kmax);
+    if (build_proj_tiles(c) != MTIP_OK) return;
+    launch_proj_gemm<PG_X>(c, ga);
     const size_t lds = ((size_t)kmax * (nmax | 1) + (size_t)kmax * (kmax | 1)) * sizeof(double2);   // unpadded minimum
     if (lds <= 158 * 1024) {
         // cold start every 64 calls bounds the accumulated rounding drift of the carried V_r
@@ -954,7 +980,7 @@ void launch_project_coefficients(mtip_ctx* c, const double2* Ilm, double2* out) 
         const double2* src = c->d_X;
         if (warm) {
             ga.dst = c->d_U;
-            launch_proj_gemm<PG_WARM>(c, ga, nmax, kmax);
+            launch_proj_gemm<PG_WARM>(c, ga);
             src = c->d_U;
         }
         const int pairs_max = kmax / 2;                         // valid pairs per round (odd k: dummy pair skipped)
@@ -980,7 +1006,7 @@ void launch_project_coefficients(mtip_ctx* c, const double2* Ilm, double2* out) 
         else JL_LAUNCH(16, 8);
 #undef JL_LAUNCH
         ga.dst = c->d_U;
-        launch_proj_gemm<PG_U>(c, ga, kmax, nmax);
+        launch_proj_gemm<PG_U>(c, ga);
         c->vr_valid = true;
         c->proj_calls += 1;
     } else {
@@ -989,7 +1015,7 @@ void launch_project_coefficients(mtip_ctx* c, const double2* Ilm, double2* out) 
                            (const int*)c->d_uoff, c->xtot, c->utot);
     }
     ga.dst = out;
-    launch_proj_gemm<PG_APPLY>(c, ga, c->N, 2 * c->L + 1);     // every order is written (unused ones copied)
+    launch_proj_gemm<PG_APPLY>(c, ga);                         // every order is written (unused ones copied)
 }
 
 // ---- B_l = I_l I_l^+ ------------------------------------------------------------------------------
