@@ -647,13 +647,18 @@ __global__ void __launch_bounds__(JL_MAX_THREADS) k_polar_jacobi_lds(const doubl
 // they have to be spread over the whole chip (one (restart, l = 32) product alone is 14 us of one CU's FP64 peak) and
 // must not re-read their operands per output element (32 bytes per complex FMA from L2 otherwise).  Tile = 33 x 33
 // outputs (2l+1 <= 65 -> two tiles, 1.5 % padding), 11 x 11 threads with 3 x 3 outputs each, inner extent in chunks
-// of 16 through LDS, the next chunk's operands in flight in registers while the current one is multiplied.
+// of 8 through LDS, the operands of the next two chunks in flight in registers while the current one is multiplied.  A
+// tile is shared by PG_KS = 4 thread sets that take the inner indices round robin and add their partial sums in a fixed
+// order at the end: a launch has only a few hundred tiles, and one 2-wave set per tile leaves the LDS latency of every
+// inner step exposed (2-3 waves per CU).
 #define PG_T 11                 // threads per tile edge
 #define PG_R 3                  // outputs per thread and edge
 #define PG_TM (PG_T * PG_R)     // tile edge (33)
 #define PG_TK 8
-#define PG_THREADS 128
-#define PG_LD ((PG_TM * PG_TK + PG_THREADS - 1) / PG_THREADS)    // staged elements per thread and operand (5)
+// thread sets that share a tile (template parameter KS: set s multiplies the inner indices kk = s (mod KS)); threads per
+// workgroup and staged elements per thread and operand follow from it
+#define PG_NT(KS) ((KS) == 1 ? 128 : 512)
+#define PG_LDN(KS) ((PG_TM * PG_TK + PG_NT(KS) - 1) / PG_NT(KS))
 
 struct ProjGemmArgs {
     const double2* Ilm;
@@ -727,10 +732,12 @@ struct ProjGemm {
 // The grid is the compact list of (order, tile) pairs that exist (host-built, `tiles`): a dense
 // (max tiles) x (L+1) x B grid is mostly workgroups that return at once, and dispatching them costs more than the
 // products (measured: 1056 workgroups of 8 waves start over 34 us).
-template <int OP>
-__global__ void __launch_bounds__(PG_THREADS) k_proj_gemm(ProjGemmArgs a, const int* __restrict__ tiles) {
+template <int OP, int PG_KS>
+__global__ void __launch_bounds__(PG_NT(PG_KS)) k_proj_gemm(ProjGemmArgs a, const int* __restrict__ tiles) {
     typedef ProjGemm<OP> G;
     constexpr int LD = PG_TM + 1;
+    constexpr int PG_THREADS = PG_NT(PG_KS);
+    constexpr int PG_LD = PG_LDN(PG_KS);
     __shared__ double2 As[2][PG_TK][LD];
     __shared__ double2 Bs[2][PG_TK][LD];
     const int tinfo = tiles[blockIdx.x];
@@ -745,8 +752,10 @@ __global__ void __launch_bounds__(PG_THREADS) k_proj_gemm(ProjGemmArgs a, const 
     const int m0 = tile_m * PG_TM, n0 = tile_n * PG_TM;
     if (m0 >= M || n0 >= Nn) return;                         // block-uniform
     const int tid = threadIdx.x;
-    const int ty = tid / PG_T, tx = tid - ty * PG_T;
-    const bool worker = tid < PG_T * PG_T;
+    const int ks = tid / (PG_T * PG_T);                      // inner-index set of this thread (set PG_KS: staging only)
+    const int wt = tid - ks * (PG_T * PG_T);
+    const int ty = wt / PG_T, tx = wt - ty * PG_T;
+    const bool worker = ks < PG_KS;
     double2 acc[PG_R][PG_R];
 #pragma unroll
     for (int i = 0; i < PG_R; ++i)
@@ -764,28 +773,30 @@ __global__ void __launch_bounds__(PG_THREADS) k_proj_gemm(ProjGemmArgs a, const 
             else { bn[u] = e / PG_TK; bk[u] = e - bn[u] * PG_TK; }
             if (e >= PG_TM * PG_TK) { am[u] = PG_TM; bn[u] = PG_TM; ak[u] = 0; bk[u] = 0; }    // no such slot
         }
-        double2 ra[PG_LD], rb[PG_LD];
-        auto request = [&](int k0) {
+        // two register sets: the operands of the next TWO chunks are in flight while one is multiplied (a dependent
+        // global round trip costs ~2.5 k cycles here, the multiply of a chunk ~1 k)
+        double2 ra0[PG_LD], rb0[PG_LD], ra1[PG_LD], rb1[PG_LD];
+        // branch-free: clamped addresses, every load is issued, out-of-range elements are zeroed by a select -- so the
+        // compiler can count the loads in flight and wait only for the older set
+        auto request = [&](int k0, double2 (&ra)[PG_LD], double2 (&rb)[PG_LD]) {
 #pragma unroll
             for (int u = 0; u < PG_LD; ++u) {
-                ra[u] = make_double2(0.0, 0.0);
-                rb[u] = make_double2(0.0, 0.0);
-                if (am[u] < PG_TM && m0 + am[u] < M && k0 + ak[u] < K) {
-                    double2 v = A.base[(size_t)(m0 + am[u]) * A.si + (size_t)(k0 + ak[u]) * A.sj];
-                    if (OP == PG_X) {
-                        const double qq = a.q[k0 + ak[u]];
-                        v = make_double2(qq * qq * v.x, -qq * qq * v.y);
-                    }
-                    ra[u] = v;
+                const bool a_ok = am[u] < PG_TM && m0 + am[u] < M && k0 + ak[u] < K;
+                const bool b_ok = bn[u] < PG_TM && n0 + bn[u] < Nn && k0 + bk[u] < K;
+                const int ma = a_ok ? m0 + am[u] : 0, ka = a_ok ? k0 + ak[u] : 0;
+                const int nb = b_ok ? n0 + bn[u] : 0, kb = b_ok ? k0 + bk[u] : 0;
+                double2 va = A.base[(size_t)ma * A.si + (size_t)ka * A.sj];
+                double2 vb = Bv.base[(size_t)kb * Bv.si + (size_t)nb * Bv.sj];
+                if (OP == PG_X) {
+                    const double qq = a.q[ka];
+                    va = make_double2(qq * qq * va.x, -qq * qq * va.y);
                 }
-                if (bn[u] < PG_TM && n0 + bn[u] < Nn && k0 + bk[u] < K) {
-                    double2 v = Bv.base[(size_t)(k0 + bk[u]) * Bv.si + (size_t)(n0 + bn[u]) * Bv.sj];
-                    if (G::B_CONJ) v.y = -v.y;
-                    rb[u] = v;
-                }
+                if (G::B_CONJ) vb.y = -vb.y;
+                ra[u] = a_ok ? va : make_double2(0.0, 0.0);
+                rb[u] = b_ok ? vb : make_double2(0.0, 0.0);
             }
         };
-        auto deposit = [&](int buf) {
+        auto deposit = [&](int buf, const double2 (&ra)[PG_LD], const double2 (&rb)[PG_LD]) {
 #pragma unroll
             for (int u = 0; u < PG_LD; ++u) {
                 if (am[u] < PG_TM) {
@@ -794,16 +805,11 @@ __global__ void __launch_bounds__(PG_THREADS) k_proj_gemm(ProjGemmArgs a, const 
                 }
             }
         };
-        request(0);
-        deposit(0);
-        __syncthreads();
-        int buf = 0;
-        for (int k0 = 0; k0 < K; k0 += PG_TK) {
-            const bool more = k0 + PG_TK < K;
-            if (more) request(k0 + PG_TK);                    // in flight during the multiply
+        auto multiply = [&](int buf) {
             if (worker) {
 #pragma unroll
-                for (int kk = 0; kk < PG_TK; ++kk) {
+                for (int kq = 0; kq < PG_TK / PG_KS; ++kq) {
+                    const int kk = kq * PG_KS + ks;
                     double2 av[PG_R], bv[PG_R];
 #pragma unroll
                     for (int i = 0; i < PG_R; ++i) {
@@ -821,12 +827,46 @@ __global__ void __launch_bounds__(PG_THREADS) k_proj_gemm(ProjGemmArgs a, const 
                         }
                 }
             }
-            if (more) deposit(buf ^ 1);
+        };
+        const int n_chunks = (K + PG_TK - 1) / PG_TK;
+        request(0, ra0, rb0);
+        request(PG_TK, ra1, rb1);                              // (requests beyond K load nothing new: clamped, zeroed)
+        deposit(0, ra0, rb0);
+        request(2 * PG_TK, ra0, rb0);
+        __syncthreads();
+        for (int i = 0; i < n_chunks; i += 2) {
+            // chunk i from buffer 0; chunk i+1 (set 1) goes to buffer 1; then set 1 asks for chunk i+3
+            multiply(0);
+            deposit(1, ra1, rb1);
             __syncthreads();
-            buf ^= 1;
+            request((i + 3) * PG_TK, ra1, rb1);
+            // chunk i+1 from buffer 1 (zeros beyond K); chunk i+2 (set 0) goes to buffer 0; then set 0 asks for chunk i+4
+            multiply(1);
+            deposit(0, ra0, rb0);
+            __syncthreads();
+            request((i + 4) * PG_TK, ra0, rb0);
         }
     }
-    if (worker) {
+    // partial sums of the sets 1..PG_KS-1 through LDS, added by set 0 in a fixed order (bitwise reproducible)
+    __shared__ double2 part[PG_KS > 1 ? PG_KS - 1 : 1][PG_KS > 1 ? PG_T * PG_T : 1][PG_R * PG_R + 1];
+    if (prod && PG_KS > 1) {
+        if (worker && ks > 0) {
+#pragma unroll
+            for (int i = 0; i < PG_R; ++i)
+#pragma unroll
+                for (int j = 0; j < PG_R; ++j) part[ks - 1][wt][i * PG_R + j] = acc[i][j];
+        }
+        __syncthreads();
+        if (ks == 0) {
+#pragma unroll
+            for (int s2 = 0; s2 < PG_KS - 1; ++s2)
+#pragma unroll
+                for (int i = 0; i < PG_R; ++i)
+#pragma unroll
+                    for (int j = 0; j < PG_R; ++j) acc[i][j] = cadd(acc[i][j], part[s2][wt][i * PG_R + j]);
+        }
+    }
+    if (ks == 0) {
 #pragma unroll
         for (int i = 0; i < PG_R; ++i)
 #pragma unroll
@@ -862,8 +902,10 @@ static int build_proj_tiles(mtip_ctx* c) {
 
 template <int OP>
 static void launch_proj_gemm(mtip_ctx* c, const ProjGemmArgs& a) {
-    hipLaunchKernelGGL(k_proj_gemm<OP>, dim3((unsigned)c->n_pg_tiles[OP], (unsigned)c->B), dim3(PG_THREADS), 0, c->stream, a,
-                       (const int*)c->d_pg_tiles[OP]);
+    // I'_l = V_l U_l has 4-8 tiles per order and all orders to write: enough workgroups already, one thread set per tile
+    constexpr int KS = (OP == PG_APPLY) ? 1 : 4;
+    hipLaunchKernelGGL((k_proj_gemm<OP, KS>), dim3((unsigned)c->n_pg_tiles[OP], (unsigned)c->B), dim3(PG_NT(KS)), 0, c->stream,
+                       a, (const int*)c->d_pg_tiles[OP]);
 }
 
 // Divide-and-conquer pairing schedule for every column count 2..kmax (see jl_sweep_resident).  Entry
