@@ -236,6 +236,30 @@ def synthetic_problem(cfg, lib_path=None, N=None, L=None):
     return data, rho
 
 
+def check_projection_vs_oracle(N, L, lib_path=None, n_batch=2, seed=1):
+    """mtip_projection (X_l, polar factor, V_l U_l, masks, l = 0 rules) of random coefficients against the oracle's
+    numpy-SVD path, at sizes chosen to hit a particular polar-factor kernel: 2l+1 up to 89 does not fit LDS and takes the
+    global-memory Jacobi fallback (config 5 has L = 48)."""
+    from oracle.fourier import FourierPair
+    from oracle.sht import SHT
+    from helpers import OracleTransforms
+    fpd = FourierPair(SHT(L), N, S.data_cutoff(N), 2.0)
+    data, _ = S.make_invariants(OracleTransforms(fpd), N, L)
+    opt = golden_settings(N, L)
+    e = Engine(opt, data, n_batch=n_batch, lib_path=lib_path)
+    om = OM.MTIP(opt, data)
+    rng = np.random.default_rng(seed)
+    Ilm = cplx(rng, (n_batch, N, e.nlm))
+    for rep in range(2):                                   # second call: warm start from the first one's V_r
+        proj = e.project_coefficients(Ilm)
+        for b in range(n_batch):
+            Il = [Ilm[b][:, l * l:(l + 1) ** 2] for l in range(L + 1)]
+            unk = om.rp.approximate_unknowns(Il)
+            ref = np.concatenate(om.rp.mtip_projection(Il, unk), axis=1)
+            assert rel_l2(proj[b], ref) < TOL_SHT, (rep, b)
+    e.close()
+
+
 def check_config_trajectory_vs_oracle(cfg, lib_path=None, fused=True, n_hio=10, n_er=10):
     """BASELINE config sizes the oracle still walks in seconds (config 2: 64 x L16): n_hio HIO + SW + n_er ER ft_stab
     steps of the product worker against the oracle's phasing loop on the same synthetic invariants and the same seeded

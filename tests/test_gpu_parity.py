@@ -58,6 +58,13 @@ def test_config2_trajectory_vs_oracle(fused):
     PC.check_config_trajectory_vs_oracle(2, fused=fused)
 
 
+@pytest.mark.parametrize('N,L', [(40, 18), (96, 44)])
+def test_projection_vs_oracle_sizes(N, L):
+    """(40, 18): LDS Jacobi with 3 row slots and odd/even k mixes; (96, 44): 2l+1 = 89 does not fit LDS -> global-memory
+    fallback kernel (the path config 5, L = 48, takes)."""
+    PC.check_projection_vs_oracle(N, L)
+
+
 def test_config3_short_trajectory_vs_oracle():
     """128 x L32 (the benchmark size): 10 HIO + shrink-wrap + 10 ER ft_stab steps against the oracle."""
     PC.check_config_trajectory_vs_oracle(3, fused=True, n_hio=10, n_er=10)
