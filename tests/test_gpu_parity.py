@@ -78,3 +78,12 @@ def test_config3_properties_full_size():
     """128 shells x L_max = 32 (the metric's configuration)."""
     errs = PC.check_full_size_properties(3, n_steps=8)
     assert np.isfinite(errs).all()
+
+
+def test_config5_properties_full_size():
+    """256 shells x L_max = 48 (BASELINE config 5): the grid no longer fits the whole-shell LDS kernels and 2l+1 = 97 does
+    not fit the LDS Jacobi, so this walks the pass-wise inverse SHT, the separate real-space kernel and the global-memory
+    polar factor; same size-independent properties as at the metric's size (fused == reference order, round trips,
+    B_l of the projection == data B_l)."""
+    errs = PC.check_full_size_properties(5, n_steps=4)
+    assert np.isfinite(errs).all()
