@@ -43,6 +43,8 @@ def parse():
     p.add_argument('--cpu-seconds', type=float, default=20.0, help='budget of the CPU baseline sample')
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--no-roofline', action='store_true')
+    p.add_argument('--dist-backend', default='nccl', help="'gloo' + --same-device rehearses the multi-rank path on a one-GPU box")
+    p.add_argument('--same-device', action='store_true', help='every rank uses GPU 0 (rehearsal only)')
     return p.parse_args()
 
 
@@ -84,8 +86,13 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if a.same_device:
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if a.dist_backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group(a.dist_backend)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (no CPU fallback)')
     dev = torch.device('cuda', local_rank)
@@ -175,7 +182,7 @@ def main():
         dist.barrier()
     elapsed = t1 - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if a.dist_backend == 'nccl' else 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     its = world * B * a.steps / elapsed
@@ -191,7 +198,7 @@ def main():
     for e in engines[:2]:                                       # bounded sample: the download is PCIe bound
         bl_sum += e.last_deg2_invariant(0)
         n_bl += 1
-    bl_mean = average_invariants(bl_sum, n_bl, device=dev if dist is not None else None)
+    bl_mean = average_invariants(bl_sum, n_bl, device=dev if (dist is not None and a.dist_backend == 'nccl') else None)
     reduce_s = time.perf_counter() - t_red
 
     # ---- roofline of the dominant kernel family: hipEvent brackets on engine 0's stream, recorded over the timed
