@@ -225,6 +225,31 @@ def check_short_trajectory_vs_oracle(g, lib_path, fused, n_hio=3, n_er=2, n_rest
     m.engine.close()
 
 
+def check_non_fxs_trajectory_vs_oracle(g, lib_path, fused, n_restarts=2):
+    """The *_non_FXS variants (reconstruct.py:899-904, sketches 530-535, 565-593): after some FXS steps the intensity
+    is frozen to |F'|^2 of the latest pair and the reciprocal projection becomes F sqrt(fixed / |F|^2)
+    (fxs_Projections.py:911-923).  HIO -> HIO_non_FXS -> ER_non_FXS -> ER against the oracle."""
+    N, L = int(g['N']), int(g['L'])
+    data = data_from_golden(g, L)
+    opt = golden_settings(N, L)
+    main = opt['main_loop']['sub_loops']['main']
+    main['methods'] = {'HIO': {'iterations': 3, 'ft_stab': True}, 'HIO_non_FXS': {'iterations': 2, 'ft_stab': True},
+                       'ER_non_FXS': {'iterations': 2, 'ft_stab': False}, 'ER': {'iterations': 2, 'ft_stab': True}}
+    main['order'] = ['HIO', 'HIO_non_FXS', 'ER_non_FXS', 'ER']
+    main['iterations'] = 2
+    ref = OM.MTIP(opt, data).phasing_loop(rho0=g['rho0'])
+    R.MTIP.preinit(opt, data)
+    m = R.MTIP(n_restarts=n_restarts, initial_densities=[g['rho0']] * n_restarts, lib_path=lib_path, fused=fused)
+    m.generate_phasing_loop()
+    res = m.phasing_loop()
+    for r in res:
+        assert np.allclose(r['error_dict']['main'], ref['error_dict']['main'], rtol=1e-8)
+        for k in ('real_density', 'last_real_density', 'reciprocal_density', 'last_reciprocal_density'):
+            assert rel_l2(r[k], ref[k]) < 1e-8, k
+        assert np.isclose(r['final_error'], ref['final_error'], rtol=1e-8)
+    m.engine.close()
+
+
 def synthetic_problem(cfg, lib_path=None, N=None, L=None):
     """Synthetic invariants for a BASELINE config, generated with the HIP transforms (product path)."""
     n, l = S._SIZES[cfg]

@@ -49,6 +49,11 @@ def test_short_trajectory_vs_oracle(emul_lib, golden_mtip16, fused):
     PC.check_short_trajectory_vs_oracle(golden_mtip16, emul_lib, fused)
 
 
+@pytest.mark.parametrize('fused', [False, True])
+def test_non_fxs_variants_vs_oracle(emul_lib, golden_mtip16, fused):
+    PC.check_non_fxs_trajectory_vs_oracle(golden_mtip16, emul_lib, fused)
+
+
 def test_wide_projection_matrices(emul_lib):
     """k_l = Nq < 2l+1 (the reference's integration test uses 8 radial points with max_order 15,
     tests/test_fxs_integration.py:326-355): polar factor of a wide matrix, compared through V_l U_l."""

@@ -42,6 +42,11 @@ def test_short_trajectory_vs_oracle(golden_mtip16, fused):
 
 
 @pytest.mark.parametrize('fused', [False, True])
+def test_non_fxs_variants_vs_oracle(golden_mtip16, fused):
+    PC.check_non_fxs_trajectory_vs_oracle(golden_mtip16, None, fused)
+
+
+@pytest.mark.parametrize('fused', [False, True])
 def test_trajectory_golden_16(golden_mtip16, fused):
     PC.check_trajectory_golden(golden_mtip16, None, fused, n_restarts=2)
 
