@@ -7,10 +7,16 @@ from collections import defaultdict
 
 
 def per_kernel(d, counter):
+    """mean counter value per kernel over its launches with the LARGEST grid (with several engines per GPU the launches of
+    the engine that holds fewer restarts are smaller; the bench line quotes engine 0, which holds the most)"""
     f = glob.glob(d + "/*/*counter_collection.csv")[0]
+    rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter]
+    gmax = defaultdict(int)
+    for r in rows:
+        gmax[r["Kernel_Name"]] = max(gmax[r["Kernel_Name"]], int(r["Grid_Size"]))
     acc = defaultdict(lambda: [0.0, 0])
-    for r in csv.DictReader(open(f)):
-        if r["Counter_Name"] != counter:
+    for r in rows:
+        if int(r["Grid_Size"]) != gmax[r["Kernel_Name"]]:
             continue
         a = acc[r["Kernel_Name"]]
         a[0] += float(r["Counter_Value"])
