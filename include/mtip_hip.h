@@ -9,7 +9,8 @@
  *
  * Conventions
  *   - every function returns 0 on success or a negative MTIP_E* code; nothing throws across the ABI;
- *     `mtip_last_error(ctx)` returns a human readable message (ctx may be NULL for create errors);
+ *     `mtip_last_error(ctx)` returns a human readable message (ctx may be NULL for create errors: the message of the
+ *     last failed mtip_create on the calling thread);
  *   - host buffers are caller-owned, C-contiguous; complex128 = interleaved (re,im) doubles
  *     (numpy complex128); masks are uint8 (numpy bool); device memory is library-owned;
  *   - a ctx is bound to one device and one hipStream_t; it is not thread-safe; several ctxs may

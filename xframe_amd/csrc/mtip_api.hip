@@ -7,7 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 
-static std::string g_create_error;
+static thread_local std::string g_create_error;     // mtip_create may run on several host threads (one engine each)
 
 #define CTX_CHECK(c)                       \
     do {                                   \
@@ -528,7 +528,10 @@ int mtip_run_async(mtip_ctx* c, int method, int ft_stab, int n_steps, const doub
     } else {
         c->fixed_valid = false;
     }
-    if (c->cfg.fused && ft_stab) MTIP_HIP_CHECK(c, hipMemsetAsync(c->d_T2, 0, (size_t)c->B * c->G * sizeof(double2), c->stream));
+    // the separate real-space kernel of the fused ft_stab step reads a zero round trip (the add-back is already in the
+    // coefficients); the epilogue path does not use T2 at all
+    if (c->cfg.fused && ft_stab && !sht_inverse_fuses_real_update(c))
+        MTIP_HIP_CHECK(c, hipMemsetAsync(c->d_T2, 0, (size_t)c->B * c->G * sizeof(double2), c->stream));
     for (int s = 0; s < n_steps; ++s) enqueue_step(c, method, ft_stab, betas[s]);
     return post_launch(c, "mtip_run");
 }
