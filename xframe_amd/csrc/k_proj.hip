@@ -1074,8 +1074,98 @@ __global__ void __launch_bounds__(256) k_deg2(const double2* __restrict__ Ilm, d
     Bl[(((size_t)b * (L + 1) + l) * N + i) * N + j] = acc;
 }
 
+// B_l = I_l I_l^+ on the f64 matrix cores (this IS a GEMM: N x (2l+1) x N per (restart, l)).  With the coefficients read
+// as real rows [re, im, re, im, ...] of length K = 2 (2l+1):  Re B[q][q'] = sum_K A[q][K] A[q'][K]  and
+// Im B[q][q'] = sum_K A'[q][K] A[q'][K]  with A'[(m,re)] = Im, A'[(m,im)] = -Re -- the neighbouring K index, i.e. the
+// lane 16 further (v_mfma_f64_16x16x4: A[i = lane&15][k = lane>>4], B[k = lane>>4][j = lane&15], D reg r =
+// D[(lane>>4) + 4r][lane&15]).  A wave owns one 16 x 16 output tile (two accumulators), the four waves of a workgroup
+// share the row tile.  METRIC: instead of storing B_l the tile adds up |ref rs - mask B|^2 (deg2_invariant_l2_diff,
+// fxs_IO_methods.py:408-447) into a per-tile partial sum; k_deg2_metric_finish adds the tiles in a fixed order.
+template <bool METRIC>
+__global__ void __launch_bounds__(256) k_deg2_mfma(const double* __restrict__ Ilm, double2* __restrict__ Bl,
+                                                   const double2* __restrict__ Bref, const uint8_t* __restrict__ rmask,
+                                                   const int* __restrict__ used, double* __restrict__ part, int N, int L,
+                                                   double inv_np) {
+    const int l = blockIdx.y, b = blockIdx.z;
+    const int nt16 = (N + 15) / 16, ng = (nt16 + 3) / 4;
+    const int ti = blockIdx.x / ng, tg = blockIdx.x - ti * ng;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int tj = tg * 4 + wave;
+    double* my_part = METRIC ? part + (((size_t)b * (L + 1) + l) * nt16 + ti) * nt16 + tj : nullptr;
+    if (tj >= nt16) return;                                      // wave-uniform
+    if (METRIC && !used[l]) {
+        if (lane == 0) *my_part = 0.0;
+        return;
+    }
+    const int nlm2 = 2 * (L + 1) * (L + 1);
+    const int K = 2 * (2 * l + 1);
+    const int li = lane & 15, kk = lane >> 4;
+    const int qi = ti * 16 + li, qj = tj * 16 + li;
+    const double* ai = Ilm + ((size_t)b * N + (qi < N ? qi : 0)) * nlm2 + 2 * l * l;
+    const double* aj = Ilm + ((size_t)b * N + (qj < N ? qj : 0)) * nlm2 + 2 * l * l;
+    v4f64 acc_re = v4f64{0.0, 0.0, 0.0, 0.0}, acc_im = acc_re;
+    for (int k0 = 0; k0 < K; k0 += 4) {
+        const int kx = k0 + kk;
+        const double a = (kx < K && qi < N) ? ai[kx] : 0.0;
+        const double bv = (kx < K && qj < N) ? aj[kx] : 0.0;
+        const double partner = __shfl_xor(a, 16, 64);            // the other half (re <-> im) of the same m
+        const double ap = (kk & 1) ? -partner : partner;
+        acc_re = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv, acc_re, 0, 0, 0);
+        acc_im = __builtin_amdgcn_mfma_f64_16x16x4f64(ap, bv, acc_im, 0, 0, 0);
+    }
+    const int col = tj * 16 + li;
+    double sum = 0.0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = ti * 16 + kk + 4 * r;
+        if (row < N && col < N) {
+            if (!METRIC) {
+                Bl[(((size_t)b * (L + 1) + l) * N + row) * N + col] = make_double2(acc_re[r], acc_im[r]);
+            } else {
+                const bool m = rmask[(size_t)l * N + row] && rmask[(size_t)l * N + col];
+                const double rs = (l == 0) ? inv_np : 1.0;
+                const double2 ref = Bref[((size_t)l * N + row) * N + col];
+                const double dx = ref.x * rs - (m ? acc_re[r] : 0.0), dy = ref.y * rs - (m ? acc_im[r] : 0.0);
+                sum += dx * dx + dy * dy;
+            }
+        }
+    }
+    if (METRIC) {
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+        if (lane == 0) *my_part = sum;
+    }
+}
+
+// one workgroup per (order, restart): the tile sums in a fixed order, then / norm
+__global__ void __launch_bounds__(256) k_deg2_metric_finish(const double* __restrict__ part, const double* __restrict__ Bnorm,
+                                                            const int* __restrict__ used, double* __restrict__ out, int n_tiles,
+                                                            int L) {
+    __shared__ double red[256];
+    const int l = blockIdx.x, b = blockIdx.y;
+    const double* p = part + ((size_t)b * (L + 1) + l) * n_tiles;
+    double acc = 0.0;
+    for (int e = threadIdx.x; e < n_tiles; e += blockDim.x) acc += p[e];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double nrm = Bnorm[l];
+        out[(size_t)b * (L + 1) + l] = (used[l] && nrm != 0.0) ? red[0] / nrm : -1.0;
+    }
+}
+
 void launch_deg2(mtip_ctx* c, const double2* Ilm, double2* Bl) {
     ProfScope ps(c, "deg2");
+    if (!c->deg2_simple) {
+        const int nt16 = div_up(c->N, 16);
+        hipLaunchKernelGGL(k_deg2_mfma<false>, dim3((unsigned)(nt16 * div_up(nt16, 4)), (unsigned)(c->L + 1), (unsigned)c->B),
+                           dim3(256), 0, c->stream, reinterpret_cast<const double*>(Ilm), Bl, (const double2*)nullptr,
+                           (const uint8_t*)nullptr, (const int*)nullptr, (double*)nullptr, c->N, c->L, 1.0);
+        return;
+    }
     hipLaunchKernelGGL(k_deg2, dim3((unsigned)div_up((long long)c->N * c->N, 256), (unsigned)(c->L + 1), (unsigned)c->B),
                        dim3(256), 0, c->stream, Ilm, Bl, c->N, c->L);
 }
@@ -1118,6 +1208,17 @@ __global__ void __launch_bounds__(256) k_deg2_metric(const double2* __restrict__
 
 void launch_deg2_metric(mtip_ctx* c, const double2* Ilm, double* out) {
     ProfScope ps(c, "deg2_metric");
+    if (!c->deg2_simple && c->d_deg2_part != nullptr) {
+        const int nt16 = div_up(c->N, 16);
+        hipLaunchKernelGGL(k_deg2_mfma<true>, dim3((unsigned)(nt16 * div_up(nt16, 4)), (unsigned)(c->L + 1), (unsigned)c->B),
+                           dim3(256), 0, c->stream, reinterpret_cast<const double*>(Ilm), (double2*)nullptr,
+                           (const double2*)c->d_Bref, (const uint8_t*)c->d_rmask, (const int*)c->d_used, c->d_deg2_part, c->N,
+                           c->L, 1.0 / c->n_particles);
+        hipLaunchKernelGGL(k_deg2_metric_finish, dim3((unsigned)(c->L + 1), (unsigned)c->B), dim3(256), 0, c->stream,
+                           (const double*)c->d_deg2_part, (const double*)c->d_Bnorm, (const int*)c->d_used, out, nt16 * nt16,
+                           c->L);
+        return;
+    }
     hipLaunchKernelGGL(k_deg2_metric, dim3((unsigned)(c->L + 1), (unsigned)c->B), dim3(256), 0, c->stream, Ilm,
                        (const double2*)c->d_Bref, (const double*)c->d_Bnorm, (const uint8_t*)c->d_rmask,
                        (const int*)c->d_used, out, c->N, c->L, 1.0 / c->n_particles);

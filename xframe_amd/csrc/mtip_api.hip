@@ -54,7 +54,7 @@ void mtip_destroy(mtip_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void* ptrs[] = {c->d_cost, c->d_gw, c->d_P, c->d_r, c->d_q, c->d_poff, c->d_PT, c->d_AB, c->d_lmtab, c->d_twN, c->d_tw, c->d_W, c->d_htiles, c->d_htiles32, c->d_kl, c->d_used, c->d_active, c->d_sweeps, c->d_jsched, c->d_jsched_off, c->d_jsched_rounds, c->d_pg_tiles[0], c->d_pg_tiles[1], c->d_pg_tiles[2], c->d_pg_tiles[3], c->d_voff,
-                    c->d_xoff, c->d_uoff, c->d_V, c->d_rmask, c->d_Bref, c->d_Bnorm, c->d_S0, c->d_sup, c->d_err_wr,
+                    c->d_xoff, c->d_uoff, c->d_V, c->d_rmask, c->d_Bref, c->d_Bnorm, c->d_deg2_part, c->d_S0, c->d_sup, c->d_err_wr,
                     c->d_err_wt, c->d_rho, c->d_Fp, c->d_slot, c->d_best_err, c->d_last_err, c->d_err_hist,
                     c->d_deg2_hist, c->d_F, c->d_T1, c->d_T2, c->d_fixed, c->d_g, c->d_c[0], c->d_c[1], c->d_c[2],
                     c->d_c[3], c->d_c[4], c->d_c[5], c->d_X, c->d_Vr, c->d_U, c->d_partial, c->d_minmax, c->d_Bl};
@@ -124,6 +124,7 @@ mtip_ctx* mtip_create(const mtip_cfg* cfg, int device) {
     A(dev_alloc(c, &c->d_PT, (size_t)(c->nt / 2 + 1) * c->npairs));
     A(dev_alloc(c, &c->d_AB, (size_t)c->npairs));
     A(dev_alloc(c, &c->d_lmtab, c->npairs));
+    if (const char* e = std::getenv("MTIP_DEG2_SIMPLE")) c->deg2_simple = std::atoi(e) != 0;
     if (const char* e = std::getenv("MTIP_HANKEL_SIMPLE")) c->hankel_simple = std::atoi(e) != 0;
     if (const char* e = std::getenv("MTIP_HANKEL_WAVE_TILES")) c->hankel_wave_tiles = std::atoi(e) != 0;
     if (const char* e = std::getenv("MTIP_FUSE_REAL")) c->fuse_real_update = std::atoi(e) != 0;
@@ -167,6 +168,7 @@ mtip_ctx* mtip_create(const mtip_cfg* cfg, int device) {
     A(dev_alloc(c, &c->d_rmask, (size_t)(L + 1) * N));
     A(dev_alloc(c, &c->d_Bref, (size_t)(L + 1) * N * N));
     A(dev_alloc(c, &c->d_Bnorm, L + 1));
+    A(dev_alloc(c, &c->d_deg2_part, (size_t)B * (L + 1) * div_up(N, 16) * div_up(N, 16)));
     A(dev_alloc(c, &c->d_S0, c->G));
     A(dev_alloc(c, &c->d_sup, (size_t)3 * B * c->G));
     A(dev_alloc(c, &c->d_err_wr, N));

@@ -160,6 +160,8 @@ struct mtip_ctx {
     int deg2_enable = 0;
     double2* d_Bref = nullptr;                        // (L+1, Nq, Nq) masked reference B_l
     double* d_Bnorm = nullptr;                        // (L+1)
+    double* d_deg2_part = nullptr;                    // (B, L+1, (Nq/16)^2) per-tile partial sums of the B_l metric
+    bool deg2_simple = false;                         // env MTIP_DEG2_SIMPLE=1: one thread per B_l element instead of MFMA tiles
     bool bref_dirty = true;
     // real-space constraints and error metric
     RealParams rp{RC_SUPPORT | RC_VALUE_LO, RC_SUPPORT | RC_VALUE_LO, 0.0, 0.0, 0.0};
