@@ -877,9 +877,88 @@ __global__ void __launch_bounds__(PG_NT(PG_KS)) k_proj_gemm(ProjGemmArgs a, cons
     }
 }
 
+// ---- the same four products on the f64 matrix cores ------------------------------------------------------------
+// They are GEMMs, so they can run on v_mfma_f64_16x16x4 with the fragments read straight from global memory (no LDS,
+// no barriers): a wave owns one 16 x 16 complex output tile (two accumulators), the four waves of a workgroup share
+// the row tile.  Complex as real: with A read as rows [re, im, ...] over the inner index (K = 2 x inner extent),
+//   Re C = sum_K A[i][K] B1[K][j],  B1[(k,re)] = Re B, B1[(k,im)] = -Im B;   Im C = sum_K A[i][K] B2[K][j],
+//   B2[(k,re)] = Im B, B2[(k,im)] = Re B,
+// i.e. every lane loads ONE complex element of A and one of B per k-step of 2 complex inner indices and picks its
+// half.  PM_PF k-steps of branch-free loads are in flight (clamped addresses, zeros by select).
+#define PM_PF 4
+
+template <int OP>
+__global__ void __launch_bounds__(256) k_proj_mfma(ProjGemmArgs a, const int* __restrict__ tiles) {
+    typedef ProjGemm<OP> G;
+    const int tinfo = tiles[blockIdx.x];
+    const int l = tinfo & 255, tile_m = (tinfo >> 8) & 255, tile_g = tinfo >> 16;
+    const int b = blockIdx.y;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const bool prod = G::has_product(a, l);
+    if (!prod && OP != PG_APPLY) return;
+    int M, Nn, K;
+    PgView A, Bv;
+    G::setup(a, b, l, M, Nn, K, A, Bv);
+    const int k = a.kl[l], n = 2 * l + 1, xo = a.xoff[l];
+    const int m0 = tile_m * 16, n0 = (tile_g * 4 + wave) * 16;
+    if (m0 >= M || n0 >= Nn) return;                             // wave-uniform
+    const int li = lane & 15, kk = lane >> 4;
+    const int ri = kk & 1, kh = kk >> 1;                         // half of the complex number, inner index within the k-step
+    v4f64 acc_re = v4f64{0.0, 0.0, 0.0, 0.0}, acc_im = acc_re;
+    if (prod) {
+        const int mi = m0 + li, nj = n0 + li;
+        const bool m_ok = mi < M, n_ok = nj < Nn;
+        const double2* ap = A.base + (size_t)(m_ok ? mi : 0) * A.si;
+        const double2* bp = Bv.base + (size_t)(n_ok ? nj : 0) * Bv.sj;
+        const int n_steps = (K + 1) / 2;
+        double fa[PM_PF], f1[PM_PF], f2[PM_PF], ga[PM_PF], g1[PM_PF], g2[PM_PF];
+        auto request = [&](int s0, double (&xa)[PM_PF], double (&x1)[PM_PF], double (&x2)[PM_PF]) {
+#pragma unroll
+            for (int u = 0; u < PM_PF; ++u) {
+                const int kc = 2 * (s0 + u) + kh;
+                const bool k_ok = kc < K;
+                const int kq = k_ok ? kc : 0;
+                double2 va = ap[(size_t)kq * A.sj];
+                double2 vb = bp[(size_t)kq * Bv.si];
+                if (OP == PG_X) {
+                    const double qq = a.q[kq];
+                    va = make_double2(qq * qq * va.x, -qq * qq * va.y);
+                }
+                if (G::B_CONJ) vb.y = -vb.y;
+                const bool aok = k_ok && m_ok, bok = k_ok && n_ok;
+                xa[u] = aok ? (ri ? va.y : va.x) : 0.0;
+                x1[u] = bok ? (ri ? -vb.y : vb.x) : 0.0;
+                x2[u] = bok ? (ri ? vb.x : vb.y) : 0.0;
+            }
+        };
+        request(0, fa, f1, f2);
+        for (int s0 = 0; s0 < n_steps; s0 += 2 * PM_PF) {
+            request(s0 + PM_PF, ga, g1, g2);                     // beyond K: clamped, zeroed
+#pragma unroll
+            for (int u = 0; u < PM_PF; ++u) {
+                acc_re = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[u], f1[u], acc_re, 0, 0, 0);
+                acc_im = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[u], f2[u], acc_im, 0, 0, 0);
+            }
+            request(s0 + 2 * PM_PF, fa, f1, f2);
+#pragma unroll
+            for (int u = 0; u < PM_PF; ++u) {
+                acc_re = __builtin_amdgcn_mfma_f64_16x16x4f64(ga[u], g1[u], acc_re, 0, 0, 0);
+                acc_im = __builtin_amdgcn_mfma_f64_16x16x4f64(ga[u], g2[u], acc_im, 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int mm = m0 + kk + 4 * r, nn = n0 + li;
+        if (mm < M && nn < Nn) G::store(a, b, l, k, n, xo, mm, nn, make_double2(acc_re[r], acc_im[r]));
+    }
+}
+
 // tile lists of the four products (order | tile_m << 8 | tile_n << 16), heavy orders first
 static int build_proj_tiles(mtip_ctx* c) {
     if (c->d_pg_tiles[0] != nullptr) return MTIP_OK;
+    const int tm_edge = c->proj_mfma ? 16 : PG_TM;               // MFMA: 16 x (4 x 16) per workgroup; VALU: 33 x 33
+    const int tn_edge = c->proj_mfma ? 64 : PG_TM;
     for (int op = 0; op < 4; ++op) {
         std::vector<int> t;
         for (int l = c->L; l >= 0; --l) {
@@ -889,8 +968,8 @@ static int build_proj_tiles(mtip_ctx* c) {
             else if (op == PG_U) { M = k; Nn = n; }
             else { M = c->N; Nn = n; }
             if (op != PG_APPLY && !c->active[l]) continue;      // PG_APPLY writes every order (unused ones are copied)
-            for (int tm = 0; tm < div_up(M, PG_TM); ++tm)
-                for (int tn = 0; tn < div_up(Nn, PG_TM); ++tn) t.push_back(l | (tm << 8) | (tn << 16));
+            for (int tm = 0; tm < div_up(M, tm_edge); ++tm)
+                for (int tn = 0; tn < div_up(Nn, tn_edge); ++tn) t.push_back(l | (tm << 8) | (tn << 16));
         }
         if (t.empty()) t.push_back(0);
         c->n_pg_tiles[op] = (int)t.size();
@@ -903,6 +982,11 @@ static int build_proj_tiles(mtip_ctx* c) {
 template <int OP>
 static void launch_proj_gemm(mtip_ctx* c, const ProjGemmArgs& a) {
     // I'_l = V_l U_l has 4-8 tiles per order and all orders to write: enough workgroups already, one thread set per tile
+    if (c->proj_mfma) {
+        hipLaunchKernelGGL(k_proj_mfma<OP>, dim3((unsigned)c->n_pg_tiles[OP], (unsigned)c->B), dim3(256), 0, c->stream, a,
+                           (const int*)c->d_pg_tiles[OP]);
+        return;
+    }
     constexpr int KS = (OP == PG_APPLY) ? 1 : 4;
     hipLaunchKernelGGL((k_proj_gemm<OP, KS>), dim3((unsigned)c->n_pg_tiles[OP], (unsigned)c->B), dim3(PG_NT(KS)), 0, c->stream,
                        a, (const int*)c->d_pg_tiles[OP]);

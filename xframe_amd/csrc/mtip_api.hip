@@ -124,6 +124,7 @@ mtip_ctx* mtip_create(const mtip_cfg* cfg, int device) {
     A(dev_alloc(c, &c->d_PT, (size_t)(c->nt / 2 + 1) * c->npairs));
     A(dev_alloc(c, &c->d_AB, (size_t)c->npairs));
     A(dev_alloc(c, &c->d_lmtab, c->npairs));
+    if (const char* e = std::getenv("MTIP_PROJ_MFMA")) c->proj_mfma = std::atoi(e) != 0;
     if (const char* e = std::getenv("MTIP_DEG2_SIMPLE")) c->deg2_simple = std::atoi(e) != 0;
     if (const char* e = std::getenv("MTIP_HANKEL_SIMPLE")) c->hankel_simple = std::atoi(e) != 0;
     if (const char* e = std::getenv("MTIP_HANKEL_WAVE_TILES")) c->hankel_wave_tiles = std::atoi(e) != 0;

@@ -161,6 +161,7 @@ struct mtip_ctx {
     double2* d_Bref = nullptr;                        // (L+1, Nq, Nq) masked reference B_l
     double* d_Bnorm = nullptr;                        // (L+1)
     double* d_deg2_part = nullptr;                    // (B, L+1, (Nq/16)^2) per-tile partial sums of the B_l metric
+    bool proj_mfma = true;                            // env MTIP_PROJ_MFMA=0: LDS-tiled VALU GEMMs for the projection products
     bool deg2_simple = false;                         // env MTIP_DEG2_SIMPLE=1: one thread per B_l element instead of MFMA tiles
     bool bref_dirty = true;
     // real-space constraints and error metric
