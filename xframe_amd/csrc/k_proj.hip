@@ -716,11 +716,17 @@ struct ProjGemm {
         } else if (OP == PG_U) {                            // row-major k x n
             a.dst[(size_t)b * a.xtot + xo + (size_t)m * n + nn] = acc;
         } else {                                            // I'_l[q = m][j = nn]: mask ? V_l U_l : I_l (+ l = 0 rules)
+            // in place on the coefficient buffer (dst holds I_l): only used orders have tiles, only changed elements
+            // are written
+            if (!a.used[l]) return;
             const size_t idx = ((size_t)b * a.N + m) * a.nlm + l * l + nn;
-            double2 v = a.Ilm[idx];
-            if (a.used[l] && a.rmask[(size_t)l * a.N + m]) v = (l == 0) ? a.V[a.voff[0] + (size_t)m * k] : acc;   // fxs_Projections.py:840
-            if (l == 0 && a.used[0]) v = cscale(v, a.inv_sqrt_np);                                                 // fxs_Projections.py:870
-            a.dst[idx] = v;
+            const bool masked = a.rmask[(size_t)l * a.N + m] != 0;
+            if (l == 0) {
+                const double2 v = masked ? a.V[a.voff[0] + (size_t)m * k] : a.dst[idx];    // fxs_Projections.py:840
+                a.dst[idx] = cscale(v, a.inv_sqrt_np);                                      // fxs_Projections.py:870
+            } else if (masked) {
+                a.dst[idx] = acc;
+            }
         }
     }
     static __device__ __forceinline__ bool has_product(const ProjGemmArgs& a, int l) {
@@ -967,7 +973,8 @@ static int build_proj_tiles(mtip_ctx* c) {
             if (op == PG_X || op == PG_WARM) { M = n; Nn = k; }
             else if (op == PG_U) { M = k; Nn = n; }
             else { M = c->N; Nn = n; }
-            if (op != PG_APPLY && !c->active[l]) continue;      // PG_APPLY writes every order (unused ones are copied)
+            if (op != PG_APPLY && !c->active[l]) continue;
+            if (op == PG_APPLY && !c->used[l]) continue;        // in place: unused orders stay as they are
             for (int tm = 0; tm < div_up(M, tm_edge); ++tm)
                 for (int tn = 0; tn < div_up(Nn, tn_edge); ++tn) t.push_back(l | (tm << 8) | (tn << 16));
         }
@@ -1140,8 +1147,11 @@ void launch_project_coefficients(mtip_ctx* c, const double2* Ilm, double2* out) 
                            c->d_Vr, c->d_U, (const int*)c->d_kl, (const int*)c->d_active, (const int*)c->d_xoff,
                            (const int*)c->d_uoff, c->xtot, c->utot);
     }
+    // I'_l = V_l U_l in place on the coefficient buffer; a separate output first receives a copy of I_l
+    if (out != Ilm)
+        (void)hipMemcpyAsync(out, Ilm, (size_t)c->B * c->C * sizeof(double2), hipMemcpyDeviceToDevice, c->stream);
     ga.dst = out;
-    launch_proj_gemm<PG_APPLY>(c, ga);                         // every order is written (unused ones copied)
+    launch_proj_gemm<PG_APPLY>(c, ga);
 }
 
 // ---- B_l = I_l I_l^+ ------------------------------------------------------------------------------

@@ -451,12 +451,12 @@ static void enqueue_step(mtip_ctx* c, int method, int ft_stab, double beta) {
         // 2-3 I_lm = SHT(|F|^2);  4-5 projection;  6-7 I' = iSHT, F' = F sqrt(I'/I) -> Fp[out]
         launch_sht_forward(c, c->d_F, cc[2], MTIP_PRE_SQUARE);
         if (c->deg2_enable) launch_deg2_metric(c, cc[2], c->d_deg2_hist + (size_t)c->n_steps_done * c->B * (c->L + 1));
-        launch_project_coefficients(c, cc[2], cc[3]);
+        launch_project_coefficients(c, cc[2], cc[2]);          // in place: I_lm is not needed afterwards
         InvEpilogue mod;
         mod.mode = EPI_MODULUS;
         mod.F = c->d_F;
         mod.out_slot = SL_OUT;
-        launch_sht_inverse(c, cc[3], c->d_Fp, mod);
+        launch_sht_inverse(c, cc[2], c->d_Fp, mod);
     } else {
         launch_modulus_fixed_slots(c, c->d_F);
     }
