@@ -468,15 +468,18 @@ __global__ void __launch_bounds__(JL_MAX_THREADS) k_polar_jacobi_lds(const doubl
                                                                     int* __restrict__ sweeps_out, int pad,
                                                                     const int* __restrict__ sched,
                                                                     const int* __restrict__ sched_off,
-                                                                    const int* __restrict__ sched_rounds, int sched_ps) {
+                                                                    const int* __restrict__ sched_rounds, int sched_ps,
+                                                                    const int* __restrict__ order_list) {
     HIP_DYNAMIC_SHARED(double2, sm)
     __shared__ double s_gmax[JL_MAX_THREADS / 8];
     __shared__ double s_isig[128];
     __shared__ int s_continue;
     __shared__ int s_perm[128];
     __shared__ int s_keff;
-    const int l = L - (int)blockIdx.x;                      // heavy orders first
-    const int b = blockIdx.y;
+    // grid = (restart, rank of the order among the active ones): the restart index runs fastest, so the heaviest order
+    // of EVERY restart is dispatched first -- these workgroups are the critical path of the launch
+    const int b = blockIdx.x;
+    const int l = order_list[blockIdx.y];
     if (!active[l]) return;                                // uniform per block
     const int k = kl[l], n = 2 * l + 1;
     const int nr = (n + TG - 1) / TG, kr = (k + TG - 1) / TG;   // rows per lane
@@ -1127,13 +1130,23 @@ void launch_project_coefficients(mtip_ctx* c, const double2* Ilm, double2* out) 
                                c->jsched_ps * 16 <= JL_MAX_THREADS;
         int threads = (((use_sched ? c->jsched_ps : pairs_max) * tg + 63) / 64) * 64;
         threads = std::min(std::max(threads, 64), JL_MAX_THREADS);
-        const dim3 gj((unsigned)(c->L + 1), (unsigned)c->B);
+        if (c->d_jorder == nullptr) {                           // active orders, heaviest (largest k_l) first
+            std::vector<int> ord;
+            for (int l = 0; l <= c->L; ++l)
+                if (c->active[l]) ord.push_back(l);
+            std::stable_sort(ord.begin(), ord.end(), [&](int x, int y) { return c->kl[x] * (2 * x + 1) > c->kl[y] * (2 * y + 1); });
+            c->n_jorder = (int)ord.size();
+            if (ord.empty()) ord.push_back(0);
+            if (hipMalloc((void**)&c->d_jorder, ord.size() * sizeof(int)) != hipSuccess) return;
+            (void)hipMemcpy(c->d_jorder, ord.data(), ord.size() * sizeof(int), hipMemcpyHostToDevice);
+        }
+        const dim3 gj((unsigned)c->B, (unsigned)std::max(c->n_jorder, 1));
 #define JL_LAUNCH(MAXR, TG)                                                                                              \
     hipLaunchKernelGGL((k_polar_jacobi_lds<MAXR, TG>), gj, dim3(threads), lds_use, c->stream, src, c->d_X, c->d_Vr,     \
                        (const int*)c->d_kl, (const int*)c->d_active, (const int*)c->d_xoff, (const int*)c->d_uoff,      \
                        c->xtot, c->utot, c->L, warm, c->polar_abs_tol * c->polar_abs_tol, c->d_sweeps, pad,             \
                        use_sched ? (const int*)c->d_jsched : (const int*)nullptr, (const int*)c->d_jsched_off,          \
-                       (const int*)c->d_jsched_rounds, c->jsched_ps)
+                       (const int*)c->d_jsched_rounds, c->jsched_ps, (const int*)c->d_jorder)
         if (tg == 16) JL_LAUNCH(5, 16);
         else if (nmax <= 9 * 8) JL_LAUNCH(9, 8);
         else JL_LAUNCH(16, 8);

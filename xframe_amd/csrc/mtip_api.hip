@@ -53,7 +53,7 @@ void mtip_destroy(mtip_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    void* ptrs[] = {c->d_cost, c->d_gw, c->d_P, c->d_r, c->d_q, c->d_poff, c->d_PT, c->d_AB, c->d_lmtab, c->d_twN, c->d_tw, c->d_W, c->d_htiles, c->d_htiles32, c->d_kl, c->d_used, c->d_active, c->d_sweeps, c->d_jsched, c->d_jsched_off, c->d_jsched_rounds, c->d_pg_tiles[0], c->d_pg_tiles[1], c->d_pg_tiles[2], c->d_pg_tiles[3], c->d_voff,
+    void* ptrs[] = {c->d_cost, c->d_gw, c->d_P, c->d_r, c->d_q, c->d_poff, c->d_PT, c->d_AB, c->d_lmtab, c->d_twN, c->d_tw, c->d_W, c->d_htiles, c->d_htiles32, c->d_kl, c->d_used, c->d_active, c->d_sweeps, c->d_jsched, c->d_jsched_off, c->d_jsched_rounds, c->d_jorder, c->d_pg_tiles[0], c->d_pg_tiles[1], c->d_pg_tiles[2], c->d_pg_tiles[3], c->d_voff,
                     c->d_xoff, c->d_uoff, c->d_V, c->d_rmask, c->d_Bref, c->d_Bnorm, c->d_deg2_part, c->d_S0, c->d_sup, c->d_err_wr,
                     c->d_err_wt, c->d_rho, c->d_Fp, c->d_slot, c->d_best_err, c->d_last_err, c->d_err_hist,
                     c->d_deg2_hist, c->d_F, c->d_T1, c->d_T2, c->d_fixed, c->d_g, c->d_c[0], c->d_c[1], c->d_c[2],
@@ -281,6 +281,11 @@ int mtip_set_projection_matrix(mtip_ctx* c, int l, const mtip_cdouble* V, int k_
     if (k_l < 1 || k_l > kmax) FAIL(c, MTIP_EINVAL, "k_l must be in [1, min(2l+1, Nq)]");
     if (used && (!V || !radial_mask)) FAIL(c, MTIP_EINVAL, "null projection matrix");
     (void)hipSetDevice(c->device);
+    if (c->d_jorder != nullptr) {                        // ... and so does the order list of the polar-factor kernel
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipFree(c->d_jorder);
+        c->d_jorder = nullptr;
+    }
     if (c->d_pg_tiles[0] != nullptr) {                   // the tile lists of the projection GEMMs depend on k_l / used
         (void)hipStreamSynchronize(c->stream);
         for (int op = 0; op < 4; ++op) {

@@ -134,6 +134,8 @@ struct mtip_ctx {
     bool jac_resident = true;                         // env MTIP_JAC_RESIDENT=0: round-robin ordering, both columns via LDS
     int *d_jsched = nullptr, *d_jsched_off = nullptr, *d_jsched_rounds = nullptr;   // resident-column pairing schedule
     int jsched_kmax = 0, jsched_ps = 0;
+    int* d_jorder = nullptr;                          // active orders, heaviest first (grid of the polar-factor kernel)
+    int n_jorder = 0;
     int* d_pg_tiles[4] = {nullptr, nullptr, nullptr, nullptr};   // (order, tile) lists of the projection GEMMs
     int n_pg_tiles[4] = {0, 0, 0, 0};
     int jac_tg = 16;                                  // env MTIP_JAC_TG=8|16: lanes per Jacobi column pair
