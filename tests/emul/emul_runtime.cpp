@@ -82,6 +82,19 @@ void fiber_yield() {
     yield_to_scheduler();
 }
 
+unsigned long long wave_ballot(int pred) {
+    Worker* w = W;
+    const int me = w->current, wv = me / WAVE;
+    w->w_buf[wv].i[me % WAVE] = pred ? 1 : 0;
+    wave_barrier();
+    w = W;
+    unsigned long long m = 0;
+    for (int l = wv * WAVE; l < (wv + 1) * WAVE && l < w->n; ++l)
+        if (w->fibers[l].state != DONE && w->w_buf[wv].i[l % WAVE]) m |= 1ull << (l % WAVE);
+    wave_barrier();
+    return m;
+}
+
 int wave_all(int pred) {
     Worker* w = W;
     const int me = w->current, wv = me / WAVE;

@@ -62,6 +62,7 @@ void wave_barrier();
 WaveBuf& wave_buf();
 void fiber_yield();                 // s_sleep inside a spin wait: let the other threads of the block run
 int wave_all(int pred);             // wave vote over the lanes that are still running
+unsigned long long wave_ballot(int pred);
 inline int lane() { return t_linear % WAVE; }
 inline int wave() { return t_linear / WAVE; }
 }  // namespace emul
@@ -161,6 +162,8 @@ static inline void __threadfence() { std::atomic_thread_fence(std::memory_order_
 static inline void __threadfence_block() { std::atomic_thread_fence(std::memory_order_seq_cst); }
 static inline void __builtin_amdgcn_s_sleep(int) { emul::fiber_yield(); }
 static inline int __all(int pred) { return emul::wave_all(pred); }
+static inline unsigned long long __ballot(int pred) { return emul::wave_ballot(pred); }
+static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 static inline double rsqrt(double x) { return 1.0 / std::sqrt(x); }
 // hardware estimates are only ~single precision: emulate that so the Newton refinement is really exercised
 static inline double emul_trunc_mantissa(double v) {

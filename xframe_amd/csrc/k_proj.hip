@@ -535,11 +535,15 @@ __global__ void __launch_bounds__(JL_MAX_THREADS) k_polar_jacobi_lds(const doubl
             }
             // Compaction: the tournament only runs over the columns that are still non-zero (numerical rank of X;
             // about half of 2l+1 once the density has a support), through the index list s_perm.
-            if (tid == 0) {
-                int ne = 0;
-                for (int cc = 0; cc < k; ++cc)
-                    if (s_isig[cc] > (JAC_DEFLATE * JAC_DEFLATE) * S) s_perm[ne++] = cc;
-                s_keff = ne;
+            if (tid < 64) {                                    // wave 0: ballot + prefix popcount (k <= 128)
+                const double thr = (JAC_DEFLATE * JAC_DEFLATE) * S;
+                const bool a0 = tid < k && s_isig[tid] > thr;
+                const bool a1 = tid + 64 < k && s_isig[tid + 64] > thr;
+                const unsigned long long m0 = __ballot(a0), m1 = __ballot(a1);
+                const unsigned long long below = (1ull << tid) - 1ull;
+                if (a0) s_perm[__popcll(m0 & below)] = tid;
+                if (a1) s_perm[__popcll(m0) + __popcll(m1 & below)] = tid + 64;
+                if (tid == 0) s_keff = __popcll(m0) + __popcll(m1);
             }
             __syncthreads();
             const int ke = s_keff;
