@@ -173,16 +173,21 @@ __global__ void __launch_bounds__(256) k_hankel_mfma(const double* __restrict__ 
 
 struct HankelTile32 { int l, cflat0; };
 
-template <int HT_CT>
+// SUB: out = H(in - in_sub) on output shells > 0 and H(in) on shell 0 in ONE pass (the ft_stab step needs
+// IFT(F') - IFT(F) above shell 0 and IFT(F') on it, misk.py:326-329): the staged panel is the difference, and the wave
+// that owns output row 0 adds H(in_sub)[0] back with a second MFMA chain whose A fragment is W_l masked to row 0.
+template <int HT_CT, bool SUB>
 __global__ void __launch_bounds__(HT_THREADS) k_hankel_tile(const double* __restrict__ in, double* __restrict__ out,
                                                             const double* __restrict__ W,
                                                             const HankelTile32* __restrict__ tiles, int N, int Np, int L,
-                                                            int B, int poffs, double scale, int sign) {
+                                                            int B, int poffs, double scale, int sign,
+                                                            const double* __restrict__ in_sub) {
     constexpr int HT_COLS = 16 * HT_CT;
     constexpr int HT_XS = HT_COLS + 16;
     constexpr int HT_NX = (HT_KC * HT_COLS + HT_THREADS - 1) / HT_THREADS;    // panel doubles per thread and chunk
     __shared__ double Ws[2][HT_KC][HT_WS];
     __shared__ double Xs[2][HT_KC][HT_XS];
+    __shared__ double Ss[SUB ? 2 : 1][SUB ? HT_KC : 1][HT_XS];   // the subtracted panel itself (row-0 correction)
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const HankelTile32 tinfo = tiles[blockIdx.x];
@@ -210,22 +215,33 @@ __global__ void __launch_bounds__(HT_THREADS) k_hankel_tile(const double* __rest
     }
     // two register sets: the operands of the next TWO chunks are in flight while one is multiplied
     double rw0[HT_NW], rx0[HT_NX], rw1[HT_NW], rx1[HT_NX];
-    auto request = [&](int p0, double (&rw)[HT_NW], double (&rx)[HT_NX]) {
+    double rs0[SUB ? HT_NX : 1], rs1[SUB ? HT_NX : 1];
+    auto request = [&](int p0, double (&rw)[HT_NW], double (&rx)[HT_NX], double (&rs)[SUB ? HT_NX : 1]) {
         const int p = p0 + wrow;
         const bool p_ok = p < Np;
         const double* wr = Wl + (size_t)(p_ok ? p : 0) * N + k_base + wcol;
 #pragma unroll
         for (int j = 0; j < HT_NW; ++j) rw[j] = (p_ok && k_base + wcol + j < N) ? wr[j] : 0.0;
 #pragma unroll
-        for (int j = 0; j < HT_NX; ++j)
-            rx[j] = (xok[j] && p0 + xrow[j] < Np) ? in[xoff[j] + (size_t)(p0 + xrow[j] + poffs) * nlm2] : 0.0;
+        for (int j = 0; j < HT_NX; ++j) {
+            const bool ok = xok[j] && p0 + xrow[j] < Np;
+            const size_t o = xoff[j] + (size_t)(p0 + xrow[j] + poffs) * nlm2;
+            rx[j] = ok ? in[o] : 0.0;
+            if (SUB) {
+                rs[j] = ok ? in_sub[o] : 0.0;
+                rx[j] -= rs[j];
+            }
+        }
     };
-    auto deposit = [&](int buf, const double (&rw)[HT_NW], const double (&rx)[HT_NX]) {
+    auto deposit = [&](int buf, const double (&rw)[HT_NW], const double (&rx)[HT_NX], const double (&rs)[SUB ? HT_NX : 1]) {
 #pragma unroll
         for (int j = 0; j < HT_NW; ++j) Ws[buf][wrow][wcol + j] = rw[j];
 #pragma unroll
         for (int j = 0; j < HT_NX; ++j)
-            if (xrow[j] < HT_KC) Xs[buf][xrow[j]][xc[j]] = rx[j];
+            if (xrow[j] < HT_KC) {
+                Xs[buf][xrow[j]][xc[j]] = rx[j];
+                if (SUB) Ss[buf][xrow[j]][xc[j]] = rs[j];
+            }
     };
     // ---- MFMA roles: wave = row tile, all HT_CT column tiles
     const int li = lane & 15, kk = lane >> 4;
@@ -241,26 +257,34 @@ __global__ void __launch_bounds__(HT_THREADS) k_hankel_tile(const double* __rest
                 const double bf = Xs[buf][4 * s + kk][16 * t + li];
                 acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(af, bf, acc[t], 0, 0, 0);
             }
+            if (SUB && wave == 0 && k_base == 0) {               // wave-uniform: output row 0 lives here
+                const double a0 = li == 0 ? af : 0.0;
+#pragma unroll
+                for (int t = 0; t < HT_CT; ++t) {
+                    const double sf = Ss[buf][4 * s + kk][16 * t + li];
+                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, sf, acc[t], 0, 0, 0);
+                }
+            }
         }
     };
     const int n_chunks = (Np + HT_KC - 1) / HT_KC;
-    request(0, rw0, rx0);
-    deposit(0, rw0, rx0);
-    if (n_chunks > 1) request(HT_KC, rw1, rx1);
-    if (n_chunks > 2) request(2 * HT_KC, rw0, rx0);
+    request(0, rw0, rx0, rs0);
+    deposit(0, rw0, rx0, rs0);
+    if (n_chunks > 1) request(HT_KC, rw1, rx1, rs1);
+    if (n_chunks > 2) request(2 * HT_KC, rw0, rx0, rs0);
     __syncthreads();
     for (int i = 0; i < n_chunks; i += 2) {
         // chunk i from buffer 0; chunk i+1 (set 1) goes to buffer 1; then set 1 asks for chunk i+3
         multiply(0);
-        if (i + 1 < n_chunks) deposit(1, rw1, rx1);
+        if (i + 1 < n_chunks) deposit(1, rw1, rx1, rs1);
         __syncthreads();
-        if (i + 3 < n_chunks) request((i + 3) * HT_KC, rw1, rx1);
+        if (i + 3 < n_chunks) request((i + 3) * HT_KC, rw1, rx1, rs1);
         if (i + 1 >= n_chunks) break;
         // chunk i+1 from buffer 1; chunk i+2 (set 0) goes to buffer 0; then set 0 asks for chunk i+4
         multiply(1);
-        if (i + 2 < n_chunks) deposit(0, rw0, rx0);
+        if (i + 2 < n_chunks) deposit(0, rw0, rx0, rs0);
         __syncthreads();
-        if (i + 4 < n_chunks) request((i + 4) * HT_KC, rw0, rx0);
+        if (i + 4 < n_chunks) request((i + 4) * HT_KC, rw0, rx0, rs0);
     }
     // epilogue: * scale * (-/+ i)^l, store
     int r = l & 3;
@@ -288,21 +312,37 @@ __global__ void __launch_bounds__(HT_THREADS) k_hankel_tile(const double* __rest
     }
 }
 
+bool hankel_has_difference(const mtip_ctx* c) { return c->d_htiles32 != nullptr && !c->hankel_wave_tiles && !c->hankel_simple; }
+
+// out = H(in - in_sub) above output shell 0, H(in) on it (in_sub == nullptr: plain transform)
+void launch_hankel_mfma_sub(mtip_ctx* c, const double2* in, const double2* in_sub, double2* out, int inverse) {
+    const dim3 grid((unsigned)c->n_htiles32, (unsigned)div_up(c->N, HT_ROWS));
+#define HT_LAUNCH(CT, SUBF)                                                                                                  \
+    hipLaunchKernelGGL((k_hankel_tile<CT, SUBF>), grid, dim3(HT_THREADS), 0, c->stream, reinterpret_cast<const double*>(in), \
+                       reinterpret_cast<double*>(out), (const double*)c->d_W, (const HankelTile32*)c->d_htiles32, c->N,      \
+                       c->Np, c->L, c->B, c->cfg.hankel_trapz ? 1 : 0, inverse ? c->inv_scale : c->fwd_scale,                \
+                       inverse ? +1 : -1, reinterpret_cast<const double*>(in_sub))
+    if (in_sub != nullptr) {
+        switch (c->htile_ct) {
+            case 1: HT_LAUNCH(1, true); break;
+            case 2: HT_LAUNCH(2, true); break;
+            case 3: HT_LAUNCH(3, true); break;
+            default: HT_LAUNCH(5, true); break;
+        }
+    } else {
+        switch (c->htile_ct) {
+            case 1: HT_LAUNCH(1, false); break;
+            case 2: HT_LAUNCH(2, false); break;
+            case 3: HT_LAUNCH(3, false); break;
+            default: HT_LAUNCH(5, false); break;
+        }
+    }
+#undef HT_LAUNCH
+}
+
 void launch_hankel_mfma(mtip_ctx* c, const double2* in, double2* out, int inverse) {
     if (c->d_htiles32 != nullptr && !c->hankel_wave_tiles) {
-        const dim3 grid((unsigned)c->n_htiles32, (unsigned)div_up(c->N, HT_ROWS));
-#define HT_LAUNCH(CT)                                                                                                   \
-    hipLaunchKernelGGL(k_hankel_tile<CT>, grid, dim3(HT_THREADS), 0, c->stream, reinterpret_cast<const double*>(in),    \
-                       reinterpret_cast<double*>(out), (const double*)c->d_W, (const HankelTile32*)c->d_htiles32, c->N, \
-                       c->Np, c->L, c->B, c->cfg.hankel_trapz ? 1 : 0, inverse ? c->inv_scale : c->fwd_scale,           \
-                       inverse ? +1 : -1)
-        switch (c->htile_ct) {
-            case 1: HT_LAUNCH(1); break;
-            case 2: HT_LAUNCH(2); break;
-            case 3: HT_LAUNCH(3); break;
-            default: HT_LAUNCH(5); break;
-        }
-#undef HT_LAUNCH
+        launch_hankel_mfma_sub(c, in, nullptr, out, inverse);
         return;
     }
     const int n_tiles = c->n_htiles;

@@ -467,16 +467,23 @@ static void enqueue_step(mtip_ctx* c, int method, int ft_stab, double beta) {
     }
     // 9  rho' = IFT(F')
     launch_sht_forward(c, c->d_Fp, cc[4], MTIP_PRE_NONE, SL_OUT);
-    launch_hankel(c, cc[4], cc[5], 1);
+    // rho'' = rho + IFT(F' - F) on shells > 0, IFT(F') on shell 0, using SHT(F) == Hankel(SHT(rho)) = cc[1]: with the
+    // workgroup-tiled Hankel kernel the difference is taken on load and shell 0 corrected in the same pass
+    const bool one_pass_diff = c->cfg.fused && ft_stab && hankel_has_difference(c) && sht_inverse_fuses_real_update(c);
+    if (one_pass_diff) {
+        ProfScope ps(c, "hankel");
+        launch_hankel_mfma_sub(c, cc[4], cc[1], cc[5], 1);
+    } else {
+        launch_hankel(c, cc[4], cc[5], 1);
+    }
     if (c->cfg.fused && ft_stab) {
-        // rho'' = rho + IFT(F' - F) on shells > 0, IFT(F') on shell 0, using SHT(F) == Hankel(SHT(rho)) = cc[1]
-        launch_hankel(c, cc[1], cc[0], 1);
+        if (!one_pass_diff) launch_hankel(c, cc[1], cc[0], 1);
         if (sht_inverse_fuses_real_update(c)) {
             // coefficient difference on load, constraints + HIO/ER + error sums in the epilogue: the density of
             // this step is written once and nothing else of grid size moves
             InvEpilogue ru;
             ru.mode = EPI_REAL_UPDATE;
-            ru.coeff_sub = cc[0];
+            ru.coeff_sub = one_pass_diff ? nullptr : cc[0];
             ru.real.prev = c->d_rho;
             ru.real.out = c->d_rho;
             ru.real.sup = c->d_sup;

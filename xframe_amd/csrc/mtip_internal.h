@@ -225,6 +225,8 @@ void launch_sht_forward_reg(mtip_ctx* c, const double2* grid, double2* coeff, in
 void launch_sht_inverse_reg(mtip_ctx* c, const double2* coeff, double2* grid, const InvEpilogue& epi);
 // Hankel
 void launch_hankel(mtip_ctx* c, const double2* in, double2* out, int inverse);
+bool hankel_has_difference(const mtip_ctx* c);       // launch_hankel_mfma_sub is available (workgroup-tiled kernel)
+void launch_hankel_mfma_sub(mtip_ctx* c, const double2* in, const double2* in_sub, double2* out, int inverse);
 int build_jacobi_schedule(mtip_ctx* c, int kmax);    // k_proj.hip: resident-column pairing schedule, verified on the host
 int build_hankel_tiles(mtip_ctx* c);
 void launch_coeff_diff(mtip_ctx* c, const double2* a, const double2* b, double2* out);
