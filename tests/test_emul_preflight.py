@@ -22,7 +22,7 @@ def emul_lib():
     return EMUL_LIB
 
 
-@pytest.mark.parametrize('N,L', [(16, 4), (10, 7), (8, 2), (6, 12), (4, 24), (3, 44)])   # n_phi = 16, 32, 8, 64, 128, 256
+@pytest.mark.parametrize('N,L', [(16, 4), (10, 7), (8, 2), (6, 12), (4, 24), (3, 32), (3, 44)])   # n_phi = 16, 32, 8, 64, 128, 128, 256
 def test_transforms(emul_lib, N, L):
     PC.check_transforms(N, L, emul_lib, seed=N + L)
 
