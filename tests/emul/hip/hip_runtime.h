@@ -34,6 +34,8 @@ struct dim3 {
 };
 struct double2 { double x, y; };
 static inline double2 make_double2(double x, double y) { return double2{x, y}; }
+struct uint4 { unsigned x, y, z, w; };
+static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
 struct int2 { int x, y; };
 static inline int2 make_int2(int x, int y) { return int2{x, y}; }
 
@@ -161,6 +163,7 @@ static inline unsigned atomicAdd(unsigned* p, unsigned v) {
 static inline void __threadfence() { std::atomic_thread_fence(std::memory_order_seq_cst); }
 static inline void __threadfence_block() { std::atomic_thread_fence(std::memory_order_seq_cst); }
 static inline void __builtin_amdgcn_s_sleep(int) { emul::fiber_yield(); }
+static inline void __builtin_amdgcn_wave_barrier() { emul::wave_barrier(); }
 static inline int __all(int pred) { return emul::wave_all(pred); }
 static inline unsigned long long __ballot(int pred) { return emul::wave_ballot(pred); }
 static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }

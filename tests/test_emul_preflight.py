@@ -54,6 +54,21 @@ def test_non_fxs_variants_vs_oracle(emul_lib, golden_mtip16, fused):
     PC.check_non_fxs_trajectory_vs_oracle(golden_mtip16, emul_lib, fused)
 
 
+@pytest.mark.parametrize('N,L', [(70, 34), (86, 42)])
+def test_projection_rotation_log_sizes(emul_lib, N, L, monkeypatch):
+    """Polar factor with the rotation log (X_l only in LDS, V_r replayed row-wise): k = 69 takes 34 slots per round
+    (64 lanes per row in the replay), k = 85 the 7-row-slot / 768-thread Jacobi variant that config 5 uses (the log is
+    automatic there; forced at the smaller size, where X_l and V_r would still share the LDS)."""
+    monkeypatch.setenv('MTIP_JAC_REPLAY', '2')
+    PC.check_projection_vs_oracle(N, L, emul_lib, n_batch=1)
+
+
+@pytest.mark.parametrize('fused', [False, True])
+def test_short_trajectory_rotation_log(emul_lib, golden_mtip16, fused, monkeypatch):
+    monkeypatch.setenv('MTIP_JAC_REPLAY', '2')
+    PC.check_short_trajectory_vs_oracle(golden_mtip16, emul_lib, fused)
+
+
 def test_wide_projection_matrices(emul_lib):
     """k_l = Nq < 2l+1 (the reference's integration test uses 8 radial points with max_order 15,
     tests/test_fxs_integration.py:326-355): polar factor of a wide matrix, compared through V_l U_l."""

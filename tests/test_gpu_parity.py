@@ -65,8 +65,16 @@ def test_config2_trajectory_vs_oracle(fused):
 
 @pytest.mark.parametrize('N,L', [(40, 18), (96, 44)])
 def test_projection_vs_oracle_sizes(N, L):
-    """(40, 18): LDS Jacobi with 3 row slots and odd/even k mixes; (96, 44): 2l+1 = 89 does not fit LDS -> global-memory
-    fallback kernel (the path config 5, L = 48, takes)."""
+    """(40, 18): LDS Jacobi with 3 row slots and odd/even k mixes; (96, 44): X_l and V_r (2l+1 = 89) do not share one
+    CU's LDS -> X_l-only Jacobi with the rotation log + row-wise V_r replay (the path config 5, L = 48, takes)."""
+    PC.check_projection_vs_oracle(N, L)
+
+
+@pytest.mark.parametrize('N,L,mode', [(40, 18, '2'), (72, 34, '2'), (96, 44, '0')])
+def test_projection_vs_oracle_jacobi_modes(N, L, mode, monkeypatch):
+    """Same projection with the other polar-factor path forced: rotation log at sizes that would run fused
+    (32 / 64 lanes per V_r row in the replay), and the global-memory fallback at the large size."""
+    monkeypatch.setenv('MTIP_JAC_REPLAY', mode)
     PC.check_projection_vs_oracle(N, L)
 
 

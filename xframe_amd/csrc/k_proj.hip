@@ -366,13 +366,25 @@ __device__ __forceinline__ void jl_pair_generic(double2* xi, double2* xj, double
 #define JS_ACTIVE (1 << 17)
 #define JS_WB (1 << 16)
 
-template <int NR, int TG>
+// One rotation of the log that k_jacobi_replay applies to V_r: columns (pr, pm) <- (pr, pm) [[c, conj(w)], [-w, c]];
+// pr < 0: nothing to do in this (round, group) slot.
+struct __align__(16) JlRec {
+    double cs, wx, wy;
+    int pr, pm;
+};
+
+// WITHV = false: V_r is not touched here; the rotation of every (round, group) slot is appended to `log` instead
+// (slot = round * ps + group) and replayed on V_r by k_jacobi_replay, which spreads the rows of V_r over the chip.
+template <int NR, int TG, bool WITHV>
 __device__ __forceinline__ void jl_sweep_resident(double2* Xs, double2* Vs, int ns, int ks, int t, int group,
                                                   const int* __restrict__ tab, int n_rounds, int ps, const int* s_perm,
-                                                  bool xl_ok, bool vl_ok, double tabs2, double S, bool& big) {
-    double2 rx[NR], rv[NR];
+                                                  bool xl_ok, bool vl_ok, double tabs2, double S, bool& big,
+                                                  JlRec* __restrict__ log) {
+    double2 rx[NR], rv[WITHV ? NR : 1];
 #pragma unroll
-    for (int u = 0; u < NR; ++u) rx[u] = rv[u] = make_double2(0.0, 0.0);
+    for (int u = 0; u < NR; ++u) rx[u] = make_double2(0.0, 0.0);
+#pragma unroll
+    for (int u = 0; u < (WITHV ? NR : 1); ++u) rv[u] = make_double2(0.0, 0.0);
     int cur = -1;                                            // compact index of the resident column
     bool dirty = false;
     // table entry and physical columns (through s_perm) of a round are resolved during the previous round
@@ -389,7 +401,7 @@ __device__ __forceinline__ void jl_sweep_resident(double2* Xs, double2* Vs, int 
         double2* vh = Vs + (size_t)pr * ks + t;
         double2* xm = Xs + (size_t)pm * ns + t;
         double2* vm = Vs + (size_t)pm * ks + t;
-        double2 mx[NR], mv[NR];
+        double2 mx[NR], mv[WITHV ? NR : 1];
 #pragma unroll
         for (int u = 0; u < NR; ++u) mx[u] = make_double2(0.0, 0.0);
         if (act) {
@@ -399,7 +411,7 @@ __device__ __forceinline__ void jl_sweep_resident(double2* Xs, double2* Vs, int 
 #pragma unroll
                 for (int u = 0; u < NR; ++u) {
                     rx[u] = xh[u * TG];
-                    rv[u] = vh[u * TG];
+                    if (WITHV) rv[u] = vh[u * TG];
                 }
                 if (!xl_ok) rx[NR - 1] = make_double2(0.0, 0.0);
                 cur = res;
@@ -417,11 +429,20 @@ __device__ __forceinline__ void jl_sweep_resident(double2* Xs, double2* Vs, int 
             gi += a.x * c2.y - a.y * c2.x;
         }
         group_sum4<TG>(alpha, beta, gr, gi);
-        double cs;
-        double2 w;
-        if (jl_params(alpha, beta, gr, gi, act, tabs2, S, big, cs, w)) {
+        double cs = 1.0;
+        double2 w = make_double2(0.0, 0.0);
+        const bool rot = jl_params(alpha, beta, gr, gi, act, tabs2, S, big, cs, w);
+        if (!WITHV && t == 0 && group < ps) {
+            JlRec rec;
+            rec.cs = cs; rec.wx = w.x; rec.wy = w.y;
+            rec.pr = rot ? pr : -1; rec.pm = pm;
+            log[(size_t)r * ps + group] = rec;
+        }
+        if (rot) {
+            if (WITHV) {
 #pragma unroll
-            for (int u = 0; u < NR; ++u) mv[u] = vm[u * TG];
+                for (int u = 0; u < NR; ++u) mv[u] = vm[u * TG];
+            }
 #pragma unroll
             for (int u = 0; u < NR; ++u) {
                 double2 an, bn;
@@ -429,12 +450,14 @@ __device__ __forceinline__ void jl_sweep_resident(double2* Xs, double2* Vs, int 
                 rx[u] = an;
                 if (u < NR - 1 || xl_ok) xm[u * TG] = bn;
             }
+            if (WITHV) {
 #pragma unroll
-            for (int u = 0; u < NR; ++u) {
-                double2 an, bn;
-                jl_rotate(cs, w, rv[u], mv[u], an, bn);
-                rv[u] = an;
-                if (u < NR - 1 || vl_ok) vm[u * TG] = bn;
+                for (int u = 0; u < NR; ++u) {
+                    double2 an, bn;
+                    jl_rotate(cs, w, rv[u], mv[u], an, bn);
+                    rv[u] = an;
+                    if (u < NR - 1 || vl_ok) vm[u * TG] = bn;
+                }
             }
             dirty = true;
         }
@@ -443,7 +466,7 @@ __device__ __forceinline__ void jl_sweep_resident(double2* Xs, double2* Vs, int 
 #pragma unroll
                 for (int u = 0; u < NR; ++u) {
                     if (u < NR - 1 || xl_ok) xh[u * TG] = rx[u];
-                    if (u < NR - 1 || vl_ok) vh[u * TG] = rv[u];
+                    if (WITHV && (u < NR - 1 || vl_ok)) vh[u * TG] = rv[u];
                 }
             }
             cur = -1;
@@ -458,8 +481,8 @@ __device__ __forceinline__ void jl_sweep_resident(double2* Xs, double2* Vs, int 
 // are zero padded to a multiple of 8 rows in LDS, so the row loops need no per-lane predicate; the two columns of
 // the pair stay in registers between the Gram reduction and the rotation.  For odd k the tournament pair that
 // contains the dummy player is skipped, so ceil(k/2) <= 32 pair-groups (one wave per SIMD at k <= 65) suffice.
-template <int MAXR, int TG>
-__global__ void __launch_bounds__(JL_MAX_THREADS) k_polar_jacobi_lds(const double2* __restrict__ Xin_all,
+template <int MAXR, int TG, int MAXT, bool LOGV>
+__global__ void __launch_bounds__(MAXT) k_polar_jacobi_lds(const double2* __restrict__ Xin_all,
                                                                     double2* __restrict__ Pn_all,
                                                                     double2* __restrict__ Vr_all, const int* __restrict__ kl,
                                                                     const int* __restrict__ active,
@@ -469,9 +492,11 @@ __global__ void __launch_bounds__(JL_MAX_THREADS) k_polar_jacobi_lds(const doubl
                                                                     const int* __restrict__ sched,
                                                                     const int* __restrict__ sched_off,
                                                                     const int* __restrict__ sched_rounds, int sched_ps,
-                                                                    const int* __restrict__ order_list) {
+                                                                    const int* __restrict__ order_list,
+                                                                    JlRec* __restrict__ log_all, int* __restrict__ log_rounds,
+                                                                    int log_cap) {
     HIP_DYNAMIC_SHARED(double2, sm)
-    __shared__ double s_gmax[JL_MAX_THREADS / 8];
+    __shared__ double s_gmax[MAXT / 8];
     __shared__ double s_isig[128];
     __shared__ int s_continue;
     __shared__ int s_perm[128];
@@ -495,12 +520,16 @@ __global__ void __launch_bounds__(JL_MAX_THREADS) k_polar_jacobi_lds(const doubl
         const int cc = e / ns, r = e - cc * ns;
         Xs[e] = r < n ? Xin[(size_t)cc * n + r] : make_double2(0.0, 0.0);
     }
-    for (int e = tid; e < k * ks; e += blockDim.x) {
+    for (int e = tid; e < (LOGV ? 0 : k * ks); e += blockDim.x) {
         const int cc = e / ks, i = e - cc * ks;
         double2 v = make_double2(0.0, 0.0);
         if (i < k) v = warm ? Vr[(size_t)cc * k + i] : make_double2(cc == i ? 1.0 : 0.0, 0.0);
         Vs[e] = v;
     }
+    // LOGV: rotations of this matrix go to its slice of the log, lr = slots (rounds) written so far
+    const size_t mat = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+    JlRec* log = LOGV ? log_all + mat * (size_t)log_cap * sched_ps : nullptr;
+    int lr = 0;
     __syncthreads();
     const int ngroups = blockDim.x / TG;
     const int group = tid / TG, t = tid - group * TG;
@@ -554,20 +583,29 @@ __global__ void __launch_bounds__(JL_MAX_THREADS) k_polar_jacobi_lds(const doubl
             const int per_group = (pairs + ngroups - 1) / ngroups;
             bool big = false;                                  // some pair of this group was above the early-exit level
             // resident-column ordering when it applies (16-lane groups, equal row counts, enough groups)
-            const bool resident = TG == 16 && sched != nullptr && nr == kr && nr <= 5 && sched_ps <= ngroups;
+            // (LOGV launches are only made when this holds for every active order)
+            constexpr int RMAX = (TG == 16 && MAXR >= 7) ? 7 : 5;
+            const bool resident = TG == 16 && sched != nullptr && nr == kr && nr <= RMAX && sched_ps <= ngroups;
             if (resident) {
                 const bool xl_ok = pad || t + (nr - 1) * TG < n, vl_ok = pad || t + (kr - 1) * TG < k;
                 const int* tab = sched + sched_off[ke];
-                const int nrd = sched_rounds[ke];
+                int nrd = sched_rounds[ke];
+                if (LOGV && lr + nrd > log_cap) nrd = 0;       // log full (never with JAC_MAX_SWEEPS sweeps sized in)
+                JlRec* lg = LOGV ? log + (size_t)lr * sched_ps : nullptr;
+#define JL_SWEEP(NR) jl_sweep_resident<NR, TG, !LOGV>(Xs, Vs, ns, ks, t, group, tab, nrd, sched_ps, s_perm, xl_ok, vl_ok, tabs2, S, big, lg)
                 switch (nr) {
-                case 1: jl_sweep_resident<1, TG>(Xs, Vs, ns, ks, t, group, tab, nrd, sched_ps, s_perm, xl_ok, vl_ok, tabs2, S, big); break;
-                case 2: jl_sweep_resident<2, TG>(Xs, Vs, ns, ks, t, group, tab, nrd, sched_ps, s_perm, xl_ok, vl_ok, tabs2, S, big); break;
-                case 3: jl_sweep_resident<3, TG>(Xs, Vs, ns, ks, t, group, tab, nrd, sched_ps, s_perm, xl_ok, vl_ok, tabs2, S, big); break;
-                case 4: jl_sweep_resident<4, TG>(Xs, Vs, ns, ks, t, group, tab, nrd, sched_ps, s_perm, xl_ok, vl_ok, tabs2, S, big); break;
-                default: jl_sweep_resident<5, TG>(Xs, Vs, ns, ks, t, group, tab, nrd, sched_ps, s_perm, xl_ok, vl_ok, tabs2, S, big); break;
+                case 1: JL_SWEEP(1); break;
+                case 2: JL_SWEEP(2); break;
+                case 3: JL_SWEEP(3); break;
+                case 4: JL_SWEEP(4); break;
+                case 5: JL_SWEEP(5); break;
+                case 6: JL_SWEEP((RMAX >= 7 ? 6 : 1)); break;
+                default: JL_SWEEP((RMAX >= 7 ? 7 : 1)); break;
                 }
+#undef JL_SWEEP
+                lr += nrd;
             }
-            for (int r = 0; r < (resident ? 0 : rounds); ++r) {
+            for (int r = 0; r < ((resident || LOGV) ? 0 : rounds); ++r) {
                 for (int it = 0; it < per_group; ++it) {
                     const int pi = group + it * ngroups;
                     int ci = 0, cj = 0;
@@ -642,9 +680,108 @@ __global__ void __launch_bounds__(JL_MAX_THREADS) k_polar_jacobi_lds(const doubl
         const int cc = e / n, r = e - cc * n;
         Pn[e] = cscale(Xs[(size_t)cc * ns + r], s_isig[cc]);
     }
-    for (int e = tid; e < k * k; e += blockDim.x) {
+    for (int e = tid; e < (LOGV ? 0 : k * k); e += blockDim.x) {
         const int cc = e / k, i = e - cc * k;
         Vr[e] = Vs[(size_t)cc * ks + i];
+    }
+    if (LOGV && tid == 0) log_rounds[mat] = lr;
+}
+
+// ---- V_r <- V_r R_1 R_2 ... : replay of the rotation log of k_polar_jacobi_lds<.., LOGV = true> ------------------------
+// Every row of V_r transforms on its own, so one matrix is spread over several workgroups (JR_ROWS rows each), and
+// inside a workgroup over waves that never have to meet: a wave owns 64 / G rows x JR_RPL, lane = (row, slot of the
+// round); the rotations of one round touch disjoint columns and LDS operations of a wave complete in order, so rounds
+// follow each other without a barrier.  The log is staged through LDS in chunks of JR_CHUNK rounds (double buffered:
+// the next chunk is in flight in registers while the current one is applied).
+#define JR_THREADS 256
+#define JR_RPL 2
+#define JR_CHUNK 16
+template <int G>                                            // lanes per row: 32 (slots per round <= 32) or 64
+__global__ void __launch_bounds__(JR_THREADS) k_jacobi_replay(const JlRec* __restrict__ log_all,
+                                                              const int* __restrict__ log_rounds,
+                                                              double2* __restrict__ Vr_all, const int* __restrict__ kl,
+                                                              const int* __restrict__ active, const int* __restrict__ roff,
+                                                              int rtot, int warm, int ps, int log_cap,
+                                                              const int* __restrict__ order_list) {
+    constexpr int ROWS_W = (64 / G) * JR_RPL;               // rows of a wave
+    constexpr int ROWS = ROWS_W * (JR_THREADS / 64);        // rows of a workgroup
+    HIP_DYNAMIC_SHARED(double2, sm)
+    const int b = blockIdx.x;
+    const int l = order_list[blockIdx.y];
+    if (!active[l]) return;
+    const int k = kl[l];
+    const int row0 = blockIdx.z * ROWS;
+    if (row0 >= k) return;
+    const int ks = k | 1;                                   // odd row stride
+    double2* Vl = sm;                                       // ROWS x ks (row-major: a rotation works inside a row)
+    uint4* Ls = reinterpret_cast<uint4*>(sm + (size_t)ROWS * ks);   // 2 x JR_CHUNK x ps records (2 x uint4 each)
+    const size_t mat = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+    const uint4* lsrc = reinterpret_cast<const uint4*>(log_all + mat * (size_t)log_cap * ps);
+    const int total = log_rounds[mat];
+    double2* Vr = Vr_all + (size_t)b * rtot + roff[l];      // column-major: Vr[col * k + row]
+    const int tid = threadIdx.x;
+    const int nrow = min(ROWS, k - row0);
+    for (int e = tid; e < ROWS * k; e += JR_THREADS) {
+        const int cc = e / ROWS, i = e - cc * ROWS;
+        double2 v = make_double2(0.0, 0.0);
+        if (i < nrow) v = warm ? Vr[(size_t)cc * k + row0 + i] : make_double2(cc == row0 + i ? 1.0 : 0.0, 0.0);
+        Vl[(size_t)i * ks + cc] = v;
+    }
+    const int per_chunk = JR_CHUNK * ps * 2;                // uint4 per chunk
+    constexpr int NLD = 8;                                  // chunk loads of a thread (per_chunk <= NLD * JR_THREADS)
+    uint4 nxt[NLD];
+    const int n_chunks = (total + JR_CHUNK - 1) / JR_CHUNK;
+    auto fetch = [&](int ch) {
+        const size_t base = (size_t)ch * per_chunk;
+        const size_t lim = (size_t)total * ps * 2;
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            const int e = tid + u * JR_THREADS;
+            nxt[u] = (e < per_chunk && base + e < lim) ? lsrc[base + e] : make_uint4(0u, 0u, 0u, 0u);
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            const int e = tid + u * JR_THREADS;
+            if (e < per_chunk) Ls[(size_t)buf * per_chunk + e] = nxt[u];
+        }
+    };
+    if (n_chunks > 0) fetch(0);
+    const int lane = tid & 63, wave = tid >> 6;
+    const int g = lane % G, rw = lane / G;
+    double2* vrow[JR_RPL];
+#pragma unroll
+    for (int u = 0; u < JR_RPL; ++u) vrow[u] = Vl + (size_t)(wave * ROWS_W + rw * JR_RPL + u) * ks;
+    for (int ch = 0; ch < n_chunks; ++ch) {
+        stash(ch & 1);
+        __syncthreads();                                     // chunk ch visible; chunk ch - 1 (other buffer) is done with
+        if (ch + 1 < n_chunks) fetch(ch + 1);
+        const int rounds = min(JR_CHUNK, total - ch * JR_CHUNK);
+        const uint4* lc = Ls + (size_t)(ch & 1) * per_chunk;
+        for (int r = 0; r < rounds; ++r) {
+            if (g < ps) {
+                const uint4 q0 = lc[(r * ps + g) * 2], q1 = lc[(r * ps + g) * 2 + 1];
+                const int pr = (int)q1.z, pm = (int)q1.w;
+                if (pr >= 0) {
+                    const double cs = __hiloint2double((int)q0.y, (int)q0.x);
+                    const double2 w = make_double2(__hiloint2double((int)q0.w, (int)q0.z), __hiloint2double((int)q1.y, (int)q1.x));
+#pragma unroll
+                    for (int u = 0; u < JR_RPL; ++u) {
+                        double2 an, bn;
+                        jl_rotate(cs, w, vrow[u][pr], vrow[u][pm], an, bn);
+                        vrow[u][pr] = an;
+                        vrow[u][pm] = bn;
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();                 // (scheduling fence only: LDS is in order within a wave)
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < ROWS * k; e += JR_THREADS) {
+        const int cc = e / ROWS, i = e - cc * ROWS;
+        if (i < nrow) Vr[(size_t)cc * k + row0 + i] = Vl[(size_t)i * ks + cc];
     }
 }
 
@@ -1114,7 +1251,19 @@ void launch_project_coefficients(mtip_ctx* c, const double2* Ilm, double2* out) 
     if (build_proj_tiles(c) != MTIP_OK) return;
     launch_proj_gemm<PG_X>(c, ga);
     const size_t lds = ((size_t)kmax * (nmax | 1) + (size_t)kmax * (kmax | 1)) * sizeof(double2);   // unpadded minimum
-    if (lds <= 158 * 1024) {
+    // Rotation-log mode: only X_l lives in the LDS of the Jacobi workgroup, V_r is updated afterwards by k_jacobi_replay
+    // (rows spread over the chip).  Needs the resident ordering for every active order (square X_l, 16-lane groups).
+    bool square = true;
+    for (int l = 0; l <= c->L; ++l)
+        if (c->active[l] && c->kl[l] != 2 * l + 1) square = false;
+    const bool sched_ok = c->jac_resident && kmax <= 255 && kmax >= 2 && build_jacobi_schedule(c, kmax) == MTIP_OK;
+    const size_t lds_x = (size_t)kmax * (nmax | 1) * sizeof(double2);
+    // Measured at k = 65 (fits either way): X-only Jacobi 497 us + replay 232 us against 572 us with V_r in the same
+    // workgroup, so the log is used where X_l and V_r do not fit one CU's LDS together (2l+1 > 71: config 5, 3 x faster
+    // than the global-memory fallback there) unless MTIP_JAC_REPLAY=2 forces it.
+    const bool logv = c->jac_replay > 0 && (c->jac_replay > 1 || lds > 158 * 1024) && c->jac_tg == 16 && square && sched_ok &&
+                      nmax <= 7 * 16 && c->jsched_ps <= 48 && lds_x + 16 * sizeof(double2) <= 158 * 1024;
+    if (logv || lds <= 158 * 1024) {
         // cold start every 64 calls bounds the accumulated rounding drift of the carried V_r
         const int warm = (c->vr_valid && (c->proj_calls % 64) != 0) ? 1 : 0;
         const double2* src = c->d_X;
@@ -1126,14 +1275,13 @@ void launch_project_coefficients(mtip_ctx* c, const double2* Ilm, double2* out) 
         const int pairs_max = kmax / 2;                         // valid pairs per round (odd k: dummy pair skipped)
         // 16 lanes per pair (two waves per SIMD at k = 65: one wave's rotation parameters overlap the other's
         // row updates) when all pairs of a round still fit one workgroup, else 8
-        const int tg = (c->jac_tg == 16 && pairs_max * 16 <= JL_MAX_THREADS && nmax <= 5 * 16) ? 16 : 8;
-        const size_t lds_pad = ((size_t)kmax * (div_up(nmax, tg) * tg + 1) + (size_t)kmax * (div_up(kmax, tg) * tg + 1)) * sizeof(double2);
-        const int pad = lds_pad <= 158 * 1024 ? 1 : 0;
-        const size_t lds_use = (pad ? lds_pad : ((size_t)kmax * (nmax | 1) + (size_t)kmax * (kmax | 1)) * sizeof(double2)) + 16 * sizeof(double2);
-        const bool use_sched = tg == 16 && c->jac_resident && kmax <= 255 && build_jacobi_schedule(c, kmax) == MTIP_OK &&
-                               c->jsched_ps * 16 <= JL_MAX_THREADS;
+        const int tg = logv ? 16 : ((c->jac_tg == 16 && pairs_max * 16 <= JL_MAX_THREADS && nmax <= 5 * 16) ? 16 : 8);
+        const size_t lds_pad = ((size_t)kmax * (div_up(nmax, tg) * tg + 1) + (logv ? 0 : (size_t)kmax * (div_up(kmax, tg) * tg + 1))) * sizeof(double2);
+        const int pad = lds_pad <= (logv ? 80 : 158) * 1024 ? 1 : 0;     // (log mode: stay below half a CU's LDS)
+        const size_t lds_use = (pad ? lds_pad : (logv ? lds_x : lds)) + 16 * sizeof(double2);
+        const bool use_sched = logv || (tg == 16 && sched_ok && c->jsched_ps * 16 <= JL_MAX_THREADS);
         int threads = (((use_sched ? c->jsched_ps : pairs_max) * tg + 63) / 64) * 64;
-        threads = std::min(std::max(threads, 64), JL_MAX_THREADS);
+        threads = std::min(std::max(threads, 64), logv ? 768 : JL_MAX_THREADS);
         if (c->d_jorder == nullptr) {                           // active orders, heaviest (largest k_l) first
             std::vector<int> ord;
             for (int l = 0; l <= c->L; ++l)
@@ -1145,15 +1293,43 @@ void launch_project_coefficients(mtip_ctx* c, const double2* Ilm, double2* out) 
             (void)hipMemcpy(c->d_jorder, ord.data(), ord.size() * sizeof(int), hipMemcpyHostToDevice);
         }
         const dim3 gj((unsigned)c->B, (unsigned)std::max(c->n_jorder, 1));
-#define JL_LAUNCH(MAXR, TG)                                                                                              \
-    hipLaunchKernelGGL((k_polar_jacobi_lds<MAXR, TG>), gj, dim3(threads), lds_use, c->stream, src, c->d_X, c->d_Vr,     \
-                       (const int*)c->d_kl, (const int*)c->d_active, (const int*)c->d_xoff, (const int*)c->d_uoff,      \
-                       c->xtot, c->utot, c->L, warm, c->polar_abs_tol * c->polar_abs_tol, c->d_sweeps, pad,             \
-                       use_sched ? (const int*)c->d_jsched : (const int*)nullptr, (const int*)c->d_jsched_off,          \
-                       (const int*)c->d_jsched_rounds, c->jsched_ps, (const int*)c->d_jorder)
-        if (tg == 16) JL_LAUNCH(5, 16);
-        else if (nmax <= 9 * 8) JL_LAUNCH(9, 8);
-        else JL_LAUNCH(16, 8);
+        const int log_cap = JAC_MAX_SWEEPS * (kmax | 1);        // rounds: at most k (odd k) or k - 1 per sweep
+        if (logv && (c->d_jlog == nullptr || c->jlog_cap != log_cap || c->jlog_ps != c->jsched_ps || c->jlog_nmat != (size_t)gj.x * gj.y)) {
+            if (c->d_jlog) (void)hipFree(c->d_jlog);
+            if (c->d_jlog_rounds) (void)hipFree(c->d_jlog_rounds);
+            c->d_jlog = nullptr; c->d_jlog_rounds = nullptr;
+            const size_t nmat = (size_t)gj.x * gj.y;
+            if (hipMalloc((void**)&c->d_jlog, nmat * log_cap * c->jsched_ps * sizeof(JlRec)) != hipSuccess) return;
+            if (hipMalloc((void**)&c->d_jlog_rounds, nmat * sizeof(int)) != hipSuccess) return;
+            (void)hipMemset(c->d_jlog_rounds, 0, nmat * sizeof(int));
+            c->jlog_cap = log_cap;
+            c->jlog_nmat = nmat;
+            c->jlog_ps = c->jsched_ps;
+        }
+#define JL_LAUNCH(MAXR, TG, MAXT, LOGV)                                                                                  \
+    hipLaunchKernelGGL((k_polar_jacobi_lds<MAXR, TG, MAXT, LOGV>), gj, dim3(threads), lds_use, c->stream, src, c->d_X,  \
+                       c->d_Vr, (const int*)c->d_kl, (const int*)c->d_active, (const int*)c->d_xoff,                    \
+                       (const int*)c->d_uoff, c->xtot, c->utot, c->L, warm, c->polar_abs_tol * c->polar_abs_tol,        \
+                       c->d_sweeps, pad, use_sched ? (const int*)c->d_jsched : (const int*)nullptr,                     \
+                       (const int*)c->d_jsched_off, (const int*)c->d_jsched_rounds, c->jsched_ps,                      \
+                       (const int*)c->d_jorder, (JlRec*)c->d_jlog, c->d_jlog_rounds, log_cap)
+        if (logv) {
+            if (nmax <= 5 * 16 && threads <= JL_MAX_THREADS) JL_LAUNCH(5, 16, JL_MAX_THREADS, true);
+            else JL_LAUNCH(7, 16, 768, true);
+            const int ps = c->jsched_ps;
+            const int rows_wg = (ps <= 32 ? 2 : 1) * JR_RPL * (JR_THREADS / 64);
+            const size_t lds_r = ((size_t)rows_wg * (kmax | 1) + 2 * (size_t)JR_CHUNK * ps * 2) * sizeof(double2);
+            const dim3 gr(gj.x, gj.y, (unsigned)div_up(kmax, rows_wg));
+#define JR_LAUNCH(G)                                                                                                     \
+    hipLaunchKernelGGL((k_jacobi_replay<G>), gr, dim3(JR_THREADS), lds_r, c->stream, (const JlRec*)c->d_jlog,           \
+                       (const int*)c->d_jlog_rounds, c->d_Vr, (const int*)c->d_kl, (const int*)c->d_active,             \
+                       (const int*)c->d_uoff, c->utot, warm, ps, log_cap, (const int*)c->d_jorder)
+            if (ps <= 32) JR_LAUNCH(32);
+            else JR_LAUNCH(64);
+#undef JR_LAUNCH
+        } else if (tg == 16) JL_LAUNCH(5, 16, JL_MAX_THREADS, false);
+        else if (nmax <= 9 * 8) JL_LAUNCH(9, 8, JL_MAX_THREADS, false);
+        else JL_LAUNCH(16, 8, JL_MAX_THREADS, false);
 #undef JL_LAUNCH
         ga.dst = c->d_U;
         launch_proj_gemm<PG_U>(c, ga);

@@ -139,6 +139,11 @@ struct mtip_ctx {
     int* d_pg_tiles[4] = {nullptr, nullptr, nullptr, nullptr};   // (order, tile) lists of the projection GEMMs
     int n_pg_tiles[4] = {0, 0, 0, 0};
     int jac_tg = 16;                                  // env MTIP_JAC_TG=8|16: lanes per Jacobi column pair
+    int jac_replay = 1;                               // env MTIP_JAC_REPLAY: 0 never, 1 rotation log + V_r replay when X_l, V_r do not share LDS, 2 always
+    void* d_jlog = nullptr;                           // rotation log of the last Jacobi launch (matrix, round, slot)
+    int* d_jlog_rounds = nullptr;                     // rounds logged per matrix
+    int jlog_cap = 0, jlog_ps = 0;
+    size_t jlog_nmat = 0;
     bool hankel_wave_tiles = false;                   // env MTIP_HANKEL_WAVE_TILES=1: per-wave tiles straight from L2 (k_hankel_mfma)
     void* d_htiles32 = nullptr;                       // workgroup tiles (order, first column) of k_hankel_tile
     int n_htiles32 = 0, htile_ct = 5;                 // 16-column MFMA tiles per workgroup
