@@ -117,6 +117,8 @@ int mtip_get_unknowns(mtip_ctx* ctx, int batch, int l, mtip_cdouble* U);
 int mtip_get_best_error(mtip_ctx* ctx, double* best_error, int64_t* n_steps_done);
 /* take the best pair as the latest one (reconstruct.py:945-949) */
 int mtip_select_best(mtip_ctx* ctx);
+/* the same for the restarts with select[b] != 0 only (the reference decides per reconstruction process); NULL = all */
+int mtip_select_best_where(mtip_ctx* ctx, const uint8_t* select);
 
 /* ---- the loop (reconstruct.py:854-951) ------------------------------------------------------------
  * runs n_steps steps of `method` for every restart without host synchronisation; betas[n_steps] is the
@@ -132,6 +134,10 @@ int mtip_fetch_errors(mtip_ctx* ctx, int64_t first_step, int64_t n_steps, double
  * enforce_initial_support_b = (last main error_b > error_limit); enforced[n_batch] (may be NULL)
  * returns the decision per restart. */
 int mtip_shrinkwrap(mtip_ctx* ctx, double sigma, double threshold, double error_limit, uint8_t* enforced);
+/* 'SW_center' (reconstruct.py:606-613, 886-897): after the support update the last (reciprocal, real) pair becomes
+ * (FT(rho), rho) -- the reference's sketch shifts nothing.  This call rebuilds the reciprocal half on device; the best
+ * pair is left untouched. */
+int mtip_refresh_reciprocal_density(mtip_ctx* ctx);
 /* B_l = I_l I_l^+ of FT(latest rho) (reconstruct.py:757-765, 992-993), (L+1, Nq, Nq) complex */
 int mtip_last_deg2_invariant(mtip_ctx* ctx, int batch, mtip_cdouble* Bl);
 

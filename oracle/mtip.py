@@ -318,6 +318,21 @@ class MTIP:
                     sw_step += 1
                     self.update_shrink_wrap(sw_step, loop_number)
                     continue
+                if key == 'SW_center':
+                    # reconstruct.py:606-613 (sketch: support of the last density; the pair handed back is
+                    # (FT(rho), rho) -- no shift, despite the name) and 886-897 (the last history pair is replaced)
+                    enforce = error_dict['main'][-1] > limit
+                    self.real_pr.enforce_initial_support = enforce
+                    eis_list.append(enforce)
+                    for _ in range(repeats):
+                        rho = np.array(state['density_pair_history'][-1][1])
+                        support = self.sw_step(rho)
+                        self.real_pr.support = support
+                        state['mask'] = self.real_pr.support
+                        state['density_pair_history'] = state['density_pair_history'][:-1] + ((self.fp.ft(np.array(rho)), rho),)
+                        sw_step += 1
+                        self.update_shrink_wrap(sw_step, loop_number)
+                    continue
                 if key in ('ER_non_FXS', 'HIO_non_FXS'):
                     if isinstance(latest_intensity, bool):
                         latest_intensity = np.abs(state['density_pair_history'][-1][0]).real

@@ -225,6 +225,69 @@ def check_short_trajectory_vs_oracle(g, lib_path, fused, n_hio=3, n_er=2, n_rest
     m.engine.close()
 
 
+def check_best_reselection_vs_oracle(g, lib_path, fused, n_restarts=2):
+    """End-of-loop reselection of the best pair (reconstruct.py:945-949): loop 'main' ends on HIO steps with a large
+    beta, so its last error is above its best one; the best density (found in iteration 3 > 1) is what loop
+    'refinement' continues from."""
+    N, L = int(g['N']), int(g['L'])
+    data = data_from_golden(g, L)
+    opt = golden_settings(N, L)
+    loops = opt['main_loop']['sub_loops']
+    loops['main']['methods'] = {'ER': {'iterations': 2, 'ft_stab': True}, 'HIO': {'iterations': 2, 'ft_stab': True}}
+    loops['main']['order'] = ['ER', 'HIO']
+    loops['main']['iterations'] = 3
+    loops['main']['best_density_not_in_first_n_iterations'] = 1
+    loops['refinement']['methods'] = {'ER': {'iterations': 2, 'ft_stab': True}, 'SW': 1}
+    loops['refinement']['order'] = ['SW', 'ER']
+    loops['refinement']['iterations'] = 1
+    loops['refinement']['best_density_not_in_first_n_iterations'] = 0
+    loops['order'] = ['main', 'refinement']
+    opt['projections']['real']['HIO']['beta'] = [[1.5, 1.5, -1 / 250, 500], [0.01, 0.002, -1 / 200, 200]]
+    ref_m = OM.MTIP(opt, data)
+    ref = ref_m.phasing_loop(rho0=g['rho0'])
+    R.MTIP.preinit(opt, data)
+    m = R.MTIP(n_restarts=n_restarts, initial_densities=[g['rho0']] * n_restarts, lib_path=lib_path, fused=fused)
+    m.generate_phasing_loop()
+    res = m.phasing_loop()
+    main_err = np.asarray(ref['error_dict']['main'])
+    assert len(main_err) == 14 and np.argmin(main_err[:12]) < 11, 'case does not exercise the reselection'
+    for b in range(n_restarts):
+        r = res[b]
+        assert np.allclose(r['error_dict']['main'], ref['error_dict']['main'], rtol=1e-8)
+        for k in ('real_density', 'last_real_density', 'reciprocal_density', 'last_reciprocal_density'):
+            assert rel_l2(r[k], ref[k]) < 1e-8, k
+        assert (r['support_mask'] != ref['support_mask']).sum() == 0
+        assert (r['last_support_mask'] != ref['last_support_mask']).sum() == 0
+    m.engine.close()
+
+
+def check_sw_center_trajectory_vs_oracle(g, lib_path, fused, n_restarts=2):
+    """'SW_center' in the schedule (reconstruct.py:606-613, 886-897): HIO -> SW -> ER -> SW_center (2 repeats) ->
+    HIO_non_FXS (which reads the refreshed reciprocal half of the last pair, 899-904) against the oracle."""
+    N, L = int(g['N']), int(g['L'])
+    data = data_from_golden(g, L)
+    opt = golden_settings(N, L)
+    main = opt['main_loop']['sub_loops']['main']
+    main['methods'] = {'HIO': {'iterations': 3, 'ft_stab': True}, 'SW': 1, 'ER': {'iterations': 2, 'ft_stab': True},
+                       'SW_center': 2, 'HIO_non_FXS': {'iterations': 2, 'ft_stab': False}}
+    main['order'] = ['HIO', 'SW', 'ER', 'SW_center', 'HIO_non_FXS']
+    main['iterations'] = 2
+    ref = OM.MTIP(opt, data).phasing_loop(rho0=g['rho0'])
+    R.MTIP.preinit(opt, data)
+    m = R.MTIP(n_restarts=n_restarts, initial_densities=[g['rho0']] * n_restarts, lib_path=lib_path, fused=fused)
+    m.generate_phasing_loop()
+    res = m.phasing_loop()
+    for b in range(n_restarts):
+        r = res[b]
+        assert np.allclose(r['error_dict']['main'], ref['error_dict']['main'], rtol=1e-8)
+        for k in ('real_density', 'last_real_density', 'reciprocal_density', 'last_reciprocal_density'):
+            assert rel_l2(r[k], ref[k]) < 1e-8, k
+        assert (r['support_mask'] != ref['support_mask']).sum() == 0
+        assert (r['last_support_mask'] != ref['last_support_mask']).sum() == 0
+        assert r['loop_iterations'] == ref['loop_iterations']
+    m.engine.close()
+
+
 def check_non_fxs_trajectory_vs_oracle(g, lib_path, fused, n_restarts=2):
     """The *_non_FXS variants (reconstruct.py:899-904, sketches 530-535, 565-593): after some FXS steps the intensity
     is frozen to |F'|^2 of the latest pair and the reciprocal projection becomes F sqrt(fixed / |F|^2)

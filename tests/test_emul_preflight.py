@@ -54,6 +54,15 @@ def test_non_fxs_variants_vs_oracle(emul_lib, golden_mtip16, fused):
     PC.check_non_fxs_trajectory_vs_oracle(golden_mtip16, emul_lib, fused)
 
 
+def test_best_reselection_vs_oracle(emul_lib, golden_mtip16):
+    PC.check_best_reselection_vs_oracle(golden_mtip16, emul_lib, True)
+
+
+@pytest.mark.parametrize('fused', [False, True])
+def test_sw_center_vs_oracle(emul_lib, golden_mtip16, fused):
+    PC.check_sw_center_trajectory_vs_oracle(golden_mtip16, emul_lib, fused)
+
+
 @pytest.mark.parametrize('N,L', [(70, 34), (86, 42)])
 def test_projection_rotation_log_sizes(emul_lib, N, L, monkeypatch):
     """Polar factor with the rotation log (X_l only in LDS, V_r replayed row-wise): k = 69 takes 34 slots per round

@@ -41,6 +41,15 @@ def test_short_trajectory_vs_oracle(golden_mtip16, fused):
     PC.check_short_trajectory_vs_oracle(golden_mtip16, None, fused)
 
 
+def test_best_reselection_vs_oracle(golden_mtip16):
+    PC.check_best_reselection_vs_oracle(golden_mtip16, None, True)
+
+
+@pytest.mark.parametrize('fused', [False, True])
+def test_sw_center_vs_oracle(golden_mtip16, fused):
+    PC.check_sw_center_trajectory_vs_oracle(golden_mtip16, None, fused)
+
+
 @pytest.mark.parametrize('fused', [False, True])
 def test_non_fxs_variants_vs_oracle(golden_mtip16, fused):
     PC.check_non_fxs_trajectory_vs_oracle(golden_mtip16, None, fused)

@@ -695,13 +695,16 @@ int mtip_get_best_error(mtip_ctx* c, double* best, int64_t* n_steps_done) {
     return MTIP_OK;
 }
 
-int mtip_select_best(mtip_ctx* c) {
+int mtip_select_best(mtip_ctx* c) { return mtip_select_best_where(c, nullptr); }
+
+int mtip_select_best_where(mtip_ctx* c, const uint8_t* select) {
     CTX_CHECK(c);
     (void)hipSetDevice(c->device);
     std::vector<int> slots((size_t)c->B * SL_N);
     MTIP_HIP_CHECK(c, hipStreamSynchronize(c->stream));
     MTIP_HIP_CHECK(c, hipMemcpy(slots.data(), c->d_slot, slots.size() * sizeof(int), hipMemcpyDeviceToHost));
     for (int b = 0; b < c->B; ++b) {
+        if (select != nullptr && !select[b]) continue;
         int* s = &slots[(size_t)b * SL_N];
         s[SL_CUR] = s[SL_BEST];
         s[SL_SUP] = s[SL_SUP_BEST];
@@ -710,6 +713,7 @@ int mtip_select_best(mtip_ctx* c) {
         s[SL_OUT] = nxt;
     }
     MTIP_HIP_CHECK(c, hipMemcpy(c->d_slot, slots.data(), slots.size() * sizeof(int), hipMemcpyHostToDevice));
+    c->fixed_valid = false;
     return MTIP_OK;
 }
 
@@ -752,6 +756,36 @@ int mtip_shrinkwrap(mtip_ctx* c, double sigma, double threshold, double error_li
         for (int b = 0; b < c->B; ++b) enforced[b] = (uint8_t)slots[(size_t)b * SL_N + SL_ENFORCE];
     }
     return MTIP_OK;
+}
+
+int mtip_refresh_reciprocal_density(mtip_ctx* c) {
+    CTX_CHECK(c);
+    int r = require_loop(c);
+    if (r) return r;
+    (void)hipSetDevice(c->device);
+    // new pair in the OUT slot (the best pair may share the CUR slot): rho copy + FT(rho), then CUR <- OUT
+    std::vector<int> slots((size_t)c->B * SL_N);
+    MTIP_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    MTIP_HIP_CHECK(c, hipMemcpy(slots.data(), c->d_slot, slots.size() * sizeof(int), hipMemcpyDeviceToHost));
+    for (int b = 0; b < c->B; ++b) {
+        const int cur = slots[(size_t)b * SL_N + SL_CUR], out = slots[(size_t)b * SL_N + SL_OUT];
+        MTIP_HIP_CHECK(c, hipMemcpyAsync(c->d_rho + ((size_t)out * c->B + b) * c->G, c->d_rho + ((size_t)cur * c->B + b) * c->G,
+                                         c->G * sizeof(double2), hipMemcpyDeviceToDevice, c->stream));
+    }
+    InvEpilogue to_slot;
+    to_slot.out_slot = SL_OUT;
+    ft_pipeline(c, c->d_rho, SL_CUR, c->d_Fp, 0, MTIP_PRE_NONE, to_slot, c->d_c[0], c->d_c[1]);
+    MTIP_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    for (int b = 0; b < c->B; ++b) {
+        int* s = slots.data() + (size_t)b * SL_N;
+        s[SL_CUR] = s[SL_OUT];
+        int f = 0;
+        while (f == s[SL_CUR] || f == s[SL_BEST]) ++f;
+        s[SL_OUT] = f;
+    }
+    MTIP_HIP_CHECK(c, hipMemcpy(c->d_slot, slots.data(), slots.size() * sizeof(int), hipMemcpyHostToDevice));
+    c->fixed_valid = false;
+    return post_launch(c, "mtip_refresh_reciprocal_density");
 }
 
 int mtip_last_deg2_invariant(mtip_ctx* c, int batch, mtip_cdouble* Bl) {

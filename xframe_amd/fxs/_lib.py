@@ -55,10 +55,12 @@ _SIGNATURES = {
     'mtip_get_unknowns': (C.c_int, [c_void, C.c_int, C.c_int, c_void]),
     'mtip_get_best_error': (C.c_int, [c_void, c_void, C.POINTER(C.c_int64)]),
     'mtip_select_best': (C.c_int, [c_void]),
+    'mtip_select_best_where': (C.c_int, [c_void, c_void]),
     'mtip_run': (C.c_int, [c_void, C.c_int, C.c_int, C.c_int, c_void, c_void, c_void]),
     'mtip_run_async': (C.c_int, [c_void, C.c_int, C.c_int, C.c_int, c_void]),
     'mtip_fetch_errors': (C.c_int, [c_void, C.c_int64, C.c_int64, c_void, c_void]),
     'mtip_shrinkwrap': (C.c_int, [c_void, C.c_double, C.c_double, C.c_double, c_void]),
+    'mtip_refresh_reciprocal_density': (C.c_int, [c_void]),
     'mtip_last_deg2_invariant': (C.c_int, [c_void, C.c_int, c_void]),
     'mtip_op_sht_forward': (C.c_int, [c_void, c_void, c_void, C.c_int]),
     'mtip_op_sht_inverse': (C.c_int, [c_void, c_void, c_void]),

@@ -234,8 +234,14 @@ class Engine:
         self._ck(self.lib.mtip_get_best_error(self.ctx, _lib.ptr(out), C.byref(n)))
         return out, int(n.value)
 
-    def select_best(self):
-        self._ck(self.lib.mtip_select_best(self.ctx))
+    def select_best(self, where=None):
+        """reconstruct.py:945-949 for all restarts, or for those flagged in `where` (bool per restart)."""
+        if where is None:
+            self._ck(self.lib.mtip_select_best(self.ctx))
+        else:
+            w = np.ascontiguousarray(np.asarray(where, dtype=np.uint8))
+            assert w.shape == (self.B,)
+            self._ck(self.lib.mtip_select_best_where(self.ctx, _lib.ptr(w)))
 
     def run(self, method, ft_stab, betas, fetch=True):
         betas = _lib.as_f64(np.atleast_1d(betas))
@@ -258,6 +264,10 @@ class Engine:
         enforced = np.empty(self.B, np.uint8)
         self._ck(self.lib.mtip_shrinkwrap(self.ctx, float(sigma), float(threshold), float(error_limit), _lib.ptr(enforced)))
         return enforced.astype(bool)
+
+    def refresh_reciprocal_density(self):
+        """'SW_center' tail (reconstruct.py:893-894): the last pair becomes (FT(rho), rho)."""
+        self._ck(self.lib.mtip_refresh_reciprocal_density(self.ctx))
 
     def last_deg2_invariant(self, batch):
         out = np.empty((self.L + 1, self.N, self.N), complex)

@@ -166,8 +166,16 @@ class MTIP:
         e.synchronize()
         t0 = time.perf_counter()
         n_steps = 0
+        # best_error / best_iteration per restart (reconstruct.py:934-938), only followed on the host when some loop
+        # reselects the best density at its end (945-949)
+        track_best = any(np.isfinite(loops[name].get('best_density_not_in_first_n_iterations', np.inf))
+                         for name in loops['order'])
+        best_err_h = np.full(B, np.inf)
+        best_iter_h = np.zeros(B, int)
         for loop_number, loop_name in enumerate(loops['order']):
             lo = loops[loop_name]
+            loop_first_step = n_steps
+            step_iteration = []
             methods = {}
             for key in lo['order']:
                 mo = lo['methods'][key]
@@ -189,16 +197,34 @@ class MTIP:
                         self._update_shrink_wrap(sw_step, loop_number)
                         continue
                     if key == 'SW_center':
-                        raise NotImplementedError('SW_center')
+                        # reconstruct.py:886-897: one enforce decision, then `iterations` support updates, each
+                        # handing back (FT(rho), rho) as the last pair (the sketch, 606-613, shifts nothing)
+                        for i in range(methods[key]['iterations']):
+                            enforced = e.shrinkwrap(self.sw_sigma, self.sw_threshold, limit)
+                            if i == 0:
+                                eis_list.append(enforced)
+                            e.refresh_reciprocal_density()
+                            sw_step += 1
+                            self._update_shrink_wrap(sw_step, loop_number)
+                        continue
                     repeats = methods[key]['iterations']
                     ft_stab = self._change_to_ft_stab(methods[key]['options'], key, eis_list)
                     betas = np.array([ramp.eval(step + i) for i in range(repeats)], dtype=float)
                     e.run(key, ft_stab, betas, fetch=False)
                     step += repeats
                     n_steps += repeats
-            best_err, _ = e.best_error()
-            if np.isfinite(lo.get('best_density_not_in_first_n_iterations', np.inf)):
-                raise NotImplementedError('best_density_not_in_first_n_iterations < inf')
+                    step_iteration += [iteration] * repeats
+            if track_best and n_steps > loop_first_step:
+                errs, _ = e.fetch_errors(loop_first_step, n_steps - loop_first_step)
+                for i, it in enumerate(step_iteration):
+                    better = best_err_h > errs[i]
+                    best_err_h = np.where(better, errs[i], best_err_h)
+                    best_iter_h = np.where(better, it, best_iter_h)
+            n_first = lo.get('best_density_not_in_first_n_iterations', np.inf)
+            if np.isfinite(n_first):
+                reselect = best_iter_h > n_first
+                if reselect.any():
+                    e.select_best(reselect)
             iterations.append(iteration)
         e.synchronize()
         t1 = time.perf_counter()
