@@ -171,6 +171,8 @@ class ReciprocalProjection:
         self.data_radial_points = q_d
         self.data_max_q, self.data_min_q = np.max(q_d), np.min(q_d)
         self.data_max_order = data['max_order']
+        lims = data.get('data_projection_matrices_q_id_limits', False)                       # 462, 594
+        self.data_q_id_limits = lims['I1I1'] if isinstance(lims, dict) else lims
         self.xray_wavelength = data.get('xray_wavelength', 1.0)
         # 473-476 (midpoint_rule: mathLibrary.py:1492-1496)
         self.integrated_intensity = (q_d[1] - q_d[0]) * np.sum(aint_d * q_d ** 2, axis=0) * 2 * np.sqrt(np.pi)
@@ -244,6 +246,19 @@ class ReciprocalProjection:
                     mask[:] = ((q >= region[0]) & (q < region[1]))[None, :]
                 else:
                     mask[:] = True
+            elif mtype == 'manual' and mask_opt['manual']['type'] == 'order_dependent_line':
+                # 619-624 with distance_from_line_2d (mathLibrary.py:1131-1137): keep the side of the line through
+                # two (order, q) points on which the rotated direction (dy, -dx) has a non-positive projection
+                p1, p2 = np.asarray(mask_opt['manual']['order_dependent_line'], dtype=float)
+                d = p2 - p1
+                rot = np.array([d[1], -d[0]])
+                grid = np.stack(np.meshgrid(np.asarray(self.positive_orders, dtype=float), q, indexing='ij'), axis=-1)
+                mask = (-1 * np.sum((grid - p1) * rot[None, None, :], axis=-1)) >= 0
+            elif mtype == 'from_projection_matrices':
+                # 592-597: per order the open q interval on which the data matrices were measured
+                mask = np.full((n_orders, len(q)), False)
+                for mask_part, lim in zip(mask, self.data_q_id_limits):
+                    mask_part[:] = (q > self.data_radial_points[lim[0]]) & (q < self.data_radial_points[lim[1] - 1])
             else:
                 raise NotImplementedError(mtype)
         return mask & data_mask

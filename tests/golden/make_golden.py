@@ -210,6 +210,26 @@ def main():
     out['G3_radial_mask'] = rp.radial_mask
     for l in range(L + 1):
         out[f'G3_pm{l}'] = np.asarray(rp.projection_matrices[l], dtype=complex)
+    # radial mask of every q_mask type (generate_radial_mask, fxs_Projections.py:578-629); no random numbers drawn here
+    nd = len(data['data_radial_points'])
+    d_lim = ref_data(data)
+    d_lim['data_projection_matrices_q_id_limits'] = {'I1I1': np.array([[l, nd - l] for l in range(L + 1)])}
+    out['G3m_q_id_limits'] = d_lim['data_projection_matrices_q_id_limits']['I1I1']
+    mask_cases = {
+        'none': {'type': 'none'},
+        'region_lo': {'type': 'manual', 'manual': {'type': 'region', 'region': [float(qs[2]), False]}},
+        'region_both': {'type': 'manual', 'manual': {'type': 'region', 'region': [float(qs[1]), float(qs[N - 4])]}},
+        'line': {'type': 'manual', 'manual': {'type': 'order_dependent_line',
+                                              'order_dependent_line': [[0.0, float(qs[2])], [float(L), float(qs[N - 3])]]}},
+        'from_pm': {'type': 'from_projection_matrices'},
+    }
+    for name, mopt in mask_cases.items():
+        settings.project = dictns(pl, make_settings(N, L, {'projections': {'reciprocal': {'q_mask': mopt}}}))
+        out['G3m_' + name] = np.array(fp_.ReciprocalProjection(grid_pair.reciprocalGrid, d_lim, L).radial_mask)
+    out['G3m_line_points'] = np.array(mask_cases['line']['manual']['order_dependent_line'])
+    out['G3m_region_lo_pt'] = np.array(float(qs[2]))
+    out['G3m_region_both_pts'] = np.array([float(qs[1]), float(qs[N - 4])])
+    settings.project = dictns(pl, opt)
     Ilm = [cplx(rng, (N, 2 * l + 1)) for l in range(L + 1)]
     unk = rp.approximate_unknowns(Ilm)
     unk = tuple(np.array(u) for u in unk)

@@ -166,3 +166,28 @@ def test_gpu_process_boundary(emul_lib):
         fn = mgr.add_gpu_process(ClProcess(kdh), lib_path=emul_lib)
         rho = rng.normal(size=(nq, nlm)) + 1j * rng.normal(size=(nq, nlm))
         assert rel_l2(fn(rho), OH.apply_direct(w[key], rho)) < 1e-12
+
+
+@pytest.mark.parametrize('name', ['none', 'region_lo', 'region_both', 'line', 'from_pm'])
+def test_radial_mask_types_golden(golden_ops, name):
+    """generate_radial_mask (fxs_Projections.py:578-629), every q_mask type: the reference's own masks (fixture
+    G3m_*, tests/golden/make_golden.py) against the oracle restatement and the host mirror."""
+    from oracle import projections as OP
+    from xframe_amd.fxs import hostsetup as hs
+    g = golden_ops
+    N, L = 16, 4
+    data = dict(data_from_golden(g, L, prefix='D16_'))
+    data['data_projection_matrices_q_id_limits'] = {'I1I1': g['G3m_q_id_limits']}
+    q_mask = {
+        'none': {'type': 'none'},
+        'region_lo': {'type': 'manual', 'manual': {'type': 'region', 'region': [float(g['G3m_region_lo_pt']), False]}},
+        'region_both': {'type': 'manual', 'manual': {'type': 'region', 'region': [float(x) for x in g['G3m_region_both_pts']]}},
+        'line': {'type': 'manual', 'manual': {'type': 'order_dependent_line',
+                                              'order_dependent_line': g['G3m_line_points'].tolist()}},
+        'from_pm': {'type': 'from_projection_matrices'},
+    }[name]
+    opt = golden_settings(N, L, {'projections': {'reciprocal': {'q_mask': q_mask}}})['projections']['reciprocal']
+    qs = np.asarray(g['G2_qs'])
+    want = g['G3m_' + name]
+    assert (OP.ReciprocalProjection(qs, data, L, opt).radial_mask == want).all()
+    assert (hs.ReciprocalSetup(qs, data, L, opt).radial_mask == want).all()

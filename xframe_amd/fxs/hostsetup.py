@@ -189,6 +189,22 @@ class ReciprocalSetup:
                     mask[:] = (self.qs >= lo)[None, :]
                 elif lo_set and hi_set:
                     mask[:] = ((self.qs >= lo) & (self.qs < hi))[None, :]
+            elif mtype == 'manual' and mopt['manual']['type'] == 'order_dependent_line':
+                # fxs_Projections.py:619-624, mathLibrary.py:1131-1137: side of the line through two (order, q) points
+                p1, p2 = np.asarray(mopt['manual']['order_dependent_line'], dtype=float)
+                rot = np.array([p2[1] - p1[1], -(p2[0] - p1[0])])
+                oq = np.stack(np.meshgrid(np.arange(max_order + 1, dtype=float), self.qs, indexing='ij'), axis=-1)
+                mask = (-1 * np.sum((oq - p1) * rot[None, None, :], axis=-1)) >= 0
+            elif mtype == 'from_projection_matrices':
+                # 592-597: per order the open q interval covered by the data matrices
+                lims = data.get('data_projection_matrices_q_id_limits', False)
+                if isinstance(lims, dict):
+                    lims = lims['I1I1']
+                if isinstance(lims, bool):
+                    raise ValueError("q_mask 'from_projection_matrices' needs data_projection_matrices_q_id_limits")
+                mask = np.zeros((max_order + 1, n), dtype=bool)
+                for row, lim in zip(mask, lims):
+                    row[:] = (self.qs > q_d[int(lim[0])]) & (self.qs < q_d[int(lim[1]) - 1])
             elif mtype != 'none':
                 raise NotImplementedError(f'q_mask type {mtype!r}')
         self.radial_mask = mask & data_mask[None, :]
