@@ -246,7 +246,7 @@ class MTIP:
         except IndexError:
             return -1
 
-    # -- generate_density_guess_method, reconstruct.py:1115-1174 ('bump' and 'ball'-free subset)
+    # -- generate_density_guess_method, reconstruct.py:1115-1174 ('bump' and 'ball')
     def density_guess(self, rng):
         dg = self.opt['density_guess']
         radius = dg['radius']
@@ -254,10 +254,17 @@ class MTIP:
             radius = self.opt['particle_radius']
         if radius < 0:
             radius = np.max(self.fp.rs)
-        amp = 1 + 1 / dg['random']['SNR'] * rng.random(self.shape)
-        assert dg['type'] == 'bump'
-        bump = P.get_test_function([-radius, radius], dg['bump']['slope'])
-        density = amp * bump(np.array(self.real_r))
+        if dg['type'] == 'ball':
+            # 1136-1153 with get_disk_function / get_shape_function (mathLibrary.py:124-167): amplitude inside r < radius
+            r = np.array(self.real_r)
+            inside = r < radius
+            density = np.zeros(self.shape)
+            density[inside] = 1 + 1 / dg['random']['SNR'] * rng.random(int(inside.sum()))
+        else:
+            assert dg['type'] == 'bump'
+            amp = 1 + 1 / dg['random']['SNR'] * rng.random(self.shape)
+            bump = P.get_test_function([-radius, radius], dg['bump']['slope'])
+            density = amp * bump(np.array(self.real_r))
         total_sq = self.integrator.integrate((density * density.conj()).real)
         density = density * np.sqrt(self.rp.integrated_intensity / total_sq)
         return density.astype(complex)

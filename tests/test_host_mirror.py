@@ -191,3 +191,26 @@ def test_radial_mask_types_golden(golden_ops, name):
     want = g['G3m_' + name]
     assert (OP.ReciprocalProjection(qs, data, L, opt).radial_mask == want).all()
     assert (hs.ReciprocalSetup(qs, data, L, opt).radial_mask == want).all()
+
+
+@pytest.mark.parametrize('kind', ['bump', 'ball'])
+def test_density_guess_matches_oracle(emul_lib, golden_mtip16, kind):
+    """generate_density_guess_method (reconstruct.py:1115-1174): the worker's seeded guess against the oracle's for
+    the same generator state, and the normalisation int |rho|^2 = integrated intensity."""
+    from oracle import mtip as OM
+    from xframe_amd.fxs import reconstruct as R
+    g = golden_mtip16
+    N, L = int(g['N']), int(g['L'])
+    data = data_from_golden(g, L)
+    opt = golden_settings(N, L, {'density_guess': {'type': kind}})
+    om = OM.MTIP(opt, data)
+    want = om.density_guess(np.random.default_rng(77))
+    R.MTIP.preinit(opt, data)
+    m = R.MTIP(n_restarts=1, seeds=[77], lib_path=emul_lib)
+    m.generate_phasing_loop()
+    got = m._initial_density(0)
+    assert rel_l2(got, want) < 1e-13
+    assert np.isclose(om.integrator.integrate((want * want.conj()).real), om.rp.integrated_intensity, rtol=1e-12)
+    if kind == 'ball':
+        assert (got == 0).any() and (got != 0).any()
+    m.engine.close()

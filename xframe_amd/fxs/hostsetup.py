@@ -296,6 +296,16 @@ def bump_density(rs, shape, radius, slope, snr, rng, integrated_intensity, wr_pl
     return (density * np.sqrt(integrated_intensity / total_sq)).astype(complex)
 
 
+def ball_density(rs, shape, radius, snr, rng, integrated_intensity, wr_plain, wt):
+    """reconstruct.py:1136-1153 ('ball': get_disk_function, mathLibrary.py:124-167): random amplitude for r < radius."""
+    r = np.broadcast_to(np.asarray(rs)[:, None, None], shape)
+    inside = r < radius
+    density = np.zeros(shape)
+    density[inside] = 1 + 1 / snr * rng.random(int(inside.sum()))
+    total_sq = np.einsum('q,t,qtp->', wr_plain, wt, density * density)
+    return (density * np.sqrt(integrated_intensity / total_sq)).astype(complex)
+
+
 def integrator_weights(rs, n_theta):
     """plain SphericalIntegrator weights: int f = sum wr[q] wt[t] sum_phi f."""
     rs = np.asarray(rs, dtype=float)

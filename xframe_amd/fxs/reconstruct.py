@@ -110,7 +110,7 @@ class MTIP:
         if self.initial_densities is not None:
             return np.asarray(self.initial_densities[i], dtype=complex)
         dg = self.opt['density_guess']
-        if dg['type'] != 'bump':
+        if dg['type'] not in ('bump', 'ball'):
             raise NotImplementedError(f"density_guess.type {dg['type']!r}")
         seed = None if self.seeds is None else self.seeds[i]
         rng = np.random.default_rng(seed)       # seed None = OS entropy, like the reference's os.urandom seeding
@@ -120,6 +120,9 @@ class MTIP:
             radius = self.opt['particle_radius']
         if radius < 0:
             radius = np.max(e.rs)
+        if dg['type'] == 'ball':
+            return hs.ball_density(e.rs, e.shape, radius, dg['random']['SNR'], rng, e.rsetup.integrated_intensity,
+                                   e.int_wr, e.int_wt)
         return hs.bump_density(e.rs, e.shape, radius, dg['bump']['slope'], dg['random']['SNR'], rng,
                                e.rsetup.integrated_intensity, e.int_wr, e.int_wt)
 
