@@ -385,6 +385,19 @@ class MTIP:
         return apply
 
     # -- main_loop + generate_output, 980-1035
+    def output_modifier(self, pair):
+        """assemble_output_modifier, reconstruct.py:721-755 (3-D: identity, or 'shift_center' 728-734): the pair
+        (reciprocal, real) becomes (reciprocal * phases, IFT(FT(real) * phases)) with phases = exp(+i k.c), c the centre
+        of mass of Re(real); the centre is kept as results['neg_center_pos']."""
+        if not self.opt.get('output_density_modifiers', {}).get('shift_to_center', False):
+            return pair
+        recip, real = np.array(pair[0]), np.array(pair[1])
+        ft = self.fp.ft(real)
+        center = P.calc_center(self.fp.rs, self.sht.n_theta, self.fp.grid.real_grid(), real)
+        self.results['neg_center_pos'] = center
+        phases = P.shift_phases(self.fp.grid.reciprocal_grid(), center, opposite_direction=True)
+        return (recip * phases, self.fp.ift(ft * phases))
+
     def phasing_loop(self, rho0=None, rng=None, step_hook=None):
         if rho0 is None:
             rho0 = self.density_guess(rng if rng is not None else np.random.default_rng())
@@ -395,8 +408,8 @@ class MTIP:
         for lid, name in enumerate(self.opt['main_loop']['sub_loops']['order']):
             state, it = self.run_sub_loop(name, lid, state, step_hook)
             iterations.append(it)
-        best = state['best_density_pair']
-        last = state['density_pair_history'][-1]
+        best = self.output_modifier(state['best_density_pair'])
+        last = self.output_modifier(state['density_pair_history'][-1])
         F_last = self.fp.ft(last[1])
         last_deg2 = P.harmonic_coeff_to_deg2_invariants_3d(self.sht.forward_l(P.square_grid(F_last)))
         err = {'main': np.array(self.errors['main']),

@@ -513,4 +513,57 @@ class ShrinkWrap:
         return c >= min_value + self._threshold * (max_value - min_value)
 
 
+# ----------------------------------------------------------------------------- output modifier 'shift_to_center'
+def spherical_to_cartesian(grid):
+    """mathLibrary.py:673-698 (3-D): (r, theta, phi) -> (x, y, z)."""
+    g = np.asarray(grid, dtype=float)
+    r, th, ph = g[..., 0], g[..., 1], g[..., 2]
+    xy = r * np.sin(th)
+    return np.stack((np.cos(ph) * xy, np.sin(ph) * xy, r * np.cos(th)), axis=-1)
+
+
+def cartesian_to_spherical(v):
+    """mathLibrary.py:629-665 (3-D): theta = 0 at r = 0, phi in [0, 2 pi)."""
+    v = np.asarray(v, dtype=float)
+    x, y, z = v[..., 0], v[..., 1], v[..., 2]
+    r = np.sqrt(x * x + y * y + z * z)
+    th = np.zeros(r.shape)
+    nz = r != 0
+    if np.any(nz):
+        th[nz] = np.arccos(z[nz] / r[nz])
+    ph = np.arctan2(y, x)
+    ph = np.where(ph < 0, ph + 2 * np.pi, ph)
+    return np.stack((r, th, ph), axis=-1)
+
+
+def calc_center(rs, n_theta, real_grid, density):
+    """generate_calc_center, misk.py:295-312, with SphericalIntegrator.integrate on vector values
+    (mathLibrary.py:1223-1232): centre of mass of Re(rho), returned in spherical coordinates."""
+    from scipy.special import roots_legendre
+    w = roots_legendre(n_theta)[1]
+    rs = np.asarray(rs)
+
+    def integrate(values):
+        w_shape = (1,) + w.shape + (1,) * (values.ndim - 3)
+        rs_shape = rs.shape + (1,) * (values.ndim - 3)
+        s2 = np.pi / n_theta * np.sum(w.reshape(w_shape) * np.sum(values, axis=2), axis=1)
+        f = s2 * (rs ** 2).reshape(rs_shape)
+        d = np.diff(rs).reshape((-1,) + (1,) * (values.ndim - 3))
+        return np.sum(d * (f[1:] + f[:-1]) / 2.0, axis=0)
+    cart = spherical_to_cartesian(real_grid)
+    total = integrate(density.real)
+    if total == 0:
+        total = 1
+    center = integrate(cart * density[..., None].real) / total
+    return cartesian_to_spherical(center)
+
+
+def shift_phases(reciprocal_grid, vector, opposite_direction=False):
+    """generate_shift_by_operator, fxs_Projections.py:1419-1444 (3-D): exp(-i s k.c), s = -1 for the opposite direction."""
+    pre = -1 if opposite_direction else 1
+    cart = spherical_to_cartesian(reciprocal_grid)
+    c = spherical_to_cartesian(np.asarray(vector, dtype=float))
+    return np.exp(-1.j * pre * np.sum(cart * c, axis=-1))
+
+
 __all__ = [n for n in dir() if not n.startswith('_')] + ['SphericalIntegrator']

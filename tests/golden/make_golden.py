@@ -316,6 +316,18 @@ def main():
     d2 = io._generate_deg2_invariant_diff_3d(qs, rp.deg2_invariants, rp.used_orders, rp.number_of_particles, inv_mask)
     out['G9_deg2_diff'] = d2(None, None, Ilm)
 
+    # ------------------------------------------------------------------ G12: calc_center / negative_shift (output modifier)
+    misk = importlib.import_module(pre + 'misk')
+    rng12 = np.random.default_rng(1212)
+    shape12 = grid_pair.realGrid[:].shape[:-1]
+    dens = (rng12.random(shape12) * np.exp(-((grid_pair.realGrid[..., 0] - 0.3 * rs.max()) / (0.4 * rs.max())) ** 2)
+            * (1 + 0.5 * np.cos(grid_pair.realGrid[..., 2])) + 0.05j * rng12.random(shape12))
+    center = misk.generate_calc_center(grid_pair.realGrid)(dens)
+    out['G12_density'], out['G12_center'] = dens, np.asarray(center)
+    shift_neg = fp_.generate_shift_by_operator(grid_pair.reciprocalGrid, opposite_direction=True)
+    shift_pos = fp_.generate_shift_by_operator(grid_pair.reciprocalGrid)
+    out['G12_phases_neg'] = shift_neg(np.ones(shape12, dtype=complex), center)
+    out['G12_phases_pos'] = shift_pos(np.ones(shape12, dtype=complex), center)
     np.savez_compressed(os.path.join(HERE, 'operators_N16_L4.npz'), **out)
     print('operators fixture:', len(out), 'arrays')
 

@@ -225,6 +225,34 @@ def check_short_trajectory_vs_oracle(g, lib_path, fused, n_hio=3, n_er=2, n_rest
     m.engine.close()
 
 
+def check_shift_to_center_vs_oracle(g, lib_path, n_restarts=2):
+    """output_density_modifiers.shift_to_center (assemble_output_modifier, reconstruct.py:721-755; calc_center
+    misk.py:295-312; shift_by fxs_Projections.py:1419-1444) after a short loop, against the oracle."""
+    N, L = int(g['N']), int(g['L'])
+    data = data_from_golden(g, L)
+    opt = golden_settings(N, L, {'output_density_modifiers': {'shift_to_center': True}})
+    main = opt['main_loop']['sub_loops']['main']
+    main['methods']['HIO']['iterations'] = 3
+    main['methods']['ER']['iterations'] = 2
+    main['iterations'] = 1
+    om = OM.MTIP(opt, data)
+    ref = om.phasing_loop(rho0=g['rho0'])
+    R.MTIP.preinit(opt, data)
+    m = R.MTIP(n_restarts=n_restarts, initial_densities=[g['rho0']] * n_restarts, lib_path=lib_path, fused=True)
+    m.generate_phasing_loop()
+    res = m.phasing_loop()
+    assert np.allclose(m.results['neg_center_pos'], om.results['neg_center_pos'], rtol=1e-7, atol=1e-9)
+    assert om.results['neg_center_pos'][0] > 0          # a real shift
+    plain = OM.MTIP(golden_settings(N, L), data)
+    for b in range(n_restarts):
+        r = res[b]
+        for k in ('real_density', 'last_real_density', 'reciprocal_density', 'last_reciprocal_density',
+                  'last_deg2_invariant'):
+            assert rel_l2(r[k], ref[k]) < 1e-8, k
+    m.engine.close()
+    del plain
+
+
 def check_best_reselection_vs_oracle(g, lib_path, fused, n_restarts=2):
     """End-of-loop reselection of the best pair (reconstruct.py:945-949): loop 'main' ends on HIO steps with a large
     beta, so its last error is above its best one; the best density (found in iteration 3 > 1) is what loop

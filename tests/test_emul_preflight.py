@@ -54,6 +54,10 @@ def test_non_fxs_variants_vs_oracle(emul_lib, golden_mtip16, fused):
     PC.check_non_fxs_trajectory_vs_oracle(golden_mtip16, emul_lib, fused)
 
 
+def test_shift_to_center_vs_oracle(emul_lib, golden_mtip16):
+    PC.check_shift_to_center_vs_oracle(golden_mtip16, emul_lib)
+
+
 def test_best_reselection_vs_oracle(emul_lib, golden_mtip16):
     PC.check_best_reselection_vs_oracle(golden_mtip16, emul_lib, True)
 

@@ -41,6 +41,10 @@ def test_short_trajectory_vs_oracle(golden_mtip16, fused):
     PC.check_short_trajectory_vs_oracle(golden_mtip16, None, fused)
 
 
+def test_shift_to_center_vs_oracle(golden_mtip16):
+    PC.check_shift_to_center_vs_oracle(golden_mtip16, None)
+
+
 def test_best_reselection_vs_oracle(golden_mtip16):
     PC.check_best_reselection_vs_oracle(golden_mtip16, None, True)
 

@@ -214,3 +214,67 @@ def test_density_guess_matches_oracle(emul_lib, golden_mtip16, kind):
     if kind == 'ball':
         assert (got == 0).any() and (got != 0).any()
     m.engine.close()
+
+
+def test_calc_center_and_shift_golden(golden_ops):
+    """calc_center (misk.py:295-312) and the shift operator (fxs_Projections.py:1419-1444): the reference's own centre
+    and phase ramps (fixture G12_*) against the oracle restatement and the host mirror."""
+    from oracle import projections as OP
+    from xframe_amd.fxs import hostsetup as hs
+    g = golden_ops
+    rs, qs, theta, phi = g['G2_rs'], g['G2_qs'], g['G2_theta'], g['G2_phi']
+    dens, want = g['G12_density'], g['G12_center']
+    r3, t3, p3 = np.meshgrid(rs, theta, phi, indexing='ij')
+    c_or = OP.calc_center(rs, len(theta), np.stack((r3, t3, p3), -1), dens)
+    c_hs = hs.calc_center(rs, theta, phi, dens)
+    assert np.allclose(c_or, want, rtol=1e-12) and np.allclose(c_hs, want, rtol=1e-12)
+    q3, t3, p3 = np.meshgrid(qs, theta, phi, indexing='ij')
+    qgrid = np.stack((q3, t3, p3), -1)
+    for name, opp in (('G12_phases_neg', True), ('G12_phases_pos', False)):
+        assert rel_l2(OP.shift_phases(qgrid, want, opp), g[name]) < 1e-13
+        assert rel_l2(hs.shift_phases(qs, theta, phi, want, opp), g[name]) < 1e-13
+
+
+def test_reference_sw_and_shift_sketches_on_registry(emul_lib, golden_mtip16):
+    """The reference's 'SW' sketch (reconstruct.py:598-605) and 'shift_center' output-modifier sketch (728-734) run
+    through RecipeFactory on the registry == the device shrink-wrap / the oracle's output modifier."""
+    from oracle import mtip as OM
+    from xframe_amd.fxs.engine import Engine
+    from xframe_amd.fxs.operators import RecipeFactory, build_operators
+    g = golden_mtip16
+    N, L = int(g['N']), int(g['L'])
+    opt = golden_settings(N, L, {'output_density_modifiers': {'shift_to_center': True}})
+    data = data_from_golden(g, L)
+    e = Engine(opt, data, n_batch=1, lib_path=emul_lib, fused=True)
+    f = RecipeFactory({})
+    ops = build_operators(e)
+    f.addOperators(ops)
+    e.set_density(0, g['rho0'])
+    e.init_state()
+    e.run('HIO', True, [0.45, 0.45])
+    rho, F = e.density(0), e.reciprocal_density(0)
+    sw_sketch = [
+        'copy',
+        ['abs_value', 'copy'],
+        [(0, 1), ['fourier_transform', 'id']],
+        [(0, 1), ['multiply_ft_gaussian', 'id']],
+        [(0, 1), ['inverse_fourier_transform', 'id']],
+        [(0, 1), ['calculate_support_mask']]]
+    ops['set_shrink_wrap'](sigma=20.0, threshold=0.09)
+    support = f.buildProcessFromSketch(sw_sketch).run(np.array(rho))
+    support = support[0] if isinstance(support, (tuple, list)) else support
+    e.shrinkwrap(20.0, 0.09, np.inf)
+    assert (np.asarray(support, bool) != e.support(0)).sum() == 0
+    results = {}
+    shift_center = [
+        [(0, 1, 1), ['copy', 'fourier_transform', 'calc_center']],
+        [(0, 1, 2), [['id', np.array([], dtype=object)], ['id', np.array([], dtype=object)],
+                     ['save_to_dict', np.array([results, 'neg_center_pos', 'replace'], dtype=object)]]],
+        [(0, 2, 1, 2), ['negative_shift', 'negative_shift']],
+        [(0, 1), ['id', 'inverse_fourier_transform']]]
+    out = f.buildProcessFromSketch(shift_center).run(np.array(F), np.array(rho))
+    om = OM.MTIP(opt, data)
+    want = om.output_modifier((F, rho))
+    assert np.allclose(results['neg_center_pos'], om.results['neg_center_pos'], rtol=1e-8)
+    assert rel_l2(out[0], want[0]) < 1e-10 and rel_l2(out[1], want[1]) < 1e-9
+    e.close()

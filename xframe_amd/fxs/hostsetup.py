@@ -314,3 +314,49 @@ def integrator_weights(rs, n_theta):
     t[:-1] += d / 2
     t[1:] += d / 2
     return t * rs ** 2, roots_legendre(n_theta)[1][::-1] * np.pi / n_theta
+
+
+# ----------------------------------------------------------------------------- output modifier 'shift_to_center'
+def spherical_to_cartesian(grid):
+    """mathLibrary.py:673-698, 3-D."""
+    g = np.asarray(grid, dtype=float)
+    xy = g[..., 0] * np.sin(g[..., 1])
+    return np.stack((np.cos(g[..., 2]) * xy, np.sin(g[..., 2]) * xy, g[..., 0] * np.cos(g[..., 1])), axis=-1)
+
+
+def cartesian_to_spherical(v):
+    """mathLibrary.py:629-665, 3-D."""
+    v = np.asarray(v, dtype=float)
+    r = np.sqrt(np.sum(v * v, axis=-1))
+    th = np.zeros(r.shape)
+    nz = r != 0
+    if np.any(nz):
+        th[nz] = np.arccos(v[..., 2][nz] / r[nz])
+    ph = np.arctan2(v[..., 1], v[..., 0])
+    return np.stack((r, th, np.where(ph < 0, ph + 2 * np.pi, ph)), axis=-1)
+
+
+def calc_center(rs, theta, phi, density):
+    """generate_calc_center (misk.py:295-312): centre of mass of Re(rho) with the plain SphericalIntegrator
+    (mathLibrary.py:1223-1232), in spherical coordinates."""
+    wr, wt = integrator_weights(rs, len(theta))
+    d = np.asarray(density).real
+    total = np.einsum('q,t,qtp->', wr, wt, d)
+    if total == 0:
+        total = 1
+    st, ct = np.sin(theta), np.cos(theta)
+    rd = np.asarray(rs)[:, None, None] * d
+    cx = np.einsum('q,t,qtp->', wr, wt * st, rd * np.cos(phi)[None, None, :])
+    cy = np.einsum('q,t,qtp->', wr, wt * st, rd * np.sin(phi)[None, None, :])
+    cz = np.einsum('q,t,qtp->', wr, wt * ct, rd)
+    return cartesian_to_spherical(np.array([cx, cy, cz]) / total)
+
+
+def shift_phases(qs, theta, phi, vector, opposite_direction=False):
+    """generate_shift_by_operator (fxs_Projections.py:1419-1444): exp(-i s k.c) on the (q, theta, phi) grid."""
+    pre = -1 if opposite_direction else 1
+    c = spherical_to_cartesian(np.asarray(vector, dtype=float))
+    st, ct = np.sin(theta)[None, :, None], np.cos(theta)[None, :, None]
+    q = np.asarray(qs)[:, None, None]
+    kc = q * (st * (np.cos(phi)[None, None, :] * c[0] + np.sin(phi)[None, None, :] * c[1]) + ct * c[2])
+    return np.exp(-1.j * pre * kc)

@@ -11,6 +11,8 @@ import inspect
 
 import numpy as np
 
+from . import hostsetup as hs
+
 
 def _id(x):
     return x
@@ -177,6 +179,70 @@ def build_operators(engine):
         r[0] = a[0]
         return r
 
+    # ---- operators of the reference registry that are plain host logic there as well ------------------------------
+    fixed = {'intensity': None}
+    results = {'n_particles': []}
+    sw = {'sigma': e.default_sigma, 'threshold': 0.06}
+
+    def project_to_fixed_intensity(reciprocal_density, square):          # fxs_Projections.py:911-923
+        if fixed['intensity'] is None:
+            raise RuntimeError("project_to_fixed_intensity: set operators['set_fixed_intensity'](I) first")
+        return e.modulus_replacement(reciprocal_density, fixed['intensity'])[0]
+
+    def set_fixed_intensity(intensity):                                  # rp.fixed_intensity setter, reconstruct.py:899-904
+        fixed['intensity'] = np.array(intensity, dtype=complex)
+
+    def save_number_of_particles():                                      # reconstruct.py:380-389
+        results['n_particles'].append(e.rsetup.number_of_particles)
+
+    def multiply_ft_gaussian(data):                                      # fxs_Projections.py:294-298, mathLibrary.py:616-624
+        a = 1.0 / (2.0 * sw['sigma'] ** 2)
+        q2 = np.asarray(e.qs)[:, None, None] ** 2
+        return data * (np.sqrt(np.pi / a) * np.exp(-np.pi ** 2 * q2 * q2 / a))
+
+    def calculate_support_mask(convolution_data):                        # fxs_Projections.py:245-258
+        c = np.array(convolution_data.real)
+        c[c < 0] = 0
+        lo, hi = c.min(), c.max()
+        return c >= lo + sw['threshold'] * (hi - lo)
+
+    def set_shrink_wrap(sigma=None, threshold=None):
+        if sigma is not None:
+            sw['sigma'] = sigma
+        if threshold is not None:
+            sw['threshold'] = threshold
+
+    def calc_center(density):                                            # misk.py:295-312
+        return hs.calc_center(e.rs, e.theta, e.phi, density)
+
+    def negative_shift(reciprocal_density, vector):                      # fxs_Projections.py:1419-1444, opposite direction
+        reciprocal_density *= hs.shift_phases(e.qs, e.theta, e.phi, vector, opposite_direction=True)
+        return reciprocal_density
+
+    def save_to_dict(dictionary, keys, mode, data):                      # misk.py:104-134
+        keys = keys if isinstance(keys, list) else [keys]
+        folder = dictionary
+        for key in keys[:-1]:
+            folder = folder[key]
+        key = keys[-1]
+        if mode == 'append':
+            folder[key] = folder.get(key, []) + [data]
+        elif mode == 'iterative_append':
+            for dkey in data:
+                folder[key][dkey] = folder[key].get(dkey, []) + [data[dkey]]
+        elif mode == 'iterative_overwrite':
+            for dkey in data:
+                folder[key][dkey] = data[dkey]
+        else:
+            folder[key] = data
+        return data
+
+    def load_from_dict(dictionary, keys):                                # misk.py:136-145
+        value = dictionary
+        for key in (keys if isinstance(keys, list) else [keys]):
+            value = value[key]
+        return value
+
     e.hio_beta = e.opt['projections']['real']['HIO']['beta'][0][0]
     return {
         'fourier_transform': fourier_transform, 'inverse_fourier_transform': inverse_fourier_transform,
@@ -188,4 +254,9 @@ def build_operators(engine):
         'real_projection': real_projection, 'real_errors': [real_errors, 2],
         'square_grid': square_grid, 'abs_value': abs_value, 'calc_deg2_invariant': calc_deg2_invariant,
         'copy': copy, 'add_above_zero_index': add_above_zero_index, 'diff': diff,
+        'project_to_fixed_intensity': project_to_fixed_intensity, 'set_fixed_intensity': set_fixed_intensity,
+        'save_number_of_particles': save_number_of_particles, 'multiply_ft_gaussian': multiply_ft_gaussian,
+        'calculate_support_mask': calculate_support_mask, 'set_shrink_wrap': set_shrink_wrap,
+        'calc_center': calc_center, 'negative_shift': negative_shift,
+        'save_to_dict': [save_to_dict, 4], 'load_from_dict': [load_from_dict, 2],
     }

@@ -250,14 +250,29 @@ class MTIP:
         q, t, p = np.meshgrid(e.qs, e.theta, e.phi, indexing='ij')
         reciprocal_grid = np.stack((q, t, p), -1)
         out = np.empty(self.n_restarts, dtype=object)
+        shift = bool(self.opt.get('output_density_modifiers', {}).get('shift_to_center', False))
+        B = self.n_restarts
+        recip = {best: np.stack([e.reciprocal_density(b, best=best) for b in range(B)]) for best in (True, False)}
+        real = {best: np.stack([e.density(b, best=best) for b in range(B)]) for best in (True, False)}
+        last_deg2 = [e.last_deg2_invariant(b) for b in range(B)]
+        if shift:
+            # assemble_output_modifier 'shift_center' (reconstruct.py:728-734), all restarts at once: transforms on the
+            # device, centre of mass and phase ramp on the host as the reference's operators do
+            for best in (True, False):
+                centers = [hs.calc_center(e.rs, e.theta, e.phi, real[best][b]) for b in range(B)]
+                self.results['neg_center_pos'] = centers[-1]
+                phases = np.stack([hs.shift_phases(e.qs, e.theta, e.phi, c, opposite_direction=True) for c in centers])
+                recip[best] = recip[best] * phases
+                real[best] = e.fourier_transform(e.fourier_transform(real[best]) * phases, True)
+            # last_deg2_invariant of the modified last density (reconstruct.py:993)
+            last_deg2 = e.deg2_invariants(e.sht_forward(e.fourier_transform(real[False]), 1))
         for b in range(self.n_restarts):
             err = {'main': real_err[:, b].copy(),
                    'real': {'l2_projection_diff': real_err[:, b].copy()},
                    'reciprocal': ({'deg2_invariant_l2_diff': deg2[:, b].copy()} if deg2 is not None else {})}
             out[b] = {
-                'real_density': e.density(b, best=True), 'last_real_density': e.density(b),
-                'reciprocal_density': e.reciprocal_density(b, best=True),
-                'last_reciprocal_density': e.reciprocal_density(b),
+                'real_density': real[True][b], 'last_real_density': real[False][b],
+                'reciprocal_density': recip[True][b], 'last_reciprocal_density': recip[False][b],
                 'final_error': float(best_err[b]), 'initial_density': initial_density[b],
                 'initial_support': initial_mask, 'error_dict': err,
                 'support_mask': e.support(b, best=True), 'last_support_mask': e.support(b),
@@ -265,7 +280,7 @@ class MTIP:
                 'n_particles': np.full((n_steps, 1), e.rsetup.number_of_particles),
                 'n_particles_gradients': np.array([]), 'n_particles_fraction': np.array([]),
                 'grid_pair': {'real_grid': real_grid, 'reciprocal_grid': reciprocal_grid},
-                'projection_matrices': masked_pm, 'last_deg2_invariant': e.last_deg2_invariant(b)}
+                'projection_matrices': masked_pm, 'last_deg2_invariant': last_deg2[b]}
         return out
 
 
