@@ -54,6 +54,15 @@ def test_non_fxs_variants_vs_oracle(emul_lib, golden_mtip16, fused):
     PC.check_non_fxs_trajectory_vs_oracle(golden_mtip16, emul_lib, fused)
 
 
+@pytest.mark.parametrize('ropt', [{'odd_orders_to_0': False}, {'use_averaged_intensity': False},
+                                  {'odd_orders_to_0': False, 'use_averaged_intensity': False},
+                                  {'used_order_ids': np.arange(3)}])
+def test_reciprocal_option_variants_vs_oracle(emul_lib, golden_mtip16, ropt):
+    """modify_projection_matrices switches (fxs_Projections.py:679-714): odd orders kept (all L+1 polar factors, some of
+    zero matrices), V_0 taken from the data, a subset of the orders (the others pass through unprojected)."""
+    PC.check_short_trajectory_vs_oracle(golden_mtip16, emul_lib, True, reciprocal_opt=ropt)
+
+
 def test_shift_to_center_vs_oracle(emul_lib, golden_mtip16):
     PC.check_shift_to_center_vs_oracle(golden_mtip16, emul_lib)
 

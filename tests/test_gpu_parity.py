@@ -41,6 +41,11 @@ def test_short_trajectory_vs_oracle(golden_mtip16, fused):
     PC.check_short_trajectory_vs_oracle(golden_mtip16, None, fused)
 
 
+@pytest.mark.parametrize('ropt', [{'odd_orders_to_0': False}, {'odd_orders_to_0': False, 'use_averaged_intensity': False}])
+def test_reciprocal_option_variants_vs_oracle(golden_mtip16, ropt):
+    PC.check_short_trajectory_vs_oracle(golden_mtip16, None, True, reciprocal_opt=ropt)
+
+
 def test_shift_to_center_vs_oracle(golden_mtip16):
     PC.check_shift_to_center_vs_oracle(golden_mtip16, None)
 

@@ -250,6 +250,8 @@ class MTIP:
         q, t, p = np.meshgrid(e.qs, e.theta, e.phi, indexing='ij')
         reciprocal_grid = np.stack((q, t, p), -1)
         out = np.empty(self.n_restarts, dtype=object)
+        # the reference's metric has one entry per used order (fxs_IO_methods.py:413, 425-427)
+        order_array = np.array(tuple(e.rsetup.used_orders.values()), dtype=int)
         shift = bool(self.opt.get('output_density_modifiers', {}).get('shift_to_center', False))
         B = self.n_restarts
         recip = {best: np.stack([e.reciprocal_density(b, best=best) for b in range(B)]) for best in (True, False)}
@@ -269,7 +271,7 @@ class MTIP:
         for b in range(self.n_restarts):
             err = {'main': real_err[:, b].copy(),
                    'real': {'l2_projection_diff': real_err[:, b].copy()},
-                   'reciprocal': ({'deg2_invariant_l2_diff': deg2[:, b].copy()} if deg2 is not None else {})}
+                   'reciprocal': ({'deg2_invariant_l2_diff': deg2[:, b][:, order_array].copy()} if deg2 is not None else {})}
             out[b] = {
                 'real_density': real[True][b], 'last_real_density': real[False][b],
                 'reciprocal_density': recip[True][b], 'last_reciprocal_density': recip[False][b],
