@@ -233,6 +233,47 @@ def check_short_trajectory_vs_oracle(g, lib_path, fused, n_hio=3, n_er=2, n_rest
     m.engine.close()
 
 
+SETTINGS_VARIANTS = {
+    'limit_imag': {'projections': {'real': {'projections': {
+        'apply': ['support', 'value_threshold', 'limit_imag'], 'limit_imag': {'threshold': 1e-3}}}}},
+    'value_lo_hi': {'projections': {'real': {'projections': {
+        'apply': ['support', 'value_threshold'], 'value_threshold': {'threshold': [0.01, 0.2]}}}}},
+    'value_hi_only': {'projections': {'real': {'projections': {
+        'apply': ['support', 'value_threshold'], 'value_threshold': {'threshold': [False, 0.15]}}}}},
+    'support_only': {'projections': {'real': {'projections': {'apply': ['support']}}}},
+    'no_enforce': {'projections': {'real': {'projections': {'support': {
+        'enforce_initial_support': {'apply': False, 'if_error_bigger_than': 6e-3}}}}}},
+    'hio_considers_support_only': {'projections': {'real': {'HIO': {'considered_projections': ['support']}}}},
+    'trapz': {'fourier_transform': {'type': 'trapz'}},
+    'pi_in_q': {'fourier_transform': {'pi_in_q': True}},
+    'history5': {'main_loop': {'history_length': 5}},
+}
+
+
+def check_settings_variant_vs_oracle(g, lib_path, name, fused=True):
+    """Settings switches of the real-space projection (fxs_Projections.py:72-130, pythonLibrary.py:1289-1320), of HIO's
+    considered projections (fxs_IO_methods.py:40-64), of the radial rule / reciprocity coefficient (misk.py:387-394)
+    and the history length: 2 x (3 HIO, SW, 2 ER) against the oracle."""
+    N, L = int(g['N']), int(g['L'])
+    data = data_from_golden(g, L)
+    opt = golden_settings(N, L, SETTINGS_VARIANTS[name])
+    main = opt['main_loop']['sub_loops']['main']
+    main['methods']['HIO']['iterations'] = 3
+    main['methods']['ER']['iterations'] = 2
+    main['iterations'] = 2
+    ref = OM.MTIP(opt, data).phasing_loop(rho0=g['rho0'])
+    R.MTIP.preinit(opt, data)
+    m = R.MTIP(n_restarts=1, initial_densities=[g['rho0']], lib_path=lib_path, fused=fused)
+    m.generate_phasing_loop()
+    r = m.phasing_loop()[0]
+    assert np.allclose(r['error_dict']['main'], ref['error_dict']['main'], rtol=1e-8)
+    for k in ('real_density', 'last_real_density', 'reciprocal_density', 'last_reciprocal_density'):
+        assert rel_l2(r[k], ref[k]) < 1e-8, k
+    assert (r['support_mask'] != ref['support_mask']).sum() == 0
+    assert (r['last_support_mask'] != ref['last_support_mask']).sum() == 0
+    m.engine.close()
+
+
 def check_shift_to_center_vs_oracle(g, lib_path, n_restarts=2):
     """output_density_modifiers.shift_to_center (assemble_output_modifier, reconstruct.py:721-755; calc_center
     misk.py:295-312; shift_by fxs_Projections.py:1419-1444) after a short loop, against the oracle."""

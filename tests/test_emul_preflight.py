@@ -63,6 +63,11 @@ def test_reciprocal_option_variants_vs_oracle(emul_lib, golden_mtip16, ropt):
     PC.check_short_trajectory_vs_oracle(golden_mtip16, emul_lib, True, reciprocal_opt=ropt)
 
 
+@pytest.mark.parametrize('name', sorted(PC.SETTINGS_VARIANTS))
+def test_settings_variants_vs_oracle(emul_lib, golden_mtip16, name):
+    PC.check_settings_variant_vs_oracle(golden_mtip16, emul_lib, name)
+
+
 def test_shift_to_center_vs_oracle(emul_lib, golden_mtip16):
     PC.check_shift_to_center_vs_oracle(golden_mtip16, emul_lib)
 

@@ -46,6 +46,11 @@ def test_reciprocal_option_variants_vs_oracle(golden_mtip16, ropt):
     PC.check_short_trajectory_vs_oracle(golden_mtip16, None, True, reciprocal_opt=ropt)
 
 
+@pytest.mark.parametrize('name', ['limit_imag', 'value_lo_hi', 'value_hi_only', 'hio_considers_support_only', 'trapz', 'pi_in_q'])
+def test_settings_variants_vs_oracle(golden_mtip16, name):
+    PC.check_settings_variant_vs_oracle(golden_mtip16, None, name)
+
+
 def test_shift_to_center_vs_oracle(golden_mtip16):
     PC.check_shift_to_center_vs_oracle(golden_mtip16, None)
 
