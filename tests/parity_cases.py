@@ -233,6 +233,33 @@ def check_short_trajectory_vs_oracle(g, lib_path, fused, n_hio=3, n_er=2, n_rest
     m.engine.close()
 
 
+def check_split_shell_steps_vs_oracle(lib_path, N=6, L=44, fused=True):
+    """Angular size of config 5 (128 x 256, L > 40) with few shells: the inverse SHT shares a shell between two
+    workgroups there (two error partial sums per shell in the fused real-space epilogue).  2 HIO + SW + 1 ER against
+    the oracle from a seeded bump guess."""
+    fpd = FourierPair(SHT(L), N, S.data_cutoff(N), 2.0)
+    data, _ = S.make_invariants(OracleTransforms(fpd), N, L)
+    opt = golden_settings(N, L)
+    main = opt['main_loop']['sub_loops']['main']
+    main['methods']['HIO']['iterations'] = 2
+    main['methods']['ER']['iterations'] = 1
+    main['iterations'] = 1
+    om = OM.MTIP(opt, data)
+    rho0 = om.density_guess(np.random.default_rng(3))
+    ref = om.phasing_loop(rho0=rho0)
+    R.MTIP.preinit(opt, data)
+    m = R.MTIP(n_restarts=2, initial_densities=[rho0] * 2, lib_path=lib_path, fused=fused)
+    m.generate_phasing_loop()
+    res = m.phasing_loop()
+    for b in range(2):
+        r = res[b]
+        assert np.allclose(r['error_dict']['main'], ref['error_dict']['main'], rtol=1e-8)
+        for k in ('real_density', 'last_real_density', 'reciprocal_density', 'last_reciprocal_density'):
+            assert rel_l2(r[k], ref[k]) < 1e-9, k
+        assert (r['last_support_mask'] != ref['last_support_mask']).sum() == 0
+    m.engine.close()
+
+
 SETTINGS_VARIANTS = {
     'limit_imag': {'projections': {'real': {'projections': {
         'apply': ['support', 'value_threshold', 'limit_imag'], 'limit_imag': {'threshold': 1e-3}}}}},

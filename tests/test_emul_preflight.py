@@ -68,6 +68,10 @@ def test_settings_variants_vs_oracle(emul_lib, golden_mtip16, name):
     PC.check_settings_variant_vs_oracle(golden_mtip16, emul_lib, name)
 
 
+def test_split_shell_steps_vs_oracle(emul_lib):
+    PC.check_split_shell_steps_vs_oracle(emul_lib)
+
+
 def test_shift_to_center_vs_oracle(emul_lib, golden_mtip16):
     PC.check_shift_to_center_vs_oracle(golden_mtip16, emul_lib)
 

@@ -51,6 +51,11 @@ def test_settings_variants_vs_oracle(golden_mtip16, name):
     PC.check_settings_variant_vs_oracle(golden_mtip16, None, name)
 
 
+@pytest.mark.parametrize('fused', [False, True])
+def test_split_shell_steps_vs_oracle(fused):
+    PC.check_split_shell_steps_vs_oracle(None, N=12, L=48, fused=fused)
+
+
 def test_shift_to_center_vs_oracle(golden_mtip16):
     PC.check_shift_to_center_vs_oracle(golden_mtip16, None)
 

@@ -333,24 +333,29 @@ __global__ void __launch_bounds__(SW_THREADS) k_sht_inv_wide(const double2* __re
                                                              int RP, int Nq, const double2* __restrict__ Fin,
                                                              const double* __restrict__ shell_scale,
                                                              const int* __restrict__ slot, int which, int B,
-                                                             const double2* __restrict__ coeff_sub, RealEpi re) {
+                                                             const double2* __restrict__ coeff_sub, RealEpi re, int nsplit) {
     constexpr int N = R1 * R2;
     constexpr int AS = R2 + 1;
     HIP_DYNAMIC_SHARED(double2, sm)
     const int nm = 2 * L + 1;
     const int nlm = (L + 1) * (L + 1);
-    double2* twN = sm;                              // N
-    double2* Gs = twN + N;                          // nt * nm        spectra: row 2j = theta_j, 2j+1 = its mirror
-    double2* ABs = Gs + (size_t)nt * nm;            // npairs         recurrence coefficients
+    // nsplit > 1: a shell is shared by nsplit workgroups, each with nt / nsplit rows (theta_j and its mirror for a
+    // contiguous range of j); the twiddles then stay in global memory to make room (256 x L48: 157 KB)
+    const int ntl = nt / nsplit;                    // rows of this workgroup
+    const double2* twN = nsplit > 1 ? twN_g : sm;   // N
+    double2* Gs = sm + (nsplit > 1 ? 0 : N);        // ntl * nm       spectra: row 2j = theta_(j0+j), 2j+1 = its mirror
+    double2* ABs = Gs + (size_t)ntl * nm;           // npairs         recurrence coefficients
     double2* cl = ABs + npairs;                     // nlm            (Legendre phase)
     double2* Bm = cl;                               // RP * R1 * AS   transpose buffer (FFT passes; reuses cl)
     const int tid = threadIdx.x;
-    const long long shell = blockIdx.x;
+    const long long shell = blockIdx.x / nsplit;
+    const int split = (int)(blockIdx.x - shell * nsplit);
     const int q = (int)(shell % Nq);
     const double2* csrc = coeff + (size_t)shell * nlm;
     // Legendre work items (m, chunk of 32 thetas), dealt to the waves in snake order of decreasing length
     const int wave = tid >> 6, lane = tid & 63, nw = blockDim.x >> 6;
-    const int nth = nt >> 1;
+    const int nth = ntl >> 1;                       // theta pairs of this workgroup, first one j0
+    const int j0 = split * nth;
     const int jj = lane & 31, sgn = lane >> 5;
     const int n_chunks = (nth + 31) >> 5;
     const int n_items = (L + 1) * n_chunks;
@@ -361,13 +366,14 @@ __global__ void __launch_bounds__(SW_THREADS) k_sht_inv_wide(const double2* __re
         if (i < n_items) {
             const int m = i / n_chunks, ch = i - m * n_chunks;
             const int j = ch * 32 + jj;
-            const int jc = j < nth ? j : nth - 1;
+            const int jc = j0 + (j < nth ? j : nth - 1);
             const double* pcol = P + (size_t)poff[m] * nt + jc;
             pmm_n = pcol[0];
             pm1_n = m < L ? pcol[nt] : 0.0;
         }
     }
-    for (int e = tid; e < N; e += blockDim.x) twN[e] = twN_g[e];
+    if (nsplit == 1)
+        for (int e = tid; e < N; e += blockDim.x) sm[e] = twN_g[e];
     for (int e = tid; e < npairs; e += blockDim.x) ABs[e] = AB[e];
     if (coeff_sub != nullptr && q > 0) {                    // ft_stab: IFT(F') - IFT(F) on shells > 0 (misk.py:326-329)
         const double2* ssrc = coeff_sub + (size_t)shell * nlm;
@@ -401,7 +407,7 @@ __global__ void __launch_bounds__(SW_THREADS) k_sht_inv_wide(const double2* __re
         const int m = i / n_chunks, ch = i - m * n_chunks;
         const int j = ch * 32 + jj;
         const bool act = (j < nth) && !(sgn == 1 && m == 0);
-        const int jc = j < nth ? j : nth - 1;
+        const int jc = j0 + (j < nth ? j : nth - 1);
         const double x = cost[jc];
         double p2 = pmm_n, p1 = pm1_n;
         {   // prefetch the start values of this wave's next item
@@ -409,7 +415,7 @@ __global__ void __launch_bounds__(SW_THREADS) k_sht_inv_wide(const double2* __re
             if (i2 < n_items) {
                 const int m2 = i2 / n_chunks, ch2 = i2 - m2 * n_chunks;
                 const int j2 = ch2 * 32 + jj;
-                const int jc2 = j2 < nth ? j2 : nth - 1;
+                const int jc2 = j0 + (j2 < nth ? j2 : nth - 1);
                 const double* pcol = P + (size_t)poff[m2] * nt + jc2;
                 pmm_n = pcol[0];
                 pm1_n = m2 < L ? pcol[nt] : 0.0;
@@ -452,7 +458,7 @@ __global__ void __launch_bounds__(SW_THREADS) k_sht_inv_wide(const double2* __re
         }
     }
     __syncthreads();
-    const int n_pass = nt / RP;
+    const int n_pass = ntl / RP;
     for (int pass = 0; pass < n_pass; ++pass) {
         // epilogue operands of this thread's step-2 outputs: requested now, they arrive behind step 1
         double2 pre[(EPI == EPI_MODULUS || EPI == EPI_REAL_UPDATE) ? R1 : 1];
@@ -460,7 +466,7 @@ __global__ void __launch_bounds__(SW_THREADS) k_sht_inv_wide(const double2* __re
         if ((EPI == EPI_MODULUS || EPI == EPI_REAL_UPDATE) && tid < RP * R2) {
             const int r = tid / R2, n2 = tid - r * R2;
             const int rr = pass * RP + r;
-            const int th = rr >> 1;
+            const int th = j0 + (rr >> 1);
             const int row = (rr & 1) ? (nt - 1 - th) : th;
 #pragma unroll
             for (int n1 = 0; n1 < R1; ++n1) {
@@ -505,7 +511,7 @@ __global__ void __launch_bounds__(SW_THREADS) k_sht_inv_wide(const double2* __re
             for (int k1 = 0; k1 < R1; ++k1) vv[k1] = br[k1 * AS];
             SmallFFT<R1, true>::run(vv);
             const int rr = pass * RP + r;
-            const int th = rr >> 1;
+            const int th = j0 + (rr >> 1);
             const int row = (rr & 1) ? (nt - 1 - th) : th;
 #pragma unroll
             for (int n1 = 0; n1 < R1; ++n1) {
@@ -555,8 +561,8 @@ __global__ void __launch_bounds__(SW_THREADS) k_sht_inv_wide(const double2* __re
                 sn += red[2 * wv];
                 sd += red[2 * wv + 1];
             }
-            re.partial[(size_t)shell * 2] = sn;
-            re.partial[(size_t)shell * 2 + 1] = sd;
+            re.partial[((size_t)shell * nsplit + split) * 2] = sn;
+            re.partial[((size_t)shell * nsplit + split) * 2 + 1] = sd;
         }
     }
 }
@@ -626,22 +632,46 @@ void launch_sht_forward_reg(mtip_ctx* c, const double2* grid, double2* coeff, in
     else launch_fwd_p<MTIP_PRE_NONE>(c, grid, coeff, in_slot);
 }
 
-static size_t wide_lds(const mtip_ctx* c, int r1, int r2, int* rp_out) {
-    const int rp = largest_even_divisor_le(c->nt, std::min(SW_THREADS / r2, SW_THREADS / r1));
+// LDS of the wide inverse kernel for `nsplit` workgroups per shell (see the kernel); *rp_out = rows per FFT pass
+static size_t wide_lds_n(const mtip_ctx* c, int r1, int r2, int nsplit, int* rp_out) {
+    if (c->nt % (2 * nsplit) != 0) return (size_t)1 << 40;
+    const int ntl = c->nt / nsplit;
+    if (nsplit > 1 && (ntl / 2) % 32 != 0) return (size_t)1 << 40;      // whole 32-theta chunks per workgroup
+    const size_t fixed = (nsplit > 1 ? 0 : (size_t)c->np) + (size_t)ntl * c->nm + c->npairs;
+    int rp = largest_even_divisor_le(ntl, std::min(SW_THREADS / r2, SW_THREADS / r1));
+    // the transpose buffer aliases the coefficient block: shrink the pass until both fit
+    while (rp >= 2 && (fixed + std::max((size_t)c->nlm, (size_t)rp * r1 * (r2 + 1))) * sizeof(double2) > 158 * 1024)
+        rp = largest_even_divisor_le(ntl, rp - 2);
     if (rp_out) *rp_out = rp;
     if (rp < 2) return (size_t)1 << 40;
-    return ((size_t)c->np + (size_t)c->nt * c->nm + c->npairs + std::max((size_t)c->nlm, (size_t)rp * r1 * (r2 + 1))) * sizeof(double2);
+    return (fixed + std::max((size_t)c->nlm, (size_t)rp * r1 * (r2 + 1))) * sizeof(double2);
+}
+
+// smallest split (1, 2) whose working set fits one CU's LDS
+static size_t wide_lds(const mtip_ctx* c, int r1, int r2, int* rp_out, int* nsplit_out = nullptr) {
+    for (int ns = 1; ns <= 2; ++ns) {
+        int rp = 0;
+        const size_t lds = wide_lds_n(c, r1, r2, ns, &rp);
+        if (lds <= 158 * 1024) {
+            if (rp_out) *rp_out = rp;
+            if (nsplit_out) *nsplit_out = ns;
+            return lds;
+        }
+    }
+    if (rp_out) *rp_out = 0;
+    if (nsplit_out) *nsplit_out = 1;
+    return (size_t)1 << 40;
 }
 
 template <int EPI, int R1, int R2>
 static void launch_inv_r(mtip_ctx* c, const double2* coeff, double2* grid, const InvEpilogue& epi) {
-    int rpw = 0;
-    const size_t lds_w = wide_lds(c, R1, R2, &rpw);
+    int rpw = 0, nsplit = 1;
+    const size_t lds_w = wide_lds(c, R1, R2, &rpw, &nsplit);
     if (c->sht_wide && c->d_AB != nullptr && lds_w <= 158 * 1024) {
         const int* slw = (epi.out_slot >= 0 || EPI == EPI_REAL_UPDATE) ? c->d_slot : nullptr;
-        hipLaunchKernelGGL((k_sht_inv_wide<EPI, R1, R2>), dim3((unsigned)(c->B * c->N)), dim3(SW_THREADS), lds_w, c->stream,
+        hipLaunchKernelGGL((k_sht_inv_wide<EPI, R1, R2>), dim3((unsigned)(c->B * c->N * nsplit)), dim3(SW_THREADS), lds_w, c->stream,
                            coeff, grid, (const double*)c->d_P, (const int*)c->d_poff, (const double2*)c->d_AB,
-                           (const double*)c->d_cost, c->npairs, (const double2*)c->d_twN, c->nt, c->L, rpw, c->N, epi.F, epi.shell_scale, slw, epi.out_slot, c->B, epi.coeff_sub, epi.real);
+                           (const double*)c->d_cost, c->npairs, (const double2*)c->d_twN, c->nt, c->L, rpw, c->N, epi.F, epi.shell_scale, slw, epi.out_slot, c->B, epi.coeff_sub, epi.real, nsplit);
         return;
     }
     const int RP = largest_even_divisor_le(c->nt, std::min(SR_THREADS / R2, SR_THREADS / R1));
@@ -671,6 +701,14 @@ void launch_sht_inverse_reg(mtip_ctx* c, const double2* coeff, double2* grid, co
         case EPI_REAL_UPDATE: launch_inv_p<EPI_REAL_UPDATE>(c, coeff, grid, epi); break;
         default: launch_inv_p<EPI_STORE>(c, coeff, grid, epi); break;
     }
+}
+
+// error partial sums the fused real-space epilogue writes per restart (one per workgroup)
+int sht_inverse_real_update_blocks(const mtip_ctx* c) {
+    int r1, r2, ns = 1;
+    if (!reg_radices(c->np, &r1, &r2)) return c->N;
+    wide_lds(c, r1, r2, nullptr, &ns);
+    return c->N * ns;
 }
 
 // the fused real-space epilogue and the on-load coefficient difference exist in the wide inverse kernel only

@@ -193,7 +193,7 @@ mtip_ctx* mtip_create(const mtip_cfg* cfg, int device) {
     A(dev_alloc(c, &c->d_Vr, (size_t)B * c->utot));
     A(dev_alloc(c, &c->d_U, (size_t)B * c->xtot));
     c->n_partial_blocks = div_up((long long)c->G, 256 * 4);
-    A(dev_alloc(c, &c->d_partial, (size_t)B * std::max(c->n_partial_blocks, N) * 2));
+    A(dev_alloc(c, &c->d_partial, (size_t)B * std::max(c->n_partial_blocks, 2 * N) * 2));
     A(dev_alloc(c, &c->d_minmax, (size_t)B * c->n_partial_blocks * 2));
     if (rc != MTIP_OK) {
         g_create_error = c->err.empty() ? "allocation failed" : c->err;
@@ -498,7 +498,7 @@ static void enqueue_step(mtip_ctx* c, int method, int ft_stab, double beta) {
             ru.real.add_prev = 1;
             ru.real.beta = beta;
             launch_sht_inverse(c, cc[5], nullptr, ru);
-            launch_finish_step(c, c->n_steps_done, c->N);
+            launch_finish_step(c, c->n_steps_done, sht_inverse_real_update_blocks(c));
             c->n_steps_done += 1;
             return;
         }

@@ -226,6 +226,7 @@ void launch_sht_forward_fused(mtip_ctx* c, const double2* grid, double2* coeff, 
 void launch_sht_inverse_fused(mtip_ctx* c, const double2* coeff, double2* grid, const InvEpilogue& epi);
 bool sht_reg_supported(const mtip_ctx* c);
 bool sht_inverse_fuses_real_update(const mtip_ctx* c);    // EPI_REAL_UPDATE / coeff_sub available (wide inverse kernel)
+int sht_inverse_real_update_blocks(const mtip_ctx* c);   // error partial sums per restart written by that epilogue
 void launch_sht_forward_reg(mtip_ctx* c, const double2* grid, double2* coeff, int prologue, int in_slot);
 void launch_sht_inverse_reg(mtip_ctx* c, const double2* coeff, double2* grid, const InvEpilogue& epi);
 // Hankel
