@@ -66,6 +66,10 @@ struct SmallFFT<1, INV> {
     static __device__ __forceinline__ void run(double2 (&)[1]) {}
 };
 
+// (l, m) pairs per thread from which the table loads of eight theta pairs are requested together: with few rows per
+// pass and many pairs per thread (n_phi = 256) every single load was a full L2 round trip (357 -> 260 us at 256 x L48);
+// at n_phi = 128 (3 pairs per thread) the extra registers cost more than they save (54 -> 59 us)
+#define FWD_BATCH_MIN 5
 // ------------------------------------------------------------------------------------------------------
 template <int PRE, int R1, int R2, int MAXI>
 __global__ void __launch_bounds__(SR_THREADS) k_sht_fwd_reg(const double2* __restrict__ grid, double2* __restrict__ coeff,
@@ -166,6 +170,27 @@ __global__ void __launch_bounds__(SR_THREADS) k_sht_fwd_reg(const double2* __res
                 const double2* src = G + (size_t)((l + m) & 1) * nm + L;
                 const double* pt = PT + (size_t)(pass * half) * npairs + idx;
                 double2 ap = accp[u], am = accm[u];
+                if (MAXI >= FWD_BATCH_MIN) {
+                    // large grids (few rows per pass, many (l, m) per thread): the table values of eight theta pairs
+                    // are requested together, otherwise every one of them costs a full L2 round trip
+                    for (int jb = 0; jb < half; jb += 8) {
+                        double pv[8];
+#pragma unroll
+                        for (int jj = 0; jj < 8; ++jj) pv[jj] = pt[(size_t)min(jb + jj, half - 1) * npairs];
+#pragma unroll
+                        for (int jj = 0; jj < 8; ++jj) {
+                            const int j = jb + jj;
+                            if (j < half) {
+                                const double2 vp = src[(size_t)(2 * j) * nm + m];
+                                const double2 vm = src[(size_t)(2 * j) * nm - m];
+                                ap.x = fma(pv[jj], vp.x, ap.x);
+                                ap.y = fma(pv[jj], vp.y, ap.y);
+                                am.x = fma(pv[jj], vm.x, am.x);
+                                am.y = fma(pv[jj], vm.y, am.y);
+                            }
+                        }
+                    }
+                } else
                 for (int j = 0; j < half; ++j) {
                     const double p = pt[(size_t)j * npairs];
                     const double2 vp = src[(size_t)(2 * j) * nm + m];
