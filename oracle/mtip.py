@@ -246,7 +246,7 @@ class MTIP:
         except IndexError:
             return -1
 
-    # -- generate_density_guess_method, reconstruct.py:1115-1174 ('bump' and 'ball')
+    # -- generate_density_guess_method, reconstruct.py:1115-1210
     def density_guess(self, rng):
         dg = self.opt['density_guess']
         radius = dg['radius']
@@ -254,6 +254,19 @@ class MTIP:
             radius = self.opt['particle_radius']
         if radius < 0:
             radius = np.max(self.fp.rs)
+        if dg['type'] == 'low_resolution_autocorrelation':
+            # 1175-1205: IFT of the inverse harmonic transform of the (modified) projection matrices, negative values cut,
+            # times the random amplitude and a bump of slope 0.1 over the particle radius
+            pr = [np.array(p) for p in self.rp.projection_matrices]
+            ac = self.fp.ift(self.sht.inverse_l(pr)).real
+            ac[ac < 0] = 0
+            amp = (1 + 1 / dg['random']['SNR'] * rng.random(self.shape)).astype(complex)
+            density = ac * amp
+            density[density < 0] = 0
+            pr_radius = self.opt['particle_radius']
+            density = density * P.get_test_function([-pr_radius, pr_radius], 0.1)(np.array(self.real_r))
+            total_sq = self.integrator.integrate((density * density.conj()).real)
+            return density * np.sqrt(self.rp.integrated_intensity / total_sq)
         if dg['type'] == 'ball':
             # 1136-1153 with get_disk_function / get_shape_function (mathLibrary.py:124-167): amplitude inside r < radius
             r = np.array(self.real_r)

@@ -193,7 +193,7 @@ def test_radial_mask_types_golden(golden_ops, name):
     assert (hs.ReciprocalSetup(qs, data, L, opt).radial_mask == want).all()
 
 
-@pytest.mark.parametrize('kind', ['bump', 'ball'])
+@pytest.mark.parametrize('kind', ['bump', 'ball', 'low_resolution_autocorrelation'])
 def test_density_guess_matches_oracle(emul_lib, golden_mtip16, kind):
     """generate_density_guess_method (reconstruct.py:1115-1174): the worker's seeded guess against the oracle's for
     the same generator state, and the normalisation int |rho|^2 = integrated intensity."""
@@ -209,7 +209,7 @@ def test_density_guess_matches_oracle(emul_lib, golden_mtip16, kind):
     m = R.MTIP(n_restarts=1, seeds=[77], lib_path=emul_lib)
     m.generate_phasing_loop()
     got = m._initial_density(0)
-    assert rel_l2(got, want) < 1e-13
+    assert rel_l2(got, want) < (1e-9 if kind == 'low_resolution_autocorrelation' else 1e-13)
     assert np.isclose(om.integrator.integrate((want * want.conj()).real), om.rp.integrated_intensity, rtol=1e-12)
     if kind == 'ball':
         assert (got == 0).any() and (got != 0).any()

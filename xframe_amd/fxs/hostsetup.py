@@ -306,6 +306,21 @@ def ball_density(rs, shape, radius, snr, rng, integrated_intensity, wr_plain, wt
     return (density * np.sqrt(integrated_intensity / total_sq)).astype(complex)
 
 
+def autocorrelation_density(autocorrelation, rs, shape, particle_radius, snr, rng, integrated_intensity, wr_plain, wt):
+    """reconstruct.py:1186-1203: low-resolution autocorrelation (already transformed) -> guess."""
+    ac = np.array(autocorrelation, dtype=float)
+    ac[ac < 0] = 0
+    density = ac * (1 + 1 / snr * rng.random(shape))
+    density[density < 0] = 0
+    r = np.broadcast_to(np.asarray(rs)[:, None, None], shape)
+    inside = (r > -particle_radius) & (r < particle_radius)
+    env = np.zeros(shape)
+    env[inside] = np.exp(-0.1 * particle_radius ** 2 / (particle_radius ** 2 - r[inside] ** 2))
+    density = density * env
+    total_sq = np.einsum('q,t,qtp->', wr_plain, wt, density * density)
+    return (density * np.sqrt(integrated_intensity / total_sq)).astype(complex)
+
+
 def integrator_weights(rs, n_theta):
     """plain SphericalIntegrator weights: int f = sum wr[q] wt[t] sum_phi f."""
     rs = np.asarray(rs, dtype=float)

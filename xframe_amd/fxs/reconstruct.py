@@ -110,8 +110,8 @@ class MTIP:
         if self.initial_densities is not None:
             return np.asarray(self.initial_densities[i], dtype=complex)
         dg = self.opt['density_guess']
-        if dg['type'] not in ('bump', 'ball'):
-            raise NotImplementedError(f"density_guess.type {dg['type']!r}")
+        if dg['type'] not in ('bump', 'ball', 'low_resolution_autocorrelation'):
+            raise AssertionError('density type "{}" is not known.'.format(dg['type']))     # reconstruct.py:1206-1209
         seed = None if self.seeds is None else self.seeds[i]
         rng = np.random.default_rng(seed)       # seed None = OS entropy, like the reference's os.urandom seeding
         e = self.engine
@@ -120,6 +120,14 @@ class MTIP:
             radius = self.opt['particle_radius']
         if radius < 0:
             radius = np.max(e.rs)
+        if dg['type'] == 'low_resolution_autocorrelation':
+            # reconstruct.py:1175-1205: transforms on the device, the rest on the host as in the reference
+            coeff = np.zeros((e.N, e.nlm), complex)
+            for l, pm in e.rsetup.projection_matrices.items():
+                coeff[:, l * l:l * l + pm.shape[1]] = pm
+            ac = e.fourier_transform(e.sht_inverse(coeff)[0], True)[0].real
+            return hs.autocorrelation_density(ac, e.rs, e.shape, self.opt['particle_radius'], dg['random']['SNR'], rng,
+                                              e.rsetup.integrated_intensity, e.int_wr, e.int_wt)
         if dg['type'] == 'ball':
             return hs.ball_density(e.rs, e.shape, radius, dg['random']['SNR'], rng, e.rsetup.integrated_intensity,
                                    e.int_wr, e.int_wt)
