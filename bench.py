@@ -34,7 +34,7 @@ sys.path.insert(0, ROOT)
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument('--gpus', type=int, default=1)
-    p.add_argument('--steps', type=int, default=200)
+    p.add_argument('--steps', type=int, default=600, help='timed steps; 600 = one pass of the tutorial schedule (SURVEY 8d, configs 3/4)')
     p.add_argument('--warmup', type=int, default=20)
     p.add_argument('--restarts-per-gpu', type=int, default=8)
     p.add_argument('--streams', type=int, default=3, help='engines (HIP streams) the restarts of a rank are split over')

@@ -619,6 +619,8 @@ int mtip_init_state(mtip_ctx* c) {
     MTIP_HIP_CHECK(c, hipMemcpy(c->d_last_err, inf.data(), c->B * sizeof(double), hipMemcpyHostToDevice));
     c->n_steps_done = 0;
     c->fixed_valid = false;
+    c->vr_valid = false;                 // a fresh reconstruction does not warm-start its polar factors
+    c->proj_calls = 0;
     c->state_ready = true;
     return post_launch(c, "mtip_init_state");
 }
