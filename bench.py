@@ -249,7 +249,7 @@ def main():
 
     # ---- CPU baseline: the oracle (numpy restatement of the reference algorithm), 1 thread, bounded sample
     cpu = None
-    if rank == 0 and not a.no_cpu_baseline:
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:       # reported at N = 1 only (bounded sample, ~20 s of host time)
         limiter = None
         try:
             import threadpoolctl
