@@ -1,0 +1,84 @@
+"""Feasibility study for the next round (CPU only): polar factor of the real X_l = PD_l I_l matrices of a running
+reconstruction (oracle, 128 x L32) by QDWH (Nakatsukasa-Bai-Gygi, QR-based, inverse free) against LAPACK's SVD-based
+u @ vh, compared the way the parity tests compare it: through V_l U_l."""
+import os
+import sys
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
+np.seterr(all='ignore')
+from helpers import OracleTransforms                                   # noqa: E402
+from oracle import mtip as OM                                          # noqa: E402
+from oracle.fourier import FourierPair                                 # noqa: E402
+from oracle.sht import SHT                                             # noqa: E402
+from xframe_amd.fxs import synthetic as S                              # noqa: E402
+
+cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+N, L = S._SIZES[cfg]
+fpd = FourierPair(SHT(L), N, S.data_cutoff(N), 2.0)
+data, _ = S.make_invariants(OracleTransforms(fpd), N, L)
+opt = OM.deep_update(OM.default_settings(), S.config_overrides(cfg))
+om = OM.MTIP(opt, data)
+captured = {}
+orig = om.rp.approximate_unknowns
+step = [0]
+
+
+def spy(Ilm):
+    step[0] += 1
+    if step[0] in (2, 30, 70):
+        for PD, oid in zip(om.rp.PDs, om.rp.used_orders.values()):
+            if oid in (8, 20, L):
+                captured[(step[0], oid)] = (PD @ Ilm[oid]).copy()
+    return orig(Ilm)
+
+
+om.rp.approximate_unknowns = spy
+main = opt['main_loop']['sub_loops']['main']
+main['iterations'] = 1
+main['methods']['ER']['iterations'] = 10
+opt['main_loop']['sub_loops']['order'] = ['main']
+om.opt = opt
+rho0 = om.density_guess(np.random.default_rng(1000))
+om.phasing_loop(rho0=rho0)
+
+
+def qdwh(A, max_it=12):
+    """polar factor U of A (m x n, m >= n) -- QR-based dynamically weighted Halley iteration"""
+    m, n = A.shape
+    alpha = np.linalg.norm(A, 2)
+    X = A / alpha
+    smin = np.linalg.svd(X, compute_uv=False)[-1]
+    l = max(smin, 1e-17)
+    its = 0
+    for its in range(1, max_it + 1):
+        l2 = l * l
+        dd = (4 * (1 - l2) / (l2 * l2)) ** (1 / 3)
+        sq = np.sqrt(1 + dd)
+        a = sq + 0.5 * np.sqrt(8 - 4 * dd + 8 * (2 - l2) / (l2 * sq))
+        b = (a - 1) ** 2 / 4
+        c = a + b - 1
+        Q, _ = np.linalg.qr(np.vstack([np.sqrt(c) * X, np.eye(n)]))
+        Q1, Q2 = Q[:m], Q[m:]
+        Xn = (b / c) * X + (1 / np.sqrt(c)) * (a - b / c) * (Q1 @ Q2.conj().T)
+        l = l * (a + b * l2) / (1 + c * l2)
+        done = np.linalg.norm(Xn - X) < 1e-15 * np.linalg.norm(Xn) or abs(1 - l) < 1e-15
+        X = Xn
+        if done:
+            break
+    return X, its
+
+
+print('cfg', cfg, 'N', N, 'L', L)
+for (st, oid), X in sorted(captured.items()):
+    V = om.rp.projection_matrices[list(om.rp.used_orders.values()).index(oid)]
+    s = np.linalg.svd(X, compute_uv=False)
+    u, _, vh = np.linalg.svd(X, full_matrices=False)
+    U_svd = u @ vh
+    U_q, its = qdwh(X)
+    ref = V @ U_svd
+    d = np.linalg.norm(V @ U_q - ref) / np.linalg.norm(ref)
+    print('step %3d l %2d  cond %.1e  rank(1e-15) %2d/%d  qdwh its %d  |V U_qdwh - V U_svd| / |V U_svd| = %.2e   unitarity %.1e'
+          % (st, oid, s[0] / max(s[-1], 1e-300), int((s > 1e-15 * s[0]).sum()), len(s), its, d,
+             np.linalg.norm(U_q.conj().T @ U_q - np.eye(U_q.shape[1]))))
