@@ -75,11 +75,41 @@ def algorithmic_bytes_per_step(N, L, nt, nphi, ft_stab=True):
     return 16 * G * n_grid + G + 16 * N * nlm * n_coef + 8 * N * N * (L + 1) * n_hankel
 
 
+def spawn_ranks(a):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a fresh child (torch.distributed.run) BEFORE
+    anything in this process touches HIP, wait for it and pass its exit code on (never exec from a GPU process)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={a.gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd).returncode
+
+
+def phase_of(warmup, steps):
+    """which steps of the tutorial schedule the timed region covers (the polar factor of an HIO step is the more
+    expensive one): the warm-up walks the first `warmup` steps of the schedule, the timed region then walks the
+    schedule again from its beginning."""
+    kinds = {'HIO': 0, 'ER': 0, 'SW': 0}
+    for kind, k in schedule(steps):
+        kinds[kind] += k if kind != 'SW' else 1
+    return {'warmup_steps': warmup, 'timed_steps': steps, 'timed_HIO_steps': kinds['HIO'], 'timed_ER_steps': kinds['ER'],
+            'timed_SW_updates': kinds['SW'],
+            'schedule': 'tutorial schedule from its first step: 5 x (60 HIO, SW, 40 ER) + (SW, 100 ER), repeated'}
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(spawn_ranks(a))
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
+    if a.gpus != world:
+        raise SystemExit(f'--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus} '
+                         f'(or run `python bench.py --gpus {a.gpus}` without a launcher)')
     np.seterr(all='ignore')
     import torch
     dist = None
@@ -247,36 +277,30 @@ def main():
                   'achieved_GBps_per_gpu': step_bytes * B * a.steps / elapsed / 1e9,
                   'frac_of_8TBps': step_bytes * B * a.steps / elapsed / 8e12}
 
-    # ---- CPU baseline: the oracle (numpy restatement of the reference algorithm), 1 thread, bounded sample
+    # ---- CPU baseline: the oracle (numpy restatement of the reference algorithm), one process per restart with one BLAS
+    #      thread each like the reference (xframe/__init__.py:5-8, reconstruct.py:141-157), bounded sample
     cpu = None
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:       # reported at N = 1 only (bounded sample, ~20 s of host time)
-        limiter = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:       # reported at N = 1 only
+        import multiprocessing as mp
+        from oracle import baseline_worker
+        cores = os.cpu_count() or 1
         try:
-            import threadpoolctl
-            limiter = threadpoolctl.threadpool_limits(1)
-        except Exception:
+            cores = len(os.sched_getaffinity(0))
+        except (AttributeError, OSError):
             pass
-        from oracle import mtip as OM
-        o_opt = OM.deep_update(OM.default_settings(), S.config_overrides(a.config))
+        n_proc = max(1, min(B, cores))
+        ctx = mp.get_context('spawn')                            # fresh interpreters: never fork a process that holds a GPU
         t_c0 = time.perf_counter()
-        om = OM.MTIP(o_opt, data)
-        state = om.create_initial_state(rho0[0])
-        rho = state['density_pair_history'][-1][1]
+        with ctx.Pool(n_proc) as pool:
+            outs = pool.map(baseline_worker.run, [(data, a.config, 1000 + i, a.cpu_seconds, 200) for i in range(n_proc)])
         t_c1 = time.perf_counter()
-        n_cpu = 0
-        om.beta = 0.45
-        while True:
-            _, rho = om.step('HIO', rho, True)
-            n_cpu += 1
-            if time.perf_counter() - t_c1 > a.cpu_seconds or n_cpu >= 200:
-                break
-        t_c2 = time.perf_counter()
-        cpu = {'value': n_cpu / (t_c2 - t_c1), 'unit': 'MTIP iterations/s', 'cores': 1, 'kind': 'port',
-               'host_cpu_count': os.cpu_count(),
-               'sample': f'{n_cpu} HIO ft_stab steps of 1 restart at {N}x L{L} on the same synthetic invariants and '
-                         f'initial density (oracle/mtip.py, numpy, BLAS pinned to 1 thread as xframe/__init__.py:5-8); '
-                         f'setup {t_c1 - t_c0:.1f}s excluded'}
-        del limiter
+        per_proc = [n / sec for n, sec, _ in outs]
+        cpu = {'value': float(sum(per_proc)), 'unit': 'MTIP iterations/s', 'cores': n_proc, 'kind': 'port',
+               'per_process': float(np.mean(per_proc)), 'host_cpu_count': os.cpu_count(), 'usable_cores': cores,
+               'sample': f'{n_proc} oracle processes (one restart each, 1 BLAS thread, as reconstruct.py:141-157), '
+                         f'{sum(n for n, _, _ in outs)} HIO ft_stab steps in total at {N}x L{L} on the same synthetic invariants, '
+                         f'{a.cpu_seconds:.0f} s of stepping per process; setup ({np.mean([st for _, _, st in outs]):.1f} s per '
+                         f'process) excluded; wall {t_c1 - t_c0:.0f} s'}
 
     if rank == 0:
         line = {
@@ -290,6 +314,7 @@ def main():
                        'restarts_per_gpu': B, 'restarts_total': B * world, 'streams_per_gpu': n_eng,
                        'parallelism': f'restart-sharded x{world}', 'step_mode': 'exact' if a.exact else 'fused'},
             'roofline': roofline, 'cpu_baseline': cpu, 'whole_step': whole_step, 'kernel_families_ms': fam_ms,
+            'phase': phase_of(a.warmup, a.steps),
             'setup_seconds': setup_s, 'final_reduce_seconds': reduce_s,
             'host_enqueue_ms_per_step': 1e3 * host['enqueue_s'] / max(a.steps, 1),
             'best_error_rank0': [float(x) for x in best_err], 'steps_done_per_restart': int(n_done),

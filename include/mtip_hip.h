@@ -104,6 +104,8 @@ int mtip_set_error_weights(mtip_ctx* ctx, const double* radial_w, const double* 
 /* ---- state ------------------------------------------------------------------------------------ */
 /* inject a starting density for restart `batch` (reconstruct.py:957-966: rho0 -> F0=FT(rho0),
  * rho0'=IFT(F0) is done by mtip_init_state) */
+/* The guesses are staged in device scratch that every mtip_op_* call may overwrite: set all restarts, then call
+ * mtip_init_state, with no mtip_op_* call in between. */
 int mtip_set_density(mtip_ctx* ctx, int batch, const mtip_cdouble* rho);
 int mtip_init_state(mtip_ctx* ctx);
 /* which = 0 latest pair, 1 best pair (reconstruct.py:934-938) */
@@ -132,7 +134,8 @@ int mtip_run_async(mtip_ctx* ctx, int method, int ft_stab, int n_steps, const do
 int mtip_fetch_errors(mtip_ctx* ctx, int64_t first_step, int64_t n_steps, double* real_err, double* deg2_err);
 /* one shrink-wrap update (reconstruct.py:598-605, 877-885; fxs_Projections.py:245-258):
  * enforce_initial_support_b = (last main error_b > error_limit); enforced[n_batch] (may be NULL)
- * returns the decision per restart. */
+ * returns the decision per restart.  The fixed amplitudes of the *_non_FXS variants survive this call and
+ * mtip_refresh_reciprocal_density (reconstruct.py:898-904: only an FXS method resets them). */
 int mtip_shrinkwrap(mtip_ctx* ctx, double sigma, double threshold, double error_limit, uint8_t* enforced);
 /* 'SW_center' (reconstruct.py:606-613, 886-897): after the support update the last (reciprocal, real) pair becomes
  * (FT(rho), rho) -- the reference's sketch shifts nothing.  This call rebuilds the reciprocal half on device; the best
@@ -149,6 +152,10 @@ int mtip_op_hankel(mtip_ctx* ctx, const mtip_cdouble* coeff_in, mtip_cdouble* co
 int mtip_op_fourier_transform(mtip_ctx* ctx, const mtip_cdouble* grid_in, mtip_cdouble* grid_out, int inverse);
 /* approximate_unknowns + mtip_projection (fxs_Projections.py:752-767, 832-872) on 'direct' coefficients */
 int mtip_op_project_coefficients(mtip_ctx* ctx, const mtip_cdouble* Ilm, mtip_cdouble* Ilm_projected);
+/* mtip_projection with caller-supplied unknowns (fxs_Projections.py:832-849, 866-871; registry operator
+ * 'mtip_projection(Ilm, unknowns)', reconstruct.py:391): U = per restart the concatenation over l = 0..L of the
+ * row-major (min(2l+1, Nq), 2l+1) blocks, i.e. the layout mtip_get_unknowns reads order by order */
+int mtip_op_apply_unknowns(mtip_ctx* ctx, const mtip_cdouble* Ilm, const mtip_cdouble* U, mtip_cdouble* Ilm_projected);
 /* project_to_modified_intensity (fxs_Projections.py:899-909): F' = F sqrt(Re I'/|F|^2) */
 int mtip_op_modulus_replacement(mtip_ctx* ctx, const mtip_cdouble* F, const mtip_cdouble* I_new, mtip_cdouble* F_new);
 /* real_projection + hybrid_input_output / error_reduction + l2 error (fxs_Projections.py:110-130,

@@ -1,0 +1,39 @@
+"""CPU baseline leg of bench.py (TEST / MEASUREMENT INFRASTRUCTURE, never on the product path): one oracle process per
+restart, BLAS pinned to one thread, as the reference runs its CPU path (xframe/__init__.py:5-8 pins the thread pools,
+reconstruct.py:141-157 forks one process per reconstruction).  Each process times HIO ft_stab steps of its own restart
+for a bounded number of seconds on the invariants bench.py hands over; nothing here touches a GPU."""
+import os
+import time
+
+
+def run(args):
+    """args = (data dict, config id, seed, seconds, max_steps) -> (steps done, loop seconds, setup seconds)"""
+    for k in ('OMP_NUM_THREADS', 'OPENBLAS_NUM_THREADS', 'MKL_NUM_THREADS'):
+        os.environ[k] = '1'
+    import numpy as np
+    np.seterr(all='ignore')
+    try:
+        import threadpoolctl
+        limiter = threadpoolctl.threadpool_limits(1)
+    except Exception:                                    # pragma: no cover - optional dependency
+        limiter = None
+    from oracle import mtip as OM
+    from xframe_amd.fxs import synthetic as S             # pure numpy module (settings of the BASELINE configs)
+    data, cfg, seed, seconds, max_steps = args
+    t0 = time.perf_counter()
+    opt = OM.deep_update(OM.default_settings(), S.config_overrides(cfg))
+    om = OM.MTIP(opt, data)
+    rho0 = om.density_guess(np.random.default_rng(seed))
+    state = om.create_initial_state(rho0)
+    rho = state['density_pair_history'][-1][1]
+    om.beta = 0.45
+    t1 = time.perf_counter()
+    n = 0
+    while True:
+        _, rho = om.step('HIO', rho, True)
+        n += 1
+        if time.perf_counter() - t1 > seconds or n >= max_steps:
+            break
+    t2 = time.perf_counter()
+    del limiter
+    return n, t2 - t1, t1 - t0

@@ -140,6 +140,13 @@ static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int, i
     else { std::fprintf(stderr, "emul: unsupported dpp ctrl 0x%x\n", ctrl); std::abort(); }
     return __shfl(src, from, 64);
 }
+// wave-uniform lane reads (the lane index is uniform in the kernels: an SGPR on the GPU)
+static inline int __builtin_amdgcn_readlane(int v, int src_lane) { return __shfl(v, src_lane, 64); }
+static inline int __builtin_amdgcn_readfirstlane(int v) { return __shfl(v, 0, 64); }
+// workgroup-scope atomics on LDS words: the fibers of a block share one OS thread, plain accesses are atomic enough
+#define __HIP_MEMORY_SCOPE_WORKGROUP 2
+template <typename T> static inline T __hip_atomic_load(const T* p, int, int) { return *const_cast<const volatile T*>(p); }
+template <typename T> static inline void __hip_atomic_store(T* p, T v, int, int) { *const_cast<volatile T*>(p) = v; }
 static inline int __double2loint(double v) { long long u; std::memcpy(&u, &v, 8); return (int)(u & 0xffffffffll); }
 static inline int __double2hiint(double v) { long long u; std::memcpy(&u, &v, 8); return (int)(u >> 32); }
 static inline double __hiloint2double(int hi, int lo) {

@@ -336,7 +336,7 @@ def main():
     run_mtip_golden(mods, N=32, L=8, name='mtip_cfg1_N32_L8', n_hio=60, n_er=40, with_steps=False)
 
 
-def run_mtip_golden(mods, N, L, name, n_hio, n_er, with_steps):
+def run_mtip_golden(mods, N, L, name, n_hio, n_er, with_steps, extra=None, save=True):
     settings = mods['xframe.settings']
     pl = mods['xframe.library.pythonLibrary']
     gl = mods['xframe.library.gridLibrary']
@@ -366,6 +366,8 @@ def run_mtip_golden(mods, N, L, name, n_hio, n_er, with_steps):
     o['main_loop']['sub_loops']['main']['methods']['HIO']['iterations'] = n_hio
     o['main_loop']['sub_loops']['main']['methods']['ER']['iterations'] = n_er
     o['main_loop']['sub_loops']['main']['iterations'] = 2 if with_steps else 1
+    if extra is not None:
+        o = OM.deep_update(o, extra)
     settings.project = pl.DictNamespace.dict_to_dictnamespace(o)
 
     for k in list(sys.modules):
@@ -410,7 +412,7 @@ def run_mtip_golden(mods, N, L, name, n_hio, n_er, with_steps):
     out = {'rho0': rho0, 'N': np.array(N), 'L': np.array(L), 'n_hio': np.array(n_hio), 'n_er': np.array(n_er),
            'loop_iterations_main': np.array(o['main_loop']['sub_loops']['main']['iterations'])}
 
-    if with_steps:
+    if with_steps and save:
         # single steps through the reference's sketches from a stored state (G10)
         F0 = ops['fourier_transform'](rho0)
         rho_s = ops['inverse_fourier_transform'](F0)
@@ -447,6 +449,16 @@ def run_mtip_golden(mods, N, L, name, n_hio, n_er, with_steps):
     out['traj_main'] = res['error_dict']['main']
     out['traj_real_err'] = res['error_dict']['real']['l2_projection_diff']
     out['traj_deg2'] = res['error_dict']['reciprocal']['deg2_invariant_l2_diff']
+    if not save:
+        keys = ('traj_main', 'traj_real_err', 'traj_deg2')
+        small = {k: np.asarray(out[k]) for k in keys}
+        for k in ('last_real_density', 'real_density', 'last_reciprocal_density', 'reciprocal_density', 'support_mask',
+                  'last_support_mask'):
+            small['traj_' + k] = np.asarray(res[k])
+        small['traj_final_error'] = np.array(res['final_error'])
+        small['traj_loop_iterations'] = np.array(res['loop_iterations'])
+        print(name, 'final error', res['final_error'], 'steps', len(res['error_dict']['main']))
+        return small
     out['traj_last_real_density'] = res['last_real_density']
     out['traj_real_density'] = res['real_density']
     out['traj_last_reciprocal_density'] = res['last_reciprocal_density']
@@ -467,5 +479,49 @@ def run_mtip_golden(mods, N, L, name, n_hio, n_er, with_steps):
     print(name, 'final error', res['final_error'], 'steps', len(res['error_dict']['main']))
 
 
+# ---- schedule / metric variants of the loop, run through the reference's own MTIP class (a14, a16) -----------------
+VARIANTS = {
+    # *_non_FXS after FXS steps and after a shrink-wrap (reconstruct.py:899-904: which pair latest_intensity is taken
+    # from), SW_center (606-613, 886-897)
+    'nonfxs': {'main_loop': {'sub_loops': {'main': {
+        'methods': {'HIO': {'iterations': 3, 'ft_stab': True}, 'HIO_non_FXS': {'iterations': 2, 'ft_stab': True},
+                    'SW': 1, 'ER_non_FXS': {'iterations': 2, 'ft_stab': False}, 'ER': {'iterations': 2, 'ft_stab': True}},
+        'order': ['HIO', 'HIO_non_FXS', 'SW', 'ER_non_FXS', 'ER'], 'iterations': 2}}}},
+    'swcenter': {'main_loop': {'sub_loops': {'main': {
+        'methods': {'HIO': {'iterations': 3, 'ft_stab': True}, 'SW': 1, 'ER': {'iterations': 2, 'ft_stab': True},
+                    'SW_center': 2, 'HIO_non_FXS': {'iterations': 2, 'ft_stab': False}},
+        'order': ['HIO', 'SW', 'ER', 'SW_center', 'HIO_non_FXS'], 'iterations': 2}}}},
+    # main error = mean / min / max / prod over real and reciprocal metrics (fxs_IO_methods.py:746-765)
+    'main_mean': {'main_loop': {'error': {'methods': {'main': {
+        'metrics': {'real': ['l2_projection_diff'], 'reciprocal': ['deg2_invariant_l2_diff']}, 'type': 'mean'}}}}},
+    'main_max': {'main_loop': {'error': {'methods': {'main': {
+        'metrics': {'real': ['l2_projection_diff'], 'reciprocal': ['deg2_invariant_l2_diff']}, 'type': 'max'}}}}},
+    'main_min': {'main_loop': {'error': {'methods': {'main': {
+        'metrics': {'real': ['l2_projection_diff'], 'reciprocal': ['deg2_invariant_l2_diff']}, 'type': 'min'}}}}},
+    'main_prod': {'main_loop': {'error': {'methods': {'main': {
+        'metrics': {'real': ['l2_projection_diff'], 'reciprocal': ['deg2_invariant_l2_diff']}, 'type': 'prod'}}}}},
+    'main_recip_only': {'main_loop': {'error': {'methods': {'main': {
+        'metrics': {'real': [], 'reciprocal': ['deg2_invariant_l2_diff']}, 'type': 'mean'}}}}},
+}
+
+
+def main_variants():
+    """tests/golden/mtip_variants_N16_L4.npz: '<variant>/<key>' arrays of short trajectories (same data and rho0 as
+    mtip_N16_L4.npz)"""
+    mods = bootstrap()
+    ml = mods['xframe.library.mathLibrary']
+    ml.shtns = ShAdapter
+    out = {}
+    for name, extra in VARIANTS.items():
+        r = run_mtip_golden(mods, N=16, L=4, name='variant ' + name, n_hio=4, n_er=3, with_steps=True, extra=extra, save=False)
+        for k, v in r.items():
+            out[name + '/' + k] = v
+    np.savez_compressed(os.path.join(HERE, 'mtip_variants_N16_L4.npz'), **out)
+    print('variants fixture:', len(out), 'arrays')
+
+
 if __name__ == '__main__':
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == 'variants':
+        main_variants()
+    else:
+        main()

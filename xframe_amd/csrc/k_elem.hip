@@ -162,7 +162,7 @@ void launch_real_update(mtip_ctx* c, const double2* rho_p, const double2* prev, 
 }
 
 void launch_finish_step(mtip_ctx* c, long long step_index, int nblk) {
-    double* hist = step_index >= 0 ? c->d_err_hist + (size_t)step_index * c->B : c->d_last_err;
+    double* hist = step_index >= 0 ? c->d_err_hist + (size_t)step_index * c->B : c->d_op_err;
     hipLaunchKernelGGL(k_finish_step, dim3((unsigned)c->B), dim3(256), 0, c->stream, (const double*)c->d_partial,
                        nblk > 0 ? nblk : c->n_partial_blocks, c->d_slot, c->d_best_err, c->d_last_err, hist, c->B, step_index >= 0 ? 1 : 0);
 }

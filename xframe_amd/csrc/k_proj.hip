@@ -1233,7 +1233,30 @@ int build_jacobi_schedule(mtip_ctx* c, int kmax) {
     return MTIP_OK;
 }
 
-void launch_project_coefficients(mtip_ctx* c, const double2* Ilm, double2* out) {
+static void fill_gemm_args(mtip_ctx* c, ProjGemmArgs& ga, const double2* Ilm) {
+    ga.Ilm = Ilm; ga.V = c->d_V; ga.X = c->d_X; ga.Xw = c->d_U; ga.Vr = c->d_Vr; ga.dst = c->d_X;
+    ga.q = c->d_q; ga.rmask = c->d_rmask; ga.kl = c->d_kl; ga.active = c->d_active; ga.used = c->d_used;
+    ga.voff = c->d_voff; ga.xoff = c->d_xoff; ga.uoff = c->d_uoff;
+    ga.N = c->N; ga.L = c->L; ga.xtot = c->xtot; ga.utot = c->utot; ga.nlm = c->nlm;
+    ga.inv_sqrt_np = 1.0 / std::sqrt(c->n_particles);
+}
+
+// I'_l = V_l U_l (+ mask / l = 0 rules) with the U_l currently in c->d_U: fxs_Projections.py:832-849, 866-871
+int launch_apply_unknowns(mtip_ctx* c, const double2* Ilm, double2* out) {
+    ProjGemmArgs ga;
+    fill_gemm_args(c, ga, Ilm);
+    if (build_proj_tiles(c) != MTIP_OK) {
+        c->err = "projection tile lists: out of device memory";
+        return MTIP_ENOMEM;
+    }
+    if (out != Ilm)
+        (void)hipMemcpyAsync(out, Ilm, (size_t)c->B * c->C * sizeof(double2), hipMemcpyDeviceToDevice, c->stream);
+    ga.dst = out;
+    launch_proj_gemm<PG_APPLY>(c, ga);
+    return MTIP_OK;
+}
+
+int launch_project_coefficients(mtip_ctx* c, const double2* Ilm, double2* out) {
     ProfScope ps(c, "proj");
     int max_kn = 1, kmax = 1, nmax = 1;
     for (int l = 0; l <= c->L; ++l) {
@@ -1243,13 +1266,20 @@ void launch_project_coefficients(mtip_ctx* c, const double2* Ilm, double2* out) 
         nmax = std::max(nmax, 2 * l + 1);
     }
     ProjGemmArgs ga;
-    ga.Ilm = Ilm; ga.V = c->d_V; ga.X = c->d_X; ga.Xw = c->d_U; ga.Vr = c->d_Vr; ga.dst = c->d_X;
-    ga.q = c->d_q; ga.rmask = c->d_rmask; ga.kl = c->d_kl; ga.active = c->d_active; ga.used = c->d_used;
-    ga.voff = c->d_voff; ga.xoff = c->d_xoff; ga.uoff = c->d_uoff;
-    ga.N = c->N; ga.L = c->L; ga.xtot = c->xtot; ga.utot = c->utot; ga.nlm = c->nlm;
-    ga.inv_sqrt_np = 1.0 / std::sqrt(c->n_particles);
-    if (build_proj_tiles(c) != MTIP_OK) return;
+    fill_gemm_args(c, ga, Ilm);
+    if (build_proj_tiles(c) != MTIP_OK) {
+        c->err = "projection tile lists: out of device memory";
+        return MTIP_ENOMEM;
+    }
     launch_proj_gemm<PG_X>(c, ga);
+    if (polar_newton_supported(c)) {
+        // square X_l: polar factor by the scaled Newton iteration (k_polar.hip), U_l written directly
+        const int rn = launch_polar_newton(c);
+        if (rn != MTIP_OK) return rn;
+        c->vr_valid = false;
+        c->proj_calls += 1;
+        return launch_apply_unknowns(c, Ilm, out);
+    }
     const size_t lds = ((size_t)kmax * (nmax | 1) + (size_t)kmax * (kmax | 1)) * sizeof(double2);   // unpadded minimum
     // Rotation-log mode: only X_l lives in the LDS of the Jacobi workgroup, V_r is updated afterwards by k_jacobi_replay
     // (rows spread over the chip).  Needs the resident ordering for every active order (square X_l, 16-lane groups).
@@ -1289,7 +1319,10 @@ void launch_project_coefficients(mtip_ctx* c, const double2* Ilm, double2* out) 
             std::stable_sort(ord.begin(), ord.end(), [&](int x, int y) { return c->kl[x] * (2 * x + 1) > c->kl[y] * (2 * y + 1); });
             c->n_jorder = (int)ord.size();
             if (ord.empty()) ord.push_back(0);
-            if (hipMalloc((void**)&c->d_jorder, ord.size() * sizeof(int)) != hipSuccess) return;
+            if (hipMalloc((void**)&c->d_jorder, ord.size() * sizeof(int)) != hipSuccess) {
+                c->err = "polar factor order list: out of device memory";
+                return MTIP_ENOMEM;
+            }
             (void)hipMemcpy(c->d_jorder, ord.data(), ord.size() * sizeof(int), hipMemcpyHostToDevice);
         }
         const dim3 gj((unsigned)c->B, (unsigned)std::max(c->n_jorder, 1));
@@ -1299,8 +1332,11 @@ void launch_project_coefficients(mtip_ctx* c, const double2* Ilm, double2* out) 
             if (c->d_jlog_rounds) (void)hipFree(c->d_jlog_rounds);
             c->d_jlog = nullptr; c->d_jlog_rounds = nullptr;
             const size_t nmat = (size_t)gj.x * gj.y;
-            if (hipMalloc((void**)&c->d_jlog, nmat * log_cap * c->jsched_ps * sizeof(JlRec)) != hipSuccess) return;
-            if (hipMalloc((void**)&c->d_jlog_rounds, nmat * sizeof(int)) != hipSuccess) return;
+            if (hipMalloc((void**)&c->d_jlog, nmat * log_cap * c->jsched_ps * sizeof(JlRec)) != hipSuccess ||
+                hipMalloc((void**)&c->d_jlog_rounds, nmat * sizeof(int)) != hipSuccess) {
+                c->err = "rotation log: out of device memory";
+                return MTIP_ENOMEM;
+            }
             (void)hipMemset(c->d_jlog_rounds, 0, nmat * sizeof(int));
             c->jlog_cap = log_cap;
             c->jlog_nmat = nmat;
@@ -1345,6 +1381,7 @@ void launch_project_coefficients(mtip_ctx* c, const double2* Ilm, double2* out) 
         (void)hipMemcpyAsync(out, Ilm, (size_t)c->B * c->C * sizeof(double2), hipMemcpyDeviceToDevice, c->stream);
     ga.dst = out;
     launch_proj_gemm<PG_APPLY>(c, ga);
+    return MTIP_OK;
 }
 
 // ---- B_l = I_l I_l^+ ------------------------------------------------------------------------------

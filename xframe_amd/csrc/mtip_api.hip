@@ -55,7 +55,7 @@ void mtip_destroy(mtip_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void* ptrs[] = {c->d_cost, c->d_gw, c->d_P, c->d_r, c->d_q, c->d_poff, c->d_PT, c->d_AB, c->d_lmtab, c->d_twN, c->d_tw, c->d_W, c->d_htiles, c->d_htiles32, c->d_kl, c->d_used, c->d_active, c->d_sweeps, c->d_jsched, c->d_jsched_off, c->d_jsched_rounds, c->d_jorder, c->d_jlog, c->d_jlog_rounds, c->d_pg_tiles[0], c->d_pg_tiles[1], c->d_pg_tiles[2], c->d_pg_tiles[3], c->d_voff,
                     c->d_xoff, c->d_uoff, c->d_V, c->d_rmask, c->d_Bref, c->d_Bnorm, c->d_deg2_part, c->d_S0, c->d_sup, c->d_err_wr,
-                    c->d_err_wt, c->d_rho, c->d_Fp, c->d_slot, c->d_best_err, c->d_last_err, c->d_err_hist,
+                    c->d_err_wt, c->d_rho, c->d_Fp, c->d_slot, c->d_best_err, c->d_last_err, c->d_op_err, c->d_gq, c->d_err_hist,
                     c->d_deg2_hist, c->d_F, c->d_T1, c->d_T2, c->d_fixed, c->d_g, c->d_c[0], c->d_c[1], c->d_c[2],
                     c->d_c[3], c->d_c[4], c->d_c[5], c->d_X, c->d_Vr, c->d_U, c->d_partial, c->d_minmax, c->d_Bl};
     for (void* p : ptrs)
@@ -131,6 +131,7 @@ mtip_ctx* mtip_create(const mtip_cfg* cfg, int device) {
     if (const char* e = std::getenv("MTIP_FUSE_REAL")) c->fuse_real_update = std::atoi(e) != 0;
     if (const char* e = std::getenv("MTIP_SHT_WIDE")) c->sht_wide = std::atoi(e) != 0;
     if (const char* e = std::getenv("MTIP_JAC_RESIDENT")) c->jac_resident = std::atoi(e) != 0;
+    if (const char* e = std::getenv("MTIP_POLAR")) c->polar_newton = std::string(e) != "jacobi";
     if (const char* e = std::getenv("MTIP_JAC_TG")) c->jac_tg = std::atoi(e) == 8 ? 8 : 16;
     if (const char* e = std::getenv("MTIP_JAC_REPLAY")) c->jac_replay = std::max(0, std::min(2, std::atoi(e)));
     if (rc == MTIP_OK) rc = build_hankel_tiles(c);
@@ -180,6 +181,8 @@ mtip_ctx* mtip_create(const mtip_cfg* cfg, int device) {
     A(dev_alloc(c, &c->d_slot, (size_t)B * SL_N));
     A(dev_alloc(c, &c->d_best_err, B));
     A(dev_alloc(c, &c->d_last_err, B));
+    A(dev_alloc(c, &c->d_op_err, B));
+    A(dev_alloc(c, &c->d_gq, N));
     c->err_cap = 4096;
     A(dev_alloc(c, &c->d_err_hist, (size_t)c->err_cap * B));
     A(dev_alloc(c, &c->d_deg2_hist, (size_t)c->err_cap * B * (L + 1)));
@@ -432,7 +435,10 @@ static int ensure_hist(mtip_ctx* c, long long need) {
     int r = dev_alloc(c, &nh, (size_t)cap * c->B);
     if (r) return r;
     r = dev_alloc(c, &nd, (size_t)cap * c->B * (c->L + 1));
-    if (r) return r;
+    if (r) {
+        (void)hipFree(nh);
+        return r;
+    }
     MTIP_HIP_CHECK(c, hipStreamSynchronize(c->stream));
     MTIP_HIP_CHECK(c, hipMemcpy(nh, c->d_err_hist, (size_t)c->n_steps_done * c->B * sizeof(double), hipMemcpyDeviceToDevice));
     MTIP_HIP_CHECK(c, hipMemcpy(nd, c->d_deg2_hist, (size_t)c->n_steps_done * c->B * (c->L + 1) * sizeof(double), hipMemcpyDeviceToDevice));
@@ -445,7 +451,7 @@ static int ensure_hist(mtip_ctx* c, long long need) {
 }
 
 // one phasing step for the whole batch (reference operator order), see file header
-static void enqueue_step(mtip_ctx* c, int method, int ft_stab, double beta) {
+static int enqueue_step(mtip_ctx* c, int method, int ft_stab, double beta) {
     const bool fxs = (method == MTIP_HIO || method == MTIP_ER);
     double2 **cc = c->d_c;
     InvEpilogue store;
@@ -457,7 +463,8 @@ static void enqueue_step(mtip_ctx* c, int method, int ft_stab, double beta) {
         // 2-3 I_lm = SHT(|F|^2);  4-5 projection;  6-7 I' = iSHT, F' = F sqrt(I'/I) -> Fp[out]
         launch_sht_forward(c, c->d_F, cc[2], MTIP_PRE_SQUARE);
         if (c->deg2_enable) launch_deg2_metric(c, cc[2], c->d_deg2_hist + (size_t)c->n_steps_done * c->B * (c->L + 1));
-        launch_project_coefficients(c, cc[2], cc[2]);          // in place: I_lm is not needed afterwards
+        const int rp = launch_project_coefficients(c, cc[2], cc[2]);          // in place: I_lm is not needed afterwards
+        if (rp != MTIP_OK) return rp;
         InvEpilogue mod;
         mod.mode = EPI_MODULUS;
         mod.F = c->d_F;
@@ -500,7 +507,7 @@ static void enqueue_step(mtip_ctx* c, int method, int ft_stab, double beta) {
             launch_sht_inverse(c, cc[5], nullptr, ru);
             launch_finish_step(c, c->n_steps_done, sht_inverse_real_update_blocks(c));
             c->n_steps_done += 1;
-            return;
+            return MTIP_OK;
         }
         launch_coeff_diff(c, cc[5], cc[0], cc[4]);
         launch_sht_inverse(c, cc[4], c->d_T1, store);
@@ -520,6 +527,7 @@ static void enqueue_step(mtip_ctx* c, int method, int ft_stab, double beta) {
     }
     launch_finish_step(c, c->n_steps_done);
     c->n_steps_done += 1;
+    return MTIP_OK;
 }
 
 int mtip_run_async(mtip_ctx* c, int method, int ft_stab, int n_steps, const double* betas) {
@@ -548,7 +556,10 @@ int mtip_run_async(mtip_ctx* c, int method, int ft_stab, int n_steps, const doub
     // coefficients); the epilogue path does not use T2 at all
     if (c->cfg.fused && ft_stab && !sht_inverse_fuses_real_update(c))
         MTIP_HIP_CHECK(c, hipMemsetAsync(c->d_T2, 0, (size_t)c->B * c->G * sizeof(double2), c->stream));
-    for (int s = 0; s < n_steps; ++s) enqueue_step(c, method, ft_stab, betas[s]);
+    for (int s = 0; s < n_steps; ++s) {
+        r = enqueue_step(c, method, ft_stab, betas[s]);
+        if (r) return r;
+    }
     return post_launch(c, "mtip_run");
 }
 
@@ -735,9 +746,8 @@ int mtip_shrinkwrap(mtip_ctx* c, double sigma, double threshold, double error_li
         const double q2 = q[i] * q[i];
         gq[i] = std::sqrt(pi / a) * std::exp(-pi * pi * (q2 * q2) / a);
     }
-    double* d_gq = c->d_fixed;                   // reuse: real scratch (only N doubles needed here)
-    // d_fixed may hold the non-FXS amplitudes: invalidate so they are rebuilt when next needed
-    c->fixed_valid = false;
+    // own buffer: d_fixed may hold the *_non_FXS amplitudes, which survive support updates (reconstruct.py:898-904)
+    double* d_gq = c->d_gq;
     MTIP_HIP_CHECK(c, hipMemcpy(d_gq, gq.data(), c->N * sizeof(double), hipMemcpyHostToDevice));
     InvEpilogue scale, store;
     scale.mode = EPI_SCALE_SHELL;
@@ -786,7 +796,6 @@ int mtip_refresh_reciprocal_density(mtip_ctx* c) {
         s[SL_OUT] = f;
     }
     MTIP_HIP_CHECK(c, hipMemcpy(c->d_slot, slots.data(), slots.size() * sizeof(int), hipMemcpyHostToDevice));
-    c->fixed_valid = false;
     return post_launch(c, "mtip_refresh_reciprocal_density");
 }
 
@@ -879,10 +888,28 @@ int mtip_op_project_coefficients(mtip_ctx* c, const mtip_cdouble* Ilm, mtip_cdou
     (void)hipSetDevice(c->device);
     SYNC();
     H2D(c->d_c[2], Ilm, (size_t)c->B * c->C * sizeof(double2));
-    launch_project_coefficients(c, c->d_c[2], c->d_c[3]);
+    const int rp = launch_project_coefficients(c, c->d_c[2], c->d_c[3]);
+    if (rp != MTIP_OK) return rp;
     SYNC();
     D2H(out, c->d_c[3], (size_t)c->B * c->C * sizeof(double2));
     return post_launch(c, "mtip_op_project_coefficients");
+}
+
+int mtip_op_apply_unknowns(mtip_ctx* c, const mtip_cdouble* Ilm, const mtip_cdouble* U, mtip_cdouble* out) {
+    CTX_CHECK(c);
+    for (int l = 0; l <= c->L; ++l)
+        if (!c->have_V[l]) FAIL(c, MTIP_ESTATE, "mtip_set_projection_matrix missing for some order");
+    if (!Ilm || !U || !out) FAIL(c, MTIP_EINVAL, "null buffer");
+    (void)hipSetDevice(c->device);
+    SYNC();
+    H2D(c->d_c[2], Ilm, (size_t)c->B * c->C * sizeof(double2));
+    H2D(c->d_U, U, (size_t)c->B * c->xtot * sizeof(double2));
+    c->vr_valid = false;                     // d_U no longer belongs to the carried right singular vectors
+    const int rp = launch_apply_unknowns(c, c->d_c[2], c->d_c[3]);
+    if (rp != MTIP_OK) return rp;
+    SYNC();
+    D2H(out, c->d_c[3], (size_t)c->B * c->C * sizeof(double2));
+    return post_launch(c, "mtip_op_apply_unknowns");
 }
 
 int mtip_op_modulus_replacement(mtip_ctx* c, const mtip_cdouble* F, const mtip_cdouble* I_new, mtip_cdouble* F_new) {
@@ -913,8 +940,7 @@ int mtip_op_real_space_update(mtip_ctx* c, const mtip_cdouble* w, const mtip_cdo
     launch_finish_step(c, -1);
     SYNC();
     D2H(rho_new, c->d_F, (size_t)c->B * c->G * sizeof(double2));
-    if (error) D2H(error, c->d_last_err, c->B * sizeof(double));
-    // d_last_err was used as scratch: restore "no error yet" only if the loop has not started
+    if (error) D2H(error, c->d_op_err, c->B * sizeof(double));
     return post_launch(c, "mtip_op_real_space_update");
 }
 

@@ -138,6 +138,7 @@ struct mtip_ctx {
     int n_jorder = 0;
     int* d_pg_tiles[4] = {nullptr, nullptr, nullptr, nullptr};   // (order, tile) lists of the projection GEMMs
     int n_pg_tiles[4] = {0, 0, 0, 0};
+    bool polar_newton = true;                         // env MTIP_POLAR=jacobi: one-sided Jacobi SVD for every order (else only for non-square X_l)
     int jac_tg = 16;                                  // env MTIP_JAC_TG=8|16: lanes per Jacobi column pair
     int jac_replay = 1;                               // env MTIP_JAC_REPLAY: 0 never, 1 rotation log + V_r replay when X_l, V_r do not share LDS, 2 always
     void* d_jlog = nullptr;                           // rotation log of the last Jacobi launch (matrix, round, slot)
@@ -180,6 +181,8 @@ struct mtip_ctx {
     double2 *d_rho = nullptr, *d_Fp = nullptr;        // (3, B, G) each
     int* d_slot = nullptr;                            // (B, SL_N)
     double *d_best_err = nullptr, *d_last_err = nullptr;   // (B)
+    double* d_op_err = nullptr;                       // (B) error of the single-operator entry point (never the loop's)
+    double* d_gq = nullptr;                           // (Nq) shrink-wrap Gaussian G_sigma(q)
     double* d_err_hist = nullptr;                     // (cap, B)
     double* d_deg2_hist = nullptr;                    // (cap, B, L+1)
     long long err_cap = 0, n_steps_done = 0;
@@ -237,13 +240,17 @@ int build_jacobi_schedule(mtip_ctx* c, int kmax);    // k_proj.hip: resident-col
 int build_hankel_tiles(mtip_ctx* c);
 void launch_coeff_diff(mtip_ctx* c, const double2* a, const double2* b, double2* out);
 // reciprocal projection
-void launch_project_coefficients(mtip_ctx* c, const double2* Ilm, double2* out);
+int launch_project_coefficients(mtip_ctx* c, const double2* Ilm, double2* out);   // MTIP_OK or an error code (c->err set)
+int launch_apply_unknowns(mtip_ctx* c, const double2* Ilm, double2* out);
+bool polar_newton_supported(const mtip_ctx* c);       // k_polar.hip: all active X_l square and at most 80 x 80
+int launch_polar_newton(mtip_ctx* c);                 // c->d_X (column-major X_l) -> c->d_U (U_l), scaled Newton iteration           // I'_l = V_l U_l with the U_l in c->d_U
 void launch_deg2(mtip_ctx* c, const double2* Ilm, double2* Bl);
 void launch_deg2_metric(mtip_ctx* c, const double2* Ilm, double* out /*(B, L+1)*/);
 // elementwise / reductions
 // rho_p = IFT(F') (B,G); prev/out: slot arrays (3,B,G) when use_slots else plain (B,G); rho_rt may be null
 void launch_real_update(mtip_ctx* c, const double2* rho_p, const double2* prev, const double2* rho_rt, double2* out,
                         int method, double beta, int use_slots);
+// step_index >= 0: loop step (history, best tracking, slot rotation); < 0: only the error, written to c->d_op_err
 void launch_finish_step(mtip_ctx* c, long long step_index, int nblk = 0);   // nblk partial sums per restart (0: grid blocks)
 void launch_abs_to_fixed(mtip_ctx* c);
 void launch_modulus_plain(mtip_ctx* c, const double2* F, const double2* Inew, double2* out);

@@ -162,6 +162,18 @@ class Engine:
         self._ck(self.lib.mtip_op_project_coefficients(self.ctx, _lib.ptr(c), _lib.ptr(out)))
         return out
 
+    def apply_unknowns(self, Ilm, unknowns):
+        """mtip_projection(Ilm, unknowns) (fxs_Projections.py:832-849): `unknowns` = per restart a sequence over l of
+        (k_l, 2l+1) arrays, or one such sequence for all restarts."""
+        c = self._bcoef(Ilm)
+        if len(unknowns) == self.L + 1 and np.ndim(unknowns[0]) == 2:
+            unknowns = [unknowns] * self.B
+        flat = np.stack([np.concatenate([_lib.as_c128(u).reshape(-1) for u in per]) for per in unknowns])
+        flat = np.ascontiguousarray(flat)
+        out = np.empty_like(c)
+        self._ck(self.lib.mtip_op_apply_unknowns(self.ctx, _lib.ptr(c), _lib.ptr(flat), _lib.ptr(out)))
+        return out
+
     def modulus_replacement(self, F, I_new):
         f, i = self._bgrid(F), self._bgrid(I_new)
         out = np.empty_like(f)

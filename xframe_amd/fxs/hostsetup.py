@@ -142,6 +142,12 @@ class ReciprocalSetup:
     """Everything ``ReciprocalProjection.__init__`` prepares on the host (fxs_Projections.py:471-537)."""
 
     def __init__(self, qs, data, max_order, opt):
+        # variants of the reference that are not on the accelerated path must not be ignored silently (DESIGN.md section 6)
+        if opt.get('SO_freedom', {}).get('use', False):
+            raise NotImplementedError('projections.reciprocal.SO_freedom.use = True (fxs_Projections.py:493, 768-780)')
+        if opt.get('number_of_particles', {}).get('estimate', False):
+            raise NotImplementedError('projections.reciprocal.number_of_particles.estimate = True (marked "NOT WORKING" upstream, '
+                                      'default_0.01.yaml:135-137)')
         q_d = np.asarray(data['data_radial_points'], dtype=float)
         aint = data['average_intensity']
         aint = np.asarray(getattr(aint, 'data', aint), dtype=float)

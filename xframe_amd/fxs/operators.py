@@ -144,8 +144,10 @@ def build_operators(engine):
         return state['unknowns']
 
     def mtip_projection(Ilm, unknowns):
-        # the device computes U_l and applies it in one pass; `unknowns` is accepted for API parity
-        return _to_lm(e.project_coefficients(_from_lm(Ilm))[0])
+        # I'_l = V_l U_l with the caller's unknowns (fxs_Projections.py:832-849); None = solve and apply in one pass
+        if unknowns is None:
+            return _to_lm(e.project_coefficients(_from_lm(Ilm))[0])
+        return _to_lm(e.apply_unknowns(_from_lm(Ilm), unknowns)[0])
 
     def project_to_modified_intensity(reciprocal_density, square, new_intensity):
         return e.modulus_replacement(reciprocal_density, new_intensity)[0]

@@ -83,6 +83,9 @@ class MTIP:
     def _sw_ramps(self):
         e = self.engine
         sw_opt = self.opt['projections']['real']['shrink_wrap']
+        if sw_opt.get('mode', 'threshold') != 'threshold':
+            raise NotImplementedError("shrink_wrap.mode = %r: only 'threshold' is on the accelerated path "
+                                      '(fixed_volume: fxs_Projections.py:260-291)' % (sw_opt.get('mode'),))
         order = self.opt['main_loop']['sub_loops']['order']
         sig, thr = [], []
         for lid in range(len(order)):
@@ -106,6 +109,11 @@ class MTIP:
             self.sw_threshold = 0 if v < 0 else (1 if v >= 1 else v)          # 218-227
 
     # ------------------------------------------------------------------ initial densities (1115-1174, 957-979)
+    def _initial_densities(self):
+        """guesses of all restarts of this batch; the seed-independent autocorrelation is transformed once"""
+        self._autocorrelation = None
+        return [self._initial_density(b) for b in range(self.n_restarts)]
+
     def _initial_density(self, i):
         if self.initial_densities is not None:
             return np.asarray(self.initial_densities[i], dtype=complex)
@@ -122,10 +130,12 @@ class MTIP:
             radius = np.max(e.rs)
         if dg['type'] == 'low_resolution_autocorrelation':
             # reconstruct.py:1175-1205: transforms on the device, the rest on the host as in the reference
-            coeff = np.zeros((e.N, e.nlm), complex)
-            for l, pm in e.rsetup.projection_matrices.items():
-                coeff[:, l * l:l * l + pm.shape[1]] = pm
-            ac = e.fourier_transform(e.sht_inverse(coeff)[0], True)[0].real
+            if getattr(self, '_autocorrelation', None) is None:
+                coeff = np.zeros((e.N, e.nlm), complex)
+                for l, pm in e.rsetup.projection_matrices.items():
+                    coeff[:, l * l:l * l + pm.shape[1]] = pm
+                self._autocorrelation = e.fourier_transform(e.sht_inverse(coeff)[0], True)[0].real
+            ac = self._autocorrelation
             return hs.autocorrelation_density(ac, e.rs, e.shape, self.opt['particle_radius'], dg['random']['SNR'], rng,
                                               e.rsetup.integrated_intensity, e.int_wr, e.int_wt)
         if dg['type'] == 'ball':
@@ -161,8 +171,11 @@ class MTIP:
         if list(main_cfg['metrics']['real']) != ['l2_projection_diff'] or list(main_cfg['metrics']['reciprocal']):
             raise NotImplementedError('main error metric other than real l2_projection_diff')
         t_setup = time.perf_counter()
+        # all guesses first: the autocorrelation guess runs transforms on the engine, whose single-operator entry
+        # points use the same device scratch that mtip_set_density stages the guesses in
+        guesses = self._initial_densities()
         for b in range(B):
-            e.set_density(b, self._initial_density(b))
+            e.set_density(b, guesses[b])
         e.init_state()
         initial_density = [e.density(b) for b in range(B)]
         initial_mask = e.initial_support.copy()
