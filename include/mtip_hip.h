@@ -86,6 +86,11 @@ int mtip_set_number_of_particles(mtip_ctx* ctx, double n_particles);   /* fxs_Pr
 /* reference B_l = V_l V_l^+ masks for the deg2_invariant_l2_diff metric are derived internally
  * (fxs_IO_methods.py:408-447); enable = 1 evaluates it every step. */
 int mtip_set_deg2_metric(mtip_ctx* ctx, int enable);
+/* generate_main_error_routine (fxs_IO_methods.py:746-765): the main error of a step is `type` (0 mean, 1 min, 2 max,
+ * 3 prod) over the last values of the chosen metrics.  use_reciprocal_deg2 = 0: the real l2_projection_diff metric (a
+ * scalar: every type returns it); 1: the per-order values of deg2_invariant_l2_diff (one entry per used order, -1 where
+ * the reference invariant vanishes).  Mixing both makes the reference itself raise (np.array of a scalar and a vector). */
+int mtip_set_main_error(mtip_ctx* ctx, int use_reciprocal_deg2, int type);
 /* real-space constraints (fxs_Projections.py:72-130, pythonLibrary.py:1289-1320):
  * flags bit0 support, bit1 value lower bound, bit2 value upper bound, bit3 limit_imag;
  * hio_mask_flags: which of those feed the HIO mask gamma ('considered_projections',
@@ -132,14 +137,21 @@ int mtip_run(mtip_ctx* ctx, int method, int ft_stab, int n_steps, const double* 
 /* same, but only enqueues (no download, no sync): errors stay on the device until mtip_fetch_errors */
 int mtip_run_async(mtip_ctx* ctx, int method, int ft_stab, int n_steps, const double* betas);
 int mtip_fetch_errors(mtip_ctx* ctx, int64_t first_step, int64_t n_steps, double* real_err, double* deg2_err);
+/* the main error per step (n_steps x n_batch): what best-pair tracking and the enforce_initial_support decision use */
+int mtip_fetch_main_errors(mtip_ctx* ctx, int64_t first_step, int64_t n_steps, double* main_err);
 /* one shrink-wrap update (reconstruct.py:598-605, 877-885; fxs_Projections.py:245-258):
  * enforce_initial_support_b = (last main error_b > error_limit); enforced[n_batch] (may be NULL)
  * returns the decision per restart.  The fixed amplitudes of the *_non_FXS variants survive this call and
- * mtip_refresh_reciprocal_density (reconstruct.py:898-904: only an FXS method resets them). */
+ * mtip_refresh_reciprocal_density (reconstruct.py:898-904: only an FXS method or a new sub-loop resets them); they are
+ * |F'| of the pair the reference's stale `hist` ends with (901): the input pair of the most recent step. */
 int mtip_shrinkwrap(mtip_ctx* ctx, double sigma, double threshold, double error_limit, uint8_t* enforced);
-/* 'SW_center' (reconstruct.py:606-613, 886-897): after the support update the last (reciprocal, real) pair becomes
- * (FT(rho), rho) -- the reference's sketch shifts nothing.  This call rebuilds the reciprocal half on device; the best
- * pair is left untouched. */
+/* Top of a sub-loop call (reconstruct.py:852-866): the reference re-reads its local `hist` from the state and forgets
+ * the fixed amplitudes of the *_non_FXS variants.  Call it before the first method of every sub-loop. */
+int mtip_begin_sub_loop(mtip_ctx* ctx);
+/* 'SW_center' (reconstruct.py:606-613, 886-897), after mtip_shrinkwrap.  Reproduces the reference literally: its process
+ * returns (support, copy(rho), FT(rho)), which the loop unpacks as (support, ft_density, density), so the latest pair
+ * becomes (reciprocal, real) = (rho, FT(rho)); the history is rebuilt from the stale `hist` (893), i.e. the pair of the
+ * most recent step is dropped.  The best pair is left untouched. */
 int mtip_refresh_reciprocal_density(mtip_ctx* ctx);
 /* B_l = I_l I_l^+ of FT(latest rho) (reconstruct.py:757-765, 992-993), (L+1, Nq, Nq) complex */
 int mtip_last_deg2_invariant(mtip_ctx* ctx, int batch, mtip_cdouble* Bl);

@@ -319,6 +319,10 @@ class MTIP:
         if 'SW' in methods:
             self.update_shrink_wrap(0, loop_number)
         error_dict = state['error_dict']
+        # reconstruct.py:859: `hist` is a local that is re-read from the state only at the top of every phasing step (913);
+        # SW_center (893) and the *_non_FXS intensity (901) read it as it was left there, i.e. the history BEFORE the most
+        # recent step (or the loop's initial history when no step has run in this call yet)
+        hist = state['density_pair_history']
         eis_list = state.get('enforce_initial_support_list', [])
         iteration = 0
         step = 0
@@ -339,8 +343,12 @@ class MTIP:
                     self.update_shrink_wrap(sw_step, loop_number)
                     continue
                 if key == 'SW_center':
-                    # reconstruct.py:606-613 (sketch: support of the last density; the pair handed back is
-                    # (FT(rho), rho) -- no shift, despite the name) and 886-897 (the last history pair is replaced)
+                    # reconstruct.py:606-613, 886-897.  Two quirks of the reference are restated literally:
+                    #  * the sketch's last stage [(0,1,2,3), ['calculate_support_mask','id','id']] feeds the one-argument
+                    #    get_new_mask (fxs_Projections.py:247) input 0 and the two 'id's inputs 1 and 2, i.e. the process
+                    #    returns (support, copy(rho), FT(rho)); the loop unpacks that as (support, ft_density, density), so
+                    #    the pair appended to the history is (rho, FT(rho)): the "real" half of the last pair is FT(rho);
+                    #  * the new history is built from the stale `hist` (893): the pair of the most recent step is dropped.
                     enforce = error_dict['main'][-1] > limit
                     self.real_pr.enforce_initial_support = enforce
                     eis_list.append(enforce)
@@ -349,13 +357,13 @@ class MTIP:
                         support = self.sw_step(rho)
                         self.real_pr.support = support
                         state['mask'] = self.real_pr.support
-                        state['density_pair_history'] = state['density_pair_history'][:-1] + ((self.fp.ft(np.array(rho)), rho),)
+                        state['density_pair_history'] = hist[1:] + ((np.array(rho), self.fp.ft(np.array(rho))),)
                         sw_step += 1
                         self.update_shrink_wrap(sw_step, loop_number)
                     continue
                 if key in ('ER_non_FXS', 'HIO_non_FXS'):
                     if isinstance(latest_intensity, bool):
-                        latest_intensity = np.abs(state['density_pair_history'][-1][0]).real
+                        latest_intensity = np.abs(hist[-1][0]).real          # stale hist: reconstruct.py:901
                         self.rp.fixed_intensity = latest_intensity
                 else:
                     latest_intensity = False

@@ -26,6 +26,11 @@ def golden_mtip16():
 
 
 @pytest.fixture(scope='session')
+def golden_variants():
+    return np.load(os.path.join(GOLDEN, 'mtip_variants_N16_L4.npz'))
+
+
+@pytest.fixture(scope='session')
 def golden_cfg1():
     return np.load(os.path.join(GOLDEN, 'mtip_cfg1_N32_L8.npz'))
 

@@ -30,7 +30,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
 np.seterr(all='ignore')
-from helpers import OracleTransforms                                   # noqa: E402
+from helpers import OracleTransforms, bl_error, radial_profile         # noqa: E402
 from oracle import mtip as OM                                          # noqa: E402
 from oracle import projections as OP                                   # noqa: E402
 from oracle.fourier import FourierPair                                 # noqa: E402
@@ -50,26 +50,6 @@ def problem(cfg):
     fpd = FourierPair(SHT(L), N, S.data_cutoff(N), 2.0)
     data, rho_true = S.make_invariants(OracleTransforms(fpd), N, L)
     return data, rho_true
-
-
-def radial_profile(rho):
-    """sqrt of the angular mean of |rho|^2 per shell (Gauss-Legendre weights in theta, uniform in phi)"""
-    from scipy.special import roots_legendre
-    wt = roots_legendre(rho.shape[1])[1]
-    return np.sqrt((np.abs(rho) ** 2 * wt[None, :, None]).sum((1, 2)) / (wt.sum() * rho.shape[2]))
-
-
-def bl_error(Bl, projection_matrices, radial_mask, used_orders, n_particles):
-    num = den = 0.0
-    for i, l in enumerate(used_orders):
-        V = projection_matrices[i]
-        m = radial_mask[i]
-        Bd = (V @ V.conj().T)[np.ix_(m, m)]
-        if l == 0:
-            Bd = Bd / n_particles
-        num += (np.abs(Bl[l][np.ix_(m, m)] - Bd) ** 2).sum()
-        den += (np.abs(Bd) ** 2).sum()
-    return num / den
 
 
 def one_restart(args):

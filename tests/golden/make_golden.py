@@ -448,7 +448,7 @@ def run_mtip_golden(mods, N, L, name, n_hio, n_er, with_steps, extra=None, save=
     res = m2.phasing_loop()
     out['traj_main'] = res['error_dict']['main']
     out['traj_real_err'] = res['error_dict']['real']['l2_projection_diff']
-    out['traj_deg2'] = res['error_dict']['reciprocal']['deg2_invariant_l2_diff']
+    out['traj_deg2'] = res['error_dict']['reciprocal'].get('deg2_invariant_l2_diff', np.zeros(0))
     if not save:
         keys = ('traj_main', 'traj_real_err', 'traj_deg2')
         small = {k: np.asarray(out[k]) for k in keys}
@@ -483,25 +483,28 @@ def run_mtip_golden(mods, N, L, name, n_hio, n_er, with_steps, extra=None, save=
 VARIANTS = {
     # *_non_FXS after FXS steps and after a shrink-wrap (reconstruct.py:899-904: which pair latest_intensity is taken
     # from), SW_center (606-613, 886-897)
-    'nonfxs': {'main_loop': {'sub_loops': {'main': {
+    # (the reference's *_non_FXS start sketch hands the reciprocal metrics a grid instead of I_lm and raises when
+    # reciprocal metrics are enabled, so these two run with the real metric only)
+    'nonfxs': {'main_loop': {'error': {'methods': {'reciprocal': {'calculate': []}}}, 'sub_loops': {'main': {
         'methods': {'HIO': {'iterations': 3, 'ft_stab': True}, 'HIO_non_FXS': {'iterations': 2, 'ft_stab': True},
                     'SW': 1, 'ER_non_FXS': {'iterations': 2, 'ft_stab': False}, 'ER': {'iterations': 2, 'ft_stab': True}},
         'order': ['HIO', 'HIO_non_FXS', 'SW', 'ER_non_FXS', 'ER'], 'iterations': 2}}}},
-    'swcenter': {'main_loop': {'sub_loops': {'main': {
+    'swcenter': {'main_loop': {'error': {'methods': {'reciprocal': {'calculate': []}}}, 'sub_loops': {'main': {
         'methods': {'HIO': {'iterations': 3, 'ft_stab': True}, 'SW': 1, 'ER': {'iterations': 2, 'ft_stab': True},
                     'SW_center': 2, 'HIO_non_FXS': {'iterations': 2, 'ft_stab': False}},
         'order': ['HIO', 'SW', 'ER', 'SW_center', 'HIO_non_FXS'], 'iterations': 2}}}},
-    # main error = mean / min / max / prod over real and reciprocal metrics (fxs_IO_methods.py:746-765)
-    'main_mean': {'main_loop': {'error': {'methods': {'main': {
-        'metrics': {'real': ['l2_projection_diff'], 'reciprocal': ['deg2_invariant_l2_diff']}, 'type': 'mean'}}}}},
-    'main_max': {'main_loop': {'error': {'methods': {'main': {
-        'metrics': {'real': ['l2_projection_diff'], 'reciprocal': ['deg2_invariant_l2_diff']}, 'type': 'max'}}}}},
-    'main_min': {'main_loop': {'error': {'methods': {'main': {
-        'metrics': {'real': ['l2_projection_diff'], 'reciprocal': ['deg2_invariant_l2_diff']}, 'type': 'min'}}}}},
-    'main_prod': {'main_loop': {'error': {'methods': {'main': {
-        'metrics': {'real': ['l2_projection_diff'], 'reciprocal': ['deg2_invariant_l2_diff']}, 'type': 'prod'}}}}},
-    'main_recip_only': {'main_loop': {'error': {'methods': {'main': {
+    # main error = mean / min / max / prod over the chosen metrics' last values (fxs_IO_methods.py:746-765).  The real
+    # metric is a scalar, deg2_invariant_l2_diff one value per order: mixing both makes np.array(...) of the reference
+    # raise (inhomogeneous shape), so the combinations that run are the real metric alone (the default) and the
+    # reciprocal metric alone, reduced over its per-order values (-1 for orders without reference invariant)
+    'main_recip_mean': {'main_loop': {'error': {'methods': {'main': {
         'metrics': {'real': [], 'reciprocal': ['deg2_invariant_l2_diff']}, 'type': 'mean'}}}}},
+    'main_recip_max': {'main_loop': {'error': {'methods': {'main': {
+        'metrics': {'real': [], 'reciprocal': ['deg2_invariant_l2_diff']}, 'type': 'max'}}}}},
+    'main_recip_min': {'main_loop': {'error': {'methods': {'main': {
+        'metrics': {'real': [], 'reciprocal': ['deg2_invariant_l2_diff']}, 'type': 'min'}}}}},
+    'main_recip_prod': {'main_loop': {'error': {'methods': {'main': {
+        'metrics': {'real': [], 'reciprocal': ['deg2_invariant_l2_diff']}, 'type': 'prod'}}}}},
 }
 
 

@@ -42,3 +42,26 @@ def golden_settings(N, L, extra=None):
     if extra:
         o = OM.deep_update(o, extra)
     return o
+
+
+# ---- rotation / inversion / translation invariant summaries of a reconstruction (converged-run comparison) ------------
+def radial_profile(rho):
+    """sqrt of the angular mean of |rho|^2 per shell (Gauss-Legendre weights in theta, uniform in phi)"""
+    from scipy.special import roots_legendre
+    wt = roots_legendre(rho.shape[1])[1]
+    return np.sqrt((np.abs(rho) ** 2 * wt[None, :, None]).sum((1, 2)) / (wt.sum() * rho.shape[2]))
+
+
+def bl_error(Bl, projection_matrices, radial_mask, used_orders, n_particles):
+    """sum_l |B_l - B_l^data|^2 / sum_l |B_l^data|^2 on the masked shells (the metric of fxs_IO_methods.py:408-447 summed
+    over the orders); projection_matrices / radial_mask are indexed like used_orders"""
+    num = den = 0.0
+    for i, l in enumerate(used_orders):
+        V = projection_matrices[i]
+        m = radial_mask[i]
+        Bd = (V @ V.conj().T)[np.ix_(m, m)]
+        if l == 0:
+            Bd = Bd / n_particles
+        num += (np.abs(Bl[l][np.ix_(m, m)] - Bd) ** 2).sum()
+        den += (np.abs(Bd) ** 2).sum()
+    return num / den

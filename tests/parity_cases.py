@@ -543,3 +543,152 @@ def check_full_size_properties(cfg, lib_path=None, n_steps=12):
     for x in eng.values():
         x.close()
     return errs_a
+
+
+def check_initial_density_batch(g, lib_path, kind='low_resolution_autocorrelation', seeds=(77, 78, 79)):
+    """Seeded density guesses of a batch of restarts through MTIP.phasing_loop (reconstruct.py:957-979, 1115-1210): the
+    autocorrelation guess runs transforms on the engine while the guesses are being staged, so every restart of the
+    batch -- not only the last one -- must come out as the oracle's IFT(FT(guess)) for its own seed."""
+    N, L = int(g['N']), int(g['L'])
+    data = data_from_golden(g, L)
+    opt = golden_settings(N, L, {'density_guess': {'type': kind}})
+    main = opt['main_loop']['sub_loops']['main']
+    main['methods']['HIO']['iterations'] = 1
+    main['methods']['ER']['iterations'] = 1
+    main['iterations'] = 1
+    R.MTIP.preinit(opt, data)
+    m = R.MTIP(n_restarts=len(seeds), seeds=list(seeds), lib_path=lib_path)
+    m.generate_phasing_loop()
+    res = m.phasing_loop()
+    for b, seed in enumerate(seeds):
+        om = OM.MTIP(opt, data)
+        ref = om.phasing_loop(rho0=om.density_guess(np.random.default_rng(seed)))
+        assert rel_l2(res[b]['initial_density'], ref['initial_density']) < 1e-8, (kind, b)
+        assert np.allclose(res[b]['error_dict']['main'], ref['error_dict']['main'], rtol=1e-7), (kind, b)
+    assert rel_l2(res[0]['initial_density'], res[1]['initial_density']) > 1e-3      # the seeds really differ
+    m.engine.close()
+
+
+def check_apply_unknowns(g, lib_path):
+    """Registry operator mtip_projection(Ilm, unknowns) (reconstruct.py:391, fxs_Projections.py:832-849, 866-871) with
+    caller-supplied unknowns: the engine's own U_l reproduce its projection, random unitary-free U_l follow the oracle's
+    V_l U_l with the mask and l = 0 rules."""
+    from xframe_amd.fxs.operators import build_operators
+    N, L = int(g['N']), int(g['L'])
+    e, om, opt, data = _engine_and_oracle(g, lib_path)
+    ops = build_operators(e)
+    rng = np.random.default_rng(11)
+    Ilm = [cplx(rng, (N, 2 * l + 1)) for l in range(L + 1)]
+    unk = ops['approximate_unknowns'](Ilm)
+    a = ops['mtip_projection'](Ilm, unk)
+    b = ops['mtip_projection'](Ilm, None)
+    ref = om.rp.mtip_projection(Ilm, om.rp.approximate_unknowns(Ilm))
+    for l in range(L + 1):
+        assert rel_l2(a[l], b[l]) < 1e-13 and rel_l2(a[l], ref[l]) < TOL_SHT, l
+    rand = [cplx(rng, (min(2 * l + 1, N), 2 * l + 1)) for l in range(L + 1)]
+    got = ops['mtip_projection'](Ilm, rand)
+    want = om.rp.mtip_projection(Ilm, rand)
+    for l in range(L + 1):
+        assert rel_l2(got[l], want[l]) < TOL_OP, l
+    e.close()
+
+
+def check_config4_worker(lib_path=None, cfg=4, n_restarts=8, n_workers=3, n_hio=10, n_er=10, oracle_restarts=(0, 5),
+                         sizes=None):
+    """BASELINE config 4 on one GPU as the benchmark runs it: ProjectWorker with multi_process.n_parallel_reconstructions = 8
+    distinct seeds and GPU.n_gpu_workers = 3 (three engines / HIP streams driven from three host threads,
+    reconstruct.py:104, 141-157), n_hio HIO + SW + n_er ER ft_stab steps.  Every restart must come out bit-identical to a
+    single-engine run holding all eight (restarts never interact), and the restarts in `oracle_restarts` (one per engine
+    group) must follow the oracle from the same seeded guess (20-step trajectory tolerance)."""
+    import xframe_amd.fxs.hostsetup as hs
+    N, L = sizes if sizes is not None else S._SIZES[cfg]
+    data, _ = synthetic_problem(cfg, lib_path, N, L)
+    opt = OM.deep_update(OM.default_settings(), S.config_overrides(cfg))
+    opt = OM.deep_update(opt, {'grid': {'n_radial_points': N, 'max_order': L},
+                               'projections': {'reciprocal': {'used_order_ids': np.arange(L + 1)}},
+                               'multi_process': {'use': True, 'n_parallel_reconstructions': n_restarts}})
+    loops = opt['main_loop']['sub_loops']
+    loops['order'] = ['main']
+    main = loops['main']
+    main['methods']['HIO']['iterations'] = n_hio
+    main['methods']['ER']['iterations'] = n_er
+    main['iterations'] = 1
+    seeds = [1000 + i for i in range(n_restarts)]
+    results = {}
+    for workers in (n_workers, 1):
+        o = OM.deep_update(opt, {'GPU': {'use': True, 'n_gpu_workers': workers}})
+        w = R.ProjectWorker(o, data, seeds=seeds, lib_path=lib_path)
+        res, _ = w.run()
+        assert len(res) == n_restarts and len(w.mtip_instances) == workers
+        results[workers] = res
+        engine = w.mtip_instances[0].engine
+        if workers == n_workers:
+            rs, shape = engine.rs, engine.shape
+            ii, wr, wt = engine.rsetup.integrated_intensity, engine.int_wr, engine.int_wt
+        for m in w.mtip_instances:
+            m.engine.close()
+    for a, b in zip(results[n_workers], results[1]):
+        for k in ('initial_density', 'real_density', 'last_real_density', 'reciprocal_density', 'last_reciprocal_density'):
+            assert np.array_equal(a[k], b[k]), k
+        assert np.array_equal(a['error_dict']['main'], b['error_dict']['main'])
+        assert np.array_equal(a['last_support_mask'], b['last_support_mask'])
+    finals = [r['error_dict']['main'][-1] for r in results[n_workers]]
+    assert len(set(finals)) == n_restarts                           # eight different reconstructions
+    for i in oracle_restarts:
+        rho0 = hs.bump_density(rs, shape, S.PARTICLE_RADIUS, 0.3, 2, np.random.default_rng(seeds[i]), ii, wr, wt)
+        ref = OM.MTIP(opt, data).phasing_loop(rho0=rho0)
+        r = results[n_workers][i]
+        assert np.allclose(r['error_dict']['main'], ref['error_dict']['main'], rtol=TOL_TRAJ), i
+        for k in ('initial_density', 'real_density', 'last_real_density', 'reciprocal_density', 'last_reciprocal_density'):
+            assert rel_l2(r[k], ref[k]) < TOL_TRAJ, (i, k)
+        assert (r['last_support_mask'] != ref['last_support_mask']).mean() < 1e-5
+    return finals
+
+
+# ---- loop variants pinned by trajectories of the reference's own MTIP class (tests/golden/make_golden.py variants) -------
+def variant_settings(N, L, name):
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location('make_golden', os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'make_golden.py'))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)                       # only the VARIANTS table is used (no reference import happens at import time)
+    opt = golden_settings(N, L, {'main_loop': {'error': {'methods': {'reciprocal': {
+        'calculate': ['deg2_invariant_l2_diff'], 'deg2_invariant_l2_diff': {'order': 2}}}}}})
+    main = opt['main_loop']['sub_loops']['main']
+    main['methods']['HIO']['iterations'] = 4
+    main['methods']['ER']['iterations'] = 3
+    main['iterations'] = 2
+    return OM.deep_update(opt, mg.VARIANTS[name])
+
+
+VARIANT_NAMES = ('nonfxs', 'swcenter', 'main_recip_mean', 'main_recip_max', 'main_recip_min', 'main_recip_prod')
+
+
+def check_variant_golden(g, v, name, lib_path=None, use_oracle=False, n_restarts=2):
+    """`name` in VARIANT_NAMES: the *_non_FXS / SW_center schedules (incl. the reference's stale `hist` and swapped
+    SW_center outputs, reconstruct.py:859-913, 606-613) and the main error over the reciprocal deg2 metric
+    (fxs_IO_methods.py:746-765), against trajectories recorded from the reference's own loop."""
+    N, L = int(g['N']), int(g['L'])
+    data = data_from_golden(g, L)
+    opt = variant_settings(N, L, name)
+    if use_oracle:
+        res = [OM.MTIP(opt, data).phasing_loop(rho0=g['rho0'])]
+        tol_e, tol_d = 1e-12, 1e-12
+    else:
+        R.MTIP.preinit(opt, data)
+        m = R.MTIP(n_restarts=n_restarts, initial_densities=[g['rho0']] * n_restarts, lib_path=lib_path)
+        m.generate_phasing_loop()
+        res = m.phasing_loop()
+        m.engine.close()
+        tol_e, tol_d = 1e-7, 1e-7
+    for r in res:
+        main_ref = v[name + '/traj_main']
+        assert len(r['error_dict']['main']) == len(main_ref)
+        assert np.allclose(r['error_dict']['main'], main_ref, rtol=tol_e, atol=1e-300), name
+        assert np.allclose(r['error_dict']['real']['l2_projection_diff'], v[name + '/traj_real_err'], rtol=tol_e), name
+        for k in ('last_real_density', 'real_density', 'last_reciprocal_density', 'reciprocal_density'):
+            assert rel_l2(r[k], v[name + '/traj_' + k]) < tol_d, (name, k)
+        assert (r['support_mask'] != v[name + '/traj_support_mask']).sum() == 0
+        assert (r['last_support_mask'] != v[name + '/traj_last_support_mask']).sum() == 0
+        assert np.isclose(r['final_error'], float(v[name + '/traj_final_error']), rtol=tol_e)
+        assert int(r['loop_iterations']) == int(v[name + '/traj_loop_iterations'])

@@ -100,6 +100,38 @@ def test_short_trajectory_rotation_log(emul_lib, golden_mtip16, fused, monkeypat
     PC.check_short_trajectory_vs_oracle(golden_mtip16, emul_lib, fused)
 
 
+@pytest.mark.parametrize('kind', ['bump', 'low_resolution_autocorrelation'])
+def test_initial_density_batch(emul_lib, golden_mtip16, kind):
+    PC.check_initial_density_batch(golden_mtip16, emul_lib, kind)
+
+
+def test_apply_unknowns_operator(emul_lib, golden_mtip16):
+    PC.check_apply_unknowns(golden_mtip16, emul_lib)
+
+
+def test_worker_engines_vs_single_and_oracle(emul_lib):
+    """the config-4 worker case of the GPU suite at a toy size: 4 restarts on 2 engines"""
+    PC.check_config4_worker(emul_lib, cfg=1, n_restarts=4, n_workers=2, n_hio=3, n_er=2, oracle_restarts=(0, 1), sizes=(12, 4))
+
+
+@pytest.mark.parametrize('N,L', [(20, 9), (36, 16)])
+def test_projection_newton_polar_sizes(emul_lib, N, L):
+    """Scaled-Newton polar factor (k_polar.hip) with two and three row slots per lane, one and two column groups per wave,
+    against the oracle's numpy SVD route (the 65 x 65 case, five slots / three groups, runs on the GPU)."""
+    PC.check_projection_vs_oracle(N, L, emul_lib, n_batch=1)
+
+
+def test_projection_jacobi_forced(emul_lib, monkeypatch):
+    """MTIP_POLAR=jacobi keeps the one-sided Jacobi SVD (the path of non-square X_l) selectable for square orders"""
+    monkeypatch.setenv('MTIP_POLAR', 'jacobi')
+    PC.check_projection_vs_oracle(20, 9, emul_lib, n_batch=1)
+
+
+@pytest.mark.parametrize('name', PC.VARIANT_NAMES)
+def test_loop_variants_golden(emul_lib, golden_mtip16, golden_variants, name):
+    PC.check_variant_golden(golden_mtip16, golden_variants, name, emul_lib, n_restarts=1)
+
+
 def test_wide_projection_matrices(emul_lib):
     """k_l = Nq < 2l+1 (the reference's integration test uses 8 radial points with max_order 15,
     tests/test_fxs_integration.py:326-355): polar factor of a wide matrix, compared through V_l U_l."""

@@ -111,6 +111,26 @@ def test_config3_short_trajectory_vs_oracle():
     PC.check_config_trajectory_vs_oracle(3, fused=True, n_hio=10, n_er=10)
 
 
+def test_config4_worker_three_engines_vs_single_and_oracle():
+    """128 x L32, eight distinct restarts on three engines (BASELINE config 4 as bench.py runs it on one GPU): bit-equal to
+    one engine holding all eight, restarts 0 and 5 (different engine groups) against the oracle."""
+    PC.check_config4_worker(None)
+
+
+@pytest.mark.parametrize('kind', ['bump', 'low_resolution_autocorrelation'])
+def test_initial_density_batch(golden_mtip16, kind):
+    PC.check_initial_density_batch(golden_mtip16, None, kind)
+
+
+def test_apply_unknowns_operator(golden_mtip16):
+    PC.check_apply_unknowns(golden_mtip16, None)
+
+
+@pytest.mark.parametrize('name', PC.VARIANT_NAMES)
+def test_loop_variants_golden(golden_mtip16, golden_variants, name):
+    PC.check_variant_golden(golden_mtip16, golden_variants, name, None)
+
+
 def test_config2_properties():
     PC.check_full_size_properties(2)
 

@@ -229,3 +229,13 @@ def test_G10_trajectory(golden_mtip16, golden_cfg1, which):
     assert np.isclose(res['final_error'], g['traj_final_error'], rtol=1e-3)
     assert rel_l2(res['last_deg2_invariant'], g['traj_last_deg2_invariant']) < 1e-4
     assert res['n_particles'].shape == g['traj_n_particles'].shape
+
+
+import parity_cases as _PC  # noqa: E402
+
+
+@pytest.mark.parametrize('name', _PC.VARIANT_NAMES)
+def test_G13_loop_variants(golden_mtip16, golden_variants, name):
+    """Oracle against trajectories of the reference's own loop for the *_non_FXS / SW_center schedules (stale `hist`,
+    swapped SW_center outputs) and for the main error over the reciprocal deg2 metric (G13)."""
+    _PC.check_variant_golden(golden_mtip16, golden_variants, name, use_oracle=True)

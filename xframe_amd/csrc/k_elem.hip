@@ -87,9 +87,14 @@ __global__ void __launch_bounds__(256) k_real_update(RealUpdateArgs a) {
 
 // one block per restart: finish the error reduction (fixed order -> bitwise reproducible), record it,
 // track the best pair (reconstruct.py:934-938) and rotate the pair slots.
+// main error (generate_main_error_routine, fxs_IO_methods.py:746-765): main_mode 0 = the real l2 metric itself (any
+// reduction of one value), 1 = mean / min / max / prod (main_type 0..3) over the per-order values of the reciprocal
+// deg2_invariant_l2_diff metric of this step (one entry per used order, -1 where the reference invariant vanishes).
 __global__ void __launch_bounds__(256) k_finish_step(const double* __restrict__ partial, int nblk, int* __restrict__ slot,
                                                      double* __restrict__ best_err, double* __restrict__ last_err,
-                                                     double* __restrict__ err_hist, int B, int update_slots) {
+                                                     double* __restrict__ err_hist, int B, int update_slots, int main_mode,
+                                                     int main_type, const double* __restrict__ deg2_step,
+                                                     const int* __restrict__ used, int L, double* __restrict__ main_hist) {
     __shared__ double red0[256];
     __shared__ double red1[256];
     const int b = blockIdx.x;
@@ -110,13 +115,30 @@ __global__ void __launch_bounds__(256) k_finish_step(const double* __restrict__ 
     }
     if (threadIdx.x == 0) {
         const double inf = __builtin_huge_val();
-        const double err = (red1[0] != 0.0) ? red0[0] / red1[0] : inf;    // fxs_IO_methods.py:123-126
-        err_hist[b] = err;
+        const double real_err = (red1[0] != 0.0) ? red0[0] / red1[0] : inf;    // fxs_IO_methods.py:123-126
+        err_hist[b] = real_err;
+        double err = real_err;
+        if (main_mode == 1 && update_slots) {
+            double acc = (main_type == 3) ? 1.0 : (main_type == 1 ? inf : (main_type == 2 ? -inf : 0.0));
+            int cnt = 0;
+            for (int l = 0; l <= L; ++l) {
+                if (!used[l]) continue;
+                const double v = deg2_step[(size_t)b * (L + 1) + l];
+                if (main_type == 0) acc += v;
+                else if (main_type == 1) acc = v < acc ? v : acc;
+                else if (main_type == 2) acc = v > acc ? v : acc;
+                else acc *= v;
+                ++cnt;
+            }
+            err = (main_type == 0) ? acc / (double)cnt : acc;
+            main_hist[b] = err;
+        }
         if (update_slots) {
             int* sl = slot + b * SL_N;
             last_err[b] = err;
             sl[SL_HAS_ERR] = 1;
             const int produced = sl[SL_OUT];
+            sl[SL_HIST] = sl[SL_CUR];                            // `hist` as re-read at the top of this step (reconstruct.py:913)
             sl[SL_CUR] = produced;
             if (best_err[b] > err) {
                 best_err[b] = err;
@@ -163,17 +185,22 @@ void launch_real_update(mtip_ctx* c, const double2* rho_p, const double2* prev, 
 
 void launch_finish_step(mtip_ctx* c, long long step_index, int nblk) {
     double* hist = step_index >= 0 ? c->d_err_hist + (size_t)step_index * c->B : c->d_op_err;
+    const bool loop_step = step_index >= 0;
+    const int mode = (loop_step && c->main_mode == 1) ? 1 : 0;
     hipLaunchKernelGGL(k_finish_step, dim3((unsigned)c->B), dim3(256), 0, c->stream, (const double*)c->d_partial,
-                       nblk > 0 ? nblk : c->n_partial_blocks, c->d_slot, c->d_best_err, c->d_last_err, hist, c->B, step_index >= 0 ? 1 : 0);
+                       nblk > 0 ? nblk : c->n_partial_blocks, c->d_slot, c->d_best_err, c->d_last_err, hist, c->B, loop_step ? 1 : 0,
+                       mode, c->main_type,
+                       mode ? (const double*)(c->d_deg2_hist + (size_t)step_index * c->B * (c->L + 1)) : (const double*)nullptr,
+                       (const int*)c->d_used, c->L, mode ? c->d_main_hist + (size_t)step_index * c->B : (double*)nullptr);
 }
 
-// ---- non-FXS variants: fixed = |F'_latest|  (reconstruct.py:899-902), F' = F sqrt(fixed/|F|^2) -------
+// ---- non-FXS variants: fixed = |F'| of the pair the stale `hist` ends with (reconstruct.py:899-902), F' = F sqrt(fixed/|F|^2) ----
 __global__ void __launch_bounds__(256) k_abs_to_fixed(const double2* __restrict__ Fp, const int* __restrict__ slot,
                                                       double* __restrict__ fixed, int B, long long G) {
     const int b = blockIdx.y;
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= G) return;
-    const double2 v = Fp[((size_t)slot[b * SL_N + SL_CUR] * B + b) * G + i];
+    const double2 v = Fp[((size_t)slot[b * SL_N + SL_HIST] * B + b) * G + i];    // np.abs(hist[-1][0]), reconstruct.py:901
     fixed[(size_t)b * G + i] = sqrt(cabs2(v));
 }
 

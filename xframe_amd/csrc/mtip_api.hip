@@ -55,7 +55,7 @@ void mtip_destroy(mtip_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void* ptrs[] = {c->d_cost, c->d_gw, c->d_P, c->d_r, c->d_q, c->d_poff, c->d_PT, c->d_AB, c->d_lmtab, c->d_twN, c->d_tw, c->d_W, c->d_htiles, c->d_htiles32, c->d_kl, c->d_used, c->d_active, c->d_sweeps, c->d_jsched, c->d_jsched_off, c->d_jsched_rounds, c->d_jorder, c->d_jlog, c->d_jlog_rounds, c->d_pg_tiles[0], c->d_pg_tiles[1], c->d_pg_tiles[2], c->d_pg_tiles[3], c->d_voff,
                     c->d_xoff, c->d_uoff, c->d_V, c->d_rmask, c->d_Bref, c->d_Bnorm, c->d_deg2_part, c->d_S0, c->d_sup, c->d_err_wr,
-                    c->d_err_wt, c->d_rho, c->d_Fp, c->d_slot, c->d_best_err, c->d_last_err, c->d_op_err, c->d_gq, c->d_err_hist,
+                    c->d_err_wt, c->d_rho, c->d_Fp, c->d_slot, c->d_best_err, c->d_last_err, c->d_op_err, c->d_gq, c->d_err_hist, c->d_main_hist,
                     c->d_deg2_hist, c->d_F, c->d_T1, c->d_T2, c->d_fixed, c->d_g, c->d_c[0], c->d_c[1], c->d_c[2],
                     c->d_c[3], c->d_c[4], c->d_c[5], c->d_X, c->d_Vr, c->d_U, c->d_partial, c->d_minmax, c->d_Bl};
     for (void* p : ptrs)
@@ -185,6 +185,7 @@ mtip_ctx* mtip_create(const mtip_cfg* cfg, int device) {
     A(dev_alloc(c, &c->d_gq, N));
     c->err_cap = 4096;
     A(dev_alloc(c, &c->d_err_hist, (size_t)c->err_cap * B));
+    A(dev_alloc(c, &c->d_main_hist, (size_t)c->err_cap * B));
     A(dev_alloc(c, &c->d_deg2_hist, (size_t)c->err_cap * B * (L + 1)));
     A(dev_alloc(c, &c->d_F, (size_t)B * c->G));
     A(dev_alloc(c, &c->d_T1, (size_t)B * c->G));
@@ -223,6 +224,7 @@ mtip_ctx* mtip_create(const mtip_cfg* cfg, int device) {
         slots[b * SL_N + SL_CUR] = 0;
         slots[b * SL_N + SL_OUT] = 1;
         slots[b * SL_N + SL_BEST] = 0;
+        slots[b * SL_N + SL_HIST] = 0;
         slots[b * SL_N + SL_ENFORCE] = 1;
     }
     (void)hipMemcpy(c->d_slot, slots.data(), slots.size() * sizeof(int), hipMemcpyHostToDevice);
@@ -362,6 +364,14 @@ int mtip_set_deg2_metric(mtip_ctx* c, int enable) {
     return MTIP_OK;
 }
 
+int mtip_set_main_error(mtip_ctx* c, int use_reciprocal_deg2, int type) {
+    CTX_CHECK(c);
+    if (type < 0 || type > 3) FAIL(c, MTIP_EINVAL, "main error type: 0 mean, 1 min, 2 max, 3 prod");
+    c->main_mode = use_reciprocal_deg2 ? 1 : 0;
+    c->main_type = type;
+    return MTIP_OK;
+}
+
 int mtip_set_real_constraints(mtip_ctx* c, uint32_t flags, double lo, double hi, double imag_thr, uint32_t hio_flags) {
     CTX_CHECK(c);
     c->rp.flags = flags;
@@ -431,16 +441,21 @@ static int ensure_hist(mtip_ctx* c, long long need) {
     if (need <= c->err_cap) return MTIP_OK;
     long long cap = c->err_cap;
     while (cap < need) cap *= 2;
-    double *nh = nullptr, *nd = nullptr;
+    double *nh = nullptr, *nd = nullptr, *nm = nullptr;
     int r = dev_alloc(c, &nh, (size_t)cap * c->B);
     if (r) return r;
     r = dev_alloc(c, &nd, (size_t)cap * c->B * (c->L + 1));
+    if (!r) r = dev_alloc(c, &nm, (size_t)cap * c->B);
     if (r) {
         (void)hipFree(nh);
+        if (nd) (void)hipFree(nd);
         return r;
     }
     MTIP_HIP_CHECK(c, hipStreamSynchronize(c->stream));
     MTIP_HIP_CHECK(c, hipMemcpy(nh, c->d_err_hist, (size_t)c->n_steps_done * c->B * sizeof(double), hipMemcpyDeviceToDevice));
+    MTIP_HIP_CHECK(c, hipMemcpy(nm, c->d_main_hist, (size_t)c->n_steps_done * c->B * sizeof(double), hipMemcpyDeviceToDevice));
+    (void)hipFree(c->d_main_hist);
+    c->d_main_hist = nm;
     MTIP_HIP_CHECK(c, hipMemcpy(nd, c->d_deg2_hist, (size_t)c->n_steps_done * c->B * (c->L + 1) * sizeof(double), hipMemcpyDeviceToDevice));
     (void)hipFree(c->d_err_hist);
     (void)hipFree(c->d_deg2_hist);
@@ -544,6 +559,8 @@ int mtip_run_async(mtip_ctx* c, int method, int ft_stab, int n_steps, const doub
         if (r) return r;
     }
     const bool fxs = (method == MTIP_HIO || method == MTIP_ER);
+    if (c->main_mode == 1 && !(c->deg2_enable && fxs))
+        FAIL(c, MTIP_ESTATE, "main error over deg2_invariant_l2_diff needs that metric enabled (mtip_set_deg2_metric) and an FXS method");
     if (!fxs) {
         if (!c->fixed_valid) {
             launch_abs_to_fixed(c);                  // reconstruct.py:899-902
@@ -574,6 +591,16 @@ int mtip_fetch_errors(mtip_ctx* c, int64_t first, int64_t n, double* real_err, d
         MTIP_HIP_CHECK(c, hipMemcpy(deg2_err, c->d_deg2_hist + (size_t)first * c->B * (c->L + 1),
                                     (size_t)n * c->B * (c->L + 1) * sizeof(double), hipMemcpyDeviceToHost));
     return post_launch(c, "mtip_fetch_errors");
+}
+
+int mtip_fetch_main_errors(mtip_ctx* c, int64_t first, int64_t n, double* main_err) {
+    CTX_CHECK(c);
+    if (first < 0 || n < 0 || first + n > c->n_steps_done || !main_err) FAIL(c, MTIP_EINVAL, "step range out of bounds / null output");
+    (void)hipSetDevice(c->device);
+    MTIP_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    const double* src = c->main_mode == 1 ? c->d_main_hist : c->d_err_hist;
+    if (n) MTIP_HIP_CHECK(c, hipMemcpy(main_err, src + (size_t)first * c->B, (size_t)n * c->B * sizeof(double), hipMemcpyDeviceToHost));
+    return post_launch(c, "mtip_fetch_main_errors");
 }
 
 int mtip_run(mtip_ctx* c, int method, int ft_stab, int n_steps, const double* betas, double* real_err, double* deg2_err) {
@@ -615,6 +642,7 @@ int mtip_init_state(mtip_ctx* c) {
         slots[b * SL_N + SL_CUR] = 0;
         slots[b * SL_N + SL_OUT] = 0;      // temporarily: writes below go to slot 0
         slots[b * SL_N + SL_BEST] = 0;
+        slots[b * SL_N + SL_HIST] = 0;
         slots[b * SL_N + SL_HAS_ERR] = 0;
     }
     MTIP_HIP_CHECK(c, hipMemcpy(c->d_slot, slots.data(), slots.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -720,6 +748,7 @@ int mtip_select_best_where(mtip_ctx* c, const uint8_t* select) {
         if (select != nullptr && !select[b]) continue;
         int* s = &slots[(size_t)b * SL_N];
         s[SL_CUR] = s[SL_BEST];
+        s[SL_HIST] = s[SL_BEST];
         s[SL_SUP] = s[SL_SUP_BEST];
         int nxt = 0;
         while (nxt == s[SL_CUR] || nxt == s[SL_BEST]) ++nxt;
@@ -770,31 +799,53 @@ int mtip_shrinkwrap(mtip_ctx* c, double sigma, double threshold, double error_li
     return MTIP_OK;
 }
 
+int mtip_begin_sub_loop(mtip_ctx* c) {
+    CTX_CHECK(c);
+    (void)hipSetDevice(c->device);
+    // reconstruct.py:859, 866: `hist` is read from the state and latest_intensity reset at the top of every sub-loop call
+    std::vector<int> slots((size_t)c->B * SL_N);
+    MTIP_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    MTIP_HIP_CHECK(c, hipMemcpy(slots.data(), c->d_slot, slots.size() * sizeof(int), hipMemcpyDeviceToHost));
+    for (int b = 0; b < c->B; ++b) slots[(size_t)b * SL_N + SL_HIST] = slots[(size_t)b * SL_N + SL_CUR];
+    MTIP_HIP_CHECK(c, hipMemcpy(c->d_slot, slots.data(), slots.size() * sizeof(int), hipMemcpyHostToDevice));
+    c->fixed_valid = false;
+    return MTIP_OK;
+}
+
 int mtip_refresh_reciprocal_density(mtip_ctx* c) {
     CTX_CHECK(c);
     int r = require_loop(c);
     if (r) return r;
     (void)hipSetDevice(c->device);
-    // new pair in the OUT slot (the best pair may share the CUR slot): rho copy + FT(rho), then CUR <- OUT
+    // The reference's SW_center process returns (support, copy(rho), FT(rho)) and the loop unpacks it as
+    // (support, ft_density, density) (reconstruct.py:606-613, 891): the pair appended to the history is (rho, FT(rho)) --
+    // its "real" half is FT(rho).  The new history is hist[1:] + (pair,) with the stale `hist` (893): everything after the
+    // pair `hist` ends with (SL_HIST) is dropped.  So the new pair overwrites the latest pair in place when that one was
+    // produced after `hist` was read and is not the best pair, else it takes the slot that holds neither SL_HIST nor the
+    // best pair.
     std::vector<int> slots((size_t)c->B * SL_N);
     MTIP_HIP_CHECK(c, hipStreamSynchronize(c->stream));
     MTIP_HIP_CHECK(c, hipMemcpy(slots.data(), c->d_slot, slots.size() * sizeof(int), hipMemcpyDeviceToHost));
-    for (int b = 0; b < c->B; ++b) {
-        const int cur = slots[(size_t)b * SL_N + SL_CUR], out = slots[(size_t)b * SL_N + SL_OUT];
-        MTIP_HIP_CHECK(c, hipMemcpyAsync(c->d_rho + ((size_t)out * c->B + b) * c->G, c->d_rho + ((size_t)cur * c->B + b) * c->G,
-                                         c->G * sizeof(double2), hipMemcpyDeviceToDevice, c->stream));
-    }
-    InvEpilogue to_slot;
-    to_slot.out_slot = SL_OUT;
-    ft_pipeline(c, c->d_rho, SL_CUR, c->d_Fp, 0, MTIP_PRE_NONE, to_slot, c->d_c[0], c->d_c[1]);
-    MTIP_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    InvEpilogue store;
+    ft_pipeline(c, c->d_rho, SL_CUR, c->d_T1, 0, MTIP_PRE_NONE, store, c->d_c[0], c->d_c[1]);
     for (int b = 0; b < c->B; ++b) {
         int* s = slots.data() + (size_t)b * SL_N;
-        s[SL_CUR] = s[SL_OUT];
+        const int cur = s[SL_CUR], hist = s[SL_HIST], best = s[SL_BEST];
+        int t = cur;
+        if (cur == hist || cur == best) {
+            t = 0;
+            while (t == hist || t == best) ++t;
+        }
+        MTIP_HIP_CHECK(c, hipMemcpyAsync(c->d_Fp + ((size_t)t * c->B + b) * c->G, c->d_rho + ((size_t)cur * c->B + b) * c->G,
+                                         c->G * sizeof(double2), hipMemcpyDeviceToDevice, c->stream));
+        MTIP_HIP_CHECK(c, hipMemcpyAsync(c->d_rho + ((size_t)t * c->B + b) * c->G, c->d_T1 + (size_t)b * c->G,
+                                         c->G * sizeof(double2), hipMemcpyDeviceToDevice, c->stream));
+        s[SL_CUR] = t;
         int f = 0;
         while (f == s[SL_CUR] || f == s[SL_BEST]) ++f;
         s[SL_OUT] = f;
     }
+    MTIP_HIP_CHECK(c, hipStreamSynchronize(c->stream));
     MTIP_HIP_CHECK(c, hipMemcpy(c->d_slot, slots.data(), slots.size() * sizeof(int), hipMemcpyHostToDevice));
     return post_launch(c, "mtip_refresh_reciprocal_density");
 }

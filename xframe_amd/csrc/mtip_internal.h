@@ -39,7 +39,10 @@ __device__ __forceinline__ double2 cmul_ipow(double2 a, int l, int sign) {
 }
 
 // ---- per-restart slot table (device ints), see DESIGN.md "state" ---------------------------------
-enum { SL_CUR = 0, SL_OUT = 1, SL_BEST = 2, SL_SUP = 3, SL_SUP_BEST = 4, SL_ENFORCE = 5, SL_HAS_ERR = 6, SL_N = 8 };
+// SL_HIST: the pair the reference's stale local `hist` ends with (reconstruct.py:859, 913): the input pair of the most
+// recent step, or the latest pair when no step has run in the current sub-loop call; read by SW_center (893) and by the
+// fixed amplitudes of the *_non_FXS variants (901)
+enum { SL_CUR = 0, SL_OUT = 1, SL_BEST = 2, SL_SUP = 3, SL_SUP_BEST = 4, SL_ENFORCE = 5, SL_HAS_ERR = 6, SL_HIST = 7, SL_N = 8 };
 
 // real-space constraint flags (mtip_set_real_constraints)
 enum { RC_SUPPORT = 1, RC_VALUE_LO = 2, RC_VALUE_HI = 4, RC_LIMIT_IMAG = 8 };
@@ -183,7 +186,9 @@ struct mtip_ctx {
     double *d_best_err = nullptr, *d_last_err = nullptr;   // (B)
     double* d_op_err = nullptr;                       // (B) error of the single-operator entry point (never the loop's)
     double* d_gq = nullptr;                           // (Nq) shrink-wrap Gaussian G_sigma(q)
-    double* d_err_hist = nullptr;                     // (cap, B)
+    double* d_err_hist = nullptr;                     // (cap, B) real l2 metric per step
+    double* d_main_hist = nullptr;                    // (cap, B) main error per step when it is not the real metric (main_mode 1)
+    int main_mode = 0, main_type = 0;                 // mtip_set_main_error
     double* d_deg2_hist = nullptr;                    // (cap, B, L+1)
     long long err_cap = 0, n_steps_done = 0;
     bool state_ready = false, fixed_valid = false;

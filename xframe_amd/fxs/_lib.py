@@ -43,6 +43,7 @@ _SIGNATURES = {
     'mtip_set_projection_matrix': (C.c_int, [c_void, C.c_int, c_void, C.c_int, c_void, C.c_int]),
     'mtip_set_number_of_particles': (C.c_int, [c_void, C.c_double]),
     'mtip_set_deg2_metric': (C.c_int, [c_void, C.c_int]),
+    'mtip_set_main_error': (C.c_int, [c_void, C.c_int, C.c_int]),
     'mtip_set_real_constraints': (C.c_int, [c_void, C.c_uint32, C.c_double, C.c_double, C.c_double, C.c_uint32]),
     'mtip_set_initial_support': (C.c_int, [c_void, c_void]),
     'mtip_set_error_weights': (C.c_int, [c_void, c_void, c_void, C.c_int]),
@@ -59,7 +60,9 @@ _SIGNATURES = {
     'mtip_run': (C.c_int, [c_void, C.c_int, C.c_int, C.c_int, c_void, c_void, c_void]),
     'mtip_run_async': (C.c_int, [c_void, C.c_int, C.c_int, C.c_int, c_void]),
     'mtip_fetch_errors': (C.c_int, [c_void, C.c_int64, C.c_int64, c_void, c_void]),
+    'mtip_fetch_main_errors': (C.c_int, [c_void, C.c_int64, C.c_int64, c_void]),
     'mtip_shrinkwrap': (C.c_int, [c_void, C.c_double, C.c_double, C.c_double, c_void]),
+    'mtip_begin_sub_loop': (C.c_int, [c_void]),
     'mtip_refresh_reciprocal_density': (C.c_int, [c_void]),
     'mtip_last_deg2_invariant': (C.c_int, [c_void, C.c_int, c_void]),
     'mtip_op_sht_forward': (C.c_int, [c_void, c_void, c_void, C.c_int]),

@@ -97,6 +97,25 @@ class Engine:
         self._ck(self.lib.mtip_set_error_weights(self.ctx, _lib.ptr(_lib.as_f64(wr)), _lib.ptr(_lib.as_f64(wt)), int(use_mask)))
         self.deg2_enabled = 'deg2_invariant_l2_diff' in em['reciprocal']['calculate']
         self._ck(self.lib.mtip_set_deg2_metric(self.ctx, int(self.deg2_enabled)))
+        # generate_main_error_routine, fxs_IO_methods.py:746-765
+        main = em.get('main', {'metrics': {'real': ['l2_projection_diff'], 'reciprocal': []}, 'type': 'mean'})
+        real_m, rec_m = list(main['metrics'].get('real', [])), list(main['metrics'].get('reciprocal', []))
+        types = {'mean': 0, 'min': 1, 'max': 2, 'prod': 3}
+        if main.get('type', 'mean') not in types:
+            raise ValueError('main error type %r (mean / min / max / prod)' % (main.get('type'),))
+        if real_m == ['l2_projection_diff'] and not rec_m:
+            self.main_is_reciprocal = False
+        elif not real_m and rec_m == ['deg2_invariant_l2_diff']:
+            if not self.deg2_enabled:
+                raise KeyError("main error uses 'deg2_invariant_l2_diff' but main_loop.error.methods.reciprocal.calculate does not list it")
+            self.main_is_reciprocal = True
+        elif real_m == ['l2_projection_diff'] and rec_m == ['deg2_invariant_l2_diff']:
+            raise NotImplementedError('main error over l2_projection_diff (a scalar) AND deg2_invariant_l2_diff (one value per order): the '
+                                      'reference itself raises there (np.array of an inhomogeneous list, fxs_IO_methods.py:760)')
+        else:
+            raise NotImplementedError('main error metrics %r / %r: only l2_projection_diff and deg2_invariant_l2_diff are on the '
+                                      'accelerated path' % (real_m, rec_m))
+        self._ck(self.lib.mtip_set_main_error(self.ctx, int(self.main_is_reciprocal), types[main.get('type', 'mean')]))
 
     def autocorrelation_guess(self):
         """reconstruct.py:400-420: ift(icht(V_l padded)).real"""
@@ -272,13 +291,22 @@ class Engine:
         self._ck(self.lib.mtip_fetch_errors(self.ctx, first, n, _lib.ptr(err), _lib.ptr(deg2)))
         return err, deg2
 
+    def fetch_main_errors(self, first, n):
+        err = np.empty((n, self.B))
+        self._ck(self.lib.mtip_fetch_main_errors(self.ctx, first, n, _lib.ptr(err)))
+        return err
+
     def shrinkwrap(self, sigma, threshold, error_limit):
         enforced = np.empty(self.B, np.uint8)
         self._ck(self.lib.mtip_shrinkwrap(self.ctx, float(sigma), float(threshold), float(error_limit), _lib.ptr(enforced)))
         return enforced.astype(bool)
 
+    def begin_sub_loop(self):
+        """top of a sub-loop call (reconstruct.py:859, 866): stale `hist` and latest_intensity are reset"""
+        self._ck(self.lib.mtip_begin_sub_loop(self.ctx))
+
     def refresh_reciprocal_density(self):
-        """'SW_center' tail (reconstruct.py:893-894): the last pair becomes (FT(rho), rho)."""
+        """'SW_center' tail (reconstruct.py:891-894), literally: the last pair becomes (reciprocal, real) = (rho, FT(rho))."""
         self._ck(self.lib.mtip_refresh_reciprocal_density(self.ctx))
 
     def last_deg2_invariant(self, batch):

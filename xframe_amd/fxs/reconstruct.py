@@ -167,9 +167,6 @@ class MTIP:
         e = self.engine
         B = self.n_restarts
         opt = self.opt
-        main_cfg = opt['main_loop']['error']['methods']['main']
-        if list(main_cfg['metrics']['real']) != ['l2_projection_diff'] or list(main_cfg['metrics']['reciprocal']):
-            raise NotImplementedError('main error metric other than real l2_projection_diff')
         t_setup = time.perf_counter()
         # all guesses first: the autocorrelation guess runs transforms on the engine, whose single-operator entry
         # points use the same device scratch that mtip_set_density stages the guesses in
@@ -198,6 +195,7 @@ class MTIP:
         best_iter_h = np.zeros(B, int)
         for loop_number, loop_name in enumerate(loops['order']):
             lo = loops[loop_name]
+            e.begin_sub_loop()
             loop_first_step = n_steps
             step_iteration = []
             methods = {}
@@ -221,8 +219,8 @@ class MTIP:
                         self._update_shrink_wrap(sw_step, loop_number)
                         continue
                     if key == 'SW_center':
-                        # reconstruct.py:886-897: one enforce decision, then `iterations` support updates, each
-                        # handing back (FT(rho), rho) as the last pair (the sketch, 606-613, shifts nothing)
+                        # reconstruct.py:886-897: one enforce decision, then `iterations` support updates, each replacing
+                        # the last pair (the sketch, 606-613, shifts nothing and hands its outputs back in swapped order)
                         for i in range(methods[key]['iterations']):
                             enforced = e.shrinkwrap(self.sw_sigma, self.sw_threshold, limit)
                             if i == 0:
@@ -239,7 +237,7 @@ class MTIP:
                     n_steps += repeats
                     step_iteration += [iteration] * repeats
             if track_best and n_steps > loop_first_step:
-                errs, _ = e.fetch_errors(loop_first_step, n_steps - loop_first_step)
+                errs = e.fetch_main_errors(loop_first_step, n_steps - loop_first_step)
                 for i, it in enumerate(step_iteration):
                     better = best_err_h > errs[i]
                     best_err_h = np.where(better, errs[i], best_err_h)
@@ -260,6 +258,7 @@ class MTIP:
     def _generate_output(self, iterations, initial_density, initial_mask, n_steps):
         e = self.engine
         real_err, deg2 = e.fetch_errors(0, n_steps)
+        main_err = e.fetch_main_errors(0, n_steps)
         best_err, _ = e.best_error()
         masked_pm = []
         for l in range(e.L + 1):
@@ -290,7 +289,7 @@ class MTIP:
             # last_deg2_invariant of the modified last density (reconstruct.py:993)
             last_deg2 = e.deg2_invariants(e.sht_forward(e.fourier_transform(real[False]), 1))
         for b in range(self.n_restarts):
-            err = {'main': real_err[:, b].copy(),
+            err = {'main': main_err[:, b].copy(),
                    'real': {'l2_projection_diff': real_err[:, b].copy()},
                    'reciprocal': ({'deg2_invariant_l2_diff': deg2[:, b][:, order_array].copy()} if deg2 is not None else {})}
             out[b] = {
