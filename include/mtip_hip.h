@@ -190,6 +190,10 @@ int mtip_profile_reset(mtip_ctx* ctx);
 /* diagnostic of the last polar-factor solve, (n_batch, L+1) int32: bits 0-7 Jacobi sweeps used, bits 8+ the
  * number of columns of X_l that were still non-zero (not deflated) in the final sweep */
 int mtip_debug_jacobi_sweeps(mtip_ctx* ctx, int32_t* out);
+/* diagnostic: phase timers of the Newton polar-factor kernel, (n_batch, L+1, 8 waves, 4) int64 shader cycles of the last
+ * projection: producing records, waiting for records, applying them, whole kernel.  The first call (out may be NULL)
+ * switches the timers on. */
+int mtip_debug_polar_timing(mtip_ctx* ctx, int64_t* out);
 /* diagnostic: build and verify the resident-column pairing schedule of the polar-factor kernel for every column
  * count 2..k_max <= 127 (every pair exactly once per sweep, no column twice in a round); MTIP_OK or MTIP_EINVAL */
 int mtip_debug_check_jacobi_schedule(mtip_ctx* ctx, int k_max);

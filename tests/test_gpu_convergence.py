@@ -58,6 +58,8 @@ def test_converged_runs_match_oracle_distribution():
     scat_h = np.median([np.abs(p - mean_h).sum() / mean_h.sum() for p in prof])
     scat_o = np.median([np.abs(p - mean_o).sum() / mean_o.sum() for p in f['profile']])
     print('radial profile: mean HIP vs mean oracle L1 %.3f; scatter HIP %.3f oracle %.3f' % (dev, scat_h, scat_o))
+    print('first 20 error values vs the oracle run of the same seed: max rel deviation per restart',
+          np.array2string(np.abs(first / f['first_errors'][:n] - 1).max(1), precision=1))
     assert len(res[0]['error_dict']['main']) == 600
     assert np.allclose(first, f['first_errors'], rtol=1e-6)
     assert 0.5 <= np.median(final) / np.median(f['final_error']) <= 2.0

@@ -6,17 +6,18 @@
 //
 // The inverse is an in-place Gauss-Jordan elimination with partial (row) pivoting, organised as a dataflow inside the
 // workgroup instead of barrier-separated rounds:
-//   * the matrix lives in registers: a wave owns a contiguous panel of column groups, a group = 4 columns x 16 S rows,
-//     lane = (row & 15) + 16 (column & 3), S row slots per lane -- 80 x 68 register slots for the 65 x 65 matrix of
-//     l = 32 (a lane-per-row layout would spend two full slots on 65 rows);
-//   * step k is published by the wave that owns column k as one LDS record {column k, pivot row p, 1 / pivot}; every
-//     wave consumes the records in order and applies the rank-1 update to its own columns, taking the pivot-row values of
-//     its columns from its own registers (one ds_bpermute pair per group) -- a step needs no barrier, the only
-//     synchronisation is the record flag (LDS operations of one wave complete in order, the flag is written last);
-//   * while a wave owns the pivot columns (its panel) it produces record k + 1 as soon as it has applied record k to
-//     its own columns; the other waves trail it by the latency of one record;
-//   * the pivot search compares the high words of |a|^2 with the row index in the low mantissa bits, so that the
-//     16-lane maximum is four v_max_u32 with DPP row operands.
+//   * the matrix lives in registers, lane = row (S = 1 or 2 row slots of 64), a wave owns a contiguous panel of columns;
+//   * step k is published by the wave that owns column k as one LDS record {pivot row p, f' = column k / pivot}; every
+//     wave consumes the records in order and applies the rank-1 update a_ij -= f'_i a_pj to its own columns: f' is lane
+//     aligned (one ds_read_b128 per slot), a_pj is a v_readlane of the wave's own registers -- no LDS round trip, no
+//     barrier; the only synchronisation is the record flag (LDS operations of one wave complete in order, the flag is
+//     written last);
+//   * while a wave owns the pivot columns (its panel) nothing on its critical path touches LDS: pivot search, 1 / pivot,
+//     f', update of its own columns from registers, next pivot search; the other waves trail it by one record;
+//   * the record carries f'_p = 1 - 1/pivot on the pivot row, so the same update scales that row (no row select in the
+//     consumers); column k of the inverse (-f', 1/pivot at row p) is set by its owner;
+//   * the pivot search compares the high words of |a|^2 with the row index in the low mantissa bits: four v_max_u32
+//     with DPP row operands, four v_readlane and three s_max_u32.
 // Pivot rows are not moved: the permutation is undone together with the conjugate transpose of the Newton update, in one
 // scatter through LDS.
 #include "mtip_internal.h"
@@ -24,14 +25,13 @@
 #define PN_THREADS 512
 #define PN_WAVES 8
 #define PN_MAXIT 16
-#define PN_MAXN 80                  // 5 row slots of 16
-#define PN_FIXED 4096               // bytes in front of the record area: headers, permutation, reduction scratch
+#define PN_MAXN 72                  // 9 columns per wave, 2 row slots
+#define PN_FIXED 2048               // bytes in front of the record area: headers, permutation, reduction scratch
 #define PN_TOL2 1e-14               // stop when |Z_new - Z|_F^2 < PN_TOL2 |Z_new|_F^2 (quadratic convergence: Z_new is then exact to ~1e-14)
 #define PN_UNSCALED2 1e-4           // below this relative change the scaling is switched off (Higham's criterion)
 
-struct __align__(16) PnHdr {
-    int flag, p, pad0, pad1;
-    double inv_re, inv_im;
+struct PnHdr {
+    int flag, p;
 };
 
 __device__ __forceinline__ double pn_rcp(double x) {
@@ -41,19 +41,21 @@ __device__ __forceinline__ double pn_rcp(double x) {
     return y;
 }
 
-// maximum over the 16 lanes of a DPP row (every lane of the row gets it)
-__device__ __forceinline__ unsigned pn_row16_max(unsigned v) {
+// maximum over the wave: DPP butterflies inside the rows of 16, then the four rows through the scalar unit (uniform result)
+__device__ __forceinline__ unsigned pn_wave_max(unsigned v) {
     v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
     v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, false));    // quad_perm [2,3,0,1]
     v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, false));   // row_half_mirror
     v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xf, 0xf, false));   // row_mirror
-    return v;
+    const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)v, 0), b = (unsigned)__builtin_amdgcn_readlane((int)v, 16);
+    const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)v, 32), d = (unsigned)__builtin_amdgcn_readlane((int)v, 48);
+    return max(max(a, b), max(c, d));
 }
 
-__device__ __forceinline__ double pn_readlane(double v, int src) {
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
-    return __hiloint2double(hi, lo);
+__device__ __forceinline__ double2 pn_readlane2(double2 v, int src) {
+    const int xl = __builtin_amdgcn_readlane(__double2loint(v.x), src), xh = __builtin_amdgcn_readlane(__double2hiint(v.x), src);
+    const int yl = __builtin_amdgcn_readlane(__double2loint(v.y), src), yh = __builtin_amdgcn_readlane(__double2hiint(v.y), src);
+    return make_double2(__hiloint2double(xh, xl), __hiloint2double(yh, yl));
 }
 
 // sums of NV values over the workgroup, in a fixed order (deterministic); every thread gets the totals
@@ -75,45 +77,61 @@ __device__ __forceinline__ void pn_block_sum(double (&v)[NV], double* red) {
     __syncthreads();
 }
 
-// S: row slots per lane (n <= 16 S), GM: column groups per wave (ceil(ceil(n / 4) / 8) <= GM)
-template <int S, int GM>
-__device__ void pn_body(const double2* __restrict__ X, double2* __restrict__ U, int n, unsigned char* smem, int* diag) {
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, lc = lane >> 4;
+// a_ij -= f'_i a_pj for the columns of this wave (SP: slot of the pivot row, a compile-time constant inside the uniform branch)
+template <int S, int CM, int SP>
+__device__ __forceinline__ void pn_apply(double2 (&A)[CM][S], const double2 (&fp)[S], int nc, int skip, int lp) {
+#pragma unroll
+    for (int c = 0; c < CM; ++c) {
+        if (c < nc && c != skip) {
+            const double2 raw = pn_readlane2(A[c][SP], lp);
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                A[c][s].x = fma(-fp[s].x, raw.x, fma(fp[s].y, raw.y, A[c][s].x));
+                A[c][s].y = fma(-fp[s].x, raw.y, fma(-fp[s].y, raw.x, A[c][s].y));
+            }
+        }
+    }
+}
+
+// S: row slots of 64 per lane (n <= 64 S), CM: columns per wave (ceil(n / 8) <= CM)
+template <int S, int CM>
+__device__ void pn_body(const double2* __restrict__ X, double2* __restrict__ U, int n, unsigned char* smem, int* diag, long long* dbg) {
+    // the wave index through readfirstlane: the compiler then knows that everything derived from it (ownership of a
+    // column, the column range) is wave-uniform and emits scalar branches instead of exec masks and per-lane selects
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     PnHdr* hdr = reinterpret_cast<PnHdr*>(smem);                          // [PN_MAXN]
     int* prow = reinterpret_cast<int*>(smem + PN_MAXN * sizeof(PnHdr));   // [PN_MAXN] pivot row of step k
     int* rowstep = prow + PN_MAXN;                                        // [PN_MAXN] step at which row i was the pivot row
-    double* red = reinterpret_cast<double*>(rowstep + PN_MAXN);           // [PN_WAVES * 4]
-    double2* recs = reinterpret_cast<double2*>(smem + PN_FIXED);          // [n][16 S] column k as published at step k
-    double2* stage = recs;                                                // [n][ld] aliases the records between two inversions
-    const int ld = (n < 16 * S) ? n + 1 : n;
-    const int NG = (n + 3) >> 2, base = NG / PN_WAVES, rem = NG % PN_WAVES;
-    const int ng = base + (wave < rem ? 1 : 0);                           // column groups of this wave
-    const int g0 = wave * base + min(wave, rem);                          // first of them
+    double* red = reinterpret_cast<double*>(rowstep + PN_MAXN);           // [PN_WAVES * 2]
+    double2* recs = reinterpret_cast<double2*>(smem + PN_FIXED);          // [n][n] f' of step k
+    double2* stage = recs;                                                // [n][n] aliases the records between two inversions
+    const int base = n / PN_WAVES, rem = n % PN_WAVES;
+    const int nc = base + (wave < rem ? 1 : 0);                           // columns of this wave
+    const int c0 = wave * base + min(wave, rem);                          // first of them
     for (int k = tid; k < PN_MAXN; k += PN_THREADS) hdr[k].flag = 0;
 
-    double2 A[GM][S], Z[GM][S];
+    double2 A[CM][S], Z[CM][S];
     double nrm[1] = {0.0};
 #pragma unroll
-    for (int g = 0; g < GM; ++g) {
-        const int j = 4 * (g0 + g) + lc;
+    for (int c = 0; c < CM; ++c) {
+        const int j = c0 + c;
 #pragma unroll
         for (int s = 0; s < S; ++s) {
-            const int i = 16 * s + lr;
-            const bool ok = (g < ng) && (i < n) && (j < n);
-            Z[g][s] = ok ? X[(size_t)j * n + i] : make_double2(0.0, 0.0);
-            nrm[0] += cabs2(Z[g][s]);
+            const int i = 64 * s + lane;
+            const bool ok = (c < nc) && (i < n);
+            Z[c][s] = ok ? X[(size_t)j * n + i] : make_double2(0.0, 0.0);
+            nrm[0] += cabs2(Z[c][s]);
         }
     }
     pn_block_sum<1>(nrm, red);                                            // (also orders the flag reset before the first record)
     double zn2 = nrm[0];
     if (!(zn2 > 0.0) || !(zn2 < __builtin_huge_val())) {                  // X = 0 (or not finite): U = 0, like 1/sigma -> 0 of the SVD route
 #pragma unroll
-        for (int g = 0; g < GM; ++g) {
-            const int j = 4 * (g0 + g) + lc;
+        for (int c = 0; c < CM; ++c) {
 #pragma unroll
             for (int s = 0; s < S; ++s) {
-                const int i = 16 * s + lr;
-                if ((g < ng) && (i < n) && (j < n)) U[(size_t)j * n + i] = make_double2(0.0, 0.0);
+                const int i = 64 * s + lane;
+                if ((c < nc) && (i < n)) U[(size_t)(c0 + c) * n + i] = make_double2(0.0, 0.0);
             }
         }
         if (tid == 0) *diag = (n << 8);
@@ -122,155 +140,147 @@ __device__ void pn_body(const double2* __restrict__ X, double2* __restrict__ U, 
     {
         const double sc = 1.0 / sqrt(zn2);                                // the polar factor does not depend on the scale of X
 #pragma unroll
-        for (int g = 0; g < GM; ++g)
+        for (int c = 0; c < CM; ++c)
 #pragma unroll
-            for (int s = 0; s < S; ++s) Z[g][s] = cscale(Z[g][s], sc);
+            for (int s = 0; s < S; ++s) Z[c][s] = cscale(Z[c][s], sc);
         zn2 = 1.0;
     }
 
+    // diagnostic phase timers (dbg != nullptr only through mtip_debug_polar_timing): cycles of this wave spent producing
+    // records, waiting for records, applying them, and in the whole kernel
+    long long t_prod = 0, t_wait = 0, t_cons = 0, t_all = dbg ? clock64() : 0;
     bool unscaled = false;
     int it = 1;
     for (; it <= PN_MAXIT; ++it) {
         // ---------------------------------------------------------------- A <- Z^-1 in place (rows stay where they are)
 #pragma unroll
-        for (int g = 0; g < GM; ++g)
+        for (int c = 0; c < CM; ++c)
 #pragma unroll
-            for (int s = 0; s < S; ++s) A[g][s] = Z[g][s];
-        unsigned rowdone = 0;                                              // bit s: row 16 s + lr has been a pivot row
+            for (int s = 0; s < S; ++s) A[c][s] = Z[c][s];
+        unsigned rowdone = 0;                                              // bit s: row 64 s + lane has been a pivot row
         const double floor2 = 1e-40 * zn2;                                 // pivots below 1e-20 |Z|_F count as that (singular X_l)
-        if (ng > 0) {
+        if (nc > 0) {
             for (int k = 0; k < n; ++k) {
-                const int gk = k >> 2, cr = k & 3;
-                const int ow = (gk < rem * (base + 1)) ? gk / (base + 1) : rem + (gk - rem * (base + 1)) / max(base, 1);
-                const int gl = gk - g0;                                    // local group of column k (owner only)
-                if (ow == wave) {
-                    // ---- produce record k: pivot search in column k (rows not used yet), publish column and pivot
+                const int ow = (k < rem * (base + 1)) ? k / (base + 1) : rem + (k - rem * (base + 1)) / max(base, 1);
+                const bool own = (ow == wave);
+                const int ck = k - c0;                                     // local index of column k (owner only)
+                double2 fp[S];
+                int p;
+                long long t0 = dbg ? clock64() : 0, t1 = 0, t2 = 0;
+                if (own) {
+                    // ---- produce record k: pivot search in column k (rows not used yet), f' = column / pivot
+                    double2 col[S];
+#pragma unroll
+                    for (int s = 0; s < S; ++s) col[s] = make_double2(0.0, 0.0);
+#pragma unroll
+                    for (int c = 0; c < CM; ++c)
+                        if (c == ck) {
+#pragma unroll
+                            for (int s = 0; s < S; ++s) col[s] = A[c][s];
+                        }
                     unsigned key = 0;
 #pragma unroll
-                    for (int g = 0; g < GM; ++g) {
-                        if (g == gl) {
-#pragma unroll
-                            for (int s = 0; s < S; ++s) {
-                                const int i = 16 * s + lr;
-                                const double m2 = fma(A[g][s].x, A[g][s].x, A[g][s].y * A[g][s].y);
-                                const unsigned ks = 0x80000000u | (((unsigned)__double2hiint(m2) >> 1) & 0x3FFFFF80u) | (unsigned)i;
-                                const bool ok = (lc == cr) && (i < n) && !((rowdone >> s) & 1u);
-                                key = max(key, ok ? ks : 0u);
-                            }
-                        }
+                    for (int s = 0; s < S; ++s) {
+                        const int i = 64 * s + lane;
+                        const double m2 = fma(col[s].x, col[s].x, col[s].y * col[s].y);
+                        const unsigned ks = 0x80000000u | (((unsigned)__double2hiint(m2) >> 1) & 0x3FFFFF80u) | (unsigned)i;
+                        const bool ok = (i < n) && !((rowdone >> s) & 1u);
+                        key = max(key, ok ? ks : 0u);
                     }
-                    key = pn_row16_max(key);
-                    const int p = __builtin_amdgcn_readlane((int)key, 16 * cr) & 127;
-                    const int sp = p >> 4, lp = p & 15;
-                    double2 cand = make_double2(0.0, 0.0);
-#pragma unroll
-                    for (int g = 0; g < GM; ++g)
-                        if (g == gl) {
-#pragma unroll
-                            for (int s = 0; s < S; ++s)
-                                if (s == sp) cand = A[g][s];
-                        }
-                    double pr = pn_readlane(cand.x, 16 * cr + lp), pi = pn_readlane(cand.y, 16 * cr + lp);
-                    double d = fma(pr, pr, pi * pi);
+                    p = (int)(pn_wave_max(key) & 127u);
+                    const int lp = p & 63;
+                    double2 piv = pn_readlane2(col[0], lp);
+                    if (S > 1 && p >= 64) piv = pn_readlane2(col[S - 1], lp);
+                    double d = fma(piv.x, piv.x, piv.y * piv.y);
                     if (!(d >= floor2)) {
-                        pr = sqrt(floor2);
-                        pi = 0.0;
+                        piv = make_double2(sqrt(floor2), 0.0);
                         d = floor2;
                     }
                     const double rd = pn_rcp(d);
-                    const double2 inv = make_double2(pr * rd, -pi * rd);
-                    // the record carries piv - 1 on the pivot row: the generic update a_pj - (piv - 1) a_pj / piv = a_pj / piv
-                    // then scales that row without a row select in the consumers
+                    const double2 inv = make_double2(piv.x * rd, -piv.y * rd);
 #pragma unroll
-                    for (int g = 0; g < GM; ++g) {
-                        if (g == gl && lc == cr) {
-#pragma unroll
-                            for (int s = 0; s < S; ++s) {
-                                double2 v = A[g][s];
-                                if (s == sp && lr == lp) v = make_double2(pr - 1.0, pi);
-                                recs[(size_t)k * (16 * S) + 16 * s + lr] = v;
-                                A[g][s] = make_double2(0.0, 0.0);          // column k of the inverse starts from zero
-                            }
-                        }
+                    for (int s = 0; s < S; ++s) {
+                        const int i = 64 * s + lane;
+                        fp[s] = cmul(col[s], inv);
+                        if (i == p) fp[s] = make_double2(1.0 - inv.x, -inv.y);   // a_pj - (1 - 1/piv) a_pj = a_pj / piv
+                        if (i < n) recs[(size_t)k * n + i] = fp[s];
+                        col[s] = (i == p) ? inv : make_double2(-fp[s].x, -fp[s].y);   // column k of the inverse
+                        if (i >= n) col[s] = make_double2(0.0, 0.0);
                     }
                     if (lane == 0) {
                         hdr[k].p = p;
-                        hdr[k].inv_re = inv.x;
-                        hdr[k].inv_im = inv.y;
                         prow[k] = p;
                         rowstep[p] = k;
                         __hip_atomic_store(&hdr[k].flag, it, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
-                }
-                // ---- consume record k: rank-1 update of the own columns
-                while (__hip_atomic_load(&hdr[k].flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != it) __builtin_amdgcn_s_sleep(1);
-                const int p = __builtin_amdgcn_readfirstlane(hdr[k].p);
-                const double2 inv = make_double2(hdr[k].inv_re, hdr[k].inv_im);
-                const int sp = p >> 4, lp = p & 15;
-                double2 f[S];
 #pragma unroll
-                for (int s = 0; s < S; ++s) f[s] = recs[(size_t)k * (16 * S) + 16 * s + lr];
-                const int srcl = (lane & 48) | lp;
+                    for (int c = 0; c < CM; ++c)
+                        if (c == ck) {
 #pragma unroll
-                for (int g = 0; g < GM; ++g) {
-                    if (g < ng) {
-                        double2 raw = A[g][0];
-#pragma unroll
-                        for (int s = 1; s < S; ++s)
-                            if (s == sp) raw = A[g][s];
-                        raw.x = __shfl(raw.x, srcl);
-                        raw.y = __shfl(raw.y, srcl);
-                        double2 r = cmul(raw, inv);
-                        const bool mine = (ow == wave) && (g == gl) && (lc == cr);   // column k itself: a_ik <- -f_i / piv
-                        if (mine) r = inv;
-#pragma unroll
-                        for (int s = 0; s < S; ++s) {
-                            A[g][s].x = fma(-f[s].x, r.x, fma(f[s].y, r.y, A[g][s].x));
-                            A[g][s].y = fma(-f[s].x, r.y, fma(-f[s].y, r.x, A[g][s].y));
-                            if (mine && s == sp && lr == lp) A[g][s] = inv;   // ... and a_pk <- 1 / piv exactly
+                            for (int s = 0; s < S; ++s) A[c][s] = col[s];
                         }
+                    t1 = t2 = dbg ? clock64() : 0;
+                } else {
+                    // ---- wait for record k
+                    t1 = dbg ? clock64() : 0;
+                    while (__hip_atomic_load(&hdr[k].flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != it) __builtin_amdgcn_s_sleep(1);
+                    t2 = dbg ? clock64() : 0;
+                    p = __builtin_amdgcn_readfirstlane(hdr[k].p);
+#pragma unroll
+                    for (int s = 0; s < S; ++s) {
+                        const int i = 64 * s + lane;
+                        fp[s] = recs[(size_t)k * n + min(i, n - 1)];
+                        if (i >= n) fp[s] = make_double2(0.0, 0.0);
                     }
                 }
-                if (lr == lp) rowdone |= 1u << sp;
+                // ---- rank-1 update of the own columns (all but column k itself)
+                const int lp = p & 63;
+                if (S > 1 && p >= 64) pn_apply<S, CM, S - 1>(A, fp, nc, own ? ck : -1, lp);
+                else pn_apply<S, CM, 0>(A, fp, nc, own ? ck : -1, lp);
+                if (lane == lp) rowdone |= 1u << (p >> 6);
+                if (dbg) {
+                    const long long t3 = clock64();
+                    t_prod += t1 - t0;
+                    t_wait += t2 - t1;
+                    t_cons += t3 - t2;
+                }
             }
         }
         __syncthreads();                                                   // every record consumed: the record area is free
         // ---------------------------------------------------------------- scaling mu = sqrt(|Z^-1|_F / |Z|_F)
         double yn2[1] = {0.0};
 #pragma unroll
-        for (int g = 0; g < GM; ++g)
+        for (int c = 0; c < CM; ++c)
 #pragma unroll
-            for (int s = 0; s < S; ++s) yn2[0] += cabs2(A[g][s]);
+            for (int s = 0; s < S; ++s) yn2[0] += cabs2(A[c][s]);
         pn_block_sum<1>(yn2, red);
         const double mu = unscaled ? 1.0 : sqrt(sqrt(yn2[0] / zn2));
         // ---------------------------------------------------------------- Z <- (mu Z + (mu Z)^-H) / 2
         // a_ij (row i was the pivot row of step rowstep[i], column j had pivot row prow[j]) is element (rowstep[i], prow[j]) of
         // Z^-1, i.e. conj(a_ij) is element (prow[j], rowstep[i]) of Z^-H
-        const double c1 = 0.5 / mu, c0 = 0.5 * mu;
+        const double c1 = 0.5 / mu, cz = 0.5 * mu;
 #pragma unroll
-        for (int g = 0; g < GM; ++g) {
-            const int j = 4 * (g0 + g) + lc;
-            const int pj = (g < ng && j < n) ? prow[j] : 0;
+        for (int c = 0; c < CM; ++c) {
+            const int pj = (c < nc) ? prow[c0 + c] : 0;
 #pragma unroll
             for (int s = 0; s < S; ++s) {
-                const int i = 16 * s + lr;
-                if ((g < ng) && (i < n) && (j < n)) stage[(size_t)pj * ld + rowstep[i]] = make_double2(c1 * A[g][s].x, -c1 * A[g][s].y);
+                const int i = 64 * s + lane;
+                if ((c < nc) && (i < n)) stage[(size_t)pj * n + rowstep[i]] = make_double2(c1 * A[c][s].x, -c1 * A[c][s].y);
             }
         }
         __syncthreads();
         double sums[2] = {0.0, 0.0};
 #pragma unroll
-        for (int g = 0; g < GM; ++g) {
-            const int j = 4 * (g0 + g) + lc;
+        for (int c = 0; c < CM; ++c) {
 #pragma unroll
             for (int s = 0; s < S; ++s) {
-                const int i = 16 * s + lr;
-                if ((g < ng) && (i < n) && (j < n)) {
-                    const double2 t = stage[(size_t)i * ld + j];
-                    const double2 zn = make_double2(fma(c0, Z[g][s].x, t.x), fma(c0, Z[g][s].y, t.y));
-                    sums[0] += cabs2(csub(zn, Z[g][s]));
+                const int i = 64 * s + lane;
+                if ((c < nc) && (i < n)) {
+                    const double2 t = stage[(size_t)i * n + (c0 + c)];
+                    const double2 zn = make_double2(fma(cz, Z[c][s].x, t.x), fma(cz, Z[c][s].y, t.y));
+                    sums[0] += cabs2(csub(zn, Z[c][s]));
                     sums[1] += cabs2(zn);
-                    Z[g][s] = zn;
+                    Z[c][s] = zn;
                 }
             }
         }
@@ -281,21 +291,26 @@ __device__ void pn_body(const double2* __restrict__ X, double2* __restrict__ U, 
     }
     // U_l = polar(X_l)^+ in the row-major (k_l, 2l+1) layout of mtip_get_unknowns = conj of the column-major polar factor
 #pragma unroll
-    for (int g = 0; g < GM; ++g) {
-        const int j = 4 * (g0 + g) + lc;
+    for (int c = 0; c < CM; ++c) {
 #pragma unroll
         for (int s = 0; s < S; ++s) {
-            const int i = 16 * s + lr;
-            if ((g < ng) && (i < n) && (j < n)) U[(size_t)j * n + i] = make_double2(Z[g][s].x, -Z[g][s].y);
+            const int i = 64 * s + lane;
+            if ((c < nc) && (i < n)) U[(size_t)(c0 + c) * n + i] = make_double2(Z[c][s].x, -Z[c][s].y);
         }
     }
     if (tid == 0) *diag = min(it, PN_MAXIT) | (n << 8);
+    if (dbg && lane == 0) {
+        dbg[wave * 4 + 0] = t_prod;
+        dbg[wave * 4 + 1] = t_wait;
+        dbg[wave * 4 + 2] = t_cons;
+        dbg[wave * 4 + 3] = clock64() - t_all;
+    }
 }
 
 __global__ void __launch_bounds__(PN_THREADS) k_polar_newton(const double2* __restrict__ Xall, double2* __restrict__ Uall,
                                                              const int* __restrict__ active, const int* __restrict__ xoff,
                                                              int xtot, int L, const int* __restrict__ jorder,
-                                                             int* __restrict__ diag) {
+                                                             int* __restrict__ diag, long long* __restrict__ dbg_all) {
     HIP_DYNAMIC_SHARED(unsigned char, pn_smem)
     const int b = blockIdx.x, l = jorder[blockIdx.y];
     if (!active[l]) return;
@@ -303,6 +318,7 @@ __global__ void __launch_bounds__(PN_THREADS) k_polar_newton(const double2* __re
     const double2* X = Xall + (size_t)b * xtot + xoff[l];
     double2* U = Uall + (size_t)b * xtot + xoff[l];
     int* dg = diag + (size_t)b * (L + 1) + l;
+    long long* dbg = dbg_all ? dbg_all + ((size_t)b * (L + 1) + l) * (PN_WAVES * 4) : nullptr;
     if (n == 1) {                                                          // l = 0: a phase
         if (threadIdx.x == 0) {
             const double2 x = X[0];
@@ -313,13 +329,10 @@ __global__ void __launch_bounds__(PN_THREADS) k_polar_newton(const double2* __re
         }
         return;
     }
-    switch ((n + 15) >> 4) {
-        case 1: pn_body<1, 1>(X, U, n, pn_smem, dg); break;
-        case 2: pn_body<2, 1>(X, U, n, pn_smem, dg); break;
-        case 3: pn_body<3, 2>(X, U, n, pn_smem, dg); break;
-        case 4: pn_body<4, 2>(X, U, n, pn_smem, dg); break;
-        default: pn_body<5, 3>(X, U, n, pn_smem, dg); break;
-    }
+    if (n <= 16) pn_body<1, 2>(X, U, n, pn_smem, dg, dbg);
+    else if (n <= 32) pn_body<1, 4>(X, U, n, pn_smem, dg, dbg);
+    else if (n <= 64) pn_body<1, 8>(X, U, n, pn_smem, dg, dbg);
+    else pn_body<2, 9>(X, U, n, pn_smem, dg, dbg);
 }
 
 bool polar_newton_supported(const mtip_ctx* c) {
@@ -328,7 +341,7 @@ bool polar_newton_supported(const mtip_ctx* c) {
     for (int l = 0; l <= c->L; ++l) {
         if (!c->active[l]) continue;
         any = true;
-        if (c->kl[l] != 2 * l + 1 || 2 * l + 1 > PN_MAXN) return false;    // square X_l up to 80 x 80 (L <= 39)
+        if (c->kl[l] != 2 * l + 1 || 2 * l + 1 > PN_MAXN) return false;    // square X_l up to 72 x 72 (L <= 35)
     }
     return any;
 }
@@ -351,10 +364,9 @@ int launch_polar_newton(mtip_ctx* c) {
         }
         (void)hipMemcpy(c->d_jorder, ord.data(), ord.size() * sizeof(int), hipMemcpyHostToDevice);
     }
-    const int S = (nmax + 15) / 16;
-    const size_t lds = PN_FIXED + (size_t)nmax * 16 * S * sizeof(double2);
+    const size_t lds = PN_FIXED + (size_t)nmax * nmax * sizeof(double2);
     hipLaunchKernelGGL(k_polar_newton, dim3((unsigned)c->B, (unsigned)std::max(c->n_jorder, 1)), dim3(PN_THREADS), lds, c->stream,
                        (const double2*)c->d_X, c->d_U, (const int*)c->d_active, (const int*)c->d_xoff, c->xtot, c->L,
-                       (const int*)c->d_jorder, c->d_sweeps);
+                       (const int*)c->d_jorder, c->d_sweeps, c->d_polar_dbg);
     return MTIP_OK;
 }

@@ -55,7 +55,7 @@ void mtip_destroy(mtip_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void* ptrs[] = {c->d_cost, c->d_gw, c->d_P, c->d_r, c->d_q, c->d_poff, c->d_PT, c->d_AB, c->d_lmtab, c->d_twN, c->d_tw, c->d_W, c->d_htiles, c->d_htiles32, c->d_kl, c->d_used, c->d_active, c->d_sweeps, c->d_jsched, c->d_jsched_off, c->d_jsched_rounds, c->d_jorder, c->d_jlog, c->d_jlog_rounds, c->d_pg_tiles[0], c->d_pg_tiles[1], c->d_pg_tiles[2], c->d_pg_tiles[3], c->d_voff,
                     c->d_xoff, c->d_uoff, c->d_V, c->d_rmask, c->d_Bref, c->d_Bnorm, c->d_deg2_part, c->d_S0, c->d_sup, c->d_err_wr,
-                    c->d_err_wt, c->d_rho, c->d_Fp, c->d_slot, c->d_best_err, c->d_last_err, c->d_op_err, c->d_gq, c->d_err_hist, c->d_main_hist,
+                    c->d_err_wt, c->d_rho, c->d_Fp, c->d_slot, c->d_best_err, c->d_last_err, c->d_op_err, c->d_gq, c->d_polar_dbg, c->d_err_hist, c->d_main_hist,
                     c->d_deg2_hist, c->d_F, c->d_T1, c->d_T2, c->d_fixed, c->d_g, c->d_c[0], c->d_c[1], c->d_c[2],
                     c->d_c[3], c->d_c[4], c->d_c[5], c->d_X, c->d_Vr, c->d_U, c->d_partial, c->d_minmax, c->d_Bl};
     for (void* p : ptrs)
@@ -1062,6 +1062,20 @@ int mtip_debug_jacobi_sweeps(mtip_ctx* c, int32_t* out) {
     (void)hipSetDevice(c->device);
     MTIP_HIP_CHECK(c, hipStreamSynchronize(c->stream));
     MTIP_HIP_CHECK(c, hipMemcpy(out, c->d_sweeps, (size_t)c->B * (c->L + 1) * sizeof(int), hipMemcpyDeviceToHost));
+    return MTIP_OK;
+}
+
+int mtip_debug_polar_timing(mtip_ctx* c, int64_t* out) {
+    CTX_CHECK(c);
+    (void)hipSetDevice(c->device);
+    const size_t n = (size_t)c->B * (c->L + 1) * 8 * 4;
+    MTIP_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    if (!c->d_polar_dbg) {                       // first call: switch the timers on (the next projections fill them)
+        int r = dev_alloc(c, &c->d_polar_dbg, n);
+        if (r) return r;
+        MTIP_HIP_CHECK(c, hipMemset(c->d_polar_dbg, 0, n * sizeof(long long)));
+    }
+    if (out) MTIP_HIP_CHECK(c, hipMemcpy(out, c->d_polar_dbg, n * sizeof(long long), hipMemcpyDeviceToHost));
     return MTIP_OK;
 }
 

@@ -80,6 +80,7 @@ _SIGNATURES = {
     'mtip_profile_reset': (C.c_int, [c_void]),
     'mtip_debug_jacobi_sweeps': (C.c_int, [c_void, c_void]),
     'mtip_debug_check_jacobi_schedule': (C.c_int, [c_void, C.c_int]),
+    'mtip_debug_polar_timing': (C.c_int, [c_void, c_void]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

@@ -96,3 +96,25 @@ class _GpuProcessManager:
 
 comm_module = _GpuProcessManager()
 add_gpu_process = comm_module.add_gpu_process
+
+
+def _child_entry(payload):
+    import cloudpickle
+    func, kwargs = cloudpickle.loads(payload)
+    return func(**kwargs)
+
+
+def process_mp_request(func, n_processes=1, max_concurrent=4, **kwargs):
+    """``Multiprocessing.process_mp_request`` look-alike (``xframe/Multiprocessing.py:360-437``) for the GPU-process contract of
+    ``tests/test_framework_integration.py:640-747``: ``func(**kwargs)`` runs in ``n_processes`` child processes, each of which
+    may call :func:`add_gpu_process`.  The reference forks its workers and talks to GPU daemons; here every child is a
+    *fresh* interpreter (``spawn``: a process that has initialised HIP must never be forked) that creates its own engine, at
+    most ``max_concurrent`` of them at a time.  The callable travels by value (cloudpickle), so closures work as in the
+    reference.  Returns the list of results in task order."""
+    import multiprocessing as mp
+
+    import cloudpickle
+    payload = cloudpickle.dumps((func, kwargs))
+    ctx = mp.get_context('spawn')
+    with ctx.Pool(max(1, min(int(n_processes), int(max_concurrent))), maxtasksperchild=1) as pool:
+        return pool.map(_child_entry, [payload] * int(n_processes), chunksize=1)
