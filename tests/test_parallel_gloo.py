@@ -24,20 +24,24 @@ rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
 dist.init_process_group('gloo', rank=rank, world_size=world)
 g = np.load(os.path.join({here!r}, 'golden', 'mtip_N16_L4.npz'))
 N, L = int(g['N']), int(g['L'])
-opt = golden_settings(N, L, {{'multi_process': {{'use': True, 'n_parallel_reconstructions': 3}}}})
+n_total, n_eng, n_full = {n_total}, {n_eng}, {n_full}
+opt = golden_settings(N, L, {{'multi_process': {{'use': True, 'n_parallel_reconstructions': n_total}},
+                              'GPU': {{'use': True, 'n_gpu_workers': n_eng}}}})
 main = opt['main_loop']['sub_loops']['main']
 main['methods']['HIO']['iterations'] = 2; main['methods']['ER']['iterations'] = 1; main['iterations'] = 1
-w = R.ProjectWorker(opt, data_from_golden(g, L), rank=rank, world_size=world, seeds=[11, 12, 13],
-                    lib_path=os.path.join({emul!r}, 'libmtip_emul.so'))
+w = R.ProjectWorker(opt, data_from_golden(g, L), seeds=[11 + i for i in range(n_total)], n_gather_full=n_full,
+                    lib_path=os.path.join({emul!r}, 'libmtip_emul.so'))        # rank / world size from the launcher's environment
 result, _ = w.run()
-mine = P.shard_restarts(3, rank, world)
+mine = P.shard_restarts(n_total, rank, world)
 own = [result[i] for i in mine] if rank == 0 else list(result)     # rank 0 holds all restarts, others only theirs
 allv = P.gather_scalars(np.array([float(len(mine)), float(rank)]))
 bl_sum = sum(r['last_deg2_invariant'] for r in own)
 mean_bl = P.average_invariants(bl_sum, len(own))
 out = {{'rank': rank, 'n_results': int(len(result)), 'mine': mine,
        'gathered': allv.tolist(), 'bl_trace': float(np.trace(mean_bl[0]).real),
-       'errs': [float(r['final_error']) for r in result],
+       'errs': [float(r['final_error']) for r in result], 'engines': len(w.mtip_instances),
+       'kinds': [r.get('gathered', 'own') for r in result],
+       'dens_norm': [float(np.linalg.norm(r['real_density'])) if 'real_density' in r else -1.0 for r in result],
        'sorted': [int(i) for i in w.results.get('sorted_ids', [])]}}
 print('RESULT ' + json.dumps(out), flush=True)
 dist.destroy_process_group()
@@ -57,11 +61,11 @@ def test_shard_restarts_round_robin():
     assert shard_restarts(2, 3, 4) == []
 
 
-def test_two_rank_gloo_worker(emul_lib, tmp_path):
+def _run_two_ranks(tmp_path, port, **fmt):
     import json
     script = tmp_path / 'worker.py'
-    script.write_text(WORKER.format(root=ROOT, here=HERE, emul=EMUL_DIR))
-    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29571', WORLD_SIZE='2', MTIP_EMUL_THREADS='2')
+    script.write_text(WORKER.format(root=ROOT, here=HERE, emul=EMUL_DIR, **fmt))
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), WORLD_SIZE='2', MTIP_EMUL_THREADS='2')
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
                               stderr=subprocess.PIPE, text=True) for r in range(2)]
     outs = []
@@ -71,7 +75,13 @@ def test_two_rank_gloo_worker(emul_lib, tmp_path):
         outs.append(json.loads([l for l in o.splitlines() if l.startswith('RESULT ')][0][7:]))
     r0 = [o for o in outs if o['rank'] == 0][0]
     r1 = [o for o in outs if o['rank'] == 1][0]
+    return r0, r1
+
+
+def test_two_rank_gloo_worker(emul_lib, tmp_path):
+    r0, r1 = _run_two_ranks(tmp_path, 29571, n_total=3, n_eng=1, n_full=8)
     assert r0['mine'] == [0, 2] and r1['mine'] == [1]
+    assert r0['kinds'] == ['own', 'full', 'own'] and r0['dens_norm'][1] > 0     # restart 1 arrived with its arrays
     assert r0['n_results'] == 3                      # rank 0 holds every restart after the gather
     assert r0['gathered'] == [[2.0, 0.0], [1.0, 1.0]] == r1['gathered']
     assert np.isclose(r0['bl_trace'], r1['bl_trace'], rtol=1e-12)       # all-reduced mean B_l identical on both ranks
@@ -79,3 +89,22 @@ def test_two_rank_gloo_worker(emul_lib, tmp_path):
     assert sorted(r0['sorted']) == [0, 1, 2]
     assert r0['errs'][r0['sorted'][0]] == min(r0['errs'])
     assert r1['n_results'] == 1
+
+
+def test_two_ranks_two_engines_best_only(emul_lib, tmp_path):
+    """world_size 2 x GPU.n_gpu_workers 2 (four restarts per rank on two engines each); only the best restart travels in full:
+    the other remote restarts reach rank 0 as light dicts (scalars and error histories, no grid arrays)."""
+    r0, r1 = _run_two_ranks(tmp_path, 29573, n_total=8, n_eng=2, n_full=1)
+    assert r0['engines'] == 2 and r1['engines'] == 2
+    assert r0['n_results'] == 8 and r1['n_results'] == 4
+    errs = np.array(r0['errs'])
+    assert np.isfinite(errs).all() and len(set(r0['errs'])) == 8
+    best = int(np.argmin(errs))
+    for i, kind in enumerate(r0['kinds']):
+        if i % 2 == 0:
+            assert kind == 'own' and r0['dens_norm'][i] > 0
+        elif i == best:
+            assert kind == 'full' and r0['dens_norm'][i] > 0
+        else:
+            assert kind == 'light' and r0['dens_norm'][i] == -1.0
+    assert np.isclose(r0['bl_trace'], r1['bl_trace'], rtol=1e-12)

@@ -4,8 +4,9 @@ The reference fans restarts out as OS processes and gathers their result dicts t
 (``xframe/projects/fxs/reconstruct.py:151-155``, ``xframe/Multiprocessing.py:360-437``); restarts never
 communicate.  Here restart ``i`` runs on rank ``i % world_size`` (the reference maps clients to GPUs with
 ``(pid // n_control_workers) % n_gpus``, ``Multiprocessing.py:1275-1277``); the only collective is the final
-gather: per-restart scalars and the rotation-invariant B_l via all_gather / all_reduce (RCCL on GPUs, gloo on
-CPU for tests), result dicts via gather_object to rank 0.
+gather: per-restart scalars via all_gather, the rotation-invariant B_l via all_reduce, the grid-sized arrays of the best
+restarts as tensors to rank 0 (RCCL on GPUs, gloo on CPU for tests); only the light parts of the result dicts travel as
+pickled objects.
 """
 import numpy as np
 
@@ -25,21 +26,89 @@ def _dist():
     return None
 
 
-def gather_results(local_results, local_ids, n_total, rank, world_size):
-    """Gather the per-restart result dicts on rank 0 (other ranks keep only their own)."""
+def _is_heavy(v):
+    """grid-shaped (Nq, n_theta, n_phi[, 3]) or B_l-shaped (L+1, Nq, Nq) arrays: these only travel for the selected restarts"""
+    return isinstance(v, np.ndarray) and v.dtype != object and v.ndim >= 3
+
+
+def _light(res):
+    """result dict without its grid-sized arrays (scalars, error histories, unknowns stay)"""
+    out = {}
+    for k, v in res.items():
+        if _is_heavy(v):
+            continue
+        if isinstance(v, dict):
+            v = {kk: vv for kk, vv in v.items() if not _is_heavy(vv)}
+        elif isinstance(v, (list, tuple)) and any(_is_heavy(x) for x in v):
+            continue
+        out[k] = v
+    return out
+
+
+def _heavy_keys(res):
+    return sorted(k for k, v in res.items() if _is_heavy(v))
+
+
+def gather_results(local_results, local_ids, n_total, rank, world_size, n_full=8, device=None):
+    """End-of-run gather (reference: Manager Queue + argsort of the final errors, reconstruct.py:160-177).
+
+    1. all_gather of the per-restart scalars (last main error) -> every rank knows the global ranking;
+    2. the light parts of the result dicts (scalars, error histories, unknowns: a few KB each) go to rank 0 as objects;
+    3. the grid-sized arrays (densities, supports, B_l: ~7 x 16 MiB per restart at 128 x L32) travel only for the ``n_full``
+       best restarts, as tensors point to point to rank 0 (RCCL send / recv over xGMI with the nccl backend, from device
+       staging buffers; gloo on CPU in the tests).
+    Rank 0 returns an object array of all restarts -- full dicts for its own and for the selected ones, light dicts (flagged
+    ``'gathered': 'light'``) for the rest; other ranks return their own results unchanged."""
     dist = _dist()
     if world_size == 1 or dist is None:
         return local_results
-    payload = [(i, r) for i, r in zip(local_ids, local_results)]
+    import torch
+    n_max = -(-n_total // world_size)
+    err = np.full(n_max, np.inf)
+    for j, r in enumerate(local_results):
+        err[j] = float(np.asarray(r['error_dict']['main'])[-1])
+    table = gather_scalars(err, device)                                    # (world, n_max)
+    final = np.full(n_total, np.inf)
+    for rk in range(world_size):
+        ids = shard_restarts(n_total, rk, world_size)
+        final[ids] = table[rk, :len(ids)]
+    selected = [int(i) for i in np.argsort(final, kind='stable')[:max(int(n_full), 0)]]
+    local_ids = list(local_ids)
+    payload = [(i, _light(r), [(k, str(r[k].dtype), tuple(r[k].shape)) for k in _heavy_keys(r)])
+               for i, r in zip(local_ids, local_results)]
     gathered = [None] * world_size if rank == 0 else None
     dist.gather_object(payload, gathered, dst=0)
-    if rank != 0:
-        return local_results
-    out = np.empty(n_total, dtype=object)
-    for part in gathered:
-        for i, r in part:
+    out = None
+    if rank == 0:
+        out = np.empty(n_total, dtype=object)
+        metas = {}
+        for part in gathered:
+            for i, r, meta in part:
+                r['gathered'] = 'light'
+                out[i] = r
+                metas[i] = meta
+        for i, r in zip(local_ids, local_results):
             out[i] = r
-    return out
+    # heavy arrays of the selected restarts, in a fixed order on both ends
+    use_dev = device is not None and dist.get_backend() == 'nccl'
+    for i in selected:
+        owner = i % world_size
+        if owner == 0:
+            continue
+        if rank == owner:
+            res = local_results[local_ids.index(i)]
+            for k in _heavy_keys(res):
+                a = np.ascontiguousarray(res[k])
+                t = torch.from_numpy(a.view(np.uint8).reshape(-1).copy())
+                dist.send(t.to(device) if use_dev else t, dst=0)
+        elif rank == 0:
+            for k, dt, shape in metas[i]:
+                nbytes = int(np.prod(shape)) * np.dtype(dt).itemsize
+                t = torch.empty(nbytes, dtype=torch.uint8, device=device if use_dev else 'cpu')
+                dist.recv(t, src=owner)
+                out[i][k] = t.cpu().numpy().view(np.dtype(dt)).reshape(shape)
+            out[i]['gathered'] = 'full'
+    return out if rank == 0 else local_results
 
 
 def gather_scalars(values, device=None):

@@ -310,12 +310,21 @@ class ProjectWorker:
     """reconstruct.py:89-209.  ``run()`` returns ``(result, locals())`` like ProjectWorkerInterface.run
     (xframe/interfaces.py:9-20)."""
 
-    def __init__(self, settings=None, invariants=None, device=0, rank=0, world_size=1, seeds=None, lib_path=None):
+    def __init__(self, settings=None, invariants=None, device=None, rank=None, world_size=None, seeds=None, lib_path=None,
+                 n_gather_full=8):
+        """rank / world_size / device default to the launcher's RANK / WORLD_SIZE / LOCAL_RANK (torch.distributed.run: one
+        process per GPU), else to a single process on device 0.  n_gather_full: restarts (best final errors first) whose
+        grid-sized arrays are brought to rank 0 at the end of a multi-rank run."""
+        import os
         self.opt = DictNamespace.dict_to_dictnamespace(resolve(settings))
         MTIP.preinit(self.opt, invariants)
         self.mtip = MTIP
         self.process_factory = RecipeFactory({})
+        rank = int(os.environ.get('RANK', 0)) if rank is None else rank
+        world_size = int(os.environ.get('WORLD_SIZE', 1)) if world_size is None else world_size
+        device = int(os.environ.get('LOCAL_RANK', 0)) if device is None else device
         self.device, self.rank, self.world_size = device, rank, world_size
+        self.n_gather_full = n_gather_full
         self.seeds = seeds
         self.lib_path = lib_path
         self.results = {'stats': {}}
@@ -365,11 +374,25 @@ class ProjectWorker:
                     result[i] = res[j]
             self.mtip_instance = outs[0][0]
             self.mtip_instances = [m for m, _ in outs]
-        result = gather_results(result, mine, total, self.rank, self.world_size)
+        result = gather_results(result, mine, total, self.rank, self.world_size, n_full=self.n_gather_full,
+                                device=self._torch_device())
         self.results['MTIP'] = result
         self.results['stats']['run_time'] = time.time() - start
         self.post_processing()
         return result, locals()
+
+    def _torch_device(self):
+        """device of the staging tensors of the final gather: the GPU with the nccl (= RCCL) backend, None otherwise"""
+        if self.world_size == 1:
+            return None
+        try:
+            import torch
+            import torch.distributed as dist
+            if dist.is_initialized() and dist.get_backend() == 'nccl':
+                return torch.device('cuda', self.device)
+        except Exception:
+            pass
+        return None
 
     def post_processing(self):
         """reconstruct.py:160-183: sort restarts by their last main error (rank 0 holds everything)."""
