@@ -26,13 +26,17 @@ e.run('HIO', True, np.full(5, 0.45))
 F = np.stack([e.reciprocal_density(b) for b in range(B)])
 Ilm = e.sht_forward(F, 1)
 e.project_coefficients(Ilm)
-e.lib.mtip_debug_polar_timing(e.ctx, None)
+timers = os.environ.get('POLAR_TIMERS', '0') == '1'
+if timers:
+    e.lib.mtip_debug_polar_timing(e.ctx, None)
 e.profile(True)
 for _ in range(reps):
     e.project_coefficients(Ilm)
 ms, n = e.profile_get('proj')
-print('proj: %.1f us per call (B = %d, %d calls)' % (1e3 * ms / n, B, n))
+print('variant %s polar %s: proj %.1f us per call (B = %d, %d calls)' % (os.environ.get('MTIP_POLAR_VARIANT', '0'), os.environ.get('MTIP_POLAR', 'newton'), 1e3 * ms / n, B, n))
 print('iterations per order (restart 0):', list(e.jacobi_sweeps()[0]))
+if not timers:
+    sys.exit(0)
 out = np.zeros((B, L + 1, 8, 4), np.int64)
 e.lib.mtip_debug_polar_timing(e.ctx, _lib.ptr(out))
 for l in (L, L - 2, 16, 8):

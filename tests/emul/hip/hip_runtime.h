@@ -145,7 +145,8 @@ static inline int __builtin_amdgcn_readlane(int v, int src_lane) { return __shfl
 static inline int __builtin_amdgcn_readfirstlane(int v) { return __shfl(v, 0, 64); }
 // workgroup-scope atomics on LDS words: the fibers of a block share one OS thread, plain accesses are atomic enough
 #define __HIP_MEMORY_SCOPE_WORKGROUP 2
-template <typename T> static inline T __hip_atomic_load(const T* p, int, int) { return *const_cast<const volatile T*>(p); }
+// (a polling loop may spin on such a load without s_sleep: let the other fibers of the block run)
+template <typename T> static inline T __hip_atomic_load(const T* p, int, int) { emul::fiber_yield(); return *const_cast<const volatile T*>(p); }
 template <typename T> static inline void __hip_atomic_store(T* p, T v, int, int) { *const_cast<volatile T*>(p) = v; }
 static inline int __double2loint(double v) { long long u; std::memcpy(&u, &v, 8); return (int)(u & 0xffffffffll); }
 static inline int __double2hiint(double v) { long long u; std::memcpy(&u, &v, 8); return (int)(u >> 32); }

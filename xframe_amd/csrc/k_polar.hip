@@ -77,25 +77,36 @@ __device__ __forceinline__ void pn_block_sum(double (&v)[NV], double* red) {
     __syncthreads();
 }
 
-// a_ij -= f'_i a_pj for the columns of this wave (SP: slot of the pivot row, a compile-time constant inside the uniform branch)
-template <int S, int CM, int SP>
-__device__ __forceinline__ void pn_apply(double2 (&A)[CM][S], const double2 (&fp)[S], int nc, int skip, int lp) {
+// a_ij -= f'_i a_pj for all CM column registers of this wave, branch free (registers past the wave's last column hold
+// zeros and stay zero; the owner of column k overwrites that column afterwards).  SP: slot of the pivot row (a
+// compile-time constant inside a uniform branch).  The pivot-row values are fetched for all columns first so that their
+// latency overlaps; BPERM: through ds_bpermute (LDS crossbar) instead of v_readlane.
+template <int S, int CM, int SP, bool BPERM>
+__device__ __forceinline__ void pn_apply(double2 (&A)[CM][S], const double2 (&fp)[S], int lp) {
+    double2 raw[CM];
 #pragma unroll
     for (int c = 0; c < CM; ++c) {
-        if (c < nc && c != skip) {
-            const double2 raw = pn_readlane2(A[c][SP], lp);
+        if (BPERM) {
+            raw[c].x = __shfl(A[c][SP].x, lp);
+            raw[c].y = __shfl(A[c][SP].y, lp);
+        } else {
+            raw[c] = pn_readlane2(A[c][SP], lp);
+        }
+    }
 #pragma unroll
-            for (int s = 0; s < S; ++s) {
-                A[c][s].x = fma(-fp[s].x, raw.x, fma(fp[s].y, raw.y, A[c][s].x));
-                A[c][s].y = fma(-fp[s].x, raw.y, fma(-fp[s].y, raw.x, A[c][s].y));
-            }
+    for (int c = 0; c < CM; ++c) {
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            A[c][s].x = fma(-fp[s].x, raw[c].x, fma(fp[s].y, raw[c].y, A[c][s].x));
+            A[c][s].y = fma(-fp[s].x, raw[c].y, fma(-fp[s].y, raw[c].x, A[c][s].y));
         }
     }
 }
 
 // S: row slots of 64 per lane (n <= 64 S), CM: columns per wave (ceil(n / 8) <= CM)
 template <int S, int CM>
-__device__ void pn_body(const double2* __restrict__ X, double2* __restrict__ U, int n, unsigned char* smem, int* diag, long long* dbg) {
+__device__ void pn_body(const double2* __restrict__ X, double2* __restrict__ U, int n, unsigned char* smem, int* diag, long long* dbg,
+                        int variant) {
     // the wave index through readfirstlane: the compiler then knows that everything derived from it (ownership of a
     // column, the column range) is wave-uniform and emits scalar branches instead of exec masks and per-lane selects
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -105,12 +116,13 @@ __device__ void pn_body(const double2* __restrict__ X, double2* __restrict__ U, 
     double* red = reinterpret_cast<double*>(rowstep + PN_MAXN);           // [PN_WAVES * 2]
     double2* recs = reinterpret_cast<double2*>(smem + PN_FIXED);          // [n][n] f' of step k
     double2* stage = recs;                                                // [n][n] aliases the records between two inversions
+    double2* zs = recs + (size_t)n * n;                                   // [n][n] the iterate Z, column-major (registers hold the matrix being inverted)
     const int base = n / PN_WAVES, rem = n % PN_WAVES;
     const int nc = base + (wave < rem ? 1 : 0);                           // columns of this wave
     const int c0 = wave * base + min(wave, rem);                          // first of them
     for (int k = tid; k < PN_MAXN; k += PN_THREADS) hdr[k].flag = 0;
 
-    double2 A[CM][S], Z[CM][S];
+    double2 A[CM][S];
     double nrm[1] = {0.0};
 #pragma unroll
     for (int c = 0; c < CM; ++c) {
@@ -119,8 +131,8 @@ __device__ void pn_body(const double2* __restrict__ X, double2* __restrict__ U, 
         for (int s = 0; s < S; ++s) {
             const int i = 64 * s + lane;
             const bool ok = (c < nc) && (i < n);
-            Z[c][s] = ok ? X[(size_t)j * n + i] : make_double2(0.0, 0.0);
-            nrm[0] += cabs2(Z[c][s]);
+            A[c][s] = ok ? X[(size_t)j * n + i] : make_double2(0.0, 0.0);
+            nrm[0] += cabs2(A[c][s]);
         }
     }
     pn_block_sum<1>(nrm, red);                                            // (also orders the flag reset before the first record)
@@ -142,7 +154,11 @@ __device__ void pn_body(const double2* __restrict__ X, double2* __restrict__ U, 
 #pragma unroll
         for (int c = 0; c < CM; ++c)
 #pragma unroll
-            for (int s = 0; s < S; ++s) Z[c][s] = cscale(Z[c][s], sc);
+            for (int s = 0; s < S; ++s) {
+                const int i = 64 * s + lane;
+                A[c][s] = cscale(A[c][s], sc);
+                if ((c < nc) && (i < n)) zs[(size_t)(c0 + c) * n + i] = A[c][s];     // own elements only: no barrier needed
+            }
         zn2 = 1.0;
     }
 
@@ -152,11 +168,7 @@ __device__ void pn_body(const double2* __restrict__ X, double2* __restrict__ U, 
     bool unscaled = false;
     int it = 1;
     for (; it <= PN_MAXIT; ++it) {
-        // ---------------------------------------------------------------- A <- Z^-1 in place (rows stay where they are)
-#pragma unroll
-        for (int c = 0; c < CM; ++c)
-#pragma unroll
-            for (int s = 0; s < S; ++s) A[c][s] = Z[c][s];
+        // ---------------------------------------------------------------- A (= Z) <- Z^-1 in place (rows stay where they are)
         unsigned rowdone = 0;                                              // bit s: row 64 s + lane has been a pivot row
         const double floor2 = 1e-40 * zn2;                                 // pivots below 1e-20 |Z|_F count as that (singular X_l)
         if (nc > 0) {
@@ -164,14 +176,13 @@ __device__ void pn_body(const double2* __restrict__ X, double2* __restrict__ U, 
                 const int ow = (k < rem * (base + 1)) ? k / (base + 1) : rem + (k - rem * (base + 1)) / max(base, 1);
                 const bool own = (ow == wave);
                 const int ck = k - c0;                                     // local index of column k (owner only)
-                double2 fp[S];
+                double2 fp[S], col[S];
                 int p;
                 long long t0 = dbg ? clock64() : 0, t1 = 0, t2 = 0;
+#pragma unroll
+                for (int s = 0; s < S; ++s) col[s] = make_double2(0.0, 0.0);
                 if (own) {
                     // ---- produce record k: pivot search in column k (rows not used yet), f' = column / pivot
-                    double2 col[S];
-#pragma unroll
-                    for (int s = 0; s < S; ++s) col[s] = make_double2(0.0, 0.0);
 #pragma unroll
                     for (int c = 0; c < CM; ++c)
                         if (c == ck) {
@@ -213,17 +224,15 @@ __device__ void pn_body(const double2* __restrict__ X, double2* __restrict__ U, 
                         rowstep[p] = k;
                         __hip_atomic_store(&hdr[k].flag, it, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
-#pragma unroll
-                    for (int c = 0; c < CM; ++c)
-                        if (c == ck) {
-#pragma unroll
-                            for (int s = 0; s < S; ++s) A[c][s] = col[s];
-                        }
                     t1 = t2 = dbg ? clock64() : 0;
                 } else {
                     // ---- wait for record k
                     t1 = dbg ? clock64() : 0;
-                    while (__hip_atomic_load(&hdr[k].flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != it) __builtin_amdgcn_s_sleep(1);
+                    if (variant & 2) {
+                        while (__hip_atomic_load(&hdr[k].flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != it) {}
+                    } else {
+                        while (__hip_atomic_load(&hdr[k].flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != it) __builtin_amdgcn_s_sleep(1);
+                    }
                     t2 = dbg ? clock64() : 0;
                     p = __builtin_amdgcn_readfirstlane(hdr[k].p);
 #pragma unroll
@@ -233,10 +242,23 @@ __device__ void pn_body(const double2* __restrict__ X, double2* __restrict__ U, 
                         if (i >= n) fp[s] = make_double2(0.0, 0.0);
                     }
                 }
-                // ---- rank-1 update of the own columns (all but column k itself)
+                // ---- rank-1 update of the own columns; the owner then installs column k of the inverse
                 const int lp = p & 63;
-                if (S > 1 && p >= 64) pn_apply<S, CM, S - 1>(A, fp, nc, own ? ck : -1, lp);
-                else pn_apply<S, CM, 0>(A, fp, nc, own ? ck : -1, lp);
+                if (variant & 1) {
+                    if (S > 1 && p >= 64) pn_apply<S, CM, S - 1, true>(A, fp, lp);
+                    else pn_apply<S, CM, 0, true>(A, fp, lp);
+                } else {
+                    if (S > 1 && p >= 64) pn_apply<S, CM, S - 1, false>(A, fp, lp);
+                    else pn_apply<S, CM, 0, false>(A, fp, lp);
+                }
+                if (own) {
+#pragma unroll
+                    for (int c = 0; c < CM; ++c)
+                        if (c == ck) {
+#pragma unroll
+                            for (int s = 0; s < S; ++s) A[c][s] = col[s];
+                        }
+                }
                 if (lane == lp) rowdone |= 1u << (p >> 6);
                 if (dbg) {
                     const long long t3 = clock64();
@@ -275,12 +297,15 @@ __device__ void pn_body(const double2* __restrict__ X, double2* __restrict__ U, 
 #pragma unroll
             for (int s = 0; s < S; ++s) {
                 const int i = 64 * s + lane;
+                A[c][s] = make_double2(0.0, 0.0);
                 if ((c < nc) && (i < n)) {
                     const double2 t = stage[(size_t)i * n + (c0 + c)];
-                    const double2 zn = make_double2(fma(cz, Z[c][s].x, t.x), fma(cz, Z[c][s].y, t.y));
-                    sums[0] += cabs2(csub(zn, Z[c][s]));
+                    const double2 zo = zs[(size_t)(c0 + c) * n + i];
+                    const double2 zn = make_double2(fma(cz, zo.x, t.x), fma(cz, zo.y, t.y));
+                    sums[0] += cabs2(csub(zn, zo));
                     sums[1] += cabs2(zn);
-                    Z[c][s] = zn;
+                    zs[(size_t)(c0 + c) * n + i] = zn;
+                    A[c][s] = zn;
                 }
             }
         }
@@ -295,7 +320,7 @@ __device__ void pn_body(const double2* __restrict__ X, double2* __restrict__ U, 
 #pragma unroll
         for (int s = 0; s < S; ++s) {
             const int i = 64 * s + lane;
-            if ((c < nc) && (i < n)) U[(size_t)(c0 + c) * n + i] = make_double2(Z[c][s].x, -Z[c][s].y);
+            if ((c < nc) && (i < n)) U[(size_t)(c0 + c) * n + i] = make_double2(A[c][s].x, -A[c][s].y);
         }
     }
     if (tid == 0) *diag = min(it, PN_MAXIT) | (n << 8);
@@ -310,7 +335,7 @@ __device__ void pn_body(const double2* __restrict__ X, double2* __restrict__ U, 
 __global__ void __launch_bounds__(PN_THREADS) k_polar_newton(const double2* __restrict__ Xall, double2* __restrict__ Uall,
                                                              const int* __restrict__ active, const int* __restrict__ xoff,
                                                              int xtot, int L, const int* __restrict__ jorder,
-                                                             int* __restrict__ diag, long long* __restrict__ dbg_all) {
+                                                             int* __restrict__ diag, long long* __restrict__ dbg_all, int variant) {
     HIP_DYNAMIC_SHARED(unsigned char, pn_smem)
     const int b = blockIdx.x, l = jorder[blockIdx.y];
     if (!active[l]) return;
@@ -329,10 +354,10 @@ __global__ void __launch_bounds__(PN_THREADS) k_polar_newton(const double2* __re
         }
         return;
     }
-    if (n <= 16) pn_body<1, 2>(X, U, n, pn_smem, dg, dbg);
-    else if (n <= 32) pn_body<1, 4>(X, U, n, pn_smem, dg, dbg);
-    else if (n <= 64) pn_body<1, 8>(X, U, n, pn_smem, dg, dbg);
-    else pn_body<2, 9>(X, U, n, pn_smem, dg, dbg);
+    if (n <= 16) pn_body<1, 2>(X, U, n, pn_smem, dg, dbg, variant);
+    else if (n <= 32) pn_body<1, 4>(X, U, n, pn_smem, dg, dbg, variant);
+    else if (n <= 64) pn_body<1, 8>(X, U, n, pn_smem, dg, dbg, variant);
+    else pn_body<2, 9>(X, U, n, pn_smem, dg, dbg, variant);
 }
 
 bool polar_newton_supported(const mtip_ctx* c) {
@@ -364,9 +389,9 @@ int launch_polar_newton(mtip_ctx* c) {
         }
         (void)hipMemcpy(c->d_jorder, ord.data(), ord.size() * sizeof(int), hipMemcpyHostToDevice);
     }
-    const size_t lds = PN_FIXED + (size_t)nmax * nmax * sizeof(double2);
+    const size_t lds = PN_FIXED + 2 * (size_t)nmax * nmax * sizeof(double2);      // records / staging + the iterate Z
     hipLaunchKernelGGL(k_polar_newton, dim3((unsigned)c->B, (unsigned)std::max(c->n_jorder, 1)), dim3(PN_THREADS), lds, c->stream,
                        (const double2*)c->d_X, c->d_U, (const int*)c->d_active, (const int*)c->d_xoff, c->xtot, c->L,
-                       (const int*)c->d_jorder, c->d_sweeps, c->d_polar_dbg);
+                       (const int*)c->d_jorder, c->d_sweeps, c->d_polar_dbg, c->polar_variant);
     return MTIP_OK;
 }

@@ -142,6 +142,7 @@ struct mtip_ctx {
     int* d_pg_tiles[4] = {nullptr, nullptr, nullptr, nullptr};   // (order, tile) lists of the projection GEMMs
     int n_pg_tiles[4] = {0, 0, 0, 0};
     long long* d_polar_dbg = nullptr;                 // (B, L+1, 8 waves, 4) phase timers of k_polar_newton, allocated by mtip_debug_polar_timing
+    int polar_variant = 0;                            // env MTIP_POLAR_VARIANT (A/B switches of k_polar_newton: 1 ds_bpermute pivot row, 2 spin without s_sleep)
     bool polar_newton = true;                         // env MTIP_POLAR=jacobi: one-sided Jacobi SVD for every order (else only for non-square X_l)
     int jac_tg = 16;                                  // env MTIP_JAC_TG=8|16: lanes per Jacobi column pair
     int jac_replay = 1;                               // env MTIP_JAC_REPLAY: 0 never, 1 rotation log + V_r replay when X_l, V_r do not share LDS, 2 always
