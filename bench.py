@@ -236,8 +236,9 @@ def main():
     roofline = None
     fam_ms = {}
     Bp = e0.B
+    e0_cus = int(torch.cuda.get_device_properties(dev).multi_processor_count)
     if not a.no_roofline:
-        for fam in ('sht_fwd', 'sht_inv', 'sht_inv_modulus', 'sht_inv_real', 'hankel', 'proj', 'real_update', 'deg2_metric'):
+        for fam in ('sht_fwd', 'sht_inv', 'sht_inv_modulus', 'sht_inv_real', 'hankel', 'proj', 'polar', 'real_update', 'deg2_metric'):
             ms, n = e0.profile_get(fam)
             if n:
                 fam_ms[fam] = {'total_ms': ms, 'launches': int(n), 'avg_ms': ms / n}
@@ -264,14 +265,46 @@ def main():
                     traffic = pmc['hbm_bytes_per_launch'].get(dom)
             except (OSError, ValueError, KeyError):
                 traffic = None
-            roofline = {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s',
+            hbm_roof = {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s',
                         'frac': achieved / 8000.0, 'traffic': traffic, 'avg_launch_ms': fam_ms[dom]['avg_ms'],
                         'algorithmic_bytes_per_launch': alg[dom], 'restarts_per_launch': Bp,
-                        'families_GBps': {k: alg[k] / (fam_ms[k]['avg_ms'] * 1e-3) / 1e9 for k in hbm},
-                        'note': 'dominant HBM-bound kernel family, timed with hipEvents over the timed region on the '
-                                'stream of engine 0; the polar-factor kernel (inside proj, LDS/latency bound in one CU '
-                                'per matrix) is listed in kernel_families_ms; traffic = FETCH_SIZE x 2 + WRITE_SIZE '
-                                'of profiles/pmc_traffic.json when it was collected at this batch size'}
+                        'families_GBps': {k: alg[k] / (fam_ms[k]['avg_ms'] * 1e-3) / 1e9 for k in hbm}}
+            # the kernel with the largest share of the step.  The polar factor ("polar", nested in the "proj" bracket) is
+            # not an HBM / MFMA kernel: one workgroup = one CU per (restart, order) matrix, bound by FP64 vector issue and
+            # the latency of its dependent pivot chain; its roofline is the FP64 vector rate of the CUs it occupies.
+            tops = {k: v for k, v in fam_ms.items() if k != 'proj'}
+            if 'polar' in fam_ms and 'proj' in fam_ms:                          # what is left of the projection: its two GEMMs
+                tops['proj_gemms'] = {'total_ms': fam_ms['proj']['total_ms'] - fam_ms['polar']['total_ms']}
+            elif 'proj' in fam_ms:
+                tops['proj'] = fam_ms['proj']
+            top = max(tops, key=lambda k: tops[k]['total_ms'])
+            if top == 'polar':
+                its = np.asarray(e0.jacobi_sweeps(), dtype=float)                  # (Bp, L+1) iterations of the last call
+                ns = 2 * np.arange(L + 1) + 1
+                active = its.mean(0) > 0
+                # one Newton iteration = one in-place complex Gauss-Jordan inverse (n^3 complex multiply-adds = 8 n^3 flop)
+                # + the update (4 n^2); iterations as reported by the kernel, averaged over the restarts of the launch
+                flops = float((its * (8.0 * ns ** 3 + 4.0 * ns ** 2)[None, :]).sum())
+                cus = int(min(Bp * int(active.sum()), e0_cus))
+                peak = cus * 4 * 32 * 2.4e9 / 1e12                                # FP64 vector: 32 flop / clk / SIMD at 2.4 GHz
+                ach = flops / (fam_ms['polar']['avg_ms'] * 1e-3) / 1e12
+                roofline = {'bound': 'fp64_valu', 'kernel': 'polar (k_polar_newton: scaled Newton polar factor, Gauss-Jordan inverse)',
+                            'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak, 'traffic': None,
+                            'cus_used': cus, 'cus_total': e0_cus, 'avg_launch_ms': fam_ms['polar']['avg_ms'],
+                            'algorithmic_flops_per_launch': flops, 'restarts_per_launch': Bp,
+                            'newton_iterations_restart0': [int(x) for x in its[0]],
+                            'share_of_step': fam_ms['polar']['total_ms'] / sum(v['total_ms'] for v in tops.values()),
+                            'hbm_family': hbm_roof,
+                            'note': 'dominant kernel by hipEvent time over the timed region on the stream of engine 0; peak = FP64 '
+                                    'vector rate of the CUs the launch occupies (one workgroup per matrix); hbm_family = the '
+                                    'dominant HBM-bound kernel family, priced against 8 TB/s; traffic of that family = FETCH_SIZE x 2 '
+                                    '+ WRITE_SIZE of profiles/pmc_traffic.json when collected at this batch size'}
+            else:
+                roofline = dict(hbm_roof)
+                roofline['share_of_step'] = fam_ms[dom]['total_ms'] / sum(v['total_ms'] for v in tops.values())
+                roofline['note'] = ('dominant kernel family (HBM bound), timed with hipEvents over the timed region on the stream '
+                                    'of engine 0; traffic = FETCH_SIZE x 2 + WRITE_SIZE of profiles/pmc_traffic.json when it was '
+                                    'collected at this batch size')
     step_bytes = algorithmic_bytes_per_step(N, L, e0.n_theta, e0.n_phi, True)
     whole_step = {'algorithmic_bytes_per_step_per_restart': step_bytes,
                   'achieved_GBps_per_gpu': step_bytes * B * a.steps / elapsed / 1e9,

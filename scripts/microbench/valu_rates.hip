@@ -1,0 +1,86 @@
+// Micro-benchmark (diagnostic, not part of the library): cycles per wave-instruction of the FP64 vector ops the
+// polar-factor kernel is built from, with 1 and 2 waves per SIMD.  hipcc --offload-arch=gfx950 valu_rates.hip -o valu_rates
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+
+#define REP 64
+template <int MODE>
+__global__ void __launch_bounds__(512) k(double* out, long long* cyc, int iters, int lp) {
+    double a[16], b0 = out[threadIdx.x & 7] + 1.0, b1 = out[(threadIdx.x + 1) & 7] + 0.5;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) a[i] = out[(threadIdx.x + i) & 15];
+    __syncthreads();
+    long long t0 = clock64();
+    for (int it = 0; it < iters; ++it) {
+        if (MODE == 0) {                       // 16 independent fma f64 chains, VGPR operands
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) a[i] = fma(a[i], b0, b1);
+        } else if (MODE == 1) {                // fma with a wave-uniform (SGPR) operand from v_readlane
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int lo = __builtin_amdgcn_readlane(__double2loint(a[(i + 1) & 15]), lp);
+                    const int hi = __builtin_amdgcn_readlane(__double2hiint(a[(i + 1) & 15]), lp);
+                    a[i] = fma(a[i], __hiloint2double(hi, lo), b1);
+                }
+        } else if (MODE == 2) {                // readlane only (result summed on the scalar side)
+            int acc = 0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc += __builtin_amdgcn_readlane(__double2loint(a[i]), (lp + i) & 63);
+            a[0] += acc;
+        } else if (MODE == 3) {                // ds_bpermute
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) a[i] += __shfl(a[(i + 1) & 15], lp);
+        } else if (MODE == 4) {                // f32 fma for reference
+            float f[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) f[i] = (float)a[i];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) f[i] = fmaf(f[i], (float)b0, (float)b1);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) a[i] = f[i];
+        }
+    }
+    long long t1 = clock64();
+    double s = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += a[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = t1 - t0;
+}
+
+template <int MODE>
+static void run(const char* name, int threads, int n_instr_per_iter) {
+    const int blocks = 256, iters = 2000;
+    double* out; long long* cyc;
+    hipMalloc(&out, blocks * threads * sizeof(double)); hipMemset(out, 0, blocks * threads * sizeof(double));
+    hipMalloc(&cyc, blocks * (threads / 64) * sizeof(long long));
+    hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(threads), 0, 0, out, cyc, iters, 5);
+    hipDeviceSynchronize();
+    std::vector<long long> h(blocks * (threads / 64));
+    hipMemcpy(h.data(), cyc, h.size() * sizeof(long long), hipMemcpyDeviceToHost);
+    double mean = 0; for (auto v : h) mean += v; mean /= h.size();
+    printf("%-28s %4d threads/CU (%d waves/SIMD): %.2f cycles per wave-instruction (per wave), %.2f per SIMD slot\n", name, threads,
+           threads / 256, mean / iters / n_instr_per_iter, mean / iters / n_instr_per_iter / (threads / 256.0));
+    hipFree(out); hipFree(cyc);
+}
+
+int main() {
+    for (int t : {256, 512}) {
+        if (t == 256) { run<0>("v_fma_f64 (VGPR)", 256, 64); run<1>("2 v_readlane + v_fma_f64", 256, 64); run<2>("v_readlane_b32", 256, 64);
+                        run<3>("ds_bpermute x2 + v_add_f64", 256, 64); run<4>("v_fma_f32", 256, 64); }
+        else { run<0>("v_fma_f64 (VGPR)", 512, 64); run<1>("2 v_readlane + v_fma_f64", 512, 64); run<2>("v_readlane_b32", 512, 64);
+               run<3>("ds_bpermute x2 + v_add_f64", 512, 64); run<4>("v_fma_f32", 512, 64); }
+    }
+    return 0;
+}

@@ -33,7 +33,7 @@ e.profile(True)
 for _ in range(reps):
     e.project_coefficients(Ilm)
 ms, n = e.profile_get('proj')
-print('variant %s polar %s: proj %.1f us per call (B = %d, %d calls)' % (os.environ.get('MTIP_POLAR_VARIANT', '0'), os.environ.get('MTIP_POLAR', 'newton'), 1e3 * ms / n, B, n))
+print('variant %s polar %s: proj %.1f us per call (B = %d, %d calls)' % (os.environ.get('MTIP_POLAR_VARIANT', '0'), os.environ.get('MTIP_POLAR', 'jacobi'), 1e3 * ms / n, B, n))
 print('iterations per order (restart 0):', list(e.jacobi_sweeps()[0]))
 if not timers:
     sys.exit(0)

@@ -115,16 +115,16 @@ def test_worker_engines_vs_single_and_oracle(emul_lib):
 
 
 @pytest.mark.parametrize('N,L', [(20, 9), (36, 16)])
-def test_projection_newton_polar_sizes(emul_lib, N, L):
-    """Scaled-Newton polar factor (k_polar.hip) with two and three row slots per lane, one and two column groups per wave,
-    against the oracle's numpy SVD route (the 65 x 65 case, five slots / three groups, runs on the GPU)."""
+def test_projection_newton_polar_sizes(emul_lib, N, L, monkeypatch):
+    """MTIP_POLAR=newton: scaled-Newton polar factor (k_polar.hip, 2 / 4 / 8 columns per wave) against the oracle's numpy SVD
+    route (the 65 x 65 case, two row slots, runs on the GPU)."""
+    monkeypatch.setenv('MTIP_POLAR', 'newton')
     PC.check_projection_vs_oracle(N, L, emul_lib, n_batch=1)
 
 
-def test_projection_jacobi_forced(emul_lib, monkeypatch):
-    """MTIP_POLAR=jacobi keeps the one-sided Jacobi SVD (the path of non-square X_l) selectable for square orders"""
-    monkeypatch.setenv('MTIP_POLAR', 'jacobi')
-    PC.check_projection_vs_oracle(20, 9, emul_lib, n_batch=1)
+def test_short_trajectory_newton_polar(emul_lib, golden_mtip16, monkeypatch):
+    monkeypatch.setenv('MTIP_POLAR', 'newton')
+    PC.check_short_trajectory_vs_oracle(golden_mtip16, emul_lib, True)
 
 
 @pytest.mark.parametrize('name', PC.VARIANT_NAMES)

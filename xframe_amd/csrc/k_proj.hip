@@ -1274,7 +1274,11 @@ int launch_project_coefficients(mtip_ctx* c, const double2* Ilm, double2* out) {
     launch_proj_gemm<PG_X>(c, ga);
     if (polar_newton_supported(c)) {
         // square X_l: polar factor by the scaled Newton iteration (k_polar.hip), U_l written directly
-        const int rn = launch_polar_newton(c);
+        int rn;
+        {
+            ProfScope pp(c, "polar");                            // the polar-factor kernel alone (nested in "proj")
+            rn = launch_polar_newton(c);
+        }
         if (rn != MTIP_OK) return rn;
         c->vr_valid = false;
         c->proj_calls += 1;

@@ -132,7 +132,7 @@ mtip_ctx* mtip_create(const mtip_cfg* cfg, int device) {
     if (const char* e = std::getenv("MTIP_SHT_WIDE")) c->sht_wide = std::atoi(e) != 0;
     if (const char* e = std::getenv("MTIP_JAC_RESIDENT")) c->jac_resident = std::atoi(e) != 0;
     if (const char* e = std::getenv("MTIP_POLAR_VARIANT")) c->polar_variant = std::atoi(e);
-    if (const char* e = std::getenv("MTIP_POLAR")) c->polar_newton = std::string(e) != "jacobi";
+    if (const char* e = std::getenv("MTIP_POLAR")) c->polar_newton = std::string(e) == "newton";
     if (const char* e = std::getenv("MTIP_JAC_TG")) c->jac_tg = std::atoi(e) == 8 ? 8 : 16;
     if (const char* e = std::getenv("MTIP_JAC_REPLAY")) c->jac_replay = std::max(0, std::min(2, std::atoi(e)));
     if (rc == MTIP_OK) rc = build_hankel_tiles(c);

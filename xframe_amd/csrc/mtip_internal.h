@@ -143,7 +143,7 @@ struct mtip_ctx {
     int n_pg_tiles[4] = {0, 0, 0, 0};
     long long* d_polar_dbg = nullptr;                 // (B, L+1, 8 waves, 4) phase timers of k_polar_newton, allocated by mtip_debug_polar_timing
     int polar_variant = 0;                            // env MTIP_POLAR_VARIANT (A/B switches of k_polar_newton: 1 ds_bpermute pivot row, 2 spin without s_sleep)
-    bool polar_newton = true;                         // env MTIP_POLAR=jacobi: one-sided Jacobi SVD for every order (else only for non-square X_l)
+    bool polar_newton = false;                        // env MTIP_POLAR=newton: scaled Newton iteration (k_polar.hip) for square X_l up to 72 x 72; default: one-sided Jacobi
     int jac_tg = 16;                                  // env MTIP_JAC_TG=8|16: lanes per Jacobi column pair
     int jac_replay = 1;                               // env MTIP_JAC_REPLAY: 0 never, 1 rotation log + V_r replay when X_l, V_r do not share LDS, 2 always
     void* d_jlog = nullptr;                           // rotation log of the last Jacobi launch (matrix, round, slot)
