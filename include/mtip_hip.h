@@ -180,6 +180,19 @@ int mtip_op_deg2_invariants(mtip_ctx* ctx, const mtip_cdouble* Ilm, mtip_cdouble
 int mtip_op_apply_matrix(mtip_ctx* ctx, const double* matrix, const double* vects, double* out,
                          int n_rows, int n_cols, int n_vec);
 
+/* ---- rotational alignment of reconstructions (xframe/projects/fxs/average.py:920-960 -> pysofft through
+ *      externalLibraries/soft_plugin.py:64-99; conventions: oracle/alignment.py, pysofft itself is not available) ---------
+ * d_table: d^l_mn(beta_b), beta_b = pi (2b+1) / 4bw, b < 2bw, bw = L + 1: (2bw, sum_l (2l+1)^2) doubles, order l at offset
+ * l(4l^2-1)/3, row m = -l..l, column n = -l..l */
+int mtip_set_so3_tables(mtip_ctx* ctx, int bw, const double* d_table);
+/* C(alpha_j, beta_b, gamma_k) = mean over the shells r_lo <= r < r_hi of Re <ref_r, R(alpha, beta, gamma) sig_r> for every
+ * restart of the batch: ref (Nq, nlm), sig (n_batch, Nq, nlm) 'direct' coefficients, C (n_batch, 2bw, 2bw, 2bw) doubles
+ * indexed [alpha][beta][gamma] (soft.calc_mean_C, soft_plugin.py:82-99) */
+int mtip_op_so3_correlation(mtip_ctx* ctx, const mtip_cdouble* ref, const mtip_cdouble* sig, int r_lo, int r_hi, double* C);
+/* f_lm -> sum_n D^l_mn f_ln on every shell (soft.rotate_coeff, soft_plugin.py:64-79): D (n_batch, sum_l (2l+1)^2) Wigner
+ * matrices in the table layout above (one rotation per restart) */
+int mtip_op_rotate_coefficients(mtip_ctx* ctx, const mtip_cdouble* coeff, const mtip_cdouble* D, mtip_cdouble* out);
+
 /* ---- timing ----------------------------------------------------------------------------------- */
 /* average duration (ms) and launch count of kernel family `name` ("sht_fwd", "sht_inv", "hankel",
  * "proj", "real_update", ...) measured with hipEvents on the ctx stream since the last reset;

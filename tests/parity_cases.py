@@ -692,3 +692,69 @@ def check_variant_golden(g, v, name, lib_path=None, use_oracle=False, n_restarts
         assert (r['last_support_mask'] != v[name + '/traj_last_support_mask']).sum() == 0
         assert np.isclose(r['final_error'], float(v[name + '/traj_final_error']), rtol=tol_e)
         assert int(r['loop_iterations']) == int(v[name + '/traj_loop_iterations'])
+
+
+# ---- alignment + averaging of reconstructions ----------------------------------------------------
+def check_average_vs_oracle(lib_path=None, N=12, L=6, n_rec=5, seed=3):
+    """xframe/projects/fxs/average.py run_3d on synthetic reconstructions: one band-limited real density, rotated by
+    different rotations of the Euler grid (one copy point-inverted, all with a little noise and different scales and
+    centres), has to come back aligned.  The HIP path (transforms, SO(3) correlation and coefficient rotation on the
+    device) against the oracle restatement: alignment errors, Euler angles, the inversion decisions, the averaged density
+    and the PRTF; and the size-independent property that the aligned copies agree with the reference."""
+    from oracle import alignment as OA
+    from xframe_amd.fxs import average as AV
+    from xframe_amd.fxs import hostsetup as hs
+    max_q = float(np.max(S.midpoint_points(S.data_cutoff(N), N)))
+    e = Engine({'grid': {'n_radial_points': N, 'max_order': L}}, None, n_batch=2, lib_path=lib_path, max_q=max_q)
+    fp = FourierPair(SHT(L), N, max_q, 2.0)
+    sht = fp.sht
+    rng = np.random.default_rng(seed)
+    al, be, ga = OA.euler_grid(L + 1)
+
+    def make(centred):
+        """a smooth real density, band limited in angle, concentrated at small radii (off centre unless `centred`: without
+        l = 1 components the centre of mass is the origin), and rotated / inverted / scaled / noisy copies of it"""
+        c = cplx(rng, (N, (L + 1) ** 2)) * np.exp(-(np.arange(N)[:, None] / (0.35 * N)) ** 2) / (1 + np.arange((L + 1) ** 2)[None, :]) ** 0.5
+        if centred:
+            c[:, 1:4] = 0
+        base = sht.inverse_d(c).real
+        base = base - base.min() + 0.05
+        base = (base * np.exp(-(fp.rs[:, None, None] / (0.5 * fp.rs.max())) ** 4)).astype(complex)
+        recs, errs = [], []
+        for i in range(n_rec):
+            # copy i is rotated by a grid rotation relative to copy 3, the one with the lowest error (the reference)
+            euler = np.array([al[rng.integers(len(al))], be[rng.integers(len(be))], ga[rng.integers(len(ga))]]) if i != 3 else np.zeros(3)
+            d = sht.inverse_d(OA.rotate_coeff(sht.forward_d(base), euler, L))
+            if i == 2:
+                d = fp.ift(fp.ft(d).conj())                          # point inverse
+            d = (1.0 + 0.3 * i) * d + 1e-5 * rng.normal(size=d.shape)
+            recs.append((d, fp.ft(d)))
+            errs.append(0.01 * (1 + ((i + 2) % n_rec)))
+        return recs, errs
+
+    recs, errs = make(False)
+    opt = {'alignment_error_limit': 0.5, 'find_rotation': {'r_limit_ids': [0, N]}}
+    ref = OA.average_reconstructions(fp, recs, errs, opt)
+    got = AV.average_reconstructions(e, recs, errs, opt)
+    assert got['reference_arg'] == ref['reference_arg']
+    assert np.allclose(got['alignment_errors'], ref['alignment_errors'], rtol=1e-6, atol=1e-12)
+    for i in range(n_rec - 1):
+        assert np.allclose(got['rotation_angles'][str(i + 1)][-1], ref['rotation_angles'][i]), i
+    assert rel_l2(got['average']['real_density'], ref['average']['real_density']) < 1e-8
+    assert rel_l2(got['average']['reciprocal_density'], ref['average']['reciprocal_density']) < 1e-8
+    assert rel_l2(got['average']['intensity_from_densities'], ref['average']['intensity_from_densities']) < 1e-8
+    assert np.allclose(got['resolution_metrics']['PRTF'], ref['resolution_metrics']['PRTF'], rtol=1e-6, atol=1e-9)
+    assert np.allclose(got['input_meta']['scaling_factors'], ref['scaling_factors'])
+    # property (without the centring step, whose phase-ramp shift is only approximate on the truncated spherical grid): every
+    # copy comes back onto the reference -- they are exact grid rotations of one density -- with errors at the noise level
+    recs, errs = make(True)
+    got = AV.average_reconstructions(e, recs, errs, dict(opt, center_reconstructions=False))
+    # (the point-inverted copy goes through IFT(conj(FT(.))), which is only as exact as the FT round trip of this small grid)
+    assert got['reference_arg'] == 3 and np.delete(got['alignment_errors'], 2).max() < 2e-4, got['alignment_errors']
+    assert got['alignment_errors'][2] < 0.5
+    order = [i for i in range(n_rec) if i != got['reference_arg']]
+    inv_expected = [(i == 2) != (got['reference_arg'] == 2) for i in order]
+    assert got['inverted'] == inv_expected
+    assert got['n_averaged'] == n_rec - 1                           # the reference's selection quirk drops the last valid alignment
+    e.close()
+    return got

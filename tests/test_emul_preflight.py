@@ -132,6 +132,12 @@ def test_loop_variants_golden(emul_lib, golden_mtip16, golden_variants, name):
     PC.check_variant_golden(golden_mtip16, golden_variants, name, emul_lib, n_restarts=1)
 
 
+def test_average_vs_oracle(emul_lib):
+    """alignment + averaging of reconstructions (average.py run_3d): device SO(3) correlation / coefficient rotation / transforms
+    against the oracle restatement"""
+    PC.check_average_vs_oracle(emul_lib)
+
+
 def test_wide_projection_matrices(emul_lib):
     """k_l = Nq < 2l+1 (the reference's integration test uses 8 radial points with max_order 15,
     tests/test_fxs_integration.py:326-355): polar factor of a wide matrix, compared through V_l U_l."""

@@ -10,7 +10,10 @@ by tests/golden/make_convergence_fixture.py in the build container) holds final 
 HIO is chaotic: after 600 steps two runs from the same seed that differ in the last bit are different samples of the same
 distribution, so beyond the first steps only distributions can be compared.  Tolerances, with the sampling noise of the
 fixture itself measured by splitting it in halves:
-  * the first 20 error values of every restart agree with the oracle run of the same seed to 1e-6 (trajectory tolerance);
+  * the first 20 error values of every restart follow the oracle run of the same seed within 5 % (the test regenerates the
+    synthetic invariants with the HIP transforms, the fixture used the oracle's: B_l agrees to 1e-13, but its eigenvectors
+    V_l of the small eigenvalues do not, which HIO amplifies to ~1e-3..1e-2 within 20 steps; the tight same-data trajectory
+    comparison, 1e-6 over HIO + SW + ER, is test_config4_worker_three_engines_vs_single_and_oracle);
   * median final error within x2 of the oracle's median, no restart outside [min / 2, 2 max] of the oracle's range;
   * B_l: every restart's relative invariant error sum_l |B_l - B_l^data|^2 / sum_l |B_l^data|^2 below 5 % (it is ~1e-4),
     and the median within x3 of the oracle's median (the oracle's own values spread over two orders of magnitude);
@@ -61,7 +64,7 @@ def test_converged_runs_match_oracle_distribution():
     print('first 20 error values vs the oracle run of the same seed: max rel deviation per restart',
           np.array2string(np.abs(first / f['first_errors'][:n] - 1).max(1), precision=1))
     assert len(res[0]['error_dict']['main']) == 600
-    assert np.allclose(first, f['first_errors'], rtol=1e-6)
+    assert np.allclose(first, f['first_errors'][:n], rtol=5e-2)
     assert 0.5 <= np.median(final) / np.median(f['final_error']) <= 2.0
     assert final.min() >= 0.5 * f['final_error'].min() and final.max() <= 2.0 * f['final_error'].max()
     assert bl.max() < 0.05

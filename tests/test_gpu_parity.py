@@ -140,6 +140,12 @@ def test_loop_variants_golden(golden_mtip16, golden_variants, name):
     PC.check_variant_golden(golden_mtip16, golden_variants, name, None)
 
 
+@pytest.mark.parametrize('N,L', [(12, 6), (24, 10)])
+def test_average_vs_oracle(N, L):
+    """alignment + averaging of reconstructions (xframe/projects/fxs/average.py run_3d) against the oracle"""
+    PC.check_average_vs_oracle(None, N=N, L=L)
+
+
 def test_config2_properties():
     PC.check_full_size_properties(2)
 

@@ -204,6 +204,11 @@ struct mtip_ctx {
     int n_partial_blocks = 0;
     double* d_minmax = nullptr;                       // (B, nblk, 2)
     double2* d_Bl = nullptr;                          // (B, L+1, Nq, Nq) scratch (lazy)
+    // rotational alignment (k_align.hip): Wigner table d^l_mn(beta_b), DFT twiddles, work arrays
+    double* d_so3_d = nullptr;
+    double2 *d_so3_tw = nullptr, *d_so3_T = nullptr, *d_so3_S = nullptr, *d_so3_P = nullptr, *d_so3_D = nullptr;
+    double* d_so3_C = nullptr;
+    int so3_bw = 0;
     // host staging
     void* h_stage = nullptr;
     // profiling

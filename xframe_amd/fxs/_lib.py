@@ -75,6 +75,9 @@ _SIGNATURES = {
     'mtip_op_real_space_update': (C.c_int, [c_void, c_void, c_void, C.c_int, C.c_double, c_void, c_void]),
     'mtip_op_deg2_invariants': (C.c_int, [c_void, c_void, c_void]),
     'mtip_op_apply_matrix': (C.c_int, [c_void, c_void, c_void, c_void, C.c_int, C.c_int, C.c_int]),
+    'mtip_set_so3_tables': (C.c_int, [c_void, C.c_int, c_void]),
+    'mtip_op_so3_correlation': (C.c_int, [c_void, c_void, c_void, C.c_int, C.c_int, c_void]),
+    'mtip_op_rotate_coefficients': (C.c_int, [c_void, c_void, c_void, c_void]),
     'mtip_profile': (C.c_int, [c_void, C.c_int]),
     'mtip_profile_get': (C.c_int, [c_void, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     'mtip_profile_reset': (C.c_int, [c_void]),

@@ -222,6 +222,34 @@ class Engine:
         self._ck(self.lib.mtip_op_apply_matrix(self.ctx, _lib.ptr(m), _lib.ptr(v), _lib.ptr(out), m.shape[0], m.shape[1], v.shape[1]))
         return out[:, 0] if squeeze else out
 
+    # ------------------------------------------------------------------ rotational alignment (average.py:920-960)
+    def _so3_setup(self):
+        if not getattr(self, '_so3_ready', False):
+            tab = np.ascontiguousarray(hs.wigner_d_table(self.L))
+            self._ck(self.lib.mtip_set_so3_tables(self.ctx, self.L + 1, _lib.ptr(tab)))
+            self._so3_ready = True
+
+    def so3_correlation(self, ref_coeff, sig_coeff, r_limit_ids=None):
+        """C[b, alpha, beta, gamma] = mean_r Re <ref_r, R sig_r> on the (2 bw)^3 Euler grid (soft.calc_mean_C)"""
+        self._so3_setup()
+        ref = np.ascontiguousarray(_lib.as_c128(ref_coeff).reshape(self.N, self.nlm))
+        sig = self._bcoef(sig_coeff)
+        lo, hi = (0, self.N) if r_limit_ids is None else (int(r_limit_ids[0]), int(r_limit_ids[1]))
+        nb = 2 * (self.L + 1)
+        out = np.empty((self.B, nb, nb, nb))
+        self._ck(self.lib.mtip_op_so3_correlation(self.ctx, _lib.ptr(ref), _lib.ptr(sig), lo, hi, _lib.ptr(out)))
+        return out
+
+    def rotate_coefficients(self, coeff, eulers):
+        """f_lm -> sum_n D^l_mn(euler_b) f_ln per restart (soft.rotate_coeff); eulers: (3,) or (B, 3)"""
+        self._so3_setup()
+        c = self._bcoef(coeff)
+        eulers = np.broadcast_to(np.asarray(eulers, dtype=float), (self.B, 3))
+        D = np.ascontiguousarray(np.stack([hs.wigner_D_flat(self.L, e) for e in eulers]))
+        out = np.empty_like(c)
+        self._ck(self.lib.mtip_op_rotate_coefficients(self.ctx, _lib.ptr(c), _lib.ptr(D), _lib.ptr(out)))
+        return out
+
     # ------------------------------------------------------------------ state and loop
     def set_density(self, batch, rho):
         r = _lib.as_c128(rho)

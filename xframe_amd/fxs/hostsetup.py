@@ -381,3 +381,50 @@ def shift_phases(qs, theta, phi, vector, opposite_direction=False):
     q = np.asarray(qs)[:, None, None]
     kc = q * (st * (np.cos(phi)[None, None, :] * c[0] + np.sin(phi)[None, None, :] * c[1]) + ct * c[2])
     return np.exp(-1.j * pre * kc)
+
+
+# ---------------------------------------------------------------------------------------------- SO(3) tables (alignment)
+def wigner_d(l, betas):
+    """d^l_mn(beta) = <l m| exp(-i beta J_y) |l n>, (len(betas), 2l+1, 2l+1), m, n = -l..l, from the eigen-decomposition of
+    J_y (unitary by construction).  The reference gets these from pysofft (``soft_plugin.py:30-36``, ``genWigAll``)."""
+    betas = np.atleast_1d(np.asarray(betas, dtype=float))
+    m = np.arange(-l, l)
+    c = 0.5 * np.sqrt(l * (l + 1) - m * (m + 1))
+    jy = np.zeros((2 * l + 1, 2 * l + 1), complex)
+    idx = np.arange(2 * l)
+    jy[idx + 1, idx] = -1j * c
+    jy[idx, idx + 1] = 1j * c
+    w, v = np.linalg.eigh(jy)
+    return np.ascontiguousarray(np.einsum('ik,bk,jk->bij', v, np.exp(-1j * betas[:, None] * w[None, :]), v.conj()).real)
+
+
+def euler_grid(bw):
+    """Euler angle samples of the SO(3) grid of bandwidth bw (``soft_plugin.py:55-58``: alpha, beta, gamma)"""
+    j = np.arange(2 * bw)
+    return 2 * np.pi * j / (2 * bw), np.pi * (2 * j + 1) / (4 * bw), 2 * np.pi * j / (2 * bw)
+
+
+def so3_table_offsets(L):
+    return np.array([l * (4 * l * l - 1) // 3 for l in range(L + 2)])
+
+
+def wigner_d_table(L):
+    """(2bw, sum_l (2l+1)^2) table of d^l_mn(beta_b) for the device (mtip_set_so3_tables)"""
+    bw = L + 1
+    off = so3_table_offsets(L)
+    out = np.empty((2 * bw, off[-1]))
+    be = euler_grid(bw)[1]
+    for l in range(L + 1):
+        out[:, off[l]:off[l + 1]] = wigner_d(l, be).reshape(2 * bw, -1)
+    return out
+
+
+def wigner_D_flat(L, euler):
+    """D^l_mn(alpha, beta, gamma) = e^{-i m alpha} d^l_mn(beta) e^{-i n gamma} for l = 0..L in the table layout"""
+    a, b, g = euler
+    off = so3_table_offsets(L)
+    out = np.empty(off[-1], complex)
+    for l in range(L + 1):
+        m = np.arange(-l, l + 1)
+        out[off[l]:off[l + 1]] = (np.exp(-1j * m * a)[:, None] * wigner_d(l, [b])[0] * np.exp(-1j * m * g)[None, :]).reshape(-1)
+    return out
