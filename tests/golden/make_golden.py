@@ -523,8 +523,41 @@ def main_variants():
     print('variants fixture:', len(out), 'arrays')
 
 
+def main_average_ops():
+    """tests/golden/average_ops.npz (G14): PRTF of the reference's resolution_metrics.py:62-110 on seeded arrays with zeros in
+    numerator and denominator, and SphericalIntegrator.integrate_normed (the alignment error metric, average.py:1047-1062)"""
+    mods = bootstrap()
+    ml = mods['xframe.library.mathLibrary']
+    ml.shtns = ShAdapter
+    rm = importlib.import_module('xframe.projects.fxs.projectLibrary.resolution_metrics')
+    rng = np.random.default_rng(1414)
+    shape = (6, 5, 8)
+    a1, a2 = cplx(rng, shape), cplx(rng, shape)
+    I1, I2 = rng.random(shape), rng.random(shape)
+    I1[0, 0, :3] = 0
+    I2[1, 2, 4] = 0
+    a1[0, 0, 1] = 0
+    out = {'G14_a1': a1, 'G14_a2': a2, 'G14_I1': I1, 'G14_I2': I2}
+    p = rm.PRTF_fxs(a1, I1, averaged_projected_scattering_amplitude=a2, averaged_projected_intensity=I2)
+    out['G14_prtf'], out['G14_prtf_std'] = p[0], p[1]
+    p = rm.PRTF_fxs(a1, I1)
+    out['G14_prtf_single'], out['G14_prtf_single_std'] = p[0], p[1]
+    from oracle.sht import SHT
+    rs = (np.arange(6) + 0.5) * 3.0
+    sh = SHT(2)
+    grid = np.stack(np.meshgrid(rs, sh.theta, sh.phi, indexing='ij'), -1)
+    vals = rng.random(grid.shape[:-1])
+    integ = ml.SphericalIntegrator(grid)
+    out['G14_int_rs'], out['G14_int_values'] = rs, vals
+    out['G14_int_normed'] = np.array(integ.integrate_normed(vals))
+    np.savez_compressed(os.path.join(HERE, 'average_ops.npz'), **out)
+    print('average ops fixture:', len(out), 'arrays')
+
+
 if __name__ == '__main__':
-    if len(sys.argv) > 1 and sys.argv[1] == 'variants':
+    if len(sys.argv) > 1 and sys.argv[1] == 'average':
+        main_average_ops()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'variants':
         main_variants()
     else:
         main()

@@ -239,3 +239,21 @@ def test_G13_loop_variants(golden_mtip16, golden_variants, name):
     """Oracle against trajectories of the reference's own loop for the *_non_FXS / SW_center schedules (stale `hist`,
     swapped SW_center outputs) and for the main error over the reciprocal deg2 metric (G13)."""
     _PC.check_variant_golden(golden_mtip16, golden_variants, name, use_oracle=True)
+
+
+def test_G14_average_metrics():
+    """PRTF (resolution_metrics.py:62-110) and the normed spherical integral of the alignment error (average.py:1047-1062):
+    oracle restatement and the product's host mirror against values of the reference's own functions."""
+    import os
+    from oracle import alignment as OA
+    from xframe_amd.fxs import average as AV
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'average_ops.npz'))
+    a1, a2, b1, b2 = g['G14_a1'], g['G14_a2'], np.sqrt(g['G14_I1']), np.sqrt(g['G14_I2'])
+    for fn in (OA.PRTF, AV.PRTF):
+        p, sd = fn(a1, a2, b1, b2)
+        assert np.allclose(p, g['G14_prtf'], rtol=1e-13) and np.allclose(sd, g['G14_prtf_std'], rtol=1e-13)
+        p, sd = fn(a1, a1, b1, b1)
+        assert np.allclose(p, g['G14_prtf_single'], rtol=1e-13) and np.allclose(sd, g['G14_prtf_single_std'], rtol=1e-13)
+    rs, vals = g['G14_int_rs'], g['G14_int_values']
+    assert np.isclose(AV.integrate_normed(rs, vals.shape[1], vals), float(g['G14_int_normed']), rtol=1e-13)
+    assert np.isclose(SphericalIntegrator(rs, vals.shape[1]).integrate_normed(vals), float(g['G14_int_normed']), rtol=1e-13)
