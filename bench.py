@@ -100,6 +100,33 @@ def phase_of(warmup, steps):
             'schedule': 'tutorial schedule from its first step: 5 x (60 HIO, SW, 40 ER) + (SW, 100 ER), repeated'}
 
 
+def cpu_baseline(a, N, L, B):
+    """The oracle (numpy restatement of the reference algorithm), one process per restart with one BLAS thread each like the
+    reference (xframe/__init__.py:5-8, reconstruct.py:141-157), a bounded sample of HIO ft_stab steps.  Runs BEFORE this
+    process touches the GPU: the children are fresh interpreters (spawn) and build the same synthetic invariants with the
+    oracle's own transforms."""
+    import multiprocessing as mp
+    from oracle import baseline_worker
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        pass
+    n_proc = max(1, min(B, cores))
+    ctx = mp.get_context('spawn')
+    t_c0 = time.perf_counter()
+    with ctx.Pool(n_proc) as pool:
+        outs = pool.map(baseline_worker.run, [(None, a.config, 1000 + i, a.cpu_seconds, 200) for i in range(n_proc)])
+    t_c1 = time.perf_counter()
+    per_proc = [n / sec for n, sec, _ in outs]
+    return {'value': float(sum(per_proc)), 'unit': 'MTIP iterations/s', 'cores': n_proc, 'kind': 'port',
+            'per_process': float(np.mean(per_proc)), 'host_cpu_count': os.cpu_count(), 'usable_cores': cores,
+            'sample': f'{n_proc} oracle processes (one restart each, 1 BLAS thread, as reconstruct.py:141-157), '
+                      f'{sum(n for n, _, _ in outs)} HIO ft_stab steps in total at {N}x L{L} on the same synthetic invariants, '
+                      f'{a.cpu_seconds:.0f} s of stepping per process; setup ({np.mean([st for _, _, st in outs]):.1f} s per '
+                      f'process) excluded; wall {t_c1 - t_c0:.0f} s'}
+
+
 def main():
     a = parse()
     if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -111,6 +138,10 @@ def main():
         raise SystemExit(f'--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus} '
                          f'(or run `python bench.py --gpus {a.gpus}` without a launcher)')
     np.seterr(all='ignore')
+    from xframe_amd.fxs import synthetic as S0
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:       # reported at N = 1 only; before any GPU call of this process
+        cpu = cpu_baseline(a, *S0._SIZES[a.config], a.restarts_per_gpu)
     import torch
     dist = None
     if world > 1:
@@ -309,31 +340,6 @@ def main():
     whole_step = {'algorithmic_bytes_per_step_per_restart': step_bytes,
                   'achieved_GBps_per_gpu': step_bytes * B * a.steps / elapsed / 1e9,
                   'frac_of_8TBps': step_bytes * B * a.steps / elapsed / 8e12}
-
-    # ---- CPU baseline: the oracle (numpy restatement of the reference algorithm), one process per restart with one BLAS
-    #      thread each like the reference (xframe/__init__.py:5-8, reconstruct.py:141-157), bounded sample
-    cpu = None
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:       # reported at N = 1 only
-        import multiprocessing as mp
-        from oracle import baseline_worker
-        cores = os.cpu_count() or 1
-        try:
-            cores = len(os.sched_getaffinity(0))
-        except (AttributeError, OSError):
-            pass
-        n_proc = max(1, min(B, cores))
-        ctx = mp.get_context('spawn')                            # fresh interpreters: never fork a process that holds a GPU
-        t_c0 = time.perf_counter()
-        with ctx.Pool(n_proc) as pool:
-            outs = pool.map(baseline_worker.run, [(data, a.config, 1000 + i, a.cpu_seconds, 200) for i in range(n_proc)])
-        t_c1 = time.perf_counter()
-        per_proc = [n / sec for n, sec, _ in outs]
-        cpu = {'value': float(sum(per_proc)), 'unit': 'MTIP iterations/s', 'cores': n_proc, 'kind': 'port',
-               'per_process': float(np.mean(per_proc)), 'host_cpu_count': os.cpu_count(), 'usable_cores': cores,
-               'sample': f'{n_proc} oracle processes (one restart each, 1 BLAS thread, as reconstruct.py:141-157), '
-                         f'{sum(n for n, _, _ in outs)} HIO ft_stab steps in total at {N}x L{L} on the same synthetic invariants, '
-                         f'{a.cpu_seconds:.0f} s of stepping per process; setup ({np.mean([st for _, _, st in outs]):.1f} s per '
-                         f'process) excluded; wall {t_c1 - t_c0:.0f} s'}
 
     if rank == 0:
         line = {

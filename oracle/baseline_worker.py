@@ -7,7 +7,7 @@ import time
 
 
 def run(args):
-    """args = (data dict, config id, seed, seconds, max_steps) -> (steps done, loop seconds, setup seconds)"""
+    """args = (data dict or None, config id, seed, seconds, max_steps) -> (steps done, loop seconds, setup seconds)"""
     for k in ('OMP_NUM_THREADS', 'OPENBLAS_NUM_THREADS', 'MKL_NUM_THREADS'):
         os.environ[k] = '1'
     import numpy as np
@@ -21,6 +21,21 @@ def run(args):
     from xframe_amd.fxs import synthetic as S             # pure numpy module (settings of the BASELINE configs)
     data, cfg, seed, seconds, max_steps = args
     t0 = time.perf_counter()
+    if data is None:                                     # the same synthetic invariants, made with the oracle's transforms
+        from oracle.fourier import FourierPair
+        from oracle.sht import SHT
+
+        class _T:
+            def __init__(s, fp):
+                s.fp, s.rs, s.thetas, s.phis = fp, fp.rs, fp.sht.theta, fp.sht.phi
+
+            def ft(s, x):
+                return s.fp.ft(x)
+
+            def forward_l(s, x):
+                return s.fp.sht.forward_l(x)
+        N, L = S._SIZES[cfg]
+        data, _ = S.make_invariants(_T(FourierPair(SHT(L), N, S.data_cutoff(N), 2.0)), N, L)
     opt = OM.deep_update(OM.default_settings(), S.config_overrides(cfg))
     om = OM.MTIP(opt, data)
     rho0 = om.density_guess(np.random.default_rng(seed))
