@@ -193,6 +193,12 @@ int mtip_op_so3_correlation(mtip_ctx* ctx, const mtip_cdouble* ref, const mtip_c
  * matrices in the table layout above (one rotation per restart) */
 int mtip_op_rotate_coefficients(mtip_ctx* ctx, const mtip_cdouble* coeff, const mtip_cdouble* D, mtip_cdouble* out);
 
+/* ---- upstream step `extract`: B_l -> V_l (fxs_invariant_tools.py:1079-1131, 1171-1207) -------------------------------
+ * eigen-decomposition of n_mat Hermitian n x n matrices A (row-major, only their Hermitian part matters): eigvals (n_mat, n)
+ * unsorted, eigvecs (n_mat, n, n) with eigenvector i of matrix k in eigvecs[k][i][:] (one eigenvector per row).  Sorting,
+ * the cut to min(2l+1, Nq) pairs, clipping of negative eigenvalues and V_l = eigvecs sqrt(eigvals) are host bookkeeping. */
+int mtip_op_hermitian_eig(mtip_ctx* ctx, int n, int n_mat, const mtip_cdouble* A, double* eigvals, mtip_cdouble* eigvecs);
+
 /* ---- timing ----------------------------------------------------------------------------------- */
 /* average duration (ms) and launch count of kernel family `name` ("sht_fwd", "sht_inv", "hankel",
  * "proj", "real_update", ...) measured with hipEvents on the ctx stream since the last reset;

@@ -758,3 +758,35 @@ def check_average_vs_oracle(lib_path=None, N=12, L=6, n_rec=5, seed=3):
     assert got['n_averaged'] == n_rec - 1                           # the reference's selection quirk drops the last valid alignment
     e.close()
     return got
+
+
+def check_extract_vs_numpy(lib_path=None, N=24, L=6):
+    """`extract` (fxs_invariant_tools.py:1079-1207): B_l -> V_l with the device eigensolver against numpy's eigh -- compared
+    through eigenvalues and through V_l V_l^+ (eigenvectors are only defined up to phases / rotations inside degenerate
+    spaces), incl. a matrix with negative eigenvalues (clipped) and the rank 2l+1 < Nq structure of real B_l."""
+    fpd = FourierPair(SHT(L), N, S.data_cutoff(N), 2.0)
+    tr = OracleTransforms(fpd)
+    e = Engine({'grid': {'n_radial_points': N, 'max_order': L}}, None, n_batch=1, lib_path=lib_path, max_q=S.data_cutoff(N))
+    d_np, _ = S.make_invariants(tr, N, L)
+    d_dev, _ = S.make_invariants(tr, N, L, eigh=e.hermitian_eig)
+    for l in range(L + 1):
+        a, b = d_np['data_projection_matrices'][l], d_dev['data_projection_matrices'][l]
+        assert a.shape == b.shape == (N, min(N, 2 * l + 1))
+        assert rel_l2(b @ b.conj().T, a @ a.conj().T) < 1e-11, l
+    assert np.allclose(d_np['average_intensity'], d_dev['average_intensity'], rtol=1e-13)
+    rng = np.random.default_rng(5)
+    m = cplx(rng, (3, N, N))
+    m = m + np.conj(np.swapaxes(m, -1, -2))                         # indefinite Hermitian matrices
+    w, v = e.hermitian_eig(m)
+    for k in range(3):
+        assert np.allclose(w[k], np.linalg.eigvalsh(m[k])[::-1], rtol=1e-12, atol=1e-12 * np.abs(w[k]).max())
+        assert rel_l2(m[k] @ v[k], v[k] * w[k][None, :]) < 1e-12
+    pms, evs = e.extract_projection_matrices(m, orders=[1, 2, 30])
+    for k, l in enumerate([1, 2, 30]):
+        kk = min(N, 2 * l + 1)
+        ww, vv = np.linalg.eigh(m[k])
+        ww, vv = ww[::-1][:kk], vv[:, ::-1][:, :kk]
+        ww = np.where(ww < 0, 0, ww)
+        assert pms[k].shape == (N, kk) and np.allclose(evs[k], ww, rtol=1e-12, atol=1e-12)
+        assert rel_l2(pms[k] @ pms[k].conj().T, (vv * ww[None, :]) @ vv.conj().T) < 1e-11
+    e.close()

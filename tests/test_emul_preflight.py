@@ -138,6 +138,10 @@ def test_average_vs_oracle(emul_lib):
     PC.check_average_vs_oracle(emul_lib)
 
 
+def test_extract_vs_numpy(emul_lib):
+    PC.check_extract_vs_numpy(emul_lib, N=12, L=4)
+
+
 def test_wide_projection_matrices(emul_lib):
     """k_l = Nq < 2l+1 (the reference's integration test uses 8 radial points with max_order 15,
     tests/test_fxs_integration.py:326-355): polar factor of a wide matrix, compared through V_l U_l."""

@@ -146,6 +146,12 @@ def test_average_vs_oracle(N, L):
     PC.check_average_vs_oracle(None, N=N, L=L)
 
 
+@pytest.mark.parametrize('N,L', [(24, 6), (128, 32)])
+def test_extract_vs_numpy(N, L):
+    """B_l -> V_l on the device (the `extract` step) against numpy eigh, small and at the benchmark size"""
+    PC.check_extract_vs_numpy(None, N=N, L=L)
+
+
 def test_config2_properties():
     PC.check_full_size_properties(2)
 

@@ -1,0 +1,130 @@
+// Upstream step `extract`: B_l -> projection matrices V_l, i.e. the eigen-decomposition of the
+// Hermitian degree-2 invariants  xframe/projects/fxs/projectLibrary/fxs_invariant_tools.py:1079-1131 (deg2_invariant_eigenvalues:
+// numpy eigh), 1171-1207 (top min(2l+1, Nq) eigenpairs, negative eigenvalues clipped, V_l = eigvecs sqrt(eigvals)).
+// One workgroup per matrix: one-sided (Hestenes) Jacobi on the columns of A = B_l with accumulation of the rotations,
+//   A V = W (orthogonal columns),  eigenvector i = column i of V,  eigenvalue_i = sign(Re v_i^+ w_i) |w_i|
+// (for a Hermitian matrix the right singular vectors are eigenvectors and the singular values |eigenvalues|).
+// A one-off setup computation (L+1 matrices of Nq x Nq): matrices stay in global memory (L2 resident), 8 lanes per pair.
+#include "mtip_internal.h"
+
+#define HE_TG 8
+#define HE_MAX_SWEEPS 60
+#define HE_TOL 1e-15
+
+__global__ void __launch_bounds__(512) k_herm_eig(double2* __restrict__ Wall, double2* __restrict__ Vall, double* __restrict__ lam_all,
+                                                  int n, int* __restrict__ sweeps_out) {
+    __shared__ int s_rotated;
+    double2* W = Wall + (size_t)blockIdx.x * n * n;           // column c at W + c * n
+    double2* V = Vall + (size_t)blockIdx.x * n * n;
+    double* lam = lam_all + (size_t)blockIdx.x * n;
+    const int tid = threadIdx.x;
+    for (int e = tid; e < n * n; e += blockDim.x) V[e] = make_double2((e / n) == (e % n) ? 1.0 : 0.0, 0.0);
+    __syncthreads();
+    const int Cp = n + (n & 1), rounds = Cp - 1, pairs = Cp / 2;
+    const int ngroups = blockDim.x / HE_TG, group = tid / HE_TG, t = tid - group * HE_TG;
+    const int per_group = (pairs + ngroups - 1) / ngroups;
+    int sweep = 0;
+    for (; sweep < HE_MAX_SWEEPS && n > 1; ++sweep) {
+        if (tid == 0) s_rotated = 0;
+        __syncthreads();
+        for (int r = 0; r < rounds; ++r) {
+            for (int it = 0; it < per_group; ++it) {
+                const int pi = group + it * ngroups;
+                int ci = 0, cj = 0;
+                bool valid = pi < pairs;
+                if (valid) {
+                    const int M = Cp - 1;                            // tournament pairing: player M stays, the others rotate
+                    if (pi == 0) { ci = r; cj = M; }
+                    else { ci = (r + pi) % M; cj = (r - pi + M) % M; }
+                    valid = (ci < n) && (cj < n);
+                }
+                double2* wi = W + (size_t)ci * n;
+                double2* wj = W + (size_t)cj * n;
+                double alpha = 0.0, beta = 0.0, gr = 0.0, gi = 0.0;
+                if (valid)
+                    for (int row = t; row < n; row += HE_TG) {
+                        const double2 a = wi[row], c = wj[row];
+                        alpha += cabs2(a);
+                        beta += cabs2(c);
+                        gr += a.x * c.x + a.y * c.y;                 // conj(a) * c
+                        gi += a.x * c.y - a.y * c.x;
+                    }
+                for (int o = HE_TG / 2; o > 0; o >>= 1) {
+                    alpha += __shfl_xor(alpha, o, HE_TG);
+                    beta += __shfl_xor(beta, o, HE_TG);
+                    gr += __shfl_xor(gr, o, HE_TG);
+                    gi += __shfl_xor(gi, o, HE_TG);
+                }
+                const double g2 = gr * gr + gi * gi;
+                if (valid && g2 > (HE_TOL * HE_TOL) * alpha * beta && g2 > 0.0) {
+                    const double gabs = sqrt(g2);
+                    const double zeta = (beta - alpha) / (2.0 * gabs);
+                    const double tt = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                    const double cs = 1.0 / sqrt(1.0 + tt * tt), sn = cs * tt;
+                    const double2 em = make_double2(gr / gabs, -gi / gabs);          // conj(gamma) / |gamma|
+                    double2* vi = V + (size_t)ci * n;
+                    double2* vj = V + (size_t)cj * n;
+                    for (int row = t; row < n; row += HE_TG) {
+                        const double2 a = wi[row], bj = cmul(em, wj[row]);
+                        wi[row] = make_double2(cs * a.x - sn * bj.x, cs * a.y - sn * bj.y);
+                        wj[row] = make_double2(sn * a.x + cs * bj.x, sn * a.y + cs * bj.y);
+                        const double2 va = vi[row], vb = cmul(em, vj[row]);
+                        vi[row] = make_double2(cs * va.x - sn * vb.x, cs * va.y - sn * vb.y);
+                        vj[row] = make_double2(sn * va.x + cs * vb.x, sn * va.y + cs * vb.y);
+                    }
+                    if (t == 0) s_rotated = 1;
+                }
+            }
+            __syncthreads();
+        }
+        const int rotated = s_rotated;
+        __syncthreads();
+        if (!rotated) break;
+    }
+    // eigenvalue_i = (v_i^+ w_i) (real for a Hermitian matrix): magnitude |w_i|, sign from the inner product
+    for (int c = tid; c < n; c += blockDim.x) {
+        double s2 = 0.0, ip = 0.0;
+        for (int row = 0; row < n; ++row) {
+            const double2 w = W[(size_t)c * n + row], v = V[(size_t)c * n + row];
+            s2 += cabs2(w);
+            ip += v.x * w.x + v.y * w.y;
+        }
+        lam[c] = (ip >= 0.0 ? 1.0 : -1.0) * sqrt(s2);
+    }
+    if (tid == 0 && sweeps_out) sweeps_out[blockIdx.x] = sweep;
+}
+
+extern "C" int mtip_op_hermitian_eig(mtip_ctx* c, int n, int n_mat, const mtip_cdouble* A, double* eigvals, mtip_cdouble* eigvecs) {
+    if (!c) return MTIP_EINVAL;
+    if (n < 1 || n > 1024 || n_mat < 1 || !A || !eigvals || !eigvecs) {
+        c->err = "hermitian_eig: bad sizes or null buffer";
+        return MTIP_EINVAL;
+    }
+    (void)hipSetDevice(c->device);
+    double2 *dW = nullptr, *dV = nullptr;
+    double* dl = nullptr;
+    const size_t nn = (size_t)n_mat * n * n;
+    int rc = MTIP_OK;
+    if (hipMalloc((void**)&dW, nn * sizeof(double2)) != hipSuccess || hipMalloc((void**)&dV, nn * sizeof(double2)) != hipSuccess ||
+        hipMalloc((void**)&dl, (size_t)n_mat * n * sizeof(double)) != hipSuccess) {
+        c->err = "hermitian_eig: out of device memory";
+        rc = MTIP_ENOMEM;
+    }
+    if (rc == MTIP_OK) {
+        hipError_t e = hipMemcpy(dW, A, nn * sizeof(double2), hipMemcpyHostToDevice);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_herm_eig, dim3((unsigned)n_mat), dim3(512), 0, c->stream, dW, dV, dl, n, (int*)nullptr);
+            e = hipStreamSynchronize(c->stream);
+        }
+        if (e == hipSuccess) e = hipMemcpy(eigvals, dl, (size_t)n_mat * n * sizeof(double), hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(eigvecs, dV, nn * sizeof(double2), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) {
+            c->err = std::string("hermitian_eig: ") + hipGetErrorString(e);
+            rc = MTIP_EHIP;
+        }
+    }
+    if (dW) (void)hipFree(dW);
+    if (dV) (void)hipFree(dV);
+    if (dl) (void)hipFree(dl);
+    return rc;
+}

@@ -222,6 +222,42 @@ class Engine:
         self._ck(self.lib.mtip_op_apply_matrix(self.ctx, _lib.ptr(m), _lib.ptr(v), _lib.ptr(out), m.shape[0], m.shape[1], v.shape[1]))
         return out[:, 0] if squeeze else out
 
+    # ------------------------------------------------------------------ extract: B_l -> V_l (fxs_invariant_tools.py:1079-1207)
+    def hermitian_eig(self, mats):
+        """eigen-decomposition of a stack of Hermitian matrices (K, n, n) on the device: eigenvalues (K, n) in descending order,
+        eigenvectors (K, n, n) with eigenvector i in [:, :, i] (numpy.linalg.eigh's layout, reversed order)"""
+        m = _lib.as_c128(mats)
+        K, n = m.shape[0], m.shape[1]
+        herm = np.ascontiguousarray((m + np.conj(np.swapaxes(m, -1, -2))) / 2)
+        # the kernel rotates the columns of its column-major work matrix: hand it B^T = conj(B), whose eigenvectors are the
+        # conjugates of B's
+        vals = np.empty((K, n))
+        vecs = np.empty((K, n, n), complex)
+        self._ck(self.lib.mtip_op_hermitian_eig(self.ctx, n, K, _lib.ptr(np.ascontiguousarray(np.swapaxes(herm, -1, -2))),
+                                                _lib.ptr(vals), _lib.ptr(vecs)))
+        order = np.argsort(vals, axis=1)[:, ::-1]
+        vals = np.take_along_axis(vals, order, axis=1)
+        vecs = np.take_along_axis(vecs, order[:, :, None], axis=1)          # rows = eigenvectors
+        return vals, np.ascontiguousarray(np.swapaxes(vecs, -1, -2))
+
+    def extract_projection_matrices(self, Bl, orders=None):
+        """deg2_invariant_to_projection_matrices_3d (fxs_invariant_tools.py:1171-1207) for B_l (L+1, Nq, Nq): V_l = the top
+        min(2l+1, Nq) eigenvectors scaled by sqrt(eigenvalue), negative eigenvalues clipped.  Returns (list of V_l, list of
+        eigenvalues)."""
+        Bl = _lib.as_c128(Bl)
+        orders = range(Bl.shape[0]) if orders is None else orders
+        vals, vecs = self.hermitian_eig(Bl)
+        pms, evs = [], []
+        for i, l in enumerate(orders):
+            k = min(Bl.shape[1], 2 * l + 1)
+            w, v = vals[i, :k].copy(), vecs[i][:, :k].copy()
+            neg = w < 0
+            w[neg] = 0
+            v[:, neg] = 0
+            pms.append((v * np.sqrt(w)[None, :]).astype(complex))
+            evs.append(w)
+        return pms, evs
+
     # ------------------------------------------------------------------ rotational alignment (average.py:920-960)
     def _so3_setup(self):
         if not getattr(self, '_so3_ready', False):

@@ -45,34 +45,42 @@ def ball_density(rs, thetas, phis, seed=20241020, n_balls=6, particle_radius=PAR
     return rho.astype(complex)
 
 
-def invariants_from_intensity_coefficients(Ilm, data_radial_points, max_order):
+def invariants_from_intensity_coefficients(Ilm, data_radial_points, max_order, eigh=None):
     """I_lm (list over l of (N,2l+1)) -> the dict ``load_invariants`` would hand to the worker
     (``xframe/projects/fxs/_database_.py:566-609``).  Stored in the reference's on-disk convention:
-    V_l halved (``fxs_Projections.py:710-713`` multiplies by 2), average_intensity from B_0."""
+    V_l halved (``fxs_Projections.py:710-713`` multiplies by 2), average_intensity from B_0.
+    ``eigh``: batched Hermitian eigensolver ``(K, N, N) -> (eigenvalues descending (K, N), eigenvectors (K, N, N))``, e.g.
+    ``Engine.hermitian_eig`` (the ``extract`` step on the device); default numpy."""
     N = len(data_radial_points)
     pms = np.empty(max_order + 1, dtype=object)
     bls = []
     for l in range(max_order + 1):
         Il = np.asarray(Ilm[l])
         B = (Il @ Il.conj().T) / 4.0                       # stored convention: (V/2)(V/2)^+
-        B = (B + B.conj().T) / 2
-        w, v = np.linalg.eigh(B)
-        order = np.argsort(w)[::-1]
-        w, v = w[order].real, v[:, order]
+        bls.append((B + B.conj().T) / 2)
+    if eigh is not None:
+        all_w, all_v = eigh(np.stack(bls))
+    for l in range(max_order + 1):
+        B = bls[l]
+        if eigh is not None:
+            w, v = np.array(all_w[l]), np.array(all_v[l])
+        else:
+            w, v = np.linalg.eigh(B)
+            order = np.argsort(w)[::-1]
+            w, v = w[order].real, v[:, order]
         k = min(N, 2 * l + 1)
         w, v = w[:k].copy(), v[:, :k].copy()
         neg = w < 0
         w[neg] = 0
         v[:, neg] = 0
         pms[l] = (v @ np.diag(np.sqrt(w))).astype(complex)
-        bls.append(B)
     aint = np.sqrt(np.diag(bls[0]).real / (4 * np.pi))
     return {'dimensions': 3, 'xray_wavelength': XRAY_WAVELENGTH, 'average_intensity': aint,
             'data_radial_points': np.asarray(data_radial_points), 'data_angular_points': np.zeros(1),
             'max_order': max_order, 'data_projection_matrices': pms}
 
 
-def make_invariants(transforms, n_radial_points, max_order, seed=20241020):
+def make_invariants(transforms, n_radial_points, max_order, seed=20241020, eigh=None):
     """transforms must be built on the *data* grid (max_q = data_cutoff(N)) and expose
     ``rs``, ``thetas``, ``phis``, ``ft(grid)->grid`` and ``forward_l(grid)->list``."""
     rho = ball_density(transforms.rs, transforms.thetas, transforms.phis, seed)
@@ -80,7 +88,7 @@ def make_invariants(transforms, n_radial_points, max_order, seed=20241020):
     I = F * F.conj()
     Ilm = transforms.forward_l(I)
     q_d = midpoint_points(data_cutoff(n_radial_points), n_radial_points)
-    return invariants_from_intensity_coefficients(Ilm, q_d, max_order), rho
+    return invariants_from_intensity_coefficients(Ilm, q_d, max_order, eigh), rho
 
 
 # ---- BASELINE.json configs (SURVEY section 8 d) ---------------------------------------------
