@@ -304,32 +304,41 @@ def main():
             # not an HBM / MFMA kernel: one workgroup = one CU per (restart, order) matrix, bound by FP64 vector issue and
             # the latency of its dependent pivot chain; its roofline is the FP64 vector rate of the CUs it occupies.
             tops = {k: v for k, v in fam_ms.items() if k != 'proj'}
-            if 'polar' in fam_ms and 'proj' in fam_ms:                          # what is left of the projection: its two GEMMs
+            if 'polar' in fam_ms and 'proj' in fam_ms:                          # what is left of the projection: its GEMMs
                 tops['proj_gemms'] = {'total_ms': fam_ms['proj']['total_ms'] - fam_ms['polar']['total_ms']}
-            elif 'proj' in fam_ms:
-                tops['proj'] = fam_ms['proj']
             top = max(tops, key=lambda k: tops[k]['total_ms'])
             if top == 'polar':
-                its = np.asarray(e0.jacobi_sweeps(), dtype=float)                  # (Bp, L+1) iterations of the last call
+                its = np.asarray(e0.jacobi_sweeps(), dtype=float)                  # (Bp, L+1): sweeps / iterations of the last call
                 ns = 2 * np.arange(L + 1) + 1
                 active = its.mean(0) > 0
-                # one Newton iteration = one in-place complex Gauss-Jordan inverse (n^3 complex multiply-adds = 8 n^3 flop)
-                # + the update (4 n^2); iterations as reported by the kernel, averaged over the restarts of the launch
-                flops = float((its * (8.0 * ns ** 3 + 4.0 * ns ** 2)[None, :]).sum())
+                newton = os.environ.get('MTIP_POLAR', 'jacobi') == 'newton'
+                if newton:
+                    # one Newton iteration = one in-place complex Gauss-Jordan inverse (n^3 complex multiply-adds = 8 n^3 flop)
+                    # + the update (4 n^2)
+                    flops = float((its * (8.0 * ns ** 3 + 4.0 * ns ** 2)[None, :]).sum())
+                    kname = 'polar (k_polar_newton: scaled Newton polar factor, Gauss-Jordan inverse)'
+                else:
+                    # one sweep of the one-sided Jacobi SVD = n (n - 1) / 2 column pairs, each 16 n flop for the Gram sums and
+                    # 24 flop per row for the rotation of the two X_l columns (n rows) and of the two V_r columns (n rows): 64 n
+                    # per pair, 32 n^3 per sweep (deflated columns are counted as if present: an upper bound of the work done)
+                    flops = float((its * (32.0 * ns ** 3)[None, :]).sum())
+                    kname = 'polar (k_polar_jacobi_lds: one-sided Jacobi SVD in LDS, one workgroup per (restart, order))'
                 cus = int(min(Bp * int(active.sum()), e0_cus))
                 peak = cus * 4 * 32 * 2.4e9 / 1e12                                # FP64 vector: 32 flop / clk / SIMD at 2.4 GHz
                 ach = flops / (fam_ms['polar']['avg_ms'] * 1e-3) / 1e12
-                roofline = {'bound': 'fp64_valu', 'kernel': 'polar (k_polar_newton: scaled Newton polar factor, Gauss-Jordan inverse)',
+                roofline = {'bound': 'fp64_valu', 'kernel': kname,
                             'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak, 'traffic': None,
                             'cus_used': cus, 'cus_total': e0_cus, 'avg_launch_ms': fam_ms['polar']['avg_ms'],
                             'algorithmic_flops_per_launch': flops, 'restarts_per_launch': Bp,
-                            'newton_iterations_restart0': [int(x) for x in its[0]],
+                            'sweeps_or_iterations_restart0': [int(x) for x in its[0]],
                             'share_of_step': fam_ms['polar']['total_ms'] / sum(v['total_ms'] for v in tops.values()),
                             'hbm_family': hbm_roof,
-                            'note': 'dominant kernel by hipEvent time over the timed region on the stream of engine 0; peak = FP64 '
-                                    'vector rate of the CUs the launch occupies (one workgroup per matrix); hbm_family = the '
-                                    'dominant HBM-bound kernel family, priced against 8 TB/s; traffic of that family = FETCH_SIZE x 2 '
-                                    '+ WRITE_SIZE of profiles/pmc_traffic.json when collected at this batch size'}
+                            'note': 'dominant kernel by hipEvent time over the timed region on the stream of engine 0; not an HBM or '
+                                    'MFMA kernel: bound by FP64 vector issue and the latency of its dependent chain inside one CU '
+                                    'per matrix; peak = FP64 vector rate of the CUs the launch occupies (one workgroup per '
+                                    'matrix); flops from the sweep / iteration counts of the last timed call; hbm_family = the '
+                                    'dominant HBM-bound kernel family against 8 TB/s, traffic = FETCH_SIZE x 2 + WRITE_SIZE of '
+                                    'profiles/pmc_traffic.json when collected at this batch size'}
             else:
                 roofline = dict(hbm_roof)
                 roofline['share_of_step'] = fam_ms[dom]['total_ms'] / sum(v['total_ms'] for v in tops.values())

@@ -1353,6 +1353,8 @@ int launch_project_coefficients(mtip_ctx* c, const double2* Ilm, double2* out) {
                        c->d_sweeps, pad, use_sched ? (const int*)c->d_jsched : (const int*)nullptr,                     \
                        (const int*)c->d_jsched_off, (const int*)c->d_jsched_rounds, c->jsched_ps,                      \
                        (const int*)c->d_jorder, (JlRec*)c->d_jlog, c->d_jlog_rounds, log_cap)
+        {
+        ProfScope pp(c, "polar");                                // the polar-factor kernels alone (nested in "proj")
         if (logv) {
             if (nmax <= 5 * 16 && threads <= JL_MAX_THREADS) JL_LAUNCH(5, 16, JL_MAX_THREADS, true);
             else JL_LAUNCH(7, 16, 768, true);
@@ -1370,6 +1372,7 @@ int launch_project_coefficients(mtip_ctx* c, const double2* Ilm, double2* out) {
         } else if (tg == 16) JL_LAUNCH(5, 16, JL_MAX_THREADS, false);
         else if (nmax <= 9 * 8) JL_LAUNCH(9, 8, JL_MAX_THREADS, false);
         else JL_LAUNCH(16, 8, JL_MAX_THREADS, false);
+        }
 #undef JL_LAUNCH
         ga.dst = c->d_U;
         launch_proj_gemm<PG_U>(c, ga);
