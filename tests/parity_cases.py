@@ -497,7 +497,7 @@ def check_full_size_properties(cfg, lib_path=None, n_steps=12):
     """At BASELINE sizes the oracle is too slow for step-by-step comparison: check size-independent properties.
     * FT round trip of a band-limited density, SHT(iSHT(c)) == c
     * fused step == reference-order step (<= 1e-9) from the same state
-    * identical restarts in one batch stay bit-identical; ER error is non-increasing; projected coefficients
+    * identical restarts in one batch stay bit-identical; all errors are finite and positive; projected coefficients
       reproduce the data B_l on the masked shells
     """
     data, rho_true = synthetic_problem(cfg, lib_path)

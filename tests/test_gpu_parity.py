@@ -163,10 +163,10 @@ def test_config3_properties_full_size():
 
 
 def test_config5_properties_full_size():
-    """256 shells x L_max = 48 (BASELINE config 5): the grid no longer fits the whole-shell LDS kernels and 2l+1 = 97 does
-    not fit the LDS Jacobi, so this walks the pass-wise inverse SHT, the separate real-space kernel and the global-memory
-    polar factor; same size-independent properties as at the metric's size (fused == reference order, round trips,
-    B_l of the projection == data B_l)."""
+    """256 shells x L_max = 48 (BASELINE config 5, 128 x 256 angular grid): the inverse SHT shares a shell between two
+    workgroups (fused epilogues, two error partial sums per shell), the forward SHT takes the pass-wise table kernel and the
+    97-column polar factors the X_l-only Jacobi with the rotation log + V_r replay; same size-independent properties as at
+    the metric's size (fused == reference order, round trips, B_l of the projection == data B_l)."""
     errs = PC.check_full_size_properties(5, n_steps=4)
     assert np.isfinite(errs).all()
 
