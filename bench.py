@@ -308,20 +308,20 @@ def main():
                 tops['proj_gemms'] = {'total_ms': fam_ms['proj']['total_ms'] - fam_ms['polar']['total_ms']}
             top = max(tops, key=lambda k: tops[k]['total_ms'])
             if top == 'polar':
-                its = np.asarray(e0.jacobi_sweeps(), dtype=float)                  # (Bp, L+1): sweeps / iterations of the last call
+                swp = np.asarray(e0.jacobi_sweeps(), dtype=float)                  # (Bp, L+1): sweeps / iterations of the last call
                 ns = 2 * np.arange(L + 1) + 1
-                active = its.mean(0) > 0
+                active = swp.mean(0) > 0
                 newton = os.environ.get('MTIP_POLAR', 'jacobi') == 'newton'
                 if newton:
                     # one Newton iteration = one in-place complex Gauss-Jordan inverse (n^3 complex multiply-adds = 8 n^3 flop)
                     # + the update (4 n^2)
-                    flops = float((its * (8.0 * ns ** 3 + 4.0 * ns ** 2)[None, :]).sum())
+                    flops = float((swp * (8.0 * ns ** 3 + 4.0 * ns ** 2)[None, :]).sum())
                     kname = 'polar (k_polar_newton: scaled Newton polar factor, Gauss-Jordan inverse)'
                 else:
                     # one sweep of the one-sided Jacobi SVD = n (n - 1) / 2 column pairs, each 16 n flop for the Gram sums and
                     # 24 flop per row for the rotation of the two X_l columns (n rows) and of the two V_r columns (n rows): 64 n
                     # per pair, 32 n^3 per sweep (deflated columns are counted as if present: an upper bound of the work done)
-                    flops = float((its * (32.0 * ns ** 3)[None, :]).sum())
+                    flops = float((swp * (32.0 * ns ** 3)[None, :]).sum())
                     kname = 'polar (k_polar_jacobi_lds: one-sided Jacobi SVD in LDS, one workgroup per (restart, order))'
                 cus = int(min(Bp * int(active.sum()), e0_cus))
                 peak = cus * 4 * 32 * 2.4e9 / 1e12                                # FP64 vector: 32 flop / clk / SIMD at 2.4 GHz
@@ -330,7 +330,7 @@ def main():
                             'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak, 'traffic': None,
                             'cus_used': cus, 'cus_total': e0_cus, 'avg_launch_ms': fam_ms['polar']['avg_ms'],
                             'algorithmic_flops_per_launch': flops, 'restarts_per_launch': Bp,
-                            'sweeps_or_iterations_restart0': [int(x) for x in its[0]],
+                            'sweeps_or_iterations_restart0': [int(x) for x in swp[0]],
                             'share_of_step': fam_ms['polar']['total_ms'] / sum(v['total_ms'] for v in tops.values()),
                             'hbm_family': hbm_roof,
                             'note': 'dominant kernel by hipEvent time over the timed region on the stream of engine 0; not an HBM or '

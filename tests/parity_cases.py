@@ -782,7 +782,16 @@ def check_extract_vs_numpy(lib_path=None, N=24, L=6):
     w, v = e.hermitian_eig(m)
     for k in range(3):
         assert np.allclose(w[k], np.linalg.eigvalsh(m[k])[::-1], rtol=1e-12, atol=1e-12 * np.abs(w[k]).max())
-        assert rel_l2(m[k] @ v[k], v[k] * w[k][None, :]) < 1e-12
+        assert rel_l2(m[k] @ v[k], v[k] * w[k][None, :]) < 1e-11
+        assert np.abs(v[k].conj().T @ v[k] - np.eye(N)).max() < 1e-12
+    # eigenvalue pairs +x / -x share a singular value: the case the shifted repeat of the solver exists for
+    q, _ = np.linalg.qr(cplx(rng, (N, N)))
+    lam = np.concatenate([np.arange(1, N // 2 + 1), -np.arange(1, N - N // 2 + 1)]).astype(float)
+    mp = (q * lam[None, :]) @ q.conj().T
+    w, v = e.hermitian_eig(np.stack([mp, m[0]]))
+    assert np.allclose(w[0], np.sort(lam)[::-1], atol=1e-11 * N)
+    assert rel_l2(mp @ v[0], v[0] * w[0][None, :]) < 1e-11
+    assert rel_l2(m[0] @ v[1], v[1] * w[1][None, :]) < 1e-11
     pms, evs = e.extract_projection_matrices(m, orders=[1, 2, 30])
     for k, l in enumerate([1, 2, 30]):
         kk = min(N, 2 * l + 1)
