@@ -39,6 +39,28 @@ __global__ void __launch_bounds__(512) k(double* out, long long* cyc, int iters,
             for (int r = 0; r < 4; ++r)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) a[i] += __shfl(a[(i + 1) & 15], lp);
+        } else if (MODE == 5 || MODE == 6 || MODE == 7) {   // f64 MFMA alone (5), MFMA + independent v_fma_f64 interleaved (6),
+            typedef double d4 __attribute__((ext_vector_type(4)));     // the same v_fma_f64 count alone (7)
+            d4 acc[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = d4{a[4 * i], a[4 * i + 1], a[4 * i + 2], a[4 * i + 3]};
+            double f[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) f[i] = a[i] + 1.0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (MODE != 7) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(b0, b1, acc[i], 0, 0, 0);
+                    if (MODE != 5) {
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) f[q & 7] = fma(f[q & 7], b0, b1);       // 16 v_fma_f64 per MFMA (64 cycles each)
+                    }
+                }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { a[4 * i] = acc[i][0]; a[4 * i + 1] = acc[i][1]; a[4 * i + 2] = acc[i][2]; a[4 * i + 3] = acc[i][3]; }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) a[i] += f[i];
         } else if (MODE == 4) {                // f32 fma for reference
             float f[16];
 #pragma unroll
@@ -81,6 +103,11 @@ int main() {
                         run<3>("ds_bpermute x2 + v_add_f64", 256, 64); run<4>("v_fma_f32", 256, 64); }
         else { run<0>("v_fma_f64 (VGPR)", 512, 64); run<1>("2 v_readlane + v_fma_f64", 512, 64); run<2>("v_readlane_b32", 512, 64);
                run<3>("ds_bpermute x2 + v_add_f64", 512, 64); run<4>("v_fma_f32", 512, 64); }
+    }
+    // matrix-core / vector co-issue: 16 MFMA (5), 16 MFMA + 256 v_fma_f64 (6), 256 v_fma_f64 (7) per iteration; cycles per iteration
+    for (int t : {256, 512}) {
+        if (t == 256) { run<5>("16 v_mfma_f64_16x16x4 [per iter]", 256, 1); run<6>("16 mfma + 256 v_fma_f64 [per iter]", 256, 1); run<7>("256 v_fma_f64 [per iter]", 256, 1); }
+        else { run<5>("16 v_mfma_f64_16x16x4 [per iter]", 512, 1); run<6>("16 mfma + 256 v_fma_f64 [per iter]", 512, 1); run<7>("256 v_fma_f64 [per iter]", 512, 1); }
     }
     return 0;
 }

@@ -374,6 +374,35 @@ int build_hankel_tiles(mtip_ctx* c) {
         }
         if ((int)t32.size() * div_up(c->N, HT_ROWS) * 5 >= c->n_cu * 4) break;
     }
+    if (!c->hankel_flat_order) {
+        // XCD-aware order: consecutive workgroup ids go round-robin to the 8 XCDs (one L2 each), so the tiles of one order
+        // are dealt to ONE residue class mod 8 and W_l is fetched into one L2 instead of up to eight.  Orders go to the
+        // least loaded XCD, heaviest first; a queue that runs dry takes tiles from the tail of the longest one.
+        const int X = 8;
+        std::vector<std::vector<HankelTile32>> q(X);
+        size_t i0 = 0;
+        while (i0 < t32.size()) {
+            size_t i1 = i0;
+            while (i1 < t32.size() && t32[i1].l == t32[i0].l) ++i1;
+            int best = 0;
+            for (int x = 1; x < X; ++x)
+                if (q[x].size() < q[best].size()) best = x;
+            q[best].insert(q[best].end(), t32.begin() + i0, t32.begin() + i1);
+            i0 = i1;
+        }
+        std::vector<size_t> head(X, 0);
+        std::vector<HankelTile32> order;
+        while (order.size() < t32.size())
+            for (int x = 0; x < X && order.size() < t32.size(); ++x) {
+                if (head[x] < q[x].size()) { order.push_back(q[x][head[x]++]); continue; }
+                int longest = 0;
+                for (int y = 1; y < X; ++y)
+                    if (q[y].size() - head[y] > q[longest].size() - head[longest]) longest = y;
+                order.push_back(q[longest].back());
+                q[longest].pop_back();
+            }
+        t32.swap(order);
+    }
     c->n_htiles32 = (int)t32.size();
     if (hipMalloc((void**)&c->d_htiles32, t32.size() * sizeof(HankelTile32)) != hipSuccess) return MTIP_ENOMEM;
     (void)hipMemcpy(c->d_htiles32, t32.data(), t32.size() * sizeof(HankelTile32), hipMemcpyHostToDevice);

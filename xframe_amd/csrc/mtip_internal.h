@@ -150,6 +150,7 @@ struct mtip_ctx {
     int* d_jlog_rounds = nullptr;                     // rounds logged per matrix
     int jlog_cap = 0, jlog_ps = 0;
     size_t jlog_nmat = 0;
+    bool hankel_flat_order = false;                   // env MTIP_HANKEL_FLAT_ORDER=1: tiles in order-major sequence (not XCD-aware)
     bool hankel_wave_tiles = false;                   // env MTIP_HANKEL_WAVE_TILES=1: per-wave tiles straight from L2 (k_hankel_mfma)
     void* d_htiles32 = nullptr;                       // workgroup tiles (order, first column) of k_hankel_tile
     int n_htiles32 = 0, htile_ct = 5;                 // 16-column MFMA tiles per workgroup
