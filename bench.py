@@ -332,6 +332,13 @@ def main():
                             'algorithmic_flops_per_launch': flops, 'restarts_per_launch': Bp,
                             'sweeps_or_iterations_restart0': [int(x) for x in swp[0]],
                             'share_of_step': fam_ms['polar']['total_ms'] / sum(v['total_ms'] for v in tops.values()),
+                            # the launch lasts as long as its largest matrix (l = L, one CU): that matrix against one CU's peak
+                            'critical_matrix': {'n': int(ns[-1]), 'flops': float(swp[:, -1].max() * (8.0 * ns[-1] ** 3 + 4.0 * ns[-1] ** 2 if newton
+                                                                                               else 32.0 * ns[-1] ** 3)),
+                                                'peak_one_cu': 4 * 32 * 2.4e9 / 1e12,
+                                                'frac_one_cu': float(swp[:, -1].max() * (8.0 * ns[-1] ** 3 + 4.0 * ns[-1] ** 2 if newton
+                                                                                    else 32.0 * ns[-1] ** 3))
+                                                / (fam_ms['polar']['avg_ms'] * 1e-3) / (4 * 32 * 2.4e9)},
                             'hbm_family': hbm_roof,
                             'note': 'dominant kernel by hipEvent time over the timed region on the stream of engine 0; not an HBM or '
                                     'MFMA kernel: bound by FP64 vector issue and the latency of its dependent chain inside one CU '

@@ -219,6 +219,167 @@ __global__ void __launch_bounds__(SR_THREADS) k_sht_fwd_reg(const double2* __res
 }
 
 // ------------------------------------------------------------------------------------------------------
+// Two shells per workgroup (the default forward kernel where the sizes allow it).  k_sht_fwd_reg above loads, per shell, the
+// Legendre table rows of all its (l, m) pairs -- more bytes than the shell's grid rows at 128 x L32 (144 KB against 128 KB) and
+// each table value is used once; the loads sit in the accumulation loop, four in flight, so a pass of 16 theta pairs is
+// twelve dependent L2 round trips.  Here a workgroup owns TWO shells and half as many theta pairs per pass: the table
+// values of a pass (MAXI x TH doubles per thread) are requested at the top of the pass, next to the grid rows, arrive while
+// the FFT phases run and are used for both shells -- half the table bytes per shell, and one round trip per pass.
+// The phases are those of k_sht_fwd_reg with the thread roles split over the two shells; LDS is the same size.
+template <int PRE, int R1, int R2, int MAXI, int TH>
+__global__ void __launch_bounds__(SR_THREADS, 2) k_sht_fwd_pair(const double2* __restrict__ grid, double2* __restrict__ coeff,
+                                                             const double* __restrict__ PT, const int* __restrict__ lmtab,
+                                                             const double2* __restrict__ twN_g, const double* __restrict__ gw,
+                                                             int nt, int L, int npairs, double norm,
+                                                             const int* __restrict__ slot, int which, int B, int Nq) {
+    constexpr int N = R1 * R2;
+    constexpr int AS = R2 + 1;                      // padded row of the transpose buffer
+    constexpr int RPS = 2 * TH;                     // panel rows per pass and shell (even + odd part of TH theta pairs)
+    constexpr int ASZ = RPS * R1 * AS;              // transpose buffer of one shell (aliased by its (theta, m) panel)
+    constexpr int GS = R1 * AS;                     // panel row stride: a compile-time constant >= n_phi + 1 > 2 L + 1
+    static_assert(2 * TH * R2 <= SR_THREADS && 2 * RPS * R1 <= SR_THREADS, "thread roles");
+    HIP_DYNAMIC_SHARED(double2, sm)
+    const int nlm = (L + 1) * (L + 1);
+    double2* twN = sm;                              // N       exp(-2 pi i j / N)
+    double2* A = twN + N;                           // 2 * ASZ
+    const int tid = threadIdx.x;
+    const long long shell0 = 2ll * blockIdx.x;
+    for (int e = tid; e < N; e += blockDim.x) twN[e] = twN_g[e];
+    // phase-1 role: (shell, theta pair, n2); phase-2 role: (shell, panel row, k1)
+    constexpr bool ALL1 = 2 * TH * R2 == SR_THREADS, ALL2 = 2 * RPS * R1 == SR_THREADS;   // every thread has a role: no exec masks
+    const bool act1 = ALL1 || tid < 2 * TH * R2;
+    const int s1 = tid / (TH * R2), j1 = (tid - s1 * TH * R2) / R2, n2 = tid % R2;
+    const bool act2 = ALL2 || tid < 2 * RPS * R1;
+    const int s2 = tid / (RPS * R1), r2 = (tid - s2 * RPS * R1) / R1, k1 = tid % R1;
+    long long src_shell = shell0 + (act1 ? s1 : 0);                 // slot-indirect input: (3, B, Nq, ...) pair array
+    if (slot != nullptr) src_shell += (long long)slot[((shell0 + (act1 ? s1 : 0)) / Nq) * SL_N + which] * B * Nq;
+    const double2* gsrc = grid + (size_t)src_shell * nt * N;
+    int my_l[MAXI], my_m[MAXI], my_i[MAXI];
+    double2 accp[2][MAXI], accm[2][MAXI];
+#pragma unroll
+    for (int u = 0; u < MAXI; ++u) {
+        const int idx = tid + u * SR_THREADS;
+        my_i[u] = min(idx, npairs - 1);             // clamped: the table loads stay branch-free
+        const int lm = lmtab[my_i[u]];
+        my_l[u] = lm & 0xff;
+        my_m[u] = lm >> 8;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            accp[s][u] = make_double2(0.0, 0.0);
+            accm[s][u] = make_double2(0.0, 0.0);
+        }
+    }
+    const int n_pass = (nt >> 1) / TH;
+    __syncthreads();
+    for (int pass = 0; pass < n_pass; ++pass) {
+        // ---- phase 1: fold theta / mirror, R1-point FFTs over n1, twiddle, transpose store
+        double2 ev[R1], ov[R1];
+        if (act1) {
+            const int th = pass * TH + j1;
+            const double2* rn = gsrc + (size_t)th * N + n2;
+            const double2* rs = gsrc + (size_t)(nt - 1 - th) * N + n2;
+#pragma unroll
+            for (int n1 = 0; n1 < R1; ++n1) {
+                ev[n1] = rn[R2 * n1];
+                ov[n1] = rs[R2 * n1];
+            }
+        }
+        if (act1) {
+#pragma unroll
+            for (int n1 = 0; n1 < R1; ++n1) {
+                double2 a = ev[n1], b = ov[n1];
+                if (PRE == MTIP_PRE_SQUARE) {
+                    a = make_double2(cabs2(a), 0.0);
+                    b = make_double2(cabs2(b), 0.0);
+                } else if (PRE == MTIP_PRE_ABS) {
+                    a = make_double2(sqrt(cabs2(a)), 0.0);
+                    b = make_double2(sqrt(cabs2(b)), 0.0);
+                }
+                ev[n1] = cadd(a, b);
+                ov[n1] = csub(a, b);
+            }
+            SmallFFT<R1, false>::run(ev);
+            SmallFFT<R1, false>::run(ov);
+            double2* ae = A + (size_t)s1 * ASZ + (size_t)(2 * j1) * R1 * AS + n2;
+            double2* ao = ae + (size_t)R1 * AS;
+#pragma unroll
+            for (int q = 0; q < R1; ++q) {
+                const double2 w = twN[n2 * q];
+                ae[q * AS] = cmul(ev[q], w);
+                ao[q * AS] = cmul(ov[q], w);
+            }
+        }
+        // the table rows of this pass, requested as soon as the registers of phase 1 are free: they arrive while phase 2 runs
+        double tab[MAXI][TH];
+#pragma unroll
+        for (int u = 0; u < MAXI; ++u)
+#pragma unroll
+            for (int jj = 0; jj < TH; ++jj) {
+                const double* row = PT + (size_t)(pass * TH + jj) * npairs;       // uniform base + 32-bit lane offset
+                tab[u][jj] = row[(unsigned)my_i[u]];
+            }
+        __syncthreads();
+        // ---- phase 2: R2-point FFTs over n2; keep |m| <= L
+        double2 uv[R2];
+        if (act2) {
+            const double2* ar = A + (size_t)s2 * ASZ + (size_t)(r2 * R1 + k1) * AS;
+#pragma unroll
+            for (int q = 0; q < R2; ++q) uv[q] = ar[q];
+        }
+        __syncthreads();                                // A is dead from here on: the panels overwrite it
+        if (act2) {
+            SmallFFT<R2, false>::run(uv);
+            const double sc = gw[pass * TH + (r2 >> 1)] * norm;
+            double2* gr = A + (size_t)s2 * ASZ + (size_t)r2 * GS + L;
+#pragma unroll
+            for (int k2 = 0; k2 < R2; ++k2) {
+                const int k = k1 + R1 * k2;
+                if (k <= L) gr[k] = cscale(uv[k2], sc);
+                else if (k >= N - L) gr[k - N] = cscale(uv[k2], sc);
+            }
+        }
+        __syncthreads();
+        // ---- Legendre accumulation (rows 2j = even part, 2j+1 = odd part of theta pair j), both shells per table value
+#pragma unroll
+        for (int u = 0; u < MAXI; ++u) {
+            const int l = my_l[u], m = my_m[u];
+            const double2* srcp = A + ((l + m) & 1) * GS + L + m;       // one lane base per slot, immediates for (shell, row)
+            const double2* srcm = A + ((l + m) & 1) * GS + L - m;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                double2 ap = accp[s][u], am = accm[s][u];
+#pragma unroll
+                for (int jj = 0; jj < TH; ++jj) {
+                    const double p = tab[u][jj];
+                    const double2 vp = srcp[s * ASZ + 2 * jj * GS];
+                    const double2 vm = srcm[s * ASZ + 2 * jj * GS];
+                    ap.x = fma(p, vp.x, ap.x);
+                    ap.y = fma(p, vp.y, ap.y);
+                    am.x = fma(p, vm.x, am.x);
+                    am.y = fma(p, vm.y, am.y);
+                }
+                accp[s][u] = ap;
+                accm[s][u] = am;
+            }
+        }
+        __syncthreads();                                // the next pass rewrites A
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        double2* cdst = coeff + (size_t)(shell0 + s) * nlm;
+#pragma unroll
+        for (int u = 0; u < MAXI; ++u) {
+            const int idx = tid + u * SR_THREADS;
+            if (idx < npairs) {
+                const int l = my_l[u], m = my_m[u];
+                cdst[l * (l + 1) + m] = accp[s][u];
+                if (m > 0) cdst[l * (l + 1) - m] = (m & 1) ? make_double2(-accm[s][u].x, -accm[s][u].y) : accm[s][u];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
 template <int EPI, int R1, int R2>
 __global__ void __launch_bounds__(SR_THREADS) k_sht_inv_reg(const double2* __restrict__ coeff, double2* __restrict__ grid,
                                                             const double* __restrict__ PT, const int* __restrict__ poff,
@@ -632,6 +793,28 @@ static void launch_fwd_r(mtip_ctx* c, const double2* grid, double2* coeff, int i
     const int* sl = in_slot >= 0 ? c->d_slot : nullptr;
     const dim3 gr((unsigned)(c->B * c->N)), bl(SR_THREADS);
     const int per = div_up(c->npairs, SR_THREADS);
+    // two shells per workgroup with prefetched, shared table rows (k_sht_fwd_pair) where the pass geometry allows it
+    const int th = RP / 4;
+    // (measured at 128 x L32: 55.9 -> 50.9 us at 8 restarts per launch, but 37.0 -> 41.6 us at 3: half as many workgroups, each
+    // twice as long, do not fill the chip any more -- so by default only when there are two workgroups per CU left)
+    const bool want_pair = c->sht_fwd_pair < 0 ? ((long long)c->B * c->N / 2 >= 2ll * c->n_cu) : c->sht_fwd_pair != 0;
+    if (want_pair && RP % 4 == 0 && (c->nt / 2) % std::max(th, 1) == 0 && ((long long)c->B * c->N) % 2 == 0 && per <= 5 &&
+        (th == 2 || th == 4 || th == 8) && 2 * th * R2 <= SR_THREADS && 4 * th * R1 <= SR_THREADS) {
+        const dim3 gp((unsigned)(c->B * c->N / 2));
+#define PAIR_ARGS grid, coeff, (const double*)c->d_PT, (const int*)c->d_lmtab, (const double2*)c->d_twN, (const double*)c->d_gw, \
+                  c->nt, c->L, c->npairs, norm, sl, in_slot, c->B, c->N
+#define PAIR_TH(MAXI)                                                                                                           \
+        if (th == 8) { if constexpr (16 * R2 <= SR_THREADS && 32 * R1 <= SR_THREADS)                                            \
+                           hipLaunchKernelGGL((k_sht_fwd_pair<PRE, R1, R2, MAXI, 8>), gp, bl, smem, c->stream, PAIR_ARGS); }      \
+        else if (th == 4) { if constexpr (8 * R2 <= SR_THREADS && 16 * R1 <= SR_THREADS)                                        \
+                                hipLaunchKernelGGL((k_sht_fwd_pair<PRE, R1, R2, MAXI, 4>), gp, bl, smem, c->stream, PAIR_ARGS); } \
+        else { if constexpr (4 * R2 <= SR_THREADS && 8 * R1 <= SR_THREADS)                                                      \
+                   hipLaunchKernelGGL((k_sht_fwd_pair<PRE, R1, R2, MAXI, 2>), gp, bl, smem, c->stream, PAIR_ARGS); }
+        if (per <= 3) { PAIR_TH(3) } else { PAIR_TH(5) }
+#undef PAIR_TH
+#undef PAIR_ARGS
+        return;
+    }
 #define FWD_ARGS grid, coeff, (const double*)c->d_PT, (const int*)c->d_lmtab, (const double2*)c->d_twN, (const double*)c->d_gw, \
                  c->nt, c->L, c->npairs, RP, norm, sl, in_slot, c->B, c->N
     if (per <= 3) hipLaunchKernelGGL((k_sht_fwd_reg<PRE, R1, R2, 3>), gr, bl, smem, c->stream, FWD_ARGS);
@@ -661,11 +844,16 @@ void launch_sht_forward_reg(mtip_ctx* c, const double2* grid, double2* coeff, in
 static size_t wide_lds_n(const mtip_ctx* c, int r1, int r2, int nsplit, int* rp_out) {
     if (c->nt % (2 * nsplit) != 0) return (size_t)1 << 40;
     const int ntl = c->nt / nsplit;
-    if (nsplit > 1 && (ntl / 2) % 32 != 0) return (size_t)1 << 40;      // whole 32-theta chunks per workgroup
+    // whole 32-theta chunks per workgroup, unless the split is asked for (half-filled Legendre items, two workgroups per CU)
+    if (nsplit > 1 && (ntl / 2) % 32 != 0 && c->sht_inv_split < nsplit) return (size_t)1 << 40;
     const size_t fixed = (nsplit > 1 ? 0 : (size_t)c->np) + (size_t)ntl * c->nm + c->npairs;
     int rp = largest_even_divisor_le(ntl, std::min(SW_THREADS / r2, SW_THREADS / r1));
-    // the transpose buffer aliases the coefficient block: shrink the pass until both fit
-    while (rp >= 2 && (fixed + std::max((size_t)c->nlm, (size_t)rp * r1 * (r2 + 1))) * sizeof(double2) > 158 * 1024)
+    // the transpose buffer aliases the coefficient block: shrink the pass until both fit -- one CU's LDS, or half of it when
+    // the split is asked for and that is possible (two workgroups per CU, their phases overlap)
+    size_t limit = 158 * 1024;
+    if (nsplit > 1 && c->sht_inv_split == nsplit && (fixed + std::max((size_t)c->nlm, (size_t)2 * r1 * (r2 + 1))) * sizeof(double2) <= 79 * 1024)
+        limit = 79 * 1024;
+    while (rp >= 2 && (fixed + std::max((size_t)c->nlm, (size_t)rp * r1 * (r2 + 1))) * sizeof(double2) > limit)
         rp = largest_even_divisor_le(ntl, rp - 2);
     if (rp_out) *rp_out = rp;
     if (rp < 2) return (size_t)1 << 40;
@@ -674,7 +862,7 @@ static size_t wide_lds_n(const mtip_ctx* c, int r1, int r2, int nsplit, int* rp_
 
 // smallest split (1, 2) whose working set fits one CU's LDS
 static size_t wide_lds(const mtip_ctx* c, int r1, int r2, int* rp_out, int* nsplit_out = nullptr) {
-    for (int ns = 1; ns <= 2; ++ns) {
+    for (int ns = c->sht_inv_split; ns <= 2; ++ns) {
         int rp = 0;
         const size_t lds = wide_lds_n(c, r1, r2, ns, &rp);
         if (lds <= 158 * 1024) {

@@ -109,22 +109,7 @@ mtip_ctx* mtip_create(const mtip_cfg* cfg, int device) {
     const int L = c->L, N = c->N, B = c->B;
     int rc = MTIP_OK;
     auto A = [&](int r) { if (rc == MTIP_OK) rc = r; };
-    {
-        // experiment switch: 1 = stream that does not synchronise with the null stream, 2/3 = additionally high / low priority
-        const char* e = std::getenv("MTIP_STREAM_MODE");
-        const int mode = e ? std::atoi(e) : 0;
-        hipError_t se;
-        if (mode == 0) se = hipStreamCreate(&c->stream);
-        else if (mode == 1) se = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-        else {
-            int lo = 0, hi = 0;
-            (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-            static int n_created = 0;
-            const int k = n_created++;
-            se = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, mode == 2 ? hi : (k % 2 ? hi : lo));
-        }
-        if (se != hipSuccess) A(MTIP_EHIP);
-    }
+    if (hipStreamCreate(&c->stream) != hipSuccess) A(MTIP_EHIP);
     {
         int ncu = 0;
         if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0) c->n_cu = ncu;
@@ -143,9 +128,11 @@ mtip_ctx* mtip_create(const mtip_cfg* cfg, int device) {
     if (const char* e = std::getenv("MTIP_DEG2_SIMPLE")) c->deg2_simple = std::atoi(e) != 0;
     if (const char* e = std::getenv("MTIP_HANKEL_SIMPLE")) c->hankel_simple = std::atoi(e) != 0;
     if (const char* e = std::getenv("MTIP_HANKEL_WAVE_TILES")) c->hankel_wave_tiles = std::atoi(e) != 0;
+    if (const char* e = std::getenv("MTIP_SHT_FWD_PAIR")) c->sht_fwd_pair = std::atoi(e) != 0 ? 1 : 0;
     if (const char* e = std::getenv("MTIP_HANKEL_FLAT_ORDER")) c->hankel_flat_order = std::atoi(e) != 0;
     if (const char* e = std::getenv("MTIP_FUSE_REAL")) c->fuse_real_update = std::atoi(e) != 0;
     if (const char* e = std::getenv("MTIP_SHT_WIDE")) c->sht_wide = std::atoi(e) != 0;
+    if (const char* e = std::getenv("MTIP_SHT_INV_SPLIT")) c->sht_inv_split = std::atoi(e) == 2 ? 2 : 1;
     if (const char* e = std::getenv("MTIP_JAC_RESIDENT")) c->jac_resident = std::atoi(e) != 0;
     if (const char* e = std::getenv("MTIP_POLAR_VARIANT")) c->polar_variant = std::atoi(e);
     if (const char* e = std::getenv("MTIP_POLAR")) c->polar_newton = std::string(e) == "newton";

@@ -133,6 +133,7 @@ struct mtip_ctx {
     int n_htiles = 0;
     int n_cu = 256;                                   // compute units of the device (persistent-grid sizing)
     bool fuse_real_update = true;                     // env MTIP_FUSE_REAL=0: separate coefficient-difference / real-space kernels
+    int sht_inv_split = 1;                            // env MTIP_SHT_INV_SPLIT=2: two workgroups per shell in the wide inverse transform
     bool sht_wide = true;                             // env MTIP_SHT_WIDE=0: pass-wise inverse Legendre synthesis
     bool jac_resident = true;                         // env MTIP_JAC_RESIDENT=0: round-robin ordering, both columns via LDS
     int *d_jsched = nullptr, *d_jsched_off = nullptr, *d_jsched_rounds = nullptr;   // resident-column pairing schedule
@@ -150,6 +151,7 @@ struct mtip_ctx {
     int* d_jlog_rounds = nullptr;                     // rounds logged per matrix
     int jlog_cap = 0, jlog_ps = 0;
     size_t jlog_nmat = 0;
+    int sht_fwd_pair = -1;                            // env MTIP_SHT_FWD_PAIR: 1 / 0 = two / one shell per forward-transform workgroup; -1 = by batch size
     bool hankel_flat_order = false;                   // env MTIP_HANKEL_FLAT_ORDER=1: tiles in order-major sequence (not XCD-aware)
     bool hankel_wave_tiles = false;                   // env MTIP_HANKEL_WAVE_TILES=1: per-wave tiles straight from L2 (k_hankel_mfma)
     void* d_htiles32 = nullptr;                       // workgroup tiles (order, first column) of k_hankel_tile
