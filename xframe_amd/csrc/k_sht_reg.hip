@@ -219,14 +219,14 @@ __global__ void __launch_bounds__(SR_THREADS) k_sht_fwd_reg(const double2* __res
 }
 
 // ------------------------------------------------------------------------------------------------------
-// Two shells per workgroup (the default forward kernel where the sizes allow it).  k_sht_fwd_reg above loads, per shell, the
+// NS shells per workgroup (NS = 1 is what ships; NS = 2 shares the table registers between two shells and measured no faster).  k_sht_fwd_reg above loads, per shell, the
 // Legendre table rows of all its (l, m) pairs -- more bytes than the shell's grid rows at 128 x L32 (144 KB against 128 KB) and
 // each table value is used once; the loads sit in the accumulation loop, four in flight, so a pass of 16 theta pairs is
 // twelve dependent L2 round trips.  Here a workgroup owns TWO shells and half as many theta pairs per pass: the table
 // values of a pass (MAXI x TH doubles per thread) are requested at the top of the pass, next to the grid rows, arrive while
 // the FFT phases run and are used for both shells -- half the table bytes per shell, and one round trip per pass.
 // The phases are those of k_sht_fwd_reg with the thread roles split over the two shells; LDS is the same size.
-template <int PRE, int R1, int R2, int MAXI, int TH>
+template <int PRE, int R1, int R2, int MAXI, int TH, int NS>
 __global__ void __launch_bounds__(SR_THREADS, 2) k_sht_fwd_pair(const double2* __restrict__ grid, double2* __restrict__ coeff,
                                                              const double* __restrict__ PT, const int* __restrict__ lmtab,
                                                              const double2* __restrict__ twN_g, const double* __restrict__ gw,
@@ -237,25 +237,25 @@ __global__ void __launch_bounds__(SR_THREADS, 2) k_sht_fwd_pair(const double2* _
     constexpr int RPS = 2 * TH;                     // panel rows per pass and shell (even + odd part of TH theta pairs)
     constexpr int ASZ = RPS * R1 * AS;              // transpose buffer of one shell (aliased by its (theta, m) panel)
     constexpr int GS = R1 * AS;                     // panel row stride: a compile-time constant >= n_phi + 1 > 2 L + 1
-    static_assert(2 * TH * R2 <= SR_THREADS && 2 * RPS * R1 <= SR_THREADS, "thread roles");
+    static_assert(NS * TH * R2 <= SR_THREADS && NS * RPS * R1 <= SR_THREADS, "thread roles");
     HIP_DYNAMIC_SHARED(double2, sm)
     const int nlm = (L + 1) * (L + 1);
     double2* twN = sm;                              // N       exp(-2 pi i j / N)
-    double2* A = twN + N;                           // 2 * ASZ
+    double2* A = twN + N;                           // NS * ASZ
     const int tid = threadIdx.x;
-    const long long shell0 = 2ll * blockIdx.x;
+    const long long shell0 = (long long)NS * blockIdx.x;
     for (int e = tid; e < N; e += blockDim.x) twN[e] = twN_g[e];
     // phase-1 role: (shell, theta pair, n2); phase-2 role: (shell, panel row, k1)
-    constexpr bool ALL1 = 2 * TH * R2 == SR_THREADS, ALL2 = 2 * RPS * R1 == SR_THREADS;   // every thread has a role: no exec masks
-    const bool act1 = ALL1 || tid < 2 * TH * R2;
+    constexpr bool ALL1 = NS * TH * R2 == SR_THREADS, ALL2 = NS * RPS * R1 == SR_THREADS;   // every thread has a role: no exec masks
+    const bool act1 = ALL1 || tid < NS * TH * R2;
     const int s1 = tid / (TH * R2), j1 = (tid - s1 * TH * R2) / R2, n2 = tid % R2;
-    const bool act2 = ALL2 || tid < 2 * RPS * R1;
+    const bool act2 = ALL2 || tid < NS * RPS * R1;
     const int s2 = tid / (RPS * R1), r2 = (tid - s2 * RPS * R1) / R1, k1 = tid % R1;
     long long src_shell = shell0 + (act1 ? s1 : 0);                 // slot-indirect input: (3, B, Nq, ...) pair array
     if (slot != nullptr) src_shell += (long long)slot[((shell0 + (act1 ? s1 : 0)) / Nq) * SL_N + which] * B * Nq;
     const double2* gsrc = grid + (size_t)src_shell * nt * N;
     int my_l[MAXI], my_m[MAXI], my_i[MAXI];
-    double2 accp[2][MAXI], accm[2][MAXI];
+    double2 accp[NS][MAXI], accm[NS][MAXI];
 #pragma unroll
     for (int u = 0; u < MAXI; ++u) {
         const int idx = tid + u * SR_THREADS;
@@ -264,7 +264,7 @@ __global__ void __launch_bounds__(SR_THREADS, 2) k_sht_fwd_pair(const double2* _
         my_l[u] = lm & 0xff;
         my_m[u] = lm >> 8;
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
+        for (int s = 0; s < NS; ++s) {
             accp[s][u] = make_double2(0.0, 0.0);
             accm[s][u] = make_double2(0.0, 0.0);
         }
@@ -346,7 +346,7 @@ __global__ void __launch_bounds__(SR_THREADS, 2) k_sht_fwd_pair(const double2* _
             const double2* srcp = A + ((l + m) & 1) * GS + L + m;       // one lane base per slot, immediates for (shell, row)
             const double2* srcm = A + ((l + m) & 1) * GS + L - m;
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
+            for (int s = 0; s < NS; ++s) {
                 double2 ap = accp[s][u], am = accm[s][u];
 #pragma unroll
                 for (int jj = 0; jj < TH; ++jj) {
@@ -365,7 +365,7 @@ __global__ void __launch_bounds__(SR_THREADS, 2) k_sht_fwd_pair(const double2* _
         __syncthreads();                                // the next pass rewrites A
     }
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
+    for (int s = 0; s < NS; ++s) {
         double2* cdst = coeff + (size_t)(shell0 + s) * nlm;
 #pragma unroll
         for (int u = 0; u < MAXI; ++u) {
@@ -539,7 +539,8 @@ __global__ void __launch_bounds__(SW_THREADS) k_sht_inv_wide(const double2* __re
     const int q = (int)(shell % Nq);
     const double2* csrc = coeff + (size_t)shell * nlm;
     // Legendre work items (m, chunk of 32 thetas), dealt to the waves in snake order of decreasing length
-    const int wave = tid >> 6, lane = tid & 63, nw = blockDim.x >> 6;
+    // the wave index as a scalar: items, m and the l loop are then wave-uniform for the compiler too (scalar loop control)
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nw = blockDim.x >> 6;
     const int nth = ntl >> 1;                       // theta pairs of this workgroup, first one j0
     const int j0 = split * nth;
     const int jj = lane & 31, sgn = lane >> 5;
@@ -620,16 +621,45 @@ __global__ void __launch_bounds__(SW_THREADS) k_sht_inv_wide(const double2* __re
             O = make_double2(p1 * co.x, p1 * co.y);
         }
         int l = m + 2;
-        for (; l + 1 <= L; l += 2) {
-            const double2 ab0 = abm[l], ab1 = abm[l + 1];
-            const double2 ce = cc[l * (l + 1)], co = cc[(l + 1) * (l + 2)];
-            const double pa = ab0.x * (x * p1 - ab0.y * p2);
-            const double pb = ab1.x * (x * pa - ab1.y * p1);
-            E.x = fma(pa, ce.x, E.x); E.y = fma(pa, ce.y, E.y);
-            O.x = fma(pb, co.x, O.x); O.y = fma(pb, co.y, O.y);
-            p2 = pa;
-            p1 = pb;
+        // The recurrence is a dependent chain and there are only two waves per SIMD: with the operands read at the top of
+        // each iteration an LDS round trip per iteration was most of the loop.  Two operand sets, A and B, alternate; a set is
+        // requested before the other one is used (clamped indices, branch-free) and the empty asm pins it there.
+        double2 Aab0, Aab1, Ace, Aco, Bab0, Bab1, Bce, Bco;
+#define LEG_LOAD(S, lq_)                                       \
+        {                                                      \
+            const int q_ = max(min((lq_), L - 1), 0);          \
+            S##ab0 = abm[q_];                                  \
+            S##ab1 = abm[q_ + 1];                              \
+            S##ce = cc[q_ * (q_ + 1)];                         \
+            S##co = cc[min((q_ + 1) * (q_ + 2), L * (L + 1))]; \
         }
+#define LEG_STEP(S)                                                   \
+        {                                                             \
+            const double pa = S##ab0.x * (x * p1 - S##ab0.y * p2);    \
+            const double pb = S##ab1.x * (x * pa - S##ab1.y * p1);    \
+            E.x = fma(pa, S##ce.x, E.x); E.y = fma(pa, S##ce.y, E.y); \
+            O.x = fma(pb, S##co.x, O.x); O.y = fma(pb, S##co.y, O.y); \
+            p2 = pa;                                                  \
+            p1 = pb;                                                  \
+        }
+#define LEG_PIN(S)                                                  \
+        MTIP_PIN_VGPRS4(S##ab0.x, S##ab0.y, S##ab1.x, S##ab1.y)     \
+        MTIP_PIN_VGPRS4(S##ce.x, S##ce.y, S##co.x, S##co.y)
+        LEG_LOAD(A, l)
+        while (l + 1 <= L) {
+            LEG_LOAD(B, l + 2)
+            LEG_STEP(A)
+            LEG_PIN(B)
+            l += 2;
+            if (l + 1 > L) break;
+            LEG_LOAD(A, l + 2)
+            LEG_STEP(B)
+            LEG_PIN(A)
+            l += 2;
+        }
+#undef LEG_LOAD
+#undef LEG_STEP
+#undef LEG_PIN
         if (l <= L) {
             const double2 ab0 = abm[l];
             const double2 ce = cc[l * (l + 1)];
@@ -793,27 +823,26 @@ static void launch_fwd_r(mtip_ctx* c, const double2* grid, double2* coeff, int i
     const int* sl = in_slot >= 0 ? c->d_slot : nullptr;
     const dim3 gr((unsigned)(c->B * c->N)), bl(SR_THREADS);
     const int per = div_up(c->npairs, SR_THREADS);
-    // two shells per workgroup with prefetched, shared table rows (k_sht_fwd_pair) where the pass geometry allows it
+    // k_sht_fwd_pair: half the rows per pass, the table rows of a pass prefetched (one round trip per pass).  Measured at
+    // 128 x L32 (hipEvent brackets, k_sht_fwd_reg / this kernel with one / with two shells per workgroup): 8 restarts per launch
+    // 54.5 / 49.9 / 50.4 us, 3 restarts per launch 37.6 / 33.9 / 42.8 us -- one shell per workgroup it is
     const int th = RP / 4;
-    // (measured at 128 x L32: 55.9 -> 50.9 us at 8 restarts per launch, but 37.0 -> 41.6 us at 3: half as many workgroups, each
-    // twice as long, do not fill the chip any more -- so by default only when there are two workgroups per CU left)
-    const bool want_pair = c->sht_fwd_pair < 0 ? ((long long)c->B * c->N / 2 >= 2ll * c->n_cu) : c->sht_fwd_pair != 0;
-    if (want_pair && RP % 4 == 0 && (c->nt / 2) % std::max(th, 1) == 0 && ((long long)c->B * c->N) % 2 == 0 && per <= 5 &&
-        (th == 2 || th == 4 || th == 8) && 2 * th * R2 <= SR_THREADS && 4 * th * R1 <= SR_THREADS) {
-        const dim3 gp((unsigned)(c->B * c->N / 2));
+    const bool pair_geom = RP % 4 == 0 && (th == 2 || th == 4 || th == 8) && (c->nt / 2) % std::max(th, 1) == 0 && per <= 5;
+    if (c->sht_fwd_pair && pair_geom) {
+        const size_t smem_p = ((size_t)c->np + (size_t)(RP / 2) * R1 * (R2 + 1)) * sizeof(double2);
 #define PAIR_ARGS grid, coeff, (const double*)c->d_PT, (const int*)c->d_lmtab, (const double2*)c->d_twN, (const double*)c->d_gw, \
                   c->nt, c->L, c->npairs, norm, sl, in_slot, c->B, c->N
-#define PAIR_TH(MAXI)                                                                                                           \
-        if (th == 8) { if constexpr (16 * R2 <= SR_THREADS && 32 * R1 <= SR_THREADS)                                            \
-                           hipLaunchKernelGGL((k_sht_fwd_pair<PRE, R1, R2, MAXI, 8>), gp, bl, smem, c->stream, PAIR_ARGS); }      \
-        else if (th == 4) { if constexpr (8 * R2 <= SR_THREADS && 16 * R1 <= SR_THREADS)                                        \
-                                hipLaunchKernelGGL((k_sht_fwd_pair<PRE, R1, R2, MAXI, 4>), gp, bl, smem, c->stream, PAIR_ARGS); } \
-        else { if constexpr (4 * R2 <= SR_THREADS && 8 * R1 <= SR_THREADS)                                                      \
-                   hipLaunchKernelGGL((k_sht_fwd_pair<PRE, R1, R2, MAXI, 2>), gp, bl, smem, c->stream, PAIR_ARGS); }
+#define PAIR_NS(MAXI, TH)                                                                                                        \
+        if constexpr (TH * R2 <= SR_THREADS && 2 * TH * R1 <= SR_THREADS) {                                                      \
+            hipLaunchKernelGGL((k_sht_fwd_pair<PRE, R1, R2, MAXI, TH, 1>), gr, bl, smem_p, c->stream, PAIR_ARGS);                 \
+            return;                                                                                                              \
+        }
+#define PAIR_TH(MAXI)                                                                                                            \
+        if (th == 8) { PAIR_NS(MAXI, 8) } else if (th == 4) { PAIR_NS(MAXI, 4) } else { PAIR_NS(MAXI, 2) }
         if (per <= 3) { PAIR_TH(3) } else { PAIR_TH(5) }
 #undef PAIR_TH
+#undef PAIR_NS
 #undef PAIR_ARGS
-        return;
     }
 #define FWD_ARGS grid, coeff, (const double*)c->d_PT, (const int*)c->d_lmtab, (const double2*)c->d_twN, (const double*)c->d_gw, \
                  c->nt, c->L, c->npairs, RP, norm, sl, in_slot, c->B, c->N
@@ -844,16 +873,11 @@ void launch_sht_forward_reg(mtip_ctx* c, const double2* grid, double2* coeff, in
 static size_t wide_lds_n(const mtip_ctx* c, int r1, int r2, int nsplit, int* rp_out) {
     if (c->nt % (2 * nsplit) != 0) return (size_t)1 << 40;
     const int ntl = c->nt / nsplit;
-    // whole 32-theta chunks per workgroup, unless the split is asked for (half-filled Legendre items, two workgroups per CU)
-    if (nsplit > 1 && (ntl / 2) % 32 != 0 && c->sht_inv_split < nsplit) return (size_t)1 << 40;
+    if (nsplit > 1 && (ntl / 2) % 32 != 0) return (size_t)1 << 40;      // whole 32-theta chunks per workgroup
     const size_t fixed = (nsplit > 1 ? 0 : (size_t)c->np) + (size_t)ntl * c->nm + c->npairs;
     int rp = largest_even_divisor_le(ntl, std::min(SW_THREADS / r2, SW_THREADS / r1));
-    // the transpose buffer aliases the coefficient block: shrink the pass until both fit -- one CU's LDS, or half of it when
-    // the split is asked for and that is possible (two workgroups per CU, their phases overlap)
-    size_t limit = 158 * 1024;
-    if (nsplit > 1 && c->sht_inv_split == nsplit && (fixed + std::max((size_t)c->nlm, (size_t)2 * r1 * (r2 + 1))) * sizeof(double2) <= 79 * 1024)
-        limit = 79 * 1024;
-    while (rp >= 2 && (fixed + std::max((size_t)c->nlm, (size_t)rp * r1 * (r2 + 1))) * sizeof(double2) > limit)
+    // the transpose buffer aliases the coefficient block: shrink the pass until both fit
+    while (rp >= 2 && (fixed + std::max((size_t)c->nlm, (size_t)rp * r1 * (r2 + 1))) * sizeof(double2) > 158 * 1024)
         rp = largest_even_divisor_le(ntl, rp - 2);
     if (rp_out) *rp_out = rp;
     if (rp < 2) return (size_t)1 << 40;
@@ -862,7 +886,7 @@ static size_t wide_lds_n(const mtip_ctx* c, int r1, int r2, int nsplit, int* rp_
 
 // smallest split (1, 2) whose working set fits one CU's LDS
 static size_t wide_lds(const mtip_ctx* c, int r1, int r2, int* rp_out, int* nsplit_out = nullptr) {
-    for (int ns = c->sht_inv_split; ns <= 2; ++ns) {
+    for (int ns = 1; ns <= 2; ++ns) {
         int rp = 0;
         const size_t lds = wide_lds_n(c, r1, r2, ns, &rp);
         if (lds <= 158 * 1024) {

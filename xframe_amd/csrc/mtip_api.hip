@@ -128,11 +128,10 @@ mtip_ctx* mtip_create(const mtip_cfg* cfg, int device) {
     if (const char* e = std::getenv("MTIP_DEG2_SIMPLE")) c->deg2_simple = std::atoi(e) != 0;
     if (const char* e = std::getenv("MTIP_HANKEL_SIMPLE")) c->hankel_simple = std::atoi(e) != 0;
     if (const char* e = std::getenv("MTIP_HANKEL_WAVE_TILES")) c->hankel_wave_tiles = std::atoi(e) != 0;
-    if (const char* e = std::getenv("MTIP_SHT_FWD_PAIR")) c->sht_fwd_pair = std::atoi(e) != 0 ? 1 : 0;
+    if (const char* e = std::getenv("MTIP_SHT_FWD_PAIR")) c->sht_fwd_pair = std::atoi(e) != 0;
     if (const char* e = std::getenv("MTIP_HANKEL_FLAT_ORDER")) c->hankel_flat_order = std::atoi(e) != 0;
     if (const char* e = std::getenv("MTIP_FUSE_REAL")) c->fuse_real_update = std::atoi(e) != 0;
     if (const char* e = std::getenv("MTIP_SHT_WIDE")) c->sht_wide = std::atoi(e) != 0;
-    if (const char* e = std::getenv("MTIP_SHT_INV_SPLIT")) c->sht_inv_split = std::atoi(e) == 2 ? 2 : 1;
     if (const char* e = std::getenv("MTIP_JAC_RESIDENT")) c->jac_resident = std::atoi(e) != 0;
     if (const char* e = std::getenv("MTIP_POLAR_VARIANT")) c->polar_variant = std::atoi(e);
     if (const char* e = std::getenv("MTIP_POLAR")) c->polar_newton = std::string(e) == "newton";

@@ -7,6 +7,13 @@
 #include <vector>
 #include "../../include/mtip_hip.h"
 
+// Scheduling fence for values in vector registers: the (empty) statement reads and writes its operands, so loads that
+// produce them stay above it and are waited for here, not where the compiler would fold them to.
+#ifndef MTIP_PIN_VGPRS4
+#define MTIP_PIN_VGPRS4(a, b, c, d) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+#endif
+
+
 typedef double v4f64 __attribute__((vector_size(32)));   // accumulator of v_mfma_f64_16x16x4_f64
 
 // ---- complex helpers (complex128 = double2, interleaved like numpy) ----------------------------
@@ -133,7 +140,6 @@ struct mtip_ctx {
     int n_htiles = 0;
     int n_cu = 256;                                   // compute units of the device (persistent-grid sizing)
     bool fuse_real_update = true;                     // env MTIP_FUSE_REAL=0: separate coefficient-difference / real-space kernels
-    int sht_inv_split = 1;                            // env MTIP_SHT_INV_SPLIT=2: two workgroups per shell in the wide inverse transform
     bool sht_wide = true;                             // env MTIP_SHT_WIDE=0: pass-wise inverse Legendre synthesis
     bool jac_resident = true;                         // env MTIP_JAC_RESIDENT=0: round-robin ordering, both columns via LDS
     int *d_jsched = nullptr, *d_jsched_off = nullptr, *d_jsched_rounds = nullptr;   // resident-column pairing schedule
@@ -151,7 +157,7 @@ struct mtip_ctx {
     int* d_jlog_rounds = nullptr;                     // rounds logged per matrix
     int jlog_cap = 0, jlog_ps = 0;
     size_t jlog_nmat = 0;
-    int sht_fwd_pair = -1;                            // env MTIP_SHT_FWD_PAIR: 1 / 0 = two / one shell per forward-transform workgroup; -1 = by batch size
+    bool sht_fwd_pair = true;                         // env MTIP_SHT_FWD_PAIR=0: k_sht_fwd_reg (table loads inside the accumulation loop)
     bool hankel_flat_order = false;                   // env MTIP_HANKEL_FLAT_ORDER=1: tiles in order-major sequence (not XCD-aware)
     bool hankel_wave_tiles = false;                   // env MTIP_HANKEL_WAVE_TILES=1: per-wave tiles straight from L2 (k_hankel_mfma)
     void* d_htiles32 = nullptr;                       // workgroup tiles (order, first column) of k_hankel_tile
