@@ -226,6 +226,9 @@ def main():
             e.synchronize()
         torch.cuda.synchronize(dev)
 
+    from xframe_amd.fxs.engine import streams_side_by_side
+    side_by_side = streams_side_by_side(engines)              # < n_eng: two engines share a hardware queue
+
     # ---- warmup, then exactly K timed steps
     run_schedule(a.warmup)
     sync_all()
@@ -367,6 +370,7 @@ def main():
                                    f'{B} restarts per GPU on {n_eng} streams, tutorial schedule (HIO/SW/ER, ft_stab on), '
                                    f'{"reference-order" if a.exact else "fused"} step',
                        'restarts_per_gpu': B, 'restarts_total': B * world, 'streams_per_gpu': n_eng,
+                       'streams_side_by_side': round(side_by_side, 2),
                        'parallelism': f'restart-sharded x{world}', 'step_mode': 'exact' if a.exact else 'fused'},
             'roofline': roofline, 'cpu_baseline': cpu, 'whole_step': whole_step, 'kernel_families_ms': fam_ms,
             'phase': phase_of(a.warmup, a.steps),

@@ -213,6 +213,10 @@ int mtip_debug_jacobi_sweeps(mtip_ctx* ctx, int32_t* out);
  * projection: producing records, waiting for records, applying them, whole kernel.  The first call (out may be NULL)
  * switches the timers on. */
 int mtip_debug_polar_timing(mtip_ctx* ctx, int64_t* out);
+/* diagnostic: enqueue a one-workgroup kernel that spins for `microseconds` on the context's stream (asynchronous).  Used to
+ * check that the streams of several engines of one process really execute side by side (HIP maps streams onto a limited
+ * pool of hardware queues, GPU_MAX_HW_QUEUES; two streams on one queue serialise). */
+int mtip_debug_spin(mtip_ctx* ctx, double microseconds);
 /* diagnostic: build and verify the resident-column pairing schedule of the polar-factor kernel for every column
  * count 2..k_max <= 127 (every pair exactly once per sweep, no column twice in a round); MTIP_OK or MTIP_EINVAL */
 int mtip_debug_check_jacobi_schedule(mtip_ctx* ctx, int k_max);

@@ -143,6 +143,7 @@ static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int, i
 // wave-uniform lane reads (the lane index is uniform in the kernels: an SGPR on the GPU)
 static inline int __builtin_amdgcn_readlane(int v, int src_lane) { return __shfl(v, src_lane, 64); }
 #define MTIP_PIN_VGPRS4(a, b, c, d)      // register-scheduling fence of the device build: nothing to do on the host
+static inline long long wall_clock64() { static thread_local long long t = 0; return t += 1000; }
 static inline int __builtin_amdgcn_readfirstlane(int v) { return __shfl(v, 0, 64); }
 // workgroup-scope atomics on LDS words: the fibers of a block share one OS thread, plain accesses are atomic enough
 #define __HIP_MEMORY_SCOPE_WORKGROUP 2
@@ -210,8 +211,8 @@ static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMem
 static inline hipError_t hipMemset(void* d, int v, size_t n) { std::memset(d, v, n); return hipSuccess; }
 static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { std::memset(d, v, n); return hipSuccess; }
 static inline hipError_t hipStreamCreate(hipStream_t* s) { *s = nullptr; return hipSuccess; }
-enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 0 };
-static inline hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) { *v = 2; return hipSuccess; }   // tiny "device": persistent grids loop
+enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 0, hipDeviceAttributeWallClockRate = 1 };
+static inline hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t a, int) { *v = a == hipDeviceAttributeWallClockRate ? 1000 : 2; return hipSuccess; }   // tiny "device": persistent grids loop
 static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }

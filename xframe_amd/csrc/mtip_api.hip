@@ -1068,6 +1068,21 @@ int mtip_debug_jacobi_sweeps(mtip_ctx* c, int32_t* out) {
     return MTIP_OK;
 }
 
+__global__ void k_debug_spin(long long ticks) {
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) {}
+}
+
+int mtip_debug_spin(mtip_ctx* c, double microseconds) {
+    CTX_CHECK(c);
+    if (!(microseconds >= 0.0) || microseconds > 1e6) FAIL(c, MTIP_EINVAL, "spin time out of range");
+    (void)hipSetDevice(c->device);
+    int khz = 0;
+    MTIP_HIP_CHECK(c, hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->device));
+    hipLaunchKernelGGL(k_debug_spin, dim3(1), dim3(64), 0, c->stream, (long long)(microseconds * 1e-3 * khz));
+    return post_launch(c, "mtip_debug_spin");
+}
+
 int mtip_debug_polar_timing(mtip_ctx* c, int64_t* out) {
     CTX_CHECK(c);
     (void)hipSetDevice(c->device);

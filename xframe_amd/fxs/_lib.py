@@ -85,6 +85,7 @@ _SIGNATURES = {
     'mtip_debug_jacobi_sweeps': (C.c_int, [c_void, c_void]),
     'mtip_debug_check_jacobi_schedule': (C.c_int, [c_void, C.c_int]),
     'mtip_debug_polar_timing': (C.c_int, [c_void, c_void]),
+    'mtip_debug_spin': (C.c_int, [c_void, C.c_double]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

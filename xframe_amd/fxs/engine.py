@@ -391,6 +391,10 @@ class Engine:
         self._ck(self.lib.mtip_profile_get(self.ctx, name.encode(), C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+    def debug_spin(self, microseconds):
+        """enqueue a kernel that spins for `microseconds` on this engine's stream (asynchronous; see streams_side_by_side)"""
+        self._ck(self.lib.mtip_debug_spin(self.ctx, float(microseconds)))
+
     def jacobi_sweeps(self):
         out = np.zeros((self.B, self.L + 1), np.int32)
         self._ck(self.lib.mtip_debug_jacobi_sweeps(self.ctx, _lib.ptr(out)))
@@ -418,3 +422,22 @@ class Engine:
     def forward_l(self, grid):
         c = self.sht_forward(grid)[0]
         return [np.array(c[:, l * l:(l + 1) ** 2]) for l in range(self.L + 1)]
+
+
+def streams_side_by_side(engines, microseconds=2000.0, reps=3):
+    """How many of the engines' streams execute at the same time: every engine gets `reps` spin kernels, the ratio of the
+    serial time to the measured wall time is the number of chains that ran side by side.  HIP maps streams onto a pool of
+    hardware queues (GPU_MAX_HW_QUEUES); two engines on one queue serialise, which no kernel timing shows directly."""
+    import time
+    for e in engines:
+        e.debug_spin(10.0)
+    for e in engines:
+        e.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        for e in engines:
+            e.debug_spin(microseconds)
+    for e in engines:
+        e.synchronize()
+    wall = time.perf_counter() - t0
+    return len(engines) * reps * microseconds * 1e-6 / wall
