@@ -1104,6 +1104,178 @@ __global__ void __launch_bounds__(256) k_proj_mfma(ProjGemmArgs a, const int* __
     }
 }
 
+// ---- two fused pairs of those products (round 2) ----------------------------------------------------------------
+// A step of a 3-restart engine spends ~55 us in the four GEMM kernels for 0.1 GFLOP: they are short latency chains, and
+// every kernel boundary of a stream costs its own start-up.  `W = X V_r` only needs the ROWS of X a workgroup has just
+// computed, and `I'_l = V_l U_l` only the COLUMNS of U: so
+//   k_proj_xw:  a workgroup owns 16 rows of X_l (all columns, one 16 x 16 tile per wave), keeps them in LDS and multiplies
+//               them with V_r of the previous step -> W (the warm-start matrix the Jacobi kernel works on); X_l itself is
+//               never stored (the cold start, every 64th call, runs the plain PG_X product instead);
+//   k_proj_ua:  a workgroup owns 16 columns of U_l = V_r Pn^+ (all rows, a tile per wave), stores them (unknowns output)
+//               and keeps them in LDS as the B operand of its column block of I'_l = V_l U_l (a row tile per wave).
+// Same fragments, same order of the inner index as k_proj_mfma: the results are bit-identical to the four-kernel path.
+
+// one 16 x 16 complex tile: acc += sum_kc A[kc] B[kc];  ap / bp point at inner index 0 of this lane's row of A / column of B,
+// consecutive inner indices a_sk / b_sk elements apart (global or LDS), XQ: A = conj(a) q^2 (the PG_X operand)
+template <bool XQ, bool B_CONJ>
+__device__ __forceinline__ void pm_accumulate(const double2* ap, size_t a_sk, bool m_ok, const double2* bp, size_t b_sk, bool n_ok,
+                                              int K, const double* __restrict__ q, int ri, int kh, v4f64& acc_re, v4f64& acc_im) {
+    const int n_steps = (K + 1) / 2;
+    double fa[PM_PF], f1[PM_PF], f2[PM_PF], ga[PM_PF], g1[PM_PF], g2[PM_PF];
+    auto request = [&](int s0, double (&xa)[PM_PF], double (&x1)[PM_PF], double (&x2)[PM_PF]) {
+#pragma unroll
+        for (int u = 0; u < PM_PF; ++u) {
+            const int kc = 2 * (s0 + u) + kh;
+            const bool k_ok = kc < K;
+            const int kq = k_ok ? kc : 0;
+            double2 va = ap[(size_t)kq * a_sk];
+            double2 vb = bp[(size_t)kq * b_sk];
+            if (XQ) {
+                const double qq = q[kq];
+                va = make_double2(qq * qq * va.x, -qq * qq * va.y);
+            }
+            if (B_CONJ) vb.y = -vb.y;
+            const bool aok = k_ok && m_ok, bok = k_ok && n_ok;
+            xa[u] = aok ? (ri ? va.y : va.x) : 0.0;
+            x1[u] = bok ? (ri ? -vb.y : vb.x) : 0.0;
+            x2[u] = bok ? (ri ? vb.x : vb.y) : 0.0;
+        }
+    };
+    request(0, fa, f1, f2);
+    for (int s0 = 0; s0 < n_steps; s0 += 2 * PM_PF) {
+        request(s0 + PM_PF, ga, g1, g2);                         // beyond K: clamped, zeroed
+#pragma unroll
+        for (int u = 0; u < PM_PF; ++u) {
+            acc_re = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[u], f1[u], acc_re, 0, 0, 0);
+            acc_im = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[u], f2[u], acc_im, 0, 0, 0);
+        }
+        request(s0 + 2 * PM_PF, fa, f1, f2);
+#pragma unroll
+        for (int u = 0; u < PM_PF; ++u) {
+            acc_re = __builtin_amdgcn_mfma_f64_16x16x4f64(ga[u], g1[u], acc_re, 0, 0, 0);
+            acc_im = __builtin_amdgcn_mfma_f64_16x16x4f64(ga[u], g2[u], acc_im, 0, 0, 0);
+        }
+    }
+}
+
+#define PF_THREADS 512          // 8 waves: up to 128 columns of X_l / 128 shells per pass of I'_l
+
+// W[16 rows of tile_m][all k columns] = (conj(I_l)^T q^2 V_l)[rows] V_r:   tiles = order | tile_m << 8
+__global__ void __launch_bounds__(PF_THREADS) k_proj_xw(ProjGemmArgs a, const int* __restrict__ tiles) {
+    HIP_DYNAMIC_SHARED(double2, sm)
+    const int tinfo = tiles[blockIdx.x];
+    const int l = tinfo & 255, tile_m = tinfo >> 8;
+    const int b = blockIdx.y;
+    if (!a.active[l]) return;
+    const int k = a.kl[l], n = 2 * l + 1, xo = a.xoff[l];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int li = lane & 15, kk = lane >> 4, ri = kk & 1, kh = kk >> 1;
+    const int m0 = tile_m * 16;
+    const int ld = k | 1;                                        // LDS row of the X block (odd: rows on different banks)
+    double2* Xs = sm;                                            // [16][ld]
+    const int ntn = (k + 15) >> 4;
+    const int mi = m0 + li;
+    const bool m_ok = mi < n;
+    // ---- X rows: A = conj(I_l[q][m]) q^2 (inner index q: stride nlm), B = V_l[q][c] (stride k)
+    for (int tn = wave; tn < ntn; tn += PF_THREADS / 64) {
+        const int nj = tn * 16 + li;
+        const bool n_ok = nj < k;
+        v4f64 acc_re = v4f64{0.0, 0.0, 0.0, 0.0}, acc_im = acc_re;
+        const double2* ap = a.Ilm + (size_t)b * a.N * a.nlm + (size_t)l * l + (m_ok ? mi : 0);
+        const double2* bp = a.V + a.voff[l] + (n_ok ? nj : 0);
+        pm_accumulate<true, false>(ap, (size_t)a.nlm, m_ok, bp, (size_t)k, n_ok, a.N, a.q, ri, kh, acc_re, acc_im);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ml = kk + 4 * r, nn = tn * 16 + li;
+            if (nn < k) Xs[(size_t)ml * ld + nn] = make_double2(acc_re[r], acc_im[r]);     // rows beyond n hold zeros
+        }
+    }
+    __syncthreads();
+    // ---- W rows: A = X rows (LDS, inner index j: stride 1), B = V_r[c][j] (column c at c * k, stride 1)
+    for (int tn = wave; tn < ntn; tn += PF_THREADS / 64) {
+        const int nj = tn * 16 + li;
+        const bool n_ok = nj < k;
+        v4f64 acc_re = v4f64{0.0, 0.0, 0.0, 0.0}, acc_im = acc_re;
+        const double2* ap = Xs + (size_t)li * ld;
+        const double2* bp = a.Vr + (size_t)b * a.utot + a.uoff[l] + (size_t)(n_ok ? nj : 0) * k;
+        pm_accumulate<false, false>(ap, 1, m_ok, bp, 1, n_ok, k, a.q, ri, kh, acc_re, acc_im);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int mm = m0 + kk + 4 * r, nn = tn * 16 + li;
+            if (mm < n && nn < k) a.dst[(size_t)b * a.xtot + xo + (size_t)nn * n + mm] = make_double2(acc_re[r], acc_im[r]);
+        }
+    }
+}
+
+// U[all k rows][16 columns of tile_n] = V_r conj(Pn)^T -> a.Xw (d_U) and LDS;  I'_l[all shells][those columns] = V_l U with the
+// mask / l = 0 rules of the PG_APPLY store, in place on a.dst:   tiles = order | tile_n << 8 (every used or solved order)
+__global__ void __launch_bounds__(PF_THREADS) k_proj_ua(ProjGemmArgs a, double2* __restrict__ U_out, const int* __restrict__ tiles) {
+    typedef ProjGemm<PG_APPLY> G;
+    HIP_DYNAMIC_SHARED(double2, sm)
+    const int tinfo = tiles[blockIdx.x];
+    const int l = tinfo & 255, tile_n = tinfo >> 8;
+    const int b = blockIdx.y;
+    const bool used = a.used[l] != 0;
+    if (!used && !a.active[l]) return;
+    const int k = a.kl[l], n = 2 * l + 1, xo = a.xoff[l];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int li = lane & 15, kk = lane >> 4, ri = kk & 1, kh = kk >> 1;
+    const int n0 = tile_n * 16;
+    const int nj = n0 + li;
+    const bool n_ok = nj < n;
+    const bool prod = l > 0;
+    double2* Us = sm;                                            // [k][16 + 1]: B operand of the second product, inner index i
+    constexpr int LDU = 17;
+    {
+        const int ntm = (k + 15) >> 4;
+        if (a.active[l]) {
+            // ---- U rows i: A = V_r[c][i] (inner index c: stride k), B = conj(Pn[c][j]) (Pn column-major n x k: stride n)
+            for (int tm = wave; tm < ntm; tm += PF_THREADS / 64) {
+                const int mi = tm * 16 + li;
+                const bool m_ok = mi < k;
+                v4f64 acc_re = v4f64{0.0, 0.0, 0.0, 0.0}, acc_im = acc_re;
+                const double2* ap = a.Vr + (size_t)b * a.utot + a.uoff[l] + (m_ok ? mi : 0);
+                const double2* bp = a.X + (size_t)b * a.xtot + xo + (n_ok ? nj : 0);
+                pm_accumulate<false, true>(ap, (size_t)k, m_ok, bp, (size_t)n, n_ok, k, a.q, ri, kh, acc_re, acc_im);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int mm = tm * 16 + kk + 4 * r;
+                    if (mm < k) {
+                        const double2 v = make_double2(acc_re[r], acc_im[r]);
+                        Us[(size_t)mm * LDU + li] = v;                                       // columns beyond n hold zeros
+                        if (n_ok) U_out[(size_t)b * a.xtot + xo + (size_t)mm * n + nj] = v;   // row-major k x n
+                    }
+                }
+            }
+        } else if (prod) {
+            // an order that is used but not solved: its unknowns stay what they are
+            for (int e = threadIdx.x; e < k * 16; e += PF_THREADS) {
+                const int i = e >> 4, j = e & 15;
+                Us[(size_t)i * LDU + j] = (n0 + j < n) ? a.Xw[(size_t)b * a.xtot + xo + (size_t)i * n + n0 + j] : make_double2(0.0, 0.0);
+            }
+        }
+    }
+    if (!used) return;                                           // solved but not applied: only its unknowns are wanted
+    __syncthreads();
+    // ---- I'_l rows q: A = V_l[q][i] (row q at q * k, stride 1), B = U[i][j] (LDS)
+    const int ntq = (a.N + 15) >> 4;
+    for (int tq = wave; tq < ntq; tq += PF_THREADS / 64) {
+        const int mi = tq * 16 + li;
+        const bool m_ok = mi < a.N;
+        v4f64 acc_re = v4f64{0.0, 0.0, 0.0, 0.0}, acc_im = acc_re;
+        if (prod) {
+            const double2* ap = a.V + a.voff[l] + (size_t)(m_ok ? mi : 0) * k;
+            const double2* bp = Us + li;
+            pm_accumulate<false, false>(ap, 1, m_ok, bp, (size_t)LDU, n_ok, k, a.q, ri, kh, acc_re, acc_im);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int mm = tq * 16 + kk + 4 * r;
+            if (mm < a.N && n_ok) G::store(a, b, l, k, n, xo, mm, nj, make_double2(acc_re[r], acc_im[r]));
+        }
+    }
+}
+
 // tile lists of the four products (order | tile_m << 8 | tile_n << 16), heavy orders first
 static int build_proj_tiles(mtip_ctx* c) {
     if (c->d_pg_tiles[0] != nullptr) return MTIP_OK;
@@ -1124,6 +1296,18 @@ static int build_proj_tiles(mtip_ctx* c) {
         }
         if (t.empty()) t.push_back(0);
         c->n_pg_tiles[op] = (int)t.size();
+        if (hipMalloc((void**)&c->d_pg_tiles[op], t.size() * sizeof(int)) != hipSuccess) return MTIP_ENOMEM;
+        (void)hipMemcpy(c->d_pg_tiles[op], t.data(), t.size() * sizeof(int), hipMemcpyHostToDevice);
+    }
+    // the fused pairs: 4 = k_proj_xw (order | row tile << 8, active orders), 5 = k_proj_ua (order | column tile << 8, used orders)
+    for (int op = 4; op < 6; ++op) {
+        std::vector<int> t;
+        for (int l = c->L; l >= 0; --l) {
+            if (op == 4 ? !c->active[l] : !(c->used[l] || c->active[l])) continue;
+            for (int tt = 0; tt < div_up(2 * l + 1, 16); ++tt) t.push_back(l | (tt << 8));
+        }
+        c->n_pg_tiles[op] = (int)t.size();
+        if (t.empty()) t.push_back(0);
         if (hipMalloc((void**)&c->d_pg_tiles[op], t.size() * sizeof(int)) != hipSuccess) return MTIP_ENOMEM;
         (void)hipMemcpy(c->d_pg_tiles[op], t.data(), t.size() * sizeof(int), hipMemcpyHostToDevice);
     }
@@ -1256,6 +1440,14 @@ int launch_apply_unknowns(mtip_ctx* c, const double2* Ilm, double2* out) {
     return MTIP_OK;
 }
 
+// largest k_l over the orders the apply product touches (LDS of k_proj_ua)
+static int kmax_used(const mtip_ctx* c) {
+    int k = 1;
+    for (int l = 0; l <= c->L; ++l)
+        if (c->used[l] || c->active[l]) k = std::max(k, c->kl[l]);
+    return k;
+}
+
 int launch_project_coefficients(mtip_ctx* c, const double2* Ilm, double2* out) {
     ProfScope ps(c, "proj");
     int max_kn = 1, kmax = 1, nmax = 1;
@@ -1271,8 +1463,10 @@ int launch_project_coefficients(mtip_ctx* c, const double2* Ilm, double2* out) {
         c->err = "projection tile lists: out of device memory";
         return MTIP_ENOMEM;
     }
-    launch_proj_gemm<PG_X>(c, ga);
+    // fused pairs (k_proj_xw, k_proj_ua) on the MFMA path when X_l fits the 8 waves of k_proj_xw
+    const bool fuse = c->proj_fuse && c->proj_mfma && kmax <= 16 * (PF_THREADS / 64);
     if (polar_newton_supported(c)) {
+        launch_proj_gemm<PG_X>(c, ga);
         // square X_l: polar factor by the scaled Newton iteration (k_polar.hip), U_l written directly
         int rn;
         {
@@ -1297,13 +1491,19 @@ int launch_project_coefficients(mtip_ctx* c, const double2* Ilm, double2* out) {
     // than the global-memory fallback there) unless MTIP_JAC_REPLAY=2 forces it.
     const bool logv = c->jac_replay > 0 && (c->jac_replay > 1 || lds > 158 * 1024) && c->jac_tg == 16 && square && sched_ok &&
                       nmax <= 7 * 16 && c->jsched_ps <= 48 && lds_x + 16 * sizeof(double2) <= 158 * 1024;
-    if (logv || lds <= 158 * 1024) {
-        // cold start every 64 calls bounds the accumulated rounding drift of the carried V_r
-        const int warm = (c->vr_valid && (c->proj_calls % 64) != 0) ? 1 : 0;
+    const bool lds_path = logv || lds <= 158 * 1024;
+    // cold start every 64 calls bounds the accumulated rounding drift of the carried V_r
+    const int warm = (lds_path && c->vr_valid && (c->proj_calls % 64) != 0) ? 1 : 0;
+    if (!(fuse && warm)) launch_proj_gemm<PG_X>(c, ga);         // (fused warm start: X_l never leaves the workgroups of k_proj_xw)
+    if (lds_path) {
         const double2* src = c->d_X;
         if (warm) {
             ga.dst = c->d_U;
-            launch_proj_gemm<PG_WARM>(c, ga);
+            if (fuse)                                           // X_l rows stay in LDS, W = X_l V_r straight into d_U
+                hipLaunchKernelGGL(k_proj_xw, dim3((unsigned)std::max(c->n_pg_tiles[4], 1), (unsigned)c->B), dim3(PF_THREADS),
+                                   (size_t)16 * (kmax | 1) * sizeof(double2), c->stream, ga, (const int*)c->d_pg_tiles[4]);
+            else
+                launch_proj_gemm<PG_WARM>(c, ga);
             src = c->d_U;
         }
         const int pairs_max = kmax / 2;                         // valid pairs per round (odd k: dummy pair skipped)
@@ -1374,10 +1574,19 @@ int launch_project_coefficients(mtip_ctx* c, const double2* Ilm, double2* out) {
         else JL_LAUNCH(16, 8, JL_MAX_THREADS, false);
         }
 #undef JL_LAUNCH
-        ga.dst = c->d_U;
-        launch_proj_gemm<PG_U>(c, ga);
         c->vr_valid = true;
         c->proj_calls += 1;
+        if (fuse) {
+            // U_l = V_r Pn^+ by column blocks, each block at once the operand of its part of I'_l = V_l U_l
+            if (out != Ilm)
+                (void)hipMemcpyAsync(out, Ilm, (size_t)c->B * c->C * sizeof(double2), hipMemcpyDeviceToDevice, c->stream);
+            ga.dst = out;
+            hipLaunchKernelGGL(k_proj_ua, dim3((unsigned)std::max(c->n_pg_tiles[5], 1), (unsigned)c->B), dim3(PF_THREADS),
+                               (size_t)kmax_used(c) * 17 * sizeof(double2), c->stream, ga, c->d_U, (const int*)c->d_pg_tiles[5]);
+            return MTIP_OK;
+        }
+        ga.dst = c->d_U;
+        launch_proj_gemm<PG_U>(c, ga);
     } else {
         hipLaunchKernelGGL(k_polar_jacobi, dim3((unsigned)(c->L + 1), (unsigned)c->B), dim3(256), 0, c->stream, c->d_X,
                            c->d_Vr, c->d_U, (const int*)c->d_kl, (const int*)c->d_active, (const int*)c->d_xoff,

@@ -146,8 +146,8 @@ struct mtip_ctx {
     int jsched_kmax = 0, jsched_ps = 0;
     int* d_jorder = nullptr;                          // active orders, heaviest first (grid of the polar-factor kernel)
     int n_jorder = 0;
-    int* d_pg_tiles[4] = {nullptr, nullptr, nullptr, nullptr};   // (order, tile) lists of the projection GEMMs
-    int n_pg_tiles[4] = {0, 0, 0, 0};
+    int* d_pg_tiles[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // (order, tile) lists of the projection GEMMs (4, 5: fused pairs)
+    int n_pg_tiles[6] = {0, 0, 0, 0, 0, 0};
     long long* d_polar_dbg = nullptr;                 // (B, L+1, 8 waves, 4) phase timers of k_polar_newton, allocated by mtip_debug_polar_timing
     int polar_variant = 0;                            // env MTIP_POLAR_VARIANT (A/B switches of k_polar_newton: 1 ds_bpermute pivot row, 2 spin without s_sleep)
     bool polar_newton = false;                        // env MTIP_POLAR=newton: scaled Newton iteration (k_polar.hip) for square X_l up to 72 x 72; default: one-sided Jacobi
@@ -183,6 +183,7 @@ struct mtip_ctx {
     double2* d_Bref = nullptr;                        // (L+1, Nq, Nq) masked reference B_l
     double* d_Bnorm = nullptr;                        // (L+1)
     double* d_deg2_part = nullptr;                    // (B, L+1, (Nq/16)^2) per-tile partial sums of the B_l metric
+    bool proj_fuse = true;                            // env MTIP_PROJ_FUSE=0: four separate projection products instead of the two fused pairs
     bool proj_mfma = true;                            // env MTIP_PROJ_MFMA=0: LDS-tiled VALU GEMMs for the projection products
     bool deg2_simple = false;                         // env MTIP_DEG2_SIMPLE=1: one thread per B_l element instead of MFMA tiles
     bool bref_dirty = true;
