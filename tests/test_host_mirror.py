@@ -173,3 +173,13 @@ def test_calc_center_and_shift_golden(golden_ops):
 
 def test_reference_sw_and_shift_sketches_on_registry(emul_lib, golden_mtip16):
     BC.check_reference_sw_and_shift_sketches_on_registry(golden_mtip16, emul_lib)
+
+
+def test_unsupported_radial_rules_raise():
+    """'Zernike' has its own weights upstream (not built), 'gauss' no spherical grid: neither may fall through to the trapz weights"""
+    from xframe_amd.fxs import hostsetup as hs
+    for mode in ('Zernike', 'zernike', 'gauss'):
+        with pytest.raises(NotImplementedError):
+            hs.radial_grids(1.0, 8, 2.0, mode)
+        with pytest.raises(NotImplementedError):
+            hs.hankel_raw_weights(2, 8, 2.0, mode)

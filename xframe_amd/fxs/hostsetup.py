@@ -40,9 +40,11 @@ def radial_grids(max_q, n, kappa, mode='midpoint'):
         dr, dq = r_cut / n, max_q / n
         return (np.linspace(dr / 2, r_cut - dr / 2, num=n, endpoint=True),
                 np.linspace(dq / 2, max_q - dq / 2, num=n, endpoint=True))
-    if mode in ('trapz', 'Zernike'):
+    if mode == 'trapz':
         return np.linspace(0, r_cut, n), np.linspace(0, max_q, n)
-    raise AssertionError(f'fourier_transform.type {mode!r} is not supported (midpoint, trapz, Zernike)')
+    # 'Zernike' shares the trapz grid upstream (ft_grid_pairs.py:545-547) but has its own weights, which are not built here;
+    # 'gauss' has no spherical grid upstream
+    raise NotImplementedError(f'fourier_transform.type {mode!r} is not supported (midpoint, trapz)')
 
 
 def hankel_raw_weights(l_max, n, kappa, mode='midpoint'):
@@ -51,9 +53,11 @@ def hankel_raw_weights(l_max, n, kappa, mode='midpoint'):
     if mode == 'midpoint':
         ps = np.arange(n) + 0.5
         ks = np.arange(n) + 0.5
-    else:
+    elif mode == 'trapz':
         ps = np.arange(1, n)
         ks = np.arange(n)
+    else:
+        raise NotImplementedError(f'fourier_transform.type {mode!r} is not supported (midpoint, trapz)')
     arg = ks[None, :] * ps[:, None] * kappa / n
     return np.ascontiguousarray(ps[None, :, None] ** 2 * spherical_jn(ls[:, None, None], arg[None, :, :]))
 
