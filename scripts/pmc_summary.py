@@ -38,7 +38,7 @@ for tot, k, n, fk, wk in rows[:24]:
 
 if len(sys.argv) > 3:
     import json
-    fam_of = [("k_sht_fwd_reg", "sht_fwd"), ("k_sht_inv_wide<0", "sht_inv"), ("k_sht_inv_wide<1", "sht_inv_modulus"),
+    fam_of = [("k_sht_fwd_pair", "sht_fwd"), ("k_sht_fwd_reg", "sht_fwd"), ("k_sht_inv_wide<0", "sht_inv"), ("k_sht_inv_wide<1", "sht_inv_modulus"),
               ("k_sht_inv_wide<4", "sht_inv_real"), ("k_hankel", "hankel"), ("k_real_update", "real_update")]
     fam = defaultdict(lambda: [0.0, 0])
     for k in fetch:
