@@ -148,6 +148,9 @@ static inline int __builtin_amdgcn_readfirstlane(int v) { return __shfl(v, 0, 64
 // workgroup-scope atomics on LDS words: the fibers of a block share one OS thread, plain accesses are atomic enough
 #define __HIP_MEMORY_SCOPE_WORKGROUP 2
 // (a polling loop may spin on such a load without s_sleep: let the other fibers of the block run)
+#ifndef __HIP_MEMORY_SCOPE_AGENT
+#define __HIP_MEMORY_SCOPE_AGENT 4
+#endif
 template <typename T> static inline T __hip_atomic_load(const T* p, int, int) { emul::fiber_yield(); return *const_cast<const volatile T*>(p); }
 template <typename T> static inline void __hip_atomic_store(T* p, T v, int, int) { *const_cast<volatile T*>(p) = v; }
 static inline int __double2loint(double v) { long long u; std::memcpy(&u, &v, 8); return (int)(u & 0xffffffffll); }
@@ -162,6 +165,12 @@ static inline double atomicAdd(double* p, double v) {
     std::lock_guard<std::mutex> g(emul_atomic_mutex);
     double o = *p; *p = o + v; return o;
 }
+static inline int atomicMin(int* p, int v) {
+    const int old = *p;
+    if (v < old) *p = v;
+    return old;
+}
+static inline long long __double_as_longlong(double v) { long long r; std::memcpy(&r, &v, 8); return r; }
 static inline int atomicAdd(int* p, int v) {
     std::lock_guard<std::mutex> g(emul_atomic_mutex);
     int o = *p; *p = o + v; return o;

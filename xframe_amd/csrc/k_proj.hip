@@ -366,20 +366,38 @@ __device__ __forceinline__ void jl_pair_generic(double2* xi, double2* xj, double
 #define JS_ACTIVE (1 << 17)
 #define JS_WB (1 << 16)
 
-// One rotation of the log that k_jacobi_replay applies to V_r: columns (pr, pm) <- (pr, pm) [[c, conj(w)], [-w, c]];
-// pr < 0: nothing to do in this (round, group) slot.
+// One rotation of the log that k_jacobi_replay applies to V_r: columns (pr, pm) <- (pr, pm) [[c, conj(w)], [-w, c]].
+// meta = pr | pm << 8 | tag << 16 (pr = 0xff: nothing to do in this (round, group) slot; tag: see jl_tag), hash = jl_hash of the
+// record -- the concurrent consumer (k_polar_conc) takes a record only when tag and hash fit its slot and call, whatever
+// order the producer's stores become visible in.
 struct __align__(16) JlRec {
     double cs, wx, wy;
-    int pr, pm;
+    unsigned int meta, hash;
 };
+#define JL_NONE 0xffu
+__device__ __forceinline__ unsigned int jl_tag(int epoch) { return (unsigned int)(epoch % 32767) + 1u; }     // 1 .. 32767, never 0
+__device__ __forceinline__ unsigned int jl_hash(double cs, double wx, double wy, unsigned int meta, unsigned int slot, int epoch) {
+    unsigned int h = (unsigned int)__double2loint(cs) * 0x9E3779B1u ^ (unsigned int)__double2hiint(cs) * 0x85EBCA6Bu;
+    h ^= (unsigned int)__double2loint(wx) * 0xC2B2AE35u ^ (unsigned int)__double2hiint(wx) * 0x27D4EB2Fu;
+    h ^= (unsigned int)__double2loint(wy) * 0x165667B1u ^ (unsigned int)__double2hiint(wy) * 0xD3A2646Du;
+    h ^= meta * 0xFD7046C5u ^ slot * 0xB55A4F09u ^ (unsigned int)epoch * 0x2545F491u;
+    return h ^ (h >> 15);
+}
+// agent-scope accesses: written through / read past the (per-XCD, mutually incoherent) L2
+__device__ __forceinline__ void st_agent(unsigned long long* p, unsigned long long v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long ld_agent(const unsigned long long* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 // WITHV = false: V_r is not touched here; the rotation of every (round, group) slot is appended to `log` instead
 // (slot = round * ps + group) and replayed on V_r by k_jacobi_replay, which spreads the rows of V_r over the chip.
-template <int NR, int TG, bool WITHV>
+template <int NR, int TG, bool WITHV, bool CONC>
 __device__ __forceinline__ void jl_sweep_resident(double2* Xs, double2* Vs, int ns, int ks, int t, int group,
                                                   const int* __restrict__ tab, int n_rounds, int ps, const int* s_perm,
                                                   bool xl_ok, bool vl_ok, double tabs2, double S, bool& big,
-                                                  JlRec* __restrict__ log) {
+                                                  JlRec* __restrict__ log, int slot0, int epoch) {
     double2 rx[NR], rv[WITHV ? NR : 1];
 #pragma unroll
     for (int u = 0; u < NR; ++u) rx[u] = make_double2(0.0, 0.0);
@@ -433,10 +451,22 @@ __device__ __forceinline__ void jl_sweep_resident(double2* Xs, double2* Vs, int 
         double2 w = make_double2(0.0, 0.0);
         const bool rot = jl_params(alpha, beta, gr, gi, act, tabs2, S, big, cs, w);
         if (!WITHV && t == 0 && group < ps) {
-            JlRec rec;
-            rec.cs = cs; rec.wx = w.x; rec.wy = w.y;
-            rec.pr = rot ? pr : -1; rec.pm = pm;
-            log[(size_t)r * ps + group] = rec;
+            const unsigned int slot = (unsigned int)(slot0 + r * ps + group);
+            const unsigned int meta = (rot ? (unsigned int)pr : JL_NONE) | ((unsigned int)pm << 8) | (jl_tag(epoch) << 16);
+            const unsigned int hash = jl_hash(cs, w.x, w.y, meta, slot, epoch);
+            JlRec* dst = log + (size_t)r * ps + group;
+            if (CONC) {                                          // published to a workgroup that runs at the same time
+                unsigned long long* d8 = reinterpret_cast<unsigned long long*>(dst);
+                st_agent(d8, (unsigned long long)__double_as_longlong(cs));
+                st_agent(d8 + 1, (unsigned long long)__double_as_longlong(w.x));
+                st_agent(d8 + 2, (unsigned long long)__double_as_longlong(w.y));
+                st_agent(d8 + 3, (unsigned long long)meta | ((unsigned long long)hash << 32));
+            } else {
+                JlRec rec;
+                rec.cs = cs; rec.wx = w.x; rec.wy = w.y;
+                rec.meta = meta; rec.hash = hash;
+                *dst = rec;
+            }
         }
         if (rot) {
             if (WITHV) {
@@ -481,31 +511,55 @@ __device__ __forceinline__ void jl_sweep_resident(double2* Xs, double2* Vs, int 
 // are zero padded to a multiple of 8 rows in LDS, so the row loops need no per-lane predicate; the two columns of
 // the pair stay in registers between the Gram reduction and the rotation.  For odd k the tournament pair that
 // contains the dummy player is skipped, so ceil(k/2) <= 32 pair-groups (one wave per SIMD at k <= 65) suffice.
-template <int MAXR, int TG, int MAXT, bool LOGV>
-__global__ void __launch_bounds__(MAXT) k_polar_jacobi_lds(const double2* __restrict__ Xin_all,
-                                                                    double2* __restrict__ Pn_all,
-                                                                    double2* __restrict__ Vr_all, const int* __restrict__ kl,
-                                                                    const int* __restrict__ active,
-                                                                    const int* __restrict__ xoff, const int* __restrict__ roff,
-                                                                    int xtot, int rtot, int L, int warm, double tabs2,
-                                                                    int* __restrict__ sweeps_out, int pad,
-                                                                    const int* __restrict__ sched,
-                                                                    const int* __restrict__ sched_off,
-                                                                    const int* __restrict__ sched_rounds, int sched_ps,
-                                                                    const int* __restrict__ order_list,
-                                                                    JlRec* __restrict__ log_all, int* __restrict__ log_rounds,
-                                                                    int log_cap) {
+// arguments of the polar-factor kernels (one struct: the Jacobi body is shared by two kernels)
+struct JacobiArgs {
+    const double2* Xin_all;
+    double2* Pn_all;
+    double2* Vr_all;
+    const int *kl, *active, *xoff, *roff;
+    int xtot, rtot, L, warm;
+    double tabs2;
+    int* sweeps_out;
+    int pad;
+    const int *sched, *sched_off, *sched_rounds;
+    int sched_ps;
+    const int* order_list;
+    JlRec* log_all;
+    int* log_rounds;
+    int log_cap, epoch;
+    int* conc_err;                     // concurrent replay: consumers that gave up waiting (must stay 0)
+};
+
+// the workgroup of matrix (restart b, order_list[oy]); CONC: its rotation log is consumed while it is written (k_polar_conc)
+template <int MAXR, int TG, int MAXT, bool LOGV, bool CONC>
+__device__ __forceinline__ void polar_jacobi_body(const JacobiArgs& A, int b, int oy, size_t mat) {
+    const double2* __restrict__ Xin_all = A.Xin_all;
+    double2* __restrict__ Pn_all = A.Pn_all;
+    double2* __restrict__ Vr_all = A.Vr_all;
+    const int* __restrict__ kl = A.kl;
+    const int* __restrict__ active = A.active;
+    const int* __restrict__ xoff = A.xoff;
+    const int* __restrict__ roff = A.roff;
+    const int xtot = A.xtot, rtot = A.rtot, L = A.L, warm = A.warm, pad = A.pad, sched_ps = A.sched_ps, log_cap = A.log_cap;
+    const double tabs2 = A.tabs2;
+    int* __restrict__ sweeps_out = A.sweeps_out;
+    const int* __restrict__ sched = A.sched;
+    const int* __restrict__ sched_off = A.sched_off;
+    const int* __restrict__ sched_rounds = A.sched_rounds;
+    JlRec* __restrict__ log_all = A.log_all;
+    int* __restrict__ log_rounds = A.log_rounds;
     HIP_DYNAMIC_SHARED(double2, sm)
     __shared__ double s_gmax[MAXT / 8];
     __shared__ double s_isig[128];
     __shared__ int s_continue;
     __shared__ int s_perm[128];
     __shared__ int s_keff;
-    // grid = (restart, rank of the order among the active ones): the restart index runs fastest, so the heaviest order
-    // of EVERY restart is dispatched first -- these workgroups are the critical path of the launch
-    const int b = blockIdx.x;
-    const int l = order_list[blockIdx.y];
-    if (!active[l]) return;                                // uniform per block
+    const int l = A.order_list[oy];
+    if (!active[l]) {                                      // uniform per block
+        if (CONC && threadIdx.x == 0)                       // (consumers of an inactive order return at once as well)
+            __hip_atomic_store(log_rounds + mat, (int)(jl_tag(A.epoch) << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
     const int k = kl[l], n = 2 * l + 1;
     const int nr = (n + TG - 1) / TG, kr = (k + TG - 1) / TG;   // rows per lane
     // column strides: odd; padded to whole lane-groups of rows when LDS allows (pad), else row predicates
@@ -527,7 +581,6 @@ __global__ void __launch_bounds__(MAXT) k_polar_jacobi_lds(const double2* __rest
         Vs[e] = v;
     }
     // LOGV: rotations of this matrix go to its slice of the log, lr = slots (rounds) written so far
-    const size_t mat = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
     JlRec* log = LOGV ? log_all + mat * (size_t)log_cap * sched_ps : nullptr;
     int lr = 0;
     __syncthreads();
@@ -592,17 +645,29 @@ __global__ void __launch_bounds__(MAXT) k_polar_jacobi_lds(const double2* __rest
                 int nrd = sched_rounds[ke];
                 if (LOGV && lr + nrd > log_cap) nrd = 0;       // log full (never with JAC_MAX_SWEEPS sweeps sized in)
                 JlRec* lg = LOGV ? log + (size_t)lr * sched_ps : nullptr;
-#define JL_SWEEP(NR) jl_sweep_resident<NR, TG, !LOGV>(Xs, Vs, ns, ks, t, group, tab, nrd, sched_ps, s_perm, xl_ok, vl_ok, tabs2, S, big, lg)
-                switch (nr) {
-                case 1: JL_SWEEP(1); break;
-                case 2: JL_SWEEP(2); break;
-                case 3: JL_SWEEP(3); break;
-                case 4: JL_SWEEP(4); break;
-                case 5: JL_SWEEP(5); break;
-                case 6: JL_SWEEP((RMAX >= 7 ? 6 : 1)); break;
-                default: JL_SWEEP((RMAX >= 7 ? 7 : 1)); break;
+#define JL_SWEEP_T(NR, TAB) jl_sweep_resident<NR, TG, !LOGV, CONC>(Xs, Vs, ns, ks, t, group, TAB, nrd, sched_ps, s_perm, xl_ok, vl_ok, tabs2, S, big, lg, lr * sched_ps, A.epoch)
+#define JL_SWEEP_ALL(TAB)                              \
+                switch (nr) {                              \
+                case 1: JL_SWEEP_T(1, TAB); break;         \
+                case 2: JL_SWEEP_T(2, TAB); break;         \
+                case 3: JL_SWEEP_T(3, TAB); break;         \
+                case 4: JL_SWEEP_T(4, TAB); break;         \
+                case 5: JL_SWEEP_T(5, TAB); break;         \
+                case 6: JL_SWEEP_T((RMAX >= 7 ? 6 : 1), TAB); break;   \
+                default: JL_SWEEP_T((RMAX >= 7 ? 7 : 1), TAB); break;  \
                 }
-#undef JL_SWEEP
+                if (CONC) {
+                    // the pairing table of this sweep in LDS (where V_r would be): a global load per round would make every
+                    // round wait, through the shared vmcnt counter, for the written-through log records of the round before
+                    int* s_tab = reinterpret_cast<int*>(sm + (size_t)k * ns);
+                    for (int e = tid; e < nrd * sched_ps; e += blockDim.x) s_tab[e] = tab[e];
+                    __syncthreads();
+                    JL_SWEEP_ALL(s_tab)
+                } else {
+                    JL_SWEEP_ALL(tab)
+                }
+#undef JL_SWEEP_ALL
+#undef JL_SWEEP_T
                 lr += nrd;
             }
             for (int r = 0; r < ((resident || LOGV) ? 0 : rounds); ++r) {
@@ -684,7 +749,17 @@ __global__ void __launch_bounds__(MAXT) k_polar_jacobi_lds(const double2* __rest
         const int cc = e / k, i = e - cc * k;
         Vr[e] = Vs[(size_t)cc * ks + i];
     }
-    if (LOGV && tid == 0) log_rounds[mat] = lr;
+    if (LOGV && tid == 0) {
+        if (CONC) __hip_atomic_store(log_rounds + mat, (int)((jl_tag(A.epoch) << 16) | (unsigned int)lr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else log_rounds[mat] = lr;
+    }
+}
+
+// grid = (restart, rank of the order among the active ones): the restart index runs fastest, so the heaviest order
+// of EVERY restart is dispatched first -- these workgroups are the critical path of the launch
+template <int MAXR, int TG, int MAXT, bool LOGV>
+__global__ void __launch_bounds__(MAXT) k_polar_jacobi_lds(JacobiArgs A) {
+    polar_jacobi_body<MAXR, TG, MAXT, LOGV, false>(A, (int)blockIdx.x, (int)blockIdx.y, (size_t)blockIdx.y * gridDim.x + blockIdx.x);
 }
 
 // ---- V_r <- V_r R_1 R_2 ... : replay of the rotation log of k_polar_jacobi_lds<.., LOGV = true> ------------------------
@@ -696,74 +771,52 @@ __global__ void __launch_bounds__(MAXT) k_polar_jacobi_lds(const double2* __rest
 #define JR_THREADS 256
 #define JR_RPL 2
 #define JR_CHUNK 16
-template <int G>                                            // lanes per row: 32 (slots per round <= 32) or 64
-__global__ void __launch_bounds__(JR_THREADS) k_jacobi_replay(const JlRec* __restrict__ log_all,
-                                                              const int* __restrict__ log_rounds,
-                                                              double2* __restrict__ Vr_all, const int* __restrict__ kl,
-                                                              const int* __restrict__ active, const int* __restrict__ roff,
-                                                              int rtot, int warm, int ps, int log_cap,
-                                                              const int* __restrict__ order_list) {
+#define JR_POLL_LIMIT 200000        // concurrent mode: polls (~2 us each) without a new round before a consumer gives up
+
+// NT threads; CONC: the log is being written by the Jacobi workgroup of the same launch (k_polar_conc) -- rounds are taken as
+// their records become valid (tag + hash, agent-scope loads), the end is the producer's round count in log_rounds
+template <int G, int NT, bool CONC>                         // G lanes per row: 32 (slots per round <= 32) or 64
+__device__ __forceinline__ void jacobi_replay_body(const JlRec* __restrict__ log_all, int* __restrict__ log_rounds,
+                                                   double2* __restrict__ Vr_all, const int* __restrict__ kl,
+                                                   const int* __restrict__ active, const int* __restrict__ roff, int rtot,
+                                                   int warm, int ps, int log_cap, const int* __restrict__ order_list, int b,
+                                                   int oy, int zrow, size_t mat, int epoch, int* __restrict__ conc_err) {
     constexpr int ROWS_W = (64 / G) * JR_RPL;               // rows of a wave
-    constexpr int ROWS = ROWS_W * (JR_THREADS / 64);        // rows of a workgroup
+    constexpr int ROWS = ROWS_W * (NT / 64);                // rows of a workgroup
     HIP_DYNAMIC_SHARED(double2, sm)
-    const int b = blockIdx.x;
-    const int l = order_list[blockIdx.y];
+    __shared__ int s_total, s_first_bad;
+    const int l = order_list[oy];
     if (!active[l]) return;
     const int k = kl[l];
-    const int row0 = blockIdx.z * ROWS;
+    const int row0 = zrow * ROWS;
     if (row0 >= k) return;
     const int ks = k | 1;                                   // odd row stride
     double2* Vl = sm;                                       // ROWS x ks (row-major: a rotation works inside a row)
     uint4* Ls = reinterpret_cast<uint4*>(sm + (size_t)ROWS * ks);   // 2 x JR_CHUNK x ps records (2 x uint4 each)
-    const size_t mat = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
     const uint4* lsrc = reinterpret_cast<const uint4*>(log_all + mat * (size_t)log_cap * ps);
-    const int total = log_rounds[mat];
     double2* Vr = Vr_all + (size_t)b * rtot + roff[l];      // column-major: Vr[col * k + row]
     const int tid = threadIdx.x;
     const int nrow = min(ROWS, k - row0);
-    for (int e = tid; e < ROWS * k; e += JR_THREADS) {
+    for (int e = tid; e < ROWS * k; e += NT) {
         const int cc = e / ROWS, i = e - cc * ROWS;
         double2 v = make_double2(0.0, 0.0);
         if (i < nrow) v = warm ? Vr[(size_t)cc * k + row0 + i] : make_double2(cc == row0 + i ? 1.0 : 0.0, 0.0);
         Vl[(size_t)i * ks + cc] = v;
     }
     const int per_chunk = JR_CHUNK * ps * 2;                // uint4 per chunk
-    constexpr int NLD = 8;                                  // chunk loads of a thread (per_chunk <= NLD * JR_THREADS)
-    uint4 nxt[NLD];
-    const int n_chunks = (total + JR_CHUNK - 1) / JR_CHUNK;
-    auto fetch = [&](int ch) {
-        const size_t base = (size_t)ch * per_chunk;
-        const size_t lim = (size_t)total * ps * 2;
-#pragma unroll
-        for (int u = 0; u < NLD; ++u) {
-            const int e = tid + u * JR_THREADS;
-            nxt[u] = (e < per_chunk && base + e < lim) ? lsrc[base + e] : make_uint4(0u, 0u, 0u, 0u);
-        }
-    };
-    auto stash = [&](int buf) {
-#pragma unroll
-        for (int u = 0; u < NLD; ++u) {
-            const int e = tid + u * JR_THREADS;
-            if (e < per_chunk) Ls[(size_t)buf * per_chunk + e] = nxt[u];
-        }
-    };
-    if (n_chunks > 0) fetch(0);
+    constexpr int NLD = (2 * JR_CHUNK * 64 + NT - 1) / NT;  // chunk loads of a thread (per_chunk <= NLD * NT, ps <= 64)
     const int lane = tid & 63, wave = tid >> 6;
     const int g = lane % G, rw = lane / G;
     double2* vrow[JR_RPL];
 #pragma unroll
     for (int u = 0; u < JR_RPL; ++u) vrow[u] = Vl + (size_t)(wave * ROWS_W + rw * JR_RPL + u) * ks;
-    for (int ch = 0; ch < n_chunks; ++ch) {
-        stash(ch & 1);
-        __syncthreads();                                     // chunk ch visible; chunk ch - 1 (other buffer) is done with
-        if (ch + 1 < n_chunks) fetch(ch + 1);
-        const int rounds = min(JR_CHUNK, total - ch * JR_CHUNK);
-        const uint4* lc = Ls + (size_t)(ch & 1) * per_chunk;
+    // the rotations of `rounds` rounds staged at lc: a wave owns whole rows, LDS is in order within a wave -> no barrier per round
+    auto apply = [&](const uint4* lc, int rounds) {
         for (int r = 0; r < rounds; ++r) {
             if (g < ps) {
                 const uint4 q0 = lc[(r * ps + g) * 2], q1 = lc[(r * ps + g) * 2 + 1];
-                const int pr = (int)q1.z, pm = (int)q1.w;
-                if (pr >= 0) {
+                const int pr = (int)(q1.z & 0xffu), pm = (int)((q1.z >> 8) & 0xffu);
+                if (pr != (int)JL_NONE) {
                     const double cs = __hiloint2double((int)q0.y, (int)q0.x);
                     const double2 w = make_double2(__hiloint2double((int)q0.w, (int)q0.z), __hiloint2double((int)q1.y, (int)q1.x));
 #pragma unroll
@@ -777,12 +830,113 @@ __global__ void __launch_bounds__(JR_THREADS) k_jacobi_replay(const JlRec* __res
             }
             __builtin_amdgcn_wave_barrier();                 // (scheduling fence only: LDS is in order within a wave)
         }
+    };
+    if (!CONC) {
+        const int total = log_rounds[mat];
+        uint4 nxt[NLD];
+        const int n_chunks = (total + JR_CHUNK - 1) / JR_CHUNK;
+        auto fetch = [&](int ch) {
+            const size_t base = (size_t)ch * per_chunk;
+            const size_t lim = (size_t)total * ps * 2;
+#pragma unroll
+            for (int u = 0; u < NLD; ++u) {
+                const int e = tid + u * NT;
+                nxt[u] = (e < per_chunk && base + e < lim) ? lsrc[base + e] : make_uint4(0u, 0u, 0u, 0u);
+            }
+        };
+        auto stash = [&](int buf) {
+#pragma unroll
+            for (int u = 0; u < NLD; ++u) {
+                const int e = tid + u * NT;
+                if (e < per_chunk) Ls[(size_t)buf * per_chunk + e] = nxt[u];
+            }
+        };
+        if (n_chunks > 0) fetch(0);
+        for (int ch = 0; ch < n_chunks; ++ch) {
+            stash(ch & 1);
+            __syncthreads();                                     // chunk ch visible; chunk ch - 1 (other buffer) is done with
+            if (ch + 1 < n_chunks) fetch(ch + 1);
+            apply(Ls + (size_t)(ch & 1) * per_chunk, min(JR_CHUNK, total - ch * JR_CHUNK));
+        }
+    } else {
+        const unsigned int tag = jl_tag(epoch);
+        int r0 = 0, polls = 0;
+        for (;;) {
+            if (tid == 0) {
+                const int d = __hip_atomic_load(log_rounds + mat, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_total = (((unsigned int)d >> 16) == tag) ? (d & 0xffff) : -1;     // the producer's last word
+                s_first_bad = JR_CHUNK;
+            }
+            __syncthreads();
+            const int total = s_total;
+            if (total >= 0 && r0 >= total) break;
+            const int want = total >= 0 ? min(JR_CHUNK, total - r0) : JR_CHUNK;
+            // records of rounds r0 .. r0 + want - 1, read past the L2; every thread checks the records it loaded the second half of
+            const unsigned long long* src8 = reinterpret_cast<const unsigned long long*>(lsrc + (size_t)r0 * ps * 2);
+#pragma unroll
+            for (int u = 0; u < NLD; ++u) {
+                const int e = tid + u * NT;                      // uint4 piece: record e >> 1, half e & 1
+                if (e < want * ps * 2) {
+                    const unsigned long long a0 = ld_agent(src8 + 2 * (size_t)e), a1 = ld_agent(src8 + 2 * (size_t)e + 1);
+                    Ls[e] = make_uint4((unsigned int)a0, (unsigned int)(a0 >> 32), (unsigned int)a1, (unsigned int)(a1 >> 32));
+                }
+            }
+            __syncthreads();
+            for (int rec = tid; rec < want * ps; rec += NT) {
+                const uint4 q0 = Ls[2 * rec], q1 = Ls[2 * rec + 1];
+                const double cs = __hiloint2double((int)q0.y, (int)q0.x), wx = __hiloint2double((int)q0.w, (int)q0.z);
+                const double wy = __hiloint2double((int)q1.y, (int)q1.x);
+                const bool ok = (q1.z >> 16) == tag && q1.w == jl_hash(cs, wx, wy, q1.z, (unsigned int)(r0 * ps + rec), epoch);
+                if (!ok) atomicMin(&s_first_bad, rec / ps);
+            }
+            __syncthreads();
+            const int nv = min(s_first_bad, want);               // leading rounds whose records have all arrived
+            if (nv == 0) {
+                if (++polls > JR_POLL_LIMIT) {                   // never seen; the host reports it (results are wrong then)
+                    if (tid == 0) atomicAdd(conc_err, 1);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(20);
+            } else {
+                polls = 0;
+                apply(Ls, nv);
+                r0 += nv;
+            }
+            __syncthreads();                                     // Ls, s_total and s_first_bad are rewritten
+        }
     }
     __syncthreads();
-    for (int e = tid; e < ROWS * k; e += JR_THREADS) {
+    for (int e = tid; e < ROWS * k; e += NT) {
         const int cc = e / ROWS, i = e - cc * ROWS;
         if (i < nrow) Vr[(size_t)cc * k + row0 + i] = Vl[(size_t)i * ks + cc];
     }
+}
+
+template <int G>
+__global__ void __launch_bounds__(JR_THREADS) k_jacobi_replay(const JlRec* __restrict__ log_all, int* __restrict__ log_rounds,
+                                                              double2* __restrict__ Vr_all, const int* __restrict__ kl,
+                                                              const int* __restrict__ active, const int* __restrict__ roff,
+                                                              int rtot, int warm, int ps, int log_cap,
+                                                              const int* __restrict__ order_list) {
+    jacobi_replay_body<G, JR_THREADS, false>(log_all, log_rounds, Vr_all, kl, active, roff, rtot, warm, ps, log_cap, order_list,
+                                             (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z,
+                                             (size_t)blockIdx.y * gridDim.x + blockIdx.x, 0, nullptr);
+}
+
+// The polar factor on more than one CU per matrix: grid z = 0 is the Jacobi workgroup of matrix (x, y) -- X_l only, every
+// rotation published to its log -- and z = 1 .. are workgroups that apply the log to their rows of V_r WHILE it is written
+// (on other CUs; rows of V_r transform independently).  The producers have the lowest workgroup ids, so they are all
+// dispatched before any consumer; a consumer only ever waits for its producer, never the other way round, and gives up after
+// JR_POLL_LIMIT polls without progress (conc_err).  Records are validated by tag + hash, so no fence is needed anywhere.
+template <int MAXR, int TG, int MAXT>
+__global__ void __launch_bounds__(MAXT) k_polar_conc(JacobiArgs A) {
+    const int b = (int)blockIdx.x, oy = (int)blockIdx.y;
+    const size_t mat = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+    if (blockIdx.z == 0)
+        polar_jacobi_body<MAXR, TG, MAXT, true, true>(A, b, oy, mat);
+    else
+        jacobi_replay_body<32, MAXT, true>(A.log_all, A.log_rounds, A.Vr_all, A.kl, A.active, A.roff, A.rtot, A.warm, A.sched_ps,
+                                           A.log_cap, A.order_list, b, oy, (int)blockIdx.z - 1, mat, A.epoch, A.conc_err);
 }
 
 // ---- register-tiled complex GEMMs around the polar factor ----------------------------------------------------
@@ -1489,8 +1643,12 @@ int launch_project_coefficients(mtip_ctx* c, const double2* Ilm, double2* out) {
     // Measured at k = 65 (fits either way): X-only Jacobi 497 us + replay 232 us against 572 us with V_r in the same
     // workgroup, so the log is used where X_l and V_r do not fit one CU's LDS together (2l+1 > 71: config 5, 3 x faster
     // than the global-memory fallback there) unless MTIP_JAC_REPLAY=2 forces it.
-    const bool logv = c->jac_replay > 0 && (c->jac_replay > 1 || lds > 158 * 1024) && c->jac_tg == 16 && square && sched_ok &&
-                      nmax <= 7 * 16 && c->jsched_ps <= 48 && lds_x + 16 * sizeof(double2) <= 158 * 1024;
+    // Concurrent replay (k_polar_conc): X-only Jacobi workgroups and, in the same launch, workgroups on other CUs that apply the
+    // rotation log to V_r while it is being written
+    const bool conc = c->jac_conc && c->jac_tg == 16 && square && sched_ok && nmax <= 5 * 16 && c->jsched_ps <= 32 &&
+                      c->jsched_ps * 16 <= JL_MAX_THREADS && lds_x + 16 * sizeof(double2) <= 80 * 1024;
+    const bool logv = conc || (c->jac_replay > 0 && (c->jac_replay > 1 || lds > 158 * 1024) && c->jac_tg == 16 && square && sched_ok &&
+                               nmax <= 7 * 16 && c->jsched_ps <= 48 && lds_x + 16 * sizeof(double2) <= 158 * 1024);
     const bool lds_path = logv || lds <= 158 * 1024;
     // cold start every 64 calls bounds the accumulated rounding drift of the carried V_r
     const int warm = (lds_path && c->vr_valid && (c->proj_calls % 64) != 0) ? 1 : 0;
@@ -1542,20 +1700,33 @@ int launch_project_coefficients(mtip_ctx* c, const double2* Ilm, double2* out) {
                 return MTIP_ENOMEM;
             }
             (void)hipMemset(c->d_jlog_rounds, 0, nmat * sizeof(int));
+            (void)hipMemset(c->d_jlog, 0, nmat * log_cap * c->jsched_ps * sizeof(JlRec));
             c->jlog_cap = log_cap;
             c->jlog_nmat = nmat;
             c->jlog_ps = c->jsched_ps;
         }
-#define JL_LAUNCH(MAXR, TG, MAXT, LOGV)                                                                                  \
-    hipLaunchKernelGGL((k_polar_jacobi_lds<MAXR, TG, MAXT, LOGV>), gj, dim3(threads), lds_use, c->stream, src, c->d_X,  \
-                       c->d_Vr, (const int*)c->d_kl, (const int*)c->d_active, (const int*)c->d_xoff,                    \
-                       (const int*)c->d_uoff, c->xtot, c->utot, c->L, warm, c->polar_abs_tol * c->polar_abs_tol,        \
-                       c->d_sweeps, pad, use_sched ? (const int*)c->d_jsched : (const int*)nullptr,                     \
-                       (const int*)c->d_jsched_off, (const int*)c->d_jsched_rounds, c->jsched_ps,                      \
-                       (const int*)c->d_jorder, (JlRec*)c->d_jlog, c->d_jlog_rounds, log_cap)
+        JacobiArgs ja;
+        ja.Xin_all = src; ja.Pn_all = c->d_X; ja.Vr_all = c->d_Vr;
+        ja.kl = c->d_kl; ja.active = c->d_active; ja.xoff = c->d_xoff; ja.roff = c->d_uoff;
+        ja.xtot = c->xtot; ja.rtot = c->utot; ja.L = c->L; ja.warm = warm;
+        ja.tabs2 = c->polar_abs_tol * c->polar_abs_tol;
+        ja.sweeps_out = c->d_sweeps; ja.pad = pad;
+        ja.sched = use_sched ? (const int*)c->d_jsched : (const int*)nullptr;
+        ja.sched_off = c->d_jsched_off; ja.sched_rounds = c->d_jsched_rounds; ja.sched_ps = c->jsched_ps;
+        ja.order_list = c->d_jorder; ja.log_all = (JlRec*)c->d_jlog; ja.log_rounds = c->d_jlog_rounds;
+        ja.log_cap = log_cap; ja.epoch = (int)(c->proj_calls & 0x3fffffff); ja.conc_err = c->d_conc_err;
+#define JL_LAUNCH(MAXR, TG, MAXT, LOGV) \
+    hipLaunchKernelGGL((k_polar_jacobi_lds<MAXR, TG, MAXT, LOGV>), gj, dim3(threads), lds_use, c->stream, ja)
         {
         ProfScope pp(c, "polar");                                // the polar-factor kernels alone (nested in "proj")
-        if (logv) {
+        if (conc) {
+            // Jacobi workgroups (z = 0) and the workgroups that replay their logs on V_r at the same time (z >= 1), one launch
+            constexpr int rows_wg = 2 * JR_RPL * (JL_MAX_THREADS / 64);
+            const size_t lds_c = ((size_t)rows_wg * (kmax | 1) + (size_t)JR_CHUNK * c->jsched_ps * 2) * sizeof(double2);
+            const dim3 gc(gj.x, gj.y, 1u + (unsigned)div_up(kmax, rows_wg));
+            const size_t lds_p = lds_use + (size_t)(kmax | 1) * c->jsched_ps * sizeof(int);      // X_l + the pairing table of a sweep
+            hipLaunchKernelGGL((k_polar_conc<5, 16, JL_MAX_THREADS>), gc, dim3(JL_MAX_THREADS), std::max(lds_p, lds_c), c->stream, ja);
+        } else if (logv) {
             if (nmax <= 5 * 16 && threads <= JL_MAX_THREADS) JL_LAUNCH(5, 16, JL_MAX_THREADS, true);
             else JL_LAUNCH(7, 16, 768, true);
             const int ps = c->jsched_ps;
@@ -1564,7 +1735,7 @@ int launch_project_coefficients(mtip_ctx* c, const double2* Ilm, double2* out) {
             const dim3 gr(gj.x, gj.y, (unsigned)div_up(kmax, rows_wg));
 #define JR_LAUNCH(G)                                                                                                     \
     hipLaunchKernelGGL((k_jacobi_replay<G>), gr, dim3(JR_THREADS), lds_r, c->stream, (const JlRec*)c->d_jlog,           \
-                       (const int*)c->d_jlog_rounds, c->d_Vr, (const int*)c->d_kl, (const int*)c->d_active,             \
+                       c->d_jlog_rounds, c->d_Vr, (const int*)c->d_kl, (const int*)c->d_active,             \
                        (const int*)c->d_uoff, c->utot, warm, ps, log_cap, (const int*)c->d_jorder)
             if (ps <= 32) JR_LAUNCH(32);
             else JR_LAUNCH(64);

@@ -183,6 +183,8 @@ struct mtip_ctx {
     double2* d_Bref = nullptr;                        // (L+1, Nq, Nq) masked reference B_l
     double* d_Bnorm = nullptr;                        // (L+1)
     double* d_deg2_part = nullptr;                    // (B, L+1, (Nq/16)^2) per-tile partial sums of the B_l metric
+    bool jac_conc = false;                            // env MTIP_JAC_CONC=1: V_r of the polar factor on other CUs, concurrently (k_polar_conc)
+    int* d_conc_err = nullptr;                        // consumers of k_polar_conc that gave up waiting (must stay 0)
     bool proj_fuse = true;                            // env MTIP_PROJ_FUSE=0: four separate projection products instead of the two fused pairs
     bool proj_mfma = true;                            // env MTIP_PROJ_MFMA=0: LDS-tiled VALU GEMMs for the projection products
     bool deg2_simple = false;                         // env MTIP_DEG2_SIMPLE=1: one thread per B_l element instead of MFMA tiles
