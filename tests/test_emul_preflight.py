@@ -100,6 +100,19 @@ def test_short_trajectory_rotation_log(emul_lib, golden_mtip16, fused, monkeypat
     PC.check_short_trajectory_vs_oracle(golden_mtip16, emul_lib, fused)
 
 
+def test_projection_concurrent_replay(emul_lib, monkeypatch):
+    """k_polar_conc: the Jacobi workgroups publish their rotations, other workgroups of the same launch apply them to V_r
+    while they are written (the emulation runs the blocks on real threads, so the publish / validate protocol is live);
+    2l+1 up to 53: two consumer workgroups per matrix"""
+    monkeypatch.setenv('MTIP_JAC_CONC', '1')
+    PC.check_projection_vs_oracle(56, 26, emul_lib, n_batch=2)
+
+
+def test_short_trajectory_concurrent_replay(emul_lib, golden_mtip16, monkeypatch):
+    monkeypatch.setenv('MTIP_JAC_CONC', '1')
+    PC.check_short_trajectory_vs_oracle(golden_mtip16, emul_lib, True)
+
+
 @pytest.mark.parametrize('kind', ['bump', 'low_resolution_autocorrelation'])
 def test_initial_density_batch(emul_lib, golden_mtip16, kind):
     PC.check_initial_density_batch(golden_mtip16, emul_lib, kind)
