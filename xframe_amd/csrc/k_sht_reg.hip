@@ -380,6 +380,7 @@ __global__ void __launch_bounds__(SR_THREADS, 2) k_sht_fwd_pair(const double2* _
 }
 
 // ------------------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------------------
 template <int EPI, int R1, int R2>
 __global__ void __launch_bounds__(SR_THREADS) k_sht_inv_reg(const double2* __restrict__ coeff, double2* __restrict__ grid,
                                                             const double* __restrict__ PT, const int* __restrict__ poff,
