@@ -228,6 +228,15 @@ def main():
 
     from xframe_amd.fxs.engine import streams_side_by_side
     side_by_side = streams_side_by_side(engines)              # < n_eng: two engines share a hardware queue
+    # diagnostic: K more streams of this process that have run one kernel and then sit idle during the timed region (as the
+    # streams of a communication library do): does a hardware queue that is merely there cost the engines anything?
+    idle_streams = []
+    for _ in range(int(os.environ.get('BENCH_IDLE_STREAMS', '0'))):
+        st = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(st):
+            torch.zeros(16, device=dev).add_(1.0)
+        idle_streams.append(st)
+    torch.cuda.synchronize(dev)
 
     # ---- warmup, then exactly K timed steps
     run_schedule(a.warmup)

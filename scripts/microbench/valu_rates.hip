@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
+#include <cmath>
 
 #define REP 64
 template <int MODE>
@@ -97,7 +98,42 @@ static void run(const char* name, int threads, int n_instr_per_iter) {
     hipFree(out); hipFree(cyc);
 }
 
+// precision of the hardware reciprocal-square-root estimate and of one / two Newton steps on it (what fast_rsqrt in k_proj.hip builds on)
+__global__ void k_rsq(const double* x, double* e0, double* e1, double* e2, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double v = x[i];
+    double y = __builtin_amdgcn_rsq(v);
+    const double ref = 1.0 / sqrt(v);
+    e0[i] = fabs(y / ref - 1.0);
+    y = y * (1.5 - 0.5 * v * y * y);
+    e1[i] = fabs(y / ref - 1.0);
+    y = y * (1.5 - 0.5 * v * y * y);
+    e2[i] = fabs(y / ref - 1.0);
+}
+
+static void rsq_precision() {
+    const int n = 1 << 20;
+    std::vector<double> h(n);
+    unsigned long long s = 88172645463325252ull;
+    for (int i = 0; i < n; ++i) {
+        s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+        const double u = (double)(s >> 11) / 9007199254740992.0;
+        h[i] = ldexp(1.0 + u, (int)(s % 61) - 30);
+    }
+    double *x, *e0, *e1, *e2;
+    hipMalloc(&x, n * 8); hipMalloc(&e0, n * 8); hipMalloc(&e1, n * 8); hipMalloc(&e2, n * 8);
+    hipMemcpy(x, h.data(), n * 8, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(k_rsq, dim3(n / 256), dim3(256), 0, 0, x, e0, e1, e2, n);
+    std::vector<double> r0(n), r1(n), r2(n);
+    hipMemcpy(r0.data(), e0, n * 8, hipMemcpyDeviceToHost); hipMemcpy(r1.data(), e1, n * 8, hipMemcpyDeviceToHost); hipMemcpy(r2.data(), e2, n * 8, hipMemcpyDeviceToHost);
+    double m0 = 0, m1 = 0, m2 = 0;
+    for (int i = 0; i < n; ++i) { m0 = fmax(m0, r0[i]); m1 = fmax(m1, r1[i]); m2 = fmax(m2, r2[i]); }
+    printf("v_rsq_f64 max relative error: estimate %.3e, after one Newton step %.3e, after two %.3e\n", m0, m1, m2);
+}
+
 int main() {
+    rsq_precision();
     for (int t : {256, 512}) {
         if (t == 256) { run<0>("v_fma_f64 (VGPR)", 256, 64); run<1>("2 v_readlane + v_fma_f64", 256, 64); run<2>("v_readlane_b32", 256, 64);
                         run<3>("ds_bpermute x2 + v_add_f64", 256, 64); run<4>("v_fma_f32", 256, 64); }
