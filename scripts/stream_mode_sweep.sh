@@ -1,3 +1,5 @@
 #!/bin/bash
 set -e
-timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -4 | tee gpurun_out/r2_smoke.txt
+timeout -k 10 400 python scripts/bench_worker.py 8 3 2>&1 | tail -5 | tee gpurun_out/r2_worker_end_to_end.txt
+timeout -k 10 900 python -m pytest tests -m gpu -x -q > gpurun_out/r2_final_gpu_tests.log 2>&1 || { tail -30 gpurun_out/r2_final_gpu_tests.log; exit 1; }
+tail -2 gpurun_out/r2_final_gpu_tests.log

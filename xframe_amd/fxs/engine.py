@@ -68,7 +68,7 @@ class Engine:
     def _setup_projections(self, data):
         opt = self.opt
         ropt = opt['projections']['reciprocal']
-        rs_ = hs.ReciprocalSetup(self.qs, data, self.L, ropt)
+        rs_ = hs.reciprocal_setup(self.qs, data, self.L, ropt)      # (shared by the engines of one worker: read only)
         self.rsetup = rs_
         used_ids = set(rs_.used_orders.values())
         for l in range(self.L + 1):

@@ -432,3 +432,27 @@ def wigner_D_flat(L, euler):
         m = np.arange(-l, l + 1)
         out[off[l]:off[l + 1]] = (np.exp(-1j * m * a)[:, None] * wigner_d(l, [b])[0] * np.exp(-1j * m * g)[None, :]).reshape(-1)
     return out
+
+
+_RSETUP_CACHE = {}
+_RSETUP_LOCK = None
+
+
+def reciprocal_setup(qs, data, l_max, ropt):
+    """ReciprocalSetup(qs, data, l_max, ropt), built once per (invariants object, grid, options): the engines of one worker
+    (GPU.n_gpu_workers restart groups) share the same invariants, and the per-column cubic regridding of the projection matrices
+    (the same scipy call the reference makes, 1089 columns at L = 32) is ~0.3 s of pure Python per engine otherwise.  The result is
+    read only.  The cache holds the last few setups and keeps `data` alive with them, so ids cannot be recycled under it."""
+    global _RSETUP_LOCK
+    import threading
+    if _RSETUP_LOCK is None:
+        _RSETUP_LOCK = threading.Lock()
+    key = (id(data), int(l_max), np.asarray(qs, dtype=float).tobytes(), repr(ropt))
+    with _RSETUP_LOCK:                                   # engines are created from worker threads: build once, the others wait
+        hit = _RSETUP_CACHE.get(key)
+        if hit is None:
+            hit = (ReciprocalSetup(qs, data, l_max, ropt), data)
+            while len(_RSETUP_CACHE) >= 4:
+                _RSETUP_CACHE.pop(next(iter(_RSETUP_CACHE)))
+            _RSETUP_CACHE[key] = hit
+    return hit[0]

@@ -17,6 +17,11 @@ def shard_restarts(n_total, rank, world_size):
 
 
 def _dist():
+    """torch.distributed when this process is part of an initialised process group, else None.  A process that has not imported
+    torch cannot be in one -- and importing it just to ask costs ~0.9 s, more than the whole tutorial schedule on the device."""
+    import sys
+    if 'torch' not in sys.modules:
+        return None
     try:
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized():
@@ -59,8 +64,10 @@ def gather_results(local_results, local_ids, n_total, rank, world_size, n_full=8
        staging buffers; gloo on CPU in the tests).
     Rank 0 returns an object array of all restarts -- full dicts for its own and for the selected ones, light dicts (flagged
     ``'gathered': 'light'``) for the rest; other ranks return their own results unchanged."""
+    if world_size == 1:
+        return local_results
     dist = _dist()
-    if world_size == 1 or dist is None:
+    if dist is None:
         return local_results
     import torch
     n_max = -(-n_total // world_size)

@@ -73,8 +73,10 @@ class MTIP:
 
     # ------------------------------------------------------------------ assembly (reference 1269-1278)
     def generate_phasing_loop(self):
+        t_engine = time.perf_counter()
         self.engine = Engine(self.opt, MTIP.mtip_data, n_batch=self.n_restarts, device=self.device, fused=self.fused,
                              lib_path=self.lib_path)
+        self._engine_seconds = time.perf_counter() - t_engine
         self.rprojection = self.engine.rsetup
         self.process_factory.addOperators(build_operators(self.engine))
         self.phasing_loop = self._main_loop
@@ -250,9 +252,13 @@ class MTIP:
             iterations.append(iteration)
         e.synchronize()
         t1 = time.perf_counter()
-        self.timing = {'loop_seconds': t1 - t0, 'setup_seconds': t0 - t_setup, 'steps_per_restart': n_steps,
+        out = self._generate_output(iterations, initial_density, initial_mask, n_steps)
+        # where a run spends its time: engine (host setup of weights / projection matrices + uploads), initial densities and
+        # state, the loop itself (device resident), the result dicts (grids back over PCIe, centring, output transforms)
+        self.timing = {'engine_seconds': getattr(self, '_engine_seconds', float('nan')), 'setup_seconds': t0 - t_setup,
+                       'loop_seconds': t1 - t0, 'output_seconds': time.perf_counter() - t1, 'steps_per_restart': n_steps,
                        'iterations_per_second': n_steps * B / (t1 - t0) if t1 > t0 else float('nan')}
-        return self._generate_output(iterations, initial_density, initial_mask, n_steps)
+        return out
 
     # ------------------------------------------------------------------ output dict (980-1022)
     def _generate_output(self, iterations, initial_density, initial_mask, n_steps):
@@ -374,6 +380,7 @@ class ProjectWorker:
                     result[i] = res[j]
             self.mtip_instance = outs[0][0]
             self.mtip_instances = [m for m, _ in outs]
+            self.results['stats']['groups'] = [dict(m.timing, restarts=len(g)) for (m, _), g in zip(outs, groups)]
         result = gather_results(result, mine, total, self.rank, self.world_size, n_full=self.n_gather_full,
                                 device=self._torch_device())
         self.results['MTIP'] = result
