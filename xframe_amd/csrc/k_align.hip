@@ -122,11 +122,11 @@ int mtip_set_so3_tables(mtip_ctx* c, int bw, const double* d_table) {
     MTIP_HIP_CHECK(c, hipMalloc((void**)&c->d_so3_S, (size_t)c->B * nb * M * M * sizeof(double2)));
     MTIP_HIP_CHECK(c, hipMalloc((void**)&c->d_so3_P, (size_t)c->B * nb * M * nb * sizeof(double2)));
     MTIP_HIP_CHECK(c, hipMalloc((void**)&c->d_so3_C, (size_t)c->B * nb * nb * nb * sizeof(double)));
-    MTIP_HIP_CHECK(c, hipMemcpy(c->d_so3_d, d_table, (size_t)nb * ntab * sizeof(double), hipMemcpyHostToDevice));
+    MTIP_HIP_CHECK(c, mtip_copy(c, c->d_so3_d, d_table, (size_t)nb * ntab * sizeof(double), hipMemcpyHostToDevice));
     std::vector<double2> tw(nb);
     const double pi = 3.14159265358979323846;
     for (int k = 0; k < nb; ++k) tw[k] = make_double2(std::cos(2 * pi * k / nb), -std::sin(2 * pi * k / nb));
-    MTIP_HIP_CHECK(c, hipMemcpy(c->d_so3_tw, tw.data(), nb * sizeof(double2), hipMemcpyHostToDevice));
+    MTIP_HIP_CHECK(c, mtip_copy(c, c->d_so3_tw, tw.data(), nb * sizeof(double2), hipMemcpyHostToDevice));
     c->so3_bw = bw;
     return MTIP_OK;
 }
@@ -144,8 +144,8 @@ int mtip_op_so3_correlation(mtip_ctx* c, const mtip_cdouble* ref, const mtip_cdo
     (void)hipSetDevice(c->device);
     const int nb = 2 * c->so3_bw, ntab = so3_ntab(c->L);
     MTIP_HIP_CHECK(c, hipStreamSynchronize(c->stream));
-    MTIP_HIP_CHECK(c, hipMemcpy(c->d_c[0], ref, c->C * sizeof(double2), hipMemcpyHostToDevice));
-    MTIP_HIP_CHECK(c, hipMemcpy(c->d_c[1], sig, (size_t)c->B * c->C * sizeof(double2), hipMemcpyHostToDevice));
+    MTIP_HIP_CHECK(c, mtip_copy(c, c->d_c[0], ref, c->C * sizeof(double2), hipMemcpyHostToDevice));
+    MTIP_HIP_CHECK(c, mtip_copy(c, c->d_c[1], sig, (size_t)c->B * c->C * sizeof(double2), hipMemcpyHostToDevice));
     hipLaunchKernelGGL(k_so3_T, dim3((unsigned)(c->L + 1), (unsigned)c->B), dim3(256), 0, c->stream, (const double2*)c->d_c[0],
                        (const double2*)c->d_c[1], c->d_so3_T, c->N, c->nlm, ntab, r_lo, r_hi);
     hipLaunchKernelGGL(k_so3_S, dim3((unsigned)nb, (unsigned)c->B), dim3(256), 0, c->stream, (const double2*)c->d_so3_T,
@@ -155,7 +155,7 @@ int mtip_op_so3_correlation(mtip_ctx* c, const mtip_cdouble* ref, const mtip_cdo
     hipLaunchKernelGGL(k_so3_C, dim3((unsigned)nb, (unsigned)c->B), dim3(256), 0, c->stream, (const double2*)c->d_so3_P,
                        (const double2*)c->d_so3_tw, c->d_so3_C, c->L);
     MTIP_HIP_CHECK(c, hipStreamSynchronize(c->stream));
-    MTIP_HIP_CHECK(c, hipMemcpy(C, c->d_so3_C, (size_t)c->B * nb * nb * nb * sizeof(double), hipMemcpyDeviceToHost));
+    MTIP_HIP_CHECK(c, mtip_copy(c, C, c->d_so3_C, (size_t)c->B * nb * nb * nb * sizeof(double), hipMemcpyDeviceToHost));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         c->err = std::string("mtip_op_so3_correlation: ") + hipGetErrorString(e);
@@ -177,12 +177,12 @@ int mtip_op_rotate_coefficients(mtip_ctx* c, const mtip_cdouble* coeff, const mt
     (void)hipSetDevice(c->device);
     const int ntab = so3_ntab(c->L);
     MTIP_HIP_CHECK(c, hipStreamSynchronize(c->stream));
-    MTIP_HIP_CHECK(c, hipMemcpy(c->d_c[0], coeff, (size_t)c->B * c->C * sizeof(double2), hipMemcpyHostToDevice));
-    MTIP_HIP_CHECK(c, hipMemcpy(c->d_so3_D, D, (size_t)c->B * ntab * sizeof(double2), hipMemcpyHostToDevice));
+    MTIP_HIP_CHECK(c, mtip_copy(c, c->d_c[0], coeff, (size_t)c->B * c->C * sizeof(double2), hipMemcpyHostToDevice));
+    MTIP_HIP_CHECK(c, mtip_copy(c, c->d_so3_D, D, (size_t)c->B * ntab * sizeof(double2), hipMemcpyHostToDevice));
     hipLaunchKernelGGL(k_rotate_coeff, dim3((unsigned)c->N, (unsigned)c->B), dim3(256), 0, c->stream, (const double2*)c->d_c[0],
                        (const double2*)c->d_so3_D, c->d_c[1], c->N, c->L, c->nlm, ntab);
     MTIP_HIP_CHECK(c, hipStreamSynchronize(c->stream));
-    MTIP_HIP_CHECK(c, hipMemcpy(out, c->d_c[1], (size_t)c->B * c->C * sizeof(double2), hipMemcpyDeviceToHost));
+    MTIP_HIP_CHECK(c, mtip_copy(c, out, c->d_c[1], (size_t)c->B * c->C * sizeof(double2), hipMemcpyDeviceToHost));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         c->err = std::string("mtip_op_rotate_coefficients: ") + hipGetErrorString(e);

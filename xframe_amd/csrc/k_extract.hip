@@ -134,15 +134,15 @@ __global__ void __launch_bounds__(512) k_herm_eig(double2* __restrict__ Wall, do
 static hipError_t herm_eig_pass(mtip_ctx* c, int n, int n_mat, const mtip_cdouble* A, const double* shift_host, double2* dW, double2* dV,
                                 double* dl, double* dshift, double* dres, double* eigvals, mtip_cdouble* eigvecs, double* resid) {
     const size_t nn = (size_t)n_mat * n * n;
-    hipError_t e = hipMemcpy(dW, A, nn * sizeof(double2), hipMemcpyHostToDevice);
-    if (e == hipSuccess && shift_host) e = hipMemcpy(dshift, shift_host, (size_t)n_mat * sizeof(double), hipMemcpyHostToDevice);
+    hipError_t e = mtip_copy(c, dW, A, nn * sizeof(double2), hipMemcpyHostToDevice);
+    if (e == hipSuccess && shift_host) e = mtip_copy(c, dshift, shift_host, (size_t)n_mat * sizeof(double), hipMemcpyHostToDevice);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_herm_eig, dim3((unsigned)n_mat), dim3(512), 0, c->stream, dW, dV, dl, n, shift_host ? dshift : (const double*)nullptr,
                        dres);
     e = hipStreamSynchronize(c->stream);
-    if (e == hipSuccess) e = hipMemcpy(eigvals, dl, (size_t)n_mat * n * sizeof(double), hipMemcpyDeviceToHost);
-    if (e == hipSuccess) e = hipMemcpy(eigvecs, dV, nn * sizeof(double2), hipMemcpyDeviceToHost);
-    if (e == hipSuccess) e = hipMemcpy(resid, dres, (size_t)n_mat * sizeof(double), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = mtip_copy(c, eigvals, dl, (size_t)n_mat * n * sizeof(double), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = mtip_copy(c, eigvecs, dV, nn * sizeof(double2), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = mtip_copy(c, resid, dres, (size_t)n_mat * sizeof(double), hipMemcpyDeviceToHost);
     return e;
 }
 

@@ -361,7 +361,7 @@ int build_hankel_tiles(mtip_ctx* c) {
     }
     c->n_htiles = (int)t.size();
     if (hipMalloc((void**)&c->d_htiles, t.size() * sizeof(HankelTile)) != hipSuccess) return MTIP_ENOMEM;
-    (void)hipMemcpy(c->d_htiles, t.data(), t.size() * sizeof(HankelTile), hipMemcpyHostToDevice);
+    (void)mtip_copy(c, c->d_htiles, t.data(), t.size() * sizeof(HankelTile), hipMemcpyHostToDevice);
     // widest workgroup tile that still gives (about) one workgroup per CU: W_l is re-read once per tile
     std::vector<HankelTile32> t32;
     const int cts[4] = {5, 3, 2, 1};
@@ -405,6 +405,6 @@ int build_hankel_tiles(mtip_ctx* c) {
     }
     c->n_htiles32 = (int)t32.size();
     if (hipMalloc((void**)&c->d_htiles32, t32.size() * sizeof(HankelTile32)) != hipSuccess) return MTIP_ENOMEM;
-    (void)hipMemcpy(c->d_htiles32, t32.data(), t32.size() * sizeof(HankelTile32), hipMemcpyHostToDevice);
+    (void)mtip_copy(c, c->d_htiles32, t32.data(), t32.size() * sizeof(HankelTile32), hipMemcpyHostToDevice);
     return MTIP_OK;
 }

@@ -387,7 +387,7 @@ int launch_polar_newton(mtip_ctx* c) {
             c->err = "polar factor order list: out of device memory";
             return MTIP_ENOMEM;
         }
-        (void)hipMemcpy(c->d_jorder, ord.data(), ord.size() * sizeof(int), hipMemcpyHostToDevice);
+        (void)mtip_copy(c, c->d_jorder, ord.data(), ord.size() * sizeof(int), hipMemcpyHostToDevice);
     }
     const size_t lds = PN_FIXED + 2 * (size_t)nmax * nmax * sizeof(double2);      // records / staging + the iterate Z
     hipLaunchKernelGGL(k_polar_newton, dim3((unsigned)c->B, (unsigned)std::max(c->n_jorder, 1)), dim3(PN_THREADS), lds, c->stream,

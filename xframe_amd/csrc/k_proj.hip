@@ -1451,7 +1451,7 @@ static int build_proj_tiles(mtip_ctx* c) {
         if (t.empty()) t.push_back(0);
         c->n_pg_tiles[op] = (int)t.size();
         if (hipMalloc((void**)&c->d_pg_tiles[op], t.size() * sizeof(int)) != hipSuccess) return MTIP_ENOMEM;
-        (void)hipMemcpy(c->d_pg_tiles[op], t.data(), t.size() * sizeof(int), hipMemcpyHostToDevice);
+        (void)mtip_copy(c, c->d_pg_tiles[op], t.data(), t.size() * sizeof(int), hipMemcpyHostToDevice);
     }
     // the fused pairs: 4 = k_proj_xw (order | row tile << 8, active orders), 5 = k_proj_ua (order | column tile << 8, used orders)
     for (int op = 4; op < 6; ++op) {
@@ -1463,7 +1463,7 @@ static int build_proj_tiles(mtip_ctx* c) {
         c->n_pg_tiles[op] = (int)t.size();
         if (t.empty()) t.push_back(0);
         if (hipMalloc((void**)&c->d_pg_tiles[op], t.size() * sizeof(int)) != hipSuccess) return MTIP_ENOMEM;
-        (void)hipMemcpy(c->d_pg_tiles[op], t.data(), t.size() * sizeof(int), hipMemcpyHostToDevice);
+        (void)mtip_copy(c, c->d_pg_tiles[op], t.data(), t.size() * sizeof(int), hipMemcpyHostToDevice);
     }
     return MTIP_OK;
 }
@@ -1563,9 +1563,9 @@ int build_jacobi_schedule(mtip_ctx* c, int kmax) {
     if (hipMalloc((void**)&c->d_jsched, all.size() * sizeof(int)) != hipSuccess) return MTIP_ENOMEM;
     if (hipMalloc((void**)&c->d_jsched_off, off.size() * sizeof(int)) != hipSuccess) return MTIP_ENOMEM;
     if (hipMalloc((void**)&c->d_jsched_rounds, nrd.size() * sizeof(int)) != hipSuccess) return MTIP_ENOMEM;
-    (void)hipMemcpy(c->d_jsched, all.data(), all.size() * sizeof(int), hipMemcpyHostToDevice);
-    (void)hipMemcpy(c->d_jsched_off, off.data(), off.size() * sizeof(int), hipMemcpyHostToDevice);
-    (void)hipMemcpy(c->d_jsched_rounds, nrd.data(), nrd.size() * sizeof(int), hipMemcpyHostToDevice);
+    (void)mtip_copy(c, c->d_jsched, all.data(), all.size() * sizeof(int), hipMemcpyHostToDevice);
+    (void)mtip_copy(c, c->d_jsched_off, off.data(), off.size() * sizeof(int), hipMemcpyHostToDevice);
+    (void)mtip_copy(c, c->d_jsched_rounds, nrd.data(), nrd.size() * sizeof(int), hipMemcpyHostToDevice);
     c->jsched_kmax = kmax;
     c->jsched_ps = ps;
     return MTIP_OK;
@@ -1685,7 +1685,7 @@ int launch_project_coefficients(mtip_ctx* c, const double2* Ilm, double2* out) {
                 c->err = "polar factor order list: out of device memory";
                 return MTIP_ENOMEM;
             }
-            (void)hipMemcpy(c->d_jorder, ord.data(), ord.size() * sizeof(int), hipMemcpyHostToDevice);
+            (void)mtip_copy(c, c->d_jorder, ord.data(), ord.size() * sizeof(int), hipMemcpyHostToDevice);
         }
         const dim3 gj((unsigned)c->B, (unsigned)std::max(c->n_jorder, 1));
         const int log_cap = JAC_MAX_SWEEPS * (kmax | 1);        // rounds: at most k (odd k) or k - 1 per sweep
@@ -1699,8 +1699,8 @@ int launch_project_coefficients(mtip_ctx* c, const double2* Ilm, double2* out) {
                 c->err = "rotation log: out of device memory";
                 return MTIP_ENOMEM;
             }
-            (void)hipMemset(c->d_jlog_rounds, 0, nmat * sizeof(int));
-            (void)hipMemset(c->d_jlog, 0, nmat * log_cap * c->jsched_ps * sizeof(JlRec));
+            (void)hipMemsetAsync(c->d_jlog_rounds, 0, nmat * sizeof(int), c->stream);
+            (void)hipMemsetAsync(c->d_jlog, 0, nmat * log_cap * c->jsched_ps * sizeof(JlRec), c->stream);
             c->jlog_cap = log_cap;
             c->jlog_nmat = nmat;
             c->jlog_ps = c->jsched_ps;

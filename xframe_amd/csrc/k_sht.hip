@@ -40,9 +40,9 @@ void build_legendre_tables(mtip_ctx* c, const double* cos_theta) {
             }
         }
     }
-    (void)hipMemcpy(c->d_P, P.data(), P.size() * sizeof(double), hipMemcpyHostToDevice);
-    (void)hipMemcpy(c->d_poff, poff.data(), poff.size() * sizeof(int), hipMemcpyHostToDevice);
-    if (c->d_AB != nullptr) (void)hipMemcpy(c->d_AB, AB.data(), AB.size() * sizeof(double2), hipMemcpyHostToDevice);
+    (void)mtip_copy(c, c->d_P, P.data(), P.size() * sizeof(double), hipMemcpyHostToDevice);
+    (void)mtip_copy(c, c->d_poff, poff.data(), poff.size() * sizeof(int), hipMemcpyHostToDevice);
+    if (c->d_AB != nullptr) (void)mtip_copy(c, c->d_AB, AB.data(), AB.size() * sizeof(double2), hipMemcpyHostToDevice);
     // theta-major copy of the northern half + (l,m) lookup for the fused kernels (k_sht_fused.hip)
     if (c->d_PT != nullptr) {
         const int nth = nt / 2;
@@ -54,8 +54,8 @@ void build_legendre_tables(mtip_ctx* c, const double* cos_theta) {
                 lmtab[idx] = l | (m << 8);
                 for (int t = 0; t < nth; ++t) PT[(size_t)t * rows + idx] = P[idx * nt + t];
             }
-        (void)hipMemcpy(c->d_PT, PT.data(), PT.size() * sizeof(double), hipMemcpyHostToDevice);
-        (void)hipMemcpy(c->d_lmtab, lmtab.data(), lmtab.size() * sizeof(int), hipMemcpyHostToDevice);
+        (void)mtip_copy(c, c->d_PT, PT.data(), PT.size() * sizeof(double), hipMemcpyHostToDevice);
+        (void)mtip_copy(c, c->d_lmtab, lmtab.data(), lmtab.size() * sizeof(int), hipMemcpyHostToDevice);
     }
     // twiddles exp(-2 pi i j / n_phi), j < n_phi/2
     std::vector<double2> tw(c->np / 2);
@@ -63,14 +63,14 @@ void build_legendre_tables(mtip_ctx* c, const double* cos_theta) {
         const double a = -2.0 * pi * j / c->np;
         tw[j] = make_double2(std::cos(a), std::sin(a));
     }
-    (void)hipMemcpy(c->d_tw, tw.data(), tw.size() * sizeof(double2), hipMemcpyHostToDevice);
+    (void)mtip_copy(c, c->d_tw, tw.data(), tw.size() * sizeof(double2), hipMemcpyHostToDevice);
     if (c->d_twN != nullptr) {                       // full-circle table for the register FFT kernels
         std::vector<double2> twn(c->np);
         for (int j = 0; j < c->np; ++j) {
             const double a = -2.0 * pi * j / c->np;
             twn[j] = make_double2(std::cos(a), std::sin(a));
         }
-        (void)hipMemcpy(c->d_twN, twn.data(), twn.size() * sizeof(double2), hipMemcpyHostToDevice);
+        (void)mtip_copy(c, c->d_twN, twn.data(), twn.size() * sizeof(double2), hipMemcpyHostToDevice);
     }
 }
 

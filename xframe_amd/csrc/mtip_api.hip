@@ -109,7 +109,8 @@ mtip_ctx* mtip_create(const mtip_cfg* cfg, int device) {
     const int L = c->L, N = c->N, B = c->B;
     int rc = MTIP_OK;
     auto A = [&](int r) { if (rc == MTIP_OK) rc = r; };
-    if (hipStreamCreate(&c->stream) != hipSuccess) A(MTIP_EHIP);
+    // not synchronised with the null stream (see mtip_copy in mtip_internal.h)
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) A(MTIP_EHIP);
     {
         int ncu = 0;
         if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0) c->n_cu = ncu;
@@ -210,21 +211,21 @@ mtip_ctx* mtip_create(const mtip_cfg* cfg, int device) {
         mtip_destroy(c);
         return nullptr;
     }
-    (void)hipMemcpy(c->d_kl, c->kl.data(), (L + 1) * sizeof(int), hipMemcpyHostToDevice);
-    (void)hipMemcpy(c->d_voff, c->voff.data(), (L + 2) * sizeof(int), hipMemcpyHostToDevice);
-    (void)hipMemcpy(c->d_xoff, c->xoff.data(), (L + 2) * sizeof(int), hipMemcpyHostToDevice);
-    (void)hipMemcpy(c->d_uoff, c->uoff.data(), (L + 2) * sizeof(int), hipMemcpyHostToDevice);
-    (void)hipMemset(c->d_used, 0, (L + 1) * sizeof(int));
-    (void)hipMemset(c->d_active, 0, (L + 1) * sizeof(int));
-    (void)hipMemset(c->d_sweeps, 0, (size_t)B * (L + 1) * sizeof(int));
-    if (c->d_conc_err) (void)hipMemset(c->d_conc_err, 0, sizeof(int));
-    (void)hipMemset(c->d_U, 0, (size_t)B * c->xtot * sizeof(double2));
-    (void)hipMemset(c->d_X, 0, (size_t)B * c->xtot * sizeof(double2));
-    (void)hipMemset(c->d_Vr, 0, (size_t)B * c->utot * sizeof(double2));
-    (void)hipMemset(c->d_V, 0, (size_t)c->vtot * sizeof(double2));
-    (void)hipMemset(c->d_rmask, 0, (size_t)(L + 1) * N);
-    (void)hipMemset(c->d_sup, 1, (size_t)3 * B * c->G);
-    (void)hipMemset(c->d_S0, 1, c->G);
+    (void)mtip_copy(c, c->d_kl, c->kl.data(), (L + 1) * sizeof(int), hipMemcpyHostToDevice);
+    (void)mtip_copy(c, c->d_voff, c->voff.data(), (L + 2) * sizeof(int), hipMemcpyHostToDevice);
+    (void)mtip_copy(c, c->d_xoff, c->xoff.data(), (L + 2) * sizeof(int), hipMemcpyHostToDevice);
+    (void)mtip_copy(c, c->d_uoff, c->uoff.data(), (L + 2) * sizeof(int), hipMemcpyHostToDevice);
+    (void)hipMemsetAsync(c->d_used, 0, (L + 1) * sizeof(int), c->stream);
+    (void)hipMemsetAsync(c->d_active, 0, (L + 1) * sizeof(int), c->stream);
+    (void)hipMemsetAsync(c->d_sweeps, 0, (size_t)B * (L + 1) * sizeof(int), c->stream);
+    if (c->d_conc_err) (void)hipMemsetAsync(c->d_conc_err, 0, sizeof(int), c->stream);
+    (void)hipMemsetAsync(c->d_U, 0, (size_t)B * c->xtot * sizeof(double2), c->stream);
+    (void)hipMemsetAsync(c->d_X, 0, (size_t)B * c->xtot * sizeof(double2), c->stream);
+    (void)hipMemsetAsync(c->d_Vr, 0, (size_t)B * c->utot * sizeof(double2), c->stream);
+    (void)hipMemsetAsync(c->d_V, 0, (size_t)c->vtot * sizeof(double2), c->stream);
+    (void)hipMemsetAsync(c->d_rmask, 0, (size_t)(L + 1) * N, c->stream);
+    (void)hipMemsetAsync(c->d_sup, 1, (size_t)3 * B * c->G, c->stream);
+    (void)hipMemsetAsync(c->d_S0, 1, c->G, c->stream);
     // default slots
     std::vector<int> slots((size_t)B * SL_N, 0);
     for (int b = 0; b < B; ++b) {
@@ -234,10 +235,10 @@ mtip_ctx* mtip_create(const mtip_cfg* cfg, int device) {
         slots[b * SL_N + SL_HIST] = 0;
         slots[b * SL_N + SL_ENFORCE] = 1;
     }
-    (void)hipMemcpy(c->d_slot, slots.data(), slots.size() * sizeof(int), hipMemcpyHostToDevice);
+    (void)mtip_copy(c, c->d_slot, slots.data(), slots.size() * sizeof(int), hipMemcpyHostToDevice);
     std::vector<double> inf(B, HUGE_VAL);
-    (void)hipMemcpy(c->d_best_err, inf.data(), B * sizeof(double), hipMemcpyHostToDevice);
-    (void)hipMemcpy(c->d_last_err, inf.data(), B * sizeof(double), hipMemcpyHostToDevice);
+    (void)mtip_copy(c, c->d_best_err, inf.data(), B * sizeof(double), hipMemcpyHostToDevice);
+    (void)mtip_copy(c, c->d_last_err, inf.data(), B * sizeof(double), hipMemcpyHostToDevice);
     return c;
 }
 
@@ -259,8 +260,8 @@ int mtip_set_angular_grid(mtip_ctx* c, const double* cos_theta, const double* ga
     CTX_CHECK(c);
     if (!cos_theta || !gauss_weights) FAIL(c, MTIP_EINVAL, "null angular grid");
     (void)hipSetDevice(c->device);
-    MTIP_HIP_CHECK(c, hipMemcpy(c->d_cost, cos_theta, c->nt * sizeof(double), hipMemcpyHostToDevice));
-    MTIP_HIP_CHECK(c, hipMemcpy(c->d_gw, gauss_weights, c->nt * sizeof(double), hipMemcpyHostToDevice));
+    MTIP_HIP_CHECK(c, mtip_copy(c, c->d_cost, cos_theta, c->nt * sizeof(double), hipMemcpyHostToDevice));
+    MTIP_HIP_CHECK(c, mtip_copy(c, c->d_gw, gauss_weights, c->nt * sizeof(double), hipMemcpyHostToDevice));
     build_legendre_tables(c, cos_theta);
     c->have_angular = true;
     return MTIP_OK;
@@ -270,8 +271,8 @@ int mtip_set_radial_grid(mtip_ctx* c, const double* r, const double* q) {
     CTX_CHECK(c);
     if (!r || !q) FAIL(c, MTIP_EINVAL, "null radial grid");
     (void)hipSetDevice(c->device);
-    MTIP_HIP_CHECK(c, hipMemcpy(c->d_r, r, c->N * sizeof(double), hipMemcpyHostToDevice));
-    MTIP_HIP_CHECK(c, hipMemcpy(c->d_q, q, c->N * sizeof(double), hipMemcpyHostToDevice));
+    MTIP_HIP_CHECK(c, mtip_copy(c, c->d_r, r, c->N * sizeof(double), hipMemcpyHostToDevice));
+    MTIP_HIP_CHECK(c, mtip_copy(c, c->d_q, q, c->N * sizeof(double), hipMemcpyHostToDevice));
     c->have_radial = true;
     return MTIP_OK;
 }
@@ -280,7 +281,7 @@ int mtip_set_hankel_weights(mtip_ctx* c, const double* w_raw, double fwd_scale, 
     CTX_CHECK(c);
     if (!w_raw) FAIL(c, MTIP_EINVAL, "null weights");
     (void)hipSetDevice(c->device);
-    MTIP_HIP_CHECK(c, hipMemcpy(c->d_W, w_raw, (size_t)(c->L + 1) * c->Np * c->N * sizeof(double), hipMemcpyHostToDevice));
+    MTIP_HIP_CHECK(c, mtip_copy(c, c->d_W, w_raw, (size_t)(c->L + 1) * c->Np * c->N * sizeof(double), hipMemcpyHostToDevice));
     c->fwd_scale = fwd_scale;
     c->inv_scale = inv_scale;
     c->have_weights = true;
@@ -312,16 +313,16 @@ int mtip_set_projection_matrix(mtip_ctx* c, int l, const mtip_cdouble* V, int k_
     if (V)
         for (int q = 0; q < c->N; ++q)
             for (int i = 0; i < k_l; ++i) tmp[(size_t)q * kmax + i] = make_double2(V[(size_t)q * k_l + i].re, V[(size_t)q * k_l + i].im);
-    MTIP_HIP_CHECK(c, hipMemcpy(c->d_V + c->voff[l], tmp.data(), tmp.size() * sizeof(double2), hipMemcpyHostToDevice));
-    if (radial_mask) MTIP_HIP_CHECK(c, hipMemcpy(c->d_rmask + (size_t)l * c->N, radial_mask, c->N, hipMemcpyHostToDevice));
+    MTIP_HIP_CHECK(c, mtip_copy(c, c->d_V + c->voff[l], tmp.data(), tmp.size() * sizeof(double2), hipMemcpyHostToDevice));
+    if (radial_mask) MTIP_HIP_CHECK(c, mtip_copy(c, c->d_rmask + (size_t)l * c->N, radial_mask, c->N, hipMemcpyHostToDevice));
     c->used[l] = used ? 1 : 0;
     bool nonzero = false;
     for (const double2& v : tmp) nonzero = nonzero || v.x != 0.0 || v.y != 0.0;
     c->active[l] = (used && nonzero) ? 1 : 0;          // V_l == 0 (odd_orders_to_0): U_l stays 0, nothing to solve
     c->vr_valid = false;
-    MTIP_HIP_CHECK(c, hipMemcpy(c->d_used, c->used.data(), (c->L + 1) * sizeof(int), hipMemcpyHostToDevice));
-    MTIP_HIP_CHECK(c, hipMemcpy(c->d_active, c->active.data(), (c->L + 1) * sizeof(int), hipMemcpyHostToDevice));
-    MTIP_HIP_CHECK(c, hipMemset(c->d_U, 0, (size_t)c->B * c->xtot * sizeof(double2)));
+    MTIP_HIP_CHECK(c, mtip_copy(c, c->d_used, c->used.data(), (c->L + 1) * sizeof(int), hipMemcpyHostToDevice));
+    MTIP_HIP_CHECK(c, mtip_copy(c, c->d_active, c->active.data(), (c->L + 1) * sizeof(int), hipMemcpyHostToDevice));
+    MTIP_HIP_CHECK(c, hipMemsetAsync(c->d_U, 0, (size_t)c->B * c->xtot * sizeof(double2), c->stream));
     c->have_V[l] = 1;
     c->bref_dirty = true;
     return MTIP_OK;
@@ -339,8 +340,8 @@ static int build_bref(mtip_ctx* c) {
     const int N = c->N, L = c->L;
     std::vector<double2> V((size_t)c->vtot);
     std::vector<uint8_t> rm((size_t)(L + 1) * N);
-    MTIP_HIP_CHECK(c, hipMemcpy(V.data(), c->d_V, V.size() * sizeof(double2), hipMemcpyDeviceToHost));
-    MTIP_HIP_CHECK(c, hipMemcpy(rm.data(), c->d_rmask, rm.size(), hipMemcpyDeviceToHost));
+    MTIP_HIP_CHECK(c, mtip_copy(c, V.data(), c->d_V, V.size() * sizeof(double2), hipMemcpyDeviceToHost));
+    MTIP_HIP_CHECK(c, mtip_copy(c, rm.data(), c->d_rmask, rm.size(), hipMemcpyDeviceToHost));
     std::vector<double2> Bref((size_t)(L + 1) * N * N, make_double2(0.0, 0.0));
     std::vector<double> norm(L + 1, 0.0);
     for (int l = 0; l <= L; ++l) {
@@ -359,8 +360,8 @@ static int build_bref(mtip_ctx* c) {
                 norm[l] += re * re + im * im;
             }
     }
-    MTIP_HIP_CHECK(c, hipMemcpy(c->d_Bref, Bref.data(), Bref.size() * sizeof(double2), hipMemcpyHostToDevice));
-    MTIP_HIP_CHECK(c, hipMemcpy(c->d_Bnorm, norm.data(), norm.size() * sizeof(double), hipMemcpyHostToDevice));
+    MTIP_HIP_CHECK(c, mtip_copy(c, c->d_Bref, Bref.data(), Bref.size() * sizeof(double2), hipMemcpyHostToDevice));
+    MTIP_HIP_CHECK(c, mtip_copy(c, c->d_Bnorm, norm.data(), norm.size() * sizeof(double), hipMemcpyHostToDevice));
     c->bref_dirty = false;
     return MTIP_OK;
 }
@@ -393,16 +394,16 @@ int mtip_set_initial_support(mtip_ctx* c, const uint8_t* support) {
     CTX_CHECK(c);
     if (!support) FAIL(c, MTIP_EINVAL, "null support");
     (void)hipSetDevice(c->device);
-    MTIP_HIP_CHECK(c, hipMemcpy(c->d_S0, support, c->G, hipMemcpyHostToDevice));
+    MTIP_HIP_CHECK(c, mtip_copy(c, c->d_S0, support, c->G, hipMemcpyHostToDevice));
     std::vector<int> slots((size_t)c->B * SL_N);
-    MTIP_HIP_CHECK(c, hipMemcpy(slots.data(), c->d_slot, slots.size() * sizeof(int), hipMemcpyDeviceToHost));
+    MTIP_HIP_CHECK(c, mtip_copy(c, slots.data(), c->d_slot, slots.size() * sizeof(int), hipMemcpyDeviceToHost));
     for (int b = 0; b < c->B; ++b) {
         slots[b * SL_N + SL_SUP] = 0;
         slots[b * SL_N + SL_SUP_BEST] = 0;
         slots[b * SL_N + SL_ENFORCE] = 1;
-        MTIP_HIP_CHECK(c, hipMemcpy(c->d_sup + (size_t)b * c->G, support, c->G, hipMemcpyHostToDevice));
+        MTIP_HIP_CHECK(c, mtip_copy(c, c->d_sup + (size_t)b * c->G, support, c->G, hipMemcpyHostToDevice));
     }
-    MTIP_HIP_CHECK(c, hipMemcpy(c->d_slot, slots.data(), slots.size() * sizeof(int), hipMemcpyHostToDevice));
+    MTIP_HIP_CHECK(c, mtip_copy(c, c->d_slot, slots.data(), slots.size() * sizeof(int), hipMemcpyHostToDevice));
     c->have_support = true;
     return MTIP_OK;
 }
@@ -411,8 +412,8 @@ int mtip_set_error_weights(mtip_ctx* c, const double* radial_w, const double* th
     CTX_CHECK(c);
     if (!radial_w || !theta_w) FAIL(c, MTIP_EINVAL, "null error weights");
     (void)hipSetDevice(c->device);
-    MTIP_HIP_CHECK(c, hipMemcpy(c->d_err_wr, radial_w, c->N * sizeof(double), hipMemcpyHostToDevice));
-    MTIP_HIP_CHECK(c, hipMemcpy(c->d_err_wt, theta_w, c->nt * sizeof(double), hipMemcpyHostToDevice));
+    MTIP_HIP_CHECK(c, mtip_copy(c, c->d_err_wr, radial_w, c->N * sizeof(double), hipMemcpyHostToDevice));
+    MTIP_HIP_CHECK(c, mtip_copy(c, c->d_err_wt, theta_w, c->nt * sizeof(double), hipMemcpyHostToDevice));
     c->err_use_mask = use_mask ? 1 : 0;
     c->have_errw = true;
     return MTIP_OK;
@@ -459,11 +460,12 @@ static int ensure_hist(mtip_ctx* c, long long need) {
         return r;
     }
     MTIP_HIP_CHECK(c, hipStreamSynchronize(c->stream));
-    MTIP_HIP_CHECK(c, hipMemcpy(nh, c->d_err_hist, (size_t)c->n_steps_done * c->B * sizeof(double), hipMemcpyDeviceToDevice));
-    MTIP_HIP_CHECK(c, hipMemcpy(nm, c->d_main_hist, (size_t)c->n_steps_done * c->B * sizeof(double), hipMemcpyDeviceToDevice));
+    MTIP_HIP_CHECK(c, hipMemcpyAsync(nh, c->d_err_hist, (size_t)c->n_steps_done * c->B * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    MTIP_HIP_CHECK(c, hipMemcpyAsync(nm, c->d_main_hist, (size_t)c->n_steps_done * c->B * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    MTIP_HIP_CHECK(c, hipMemcpyAsync(nd, c->d_deg2_hist, (size_t)c->n_steps_done * c->B * (c->L + 1) * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    MTIP_HIP_CHECK(c, hipStreamSynchronize(c->stream));
     (void)hipFree(c->d_main_hist);
     c->d_main_hist = nm;
-    MTIP_HIP_CHECK(c, hipMemcpy(nd, c->d_deg2_hist, (size_t)c->n_steps_done * c->B * (c->L + 1) * sizeof(double), hipMemcpyDeviceToDevice));
     (void)hipFree(c->d_err_hist);
     (void)hipFree(c->d_deg2_hist);
     c->d_err_hist = nh;
@@ -593,9 +595,9 @@ int mtip_fetch_errors(mtip_ctx* c, int64_t first, int64_t n, double* real_err, d
     (void)hipSetDevice(c->device);
     MTIP_HIP_CHECK(c, hipStreamSynchronize(c->stream));
     if (real_err && n)
-        MTIP_HIP_CHECK(c, hipMemcpy(real_err, c->d_err_hist + (size_t)first * c->B, (size_t)n * c->B * sizeof(double), hipMemcpyDeviceToHost));
+        MTIP_HIP_CHECK(c, mtip_copy(c, real_err, c->d_err_hist + (size_t)first * c->B, (size_t)n * c->B * sizeof(double), hipMemcpyDeviceToHost));
     if (deg2_err && n)
-        MTIP_HIP_CHECK(c, hipMemcpy(deg2_err, c->d_deg2_hist + (size_t)first * c->B * (c->L + 1),
+        MTIP_HIP_CHECK(c, mtip_copy(c, deg2_err, c->d_deg2_hist + (size_t)first * c->B * (c->L + 1),
                                     (size_t)n * c->B * (c->L + 1) * sizeof(double), hipMemcpyDeviceToHost));
     return post_launch(c, "mtip_fetch_errors");
 }
@@ -606,7 +608,7 @@ int mtip_fetch_main_errors(mtip_ctx* c, int64_t first, int64_t n, double* main_e
     (void)hipSetDevice(c->device);
     MTIP_HIP_CHECK(c, hipStreamSynchronize(c->stream));
     const double* src = c->main_mode == 1 ? c->d_main_hist : c->d_err_hist;
-    if (n) MTIP_HIP_CHECK(c, hipMemcpy(main_err, src + (size_t)first * c->B, (size_t)n * c->B * sizeof(double), hipMemcpyDeviceToHost));
+    if (n) MTIP_HIP_CHECK(c, mtip_copy(c, main_err, src + (size_t)first * c->B, (size_t)n * c->B * sizeof(double), hipMemcpyDeviceToHost));
     return post_launch(c, "mtip_fetch_main_errors");
 }
 
@@ -622,7 +624,7 @@ int mtip_run(mtip_ctx* c, int method, int ft_stab, int n_steps, const double* be
 static int slot_of(mtip_ctx* c, int batch, int which, int* out) {
     std::vector<int> s(SL_N);
     MTIP_HIP_CHECK(c, hipStreamSynchronize(c->stream));
-    MTIP_HIP_CHECK(c, hipMemcpy(s.data(), c->d_slot + (size_t)batch * SL_N, SL_N * sizeof(int), hipMemcpyDeviceToHost));
+    MTIP_HIP_CHECK(c, mtip_copy(c, s.data(), c->d_slot + (size_t)batch * SL_N, SL_N * sizeof(int), hipMemcpyDeviceToHost));
     *out = s[which];
     return MTIP_OK;
 }
@@ -632,7 +634,7 @@ int mtip_set_density(mtip_ctx* c, int batch, const mtip_cdouble* rho) {
     if (batch < 0 || batch >= c->B || !rho) FAIL(c, MTIP_EINVAL, "bad batch / null density");
     (void)hipSetDevice(c->device);
     MTIP_HIP_CHECK(c, hipStreamSynchronize(c->stream));
-    MTIP_HIP_CHECK(c, hipMemcpy(c->d_T1 + (size_t)batch * c->G, rho, c->G * sizeof(double2), hipMemcpyHostToDevice));
+    MTIP_HIP_CHECK(c, mtip_copy(c, c->d_T1 + (size_t)batch * c->G, rho, c->G * sizeof(double2), hipMemcpyHostToDevice));
     return MTIP_OK;
 }
 
@@ -644,7 +646,7 @@ int mtip_init_state(mtip_ctx* c) {
     // reconstruct.py:957-979: F0 = FT(rho0); rho0 <- IFT(F0); history = copies of that pair; best_error = inf
     std::vector<int> slots((size_t)c->B * SL_N);
     MTIP_HIP_CHECK(c, hipStreamSynchronize(c->stream));
-    MTIP_HIP_CHECK(c, hipMemcpy(slots.data(), c->d_slot, slots.size() * sizeof(int), hipMemcpyDeviceToHost));
+    MTIP_HIP_CHECK(c, mtip_copy(c, slots.data(), c->d_slot, slots.size() * sizeof(int), hipMemcpyDeviceToHost));
     for (int b = 0; b < c->B; ++b) {
         slots[b * SL_N + SL_CUR] = 0;
         slots[b * SL_N + SL_OUT] = 0;      // temporarily: writes below go to slot 0
@@ -652,17 +654,17 @@ int mtip_init_state(mtip_ctx* c) {
         slots[b * SL_N + SL_HIST] = 0;
         slots[b * SL_N + SL_HAS_ERR] = 0;
     }
-    MTIP_HIP_CHECK(c, hipMemcpy(c->d_slot, slots.data(), slots.size() * sizeof(int), hipMemcpyHostToDevice));
+    MTIP_HIP_CHECK(c, mtip_copy(c, c->d_slot, slots.data(), slots.size() * sizeof(int), hipMemcpyHostToDevice));
     InvEpilogue to_slot;
     to_slot.out_slot = SL_OUT;
     ft_pipeline(c, c->d_T1, -1, c->d_Fp, 0, MTIP_PRE_NONE, to_slot, c->d_c[0], c->d_c[1]);
     ft_pipeline(c, c->d_Fp, SL_CUR, c->d_rho, 1, MTIP_PRE_NONE, to_slot, c->d_c[0], c->d_c[1]);
     MTIP_HIP_CHECK(c, hipStreamSynchronize(c->stream));
     for (int b = 0; b < c->B; ++b) slots[b * SL_N + SL_OUT] = 1;
-    MTIP_HIP_CHECK(c, hipMemcpy(c->d_slot, slots.data(), slots.size() * sizeof(int), hipMemcpyHostToDevice));
+    MTIP_HIP_CHECK(c, mtip_copy(c, c->d_slot, slots.data(), slots.size() * sizeof(int), hipMemcpyHostToDevice));
     std::vector<double> inf(c->B, HUGE_VAL);
-    MTIP_HIP_CHECK(c, hipMemcpy(c->d_best_err, inf.data(), c->B * sizeof(double), hipMemcpyHostToDevice));
-    MTIP_HIP_CHECK(c, hipMemcpy(c->d_last_err, inf.data(), c->B * sizeof(double), hipMemcpyHostToDevice));
+    MTIP_HIP_CHECK(c, mtip_copy(c, c->d_best_err, inf.data(), c->B * sizeof(double), hipMemcpyHostToDevice));
+    MTIP_HIP_CHECK(c, mtip_copy(c, c->d_last_err, inf.data(), c->B * sizeof(double), hipMemcpyHostToDevice));
     c->n_steps_done = 0;
     c->fixed_valid = false;
     c->vr_valid = false;                 // a fresh reconstruction does not warm-start its polar factors
@@ -677,7 +679,7 @@ static int get_grid_slot(mtip_ctx* c, const double2* base, int batch, int which,
     int s = 0;
     int r = slot_of(c, batch, which == 0 ? SL_CUR : SL_BEST, &s);
     if (r) return r;
-    MTIP_HIP_CHECK(c, hipMemcpy(out, base + ((size_t)s * c->B + batch) * c->G, c->G * sizeof(double2), hipMemcpyDeviceToHost));
+    MTIP_HIP_CHECK(c, mtip_copy(c, out, base + ((size_t)s * c->B + batch) * c->G, c->G * sizeof(double2), hipMemcpyDeviceToHost));
     return MTIP_OK;
 }
 
@@ -698,7 +700,7 @@ int mtip_get_support(mtip_ctx* c, int batch, int which, uint8_t* support) {
     int s = 0;
     int r = slot_of(c, batch, which == 0 ? SL_SUP : SL_SUP_BEST, &s);
     if (r) return r;
-    MTIP_HIP_CHECK(c, hipMemcpy(support, c->d_sup + ((size_t)s * c->B + batch) * c->G, c->G, hipMemcpyDeviceToHost));
+    MTIP_HIP_CHECK(c, mtip_copy(c, support, c->d_sup + ((size_t)s * c->B + batch) * c->G, c->G, hipMemcpyDeviceToHost));
     return MTIP_OK;
 }
 
@@ -708,20 +710,20 @@ int mtip_set_support(mtip_ctx* c, int batch, const uint8_t* support, int enforce
     (void)hipSetDevice(c->device);
     std::vector<int> s(SL_N);
     MTIP_HIP_CHECK(c, hipStreamSynchronize(c->stream));
-    MTIP_HIP_CHECK(c, hipMemcpy(s.data(), c->d_slot + (size_t)batch * SL_N, SL_N * sizeof(int), hipMemcpyDeviceToHost));
+    MTIP_HIP_CHECK(c, mtip_copy(c, s.data(), c->d_slot + (size_t)batch * SL_N, SL_N * sizeof(int), hipMemcpyDeviceToHost));
     int fs = 0;
     while (fs == s[SL_SUP] || fs == s[SL_SUP_BEST]) ++fs;
     // fxs_Projections.py:53-58: effective support = S0 & support when the initial support is enforced
     std::vector<uint8_t> eff(support, support + c->G);
     if (enforce) {
         std::vector<uint8_t> s0(c->G);
-        MTIP_HIP_CHECK(c, hipMemcpy(s0.data(), c->d_S0, c->G, hipMemcpyDeviceToHost));
+        MTIP_HIP_CHECK(c, mtip_copy(c, s0.data(), c->d_S0, c->G, hipMemcpyDeviceToHost));
         for (size_t i = 0; i < c->G; ++i) eff[i] = (eff[i] && s0[i]) ? 1 : 0;
     }
-    MTIP_HIP_CHECK(c, hipMemcpy(c->d_sup + ((size_t)fs * c->B + batch) * c->G, eff.data(), c->G, hipMemcpyHostToDevice));
+    MTIP_HIP_CHECK(c, mtip_copy(c, c->d_sup + ((size_t)fs * c->B + batch) * c->G, eff.data(), c->G, hipMemcpyHostToDevice));
     s[SL_SUP] = fs;
     s[SL_ENFORCE] = enforce ? 1 : 0;
-    MTIP_HIP_CHECK(c, hipMemcpy(c->d_slot + (size_t)batch * SL_N, s.data(), SL_N * sizeof(int), hipMemcpyHostToDevice));
+    MTIP_HIP_CHECK(c, mtip_copy(c, c->d_slot + (size_t)batch * SL_N, s.data(), SL_N * sizeof(int), hipMemcpyHostToDevice));
     return MTIP_OK;
 }
 
@@ -730,7 +732,7 @@ int mtip_get_unknowns(mtip_ctx* c, int batch, int l, mtip_cdouble* U) {
     if (batch < 0 || batch >= c->B || l < 0 || l > c->L || !U) FAIL(c, MTIP_EINVAL, "bad batch / order / null output");
     (void)hipSetDevice(c->device);
     MTIP_HIP_CHECK(c, hipStreamSynchronize(c->stream));
-    MTIP_HIP_CHECK(c, hipMemcpy(U, c->d_U + (size_t)batch * c->xtot + c->xoff[l], (size_t)c->kl[l] * (2 * l + 1) * sizeof(double2), hipMemcpyDeviceToHost));
+    MTIP_HIP_CHECK(c, mtip_copy(c, U, c->d_U + (size_t)batch * c->xtot + c->xoff[l], (size_t)c->kl[l] * (2 * l + 1) * sizeof(double2), hipMemcpyDeviceToHost));
     return MTIP_OK;
 }
 
@@ -738,7 +740,7 @@ int mtip_get_best_error(mtip_ctx* c, double* best, int64_t* n_steps_done) {
     CTX_CHECK(c);
     (void)hipSetDevice(c->device);
     MTIP_HIP_CHECK(c, hipStreamSynchronize(c->stream));
-    if (best) MTIP_HIP_CHECK(c, hipMemcpy(best, c->d_best_err, c->B * sizeof(double), hipMemcpyDeviceToHost));
+    if (best) MTIP_HIP_CHECK(c, mtip_copy(c, best, c->d_best_err, c->B * sizeof(double), hipMemcpyDeviceToHost));
     if (n_steps_done) *n_steps_done = c->n_steps_done;
     return MTIP_OK;
 }
@@ -750,7 +752,7 @@ int mtip_select_best_where(mtip_ctx* c, const uint8_t* select) {
     (void)hipSetDevice(c->device);
     std::vector<int> slots((size_t)c->B * SL_N);
     MTIP_HIP_CHECK(c, hipStreamSynchronize(c->stream));
-    MTIP_HIP_CHECK(c, hipMemcpy(slots.data(), c->d_slot, slots.size() * sizeof(int), hipMemcpyDeviceToHost));
+    MTIP_HIP_CHECK(c, mtip_copy(c, slots.data(), c->d_slot, slots.size() * sizeof(int), hipMemcpyDeviceToHost));
     for (int b = 0; b < c->B; ++b) {
         if (select != nullptr && !select[b]) continue;
         int* s = &slots[(size_t)b * SL_N];
@@ -761,7 +763,7 @@ int mtip_select_best_where(mtip_ctx* c, const uint8_t* select) {
         while (nxt == s[SL_CUR] || nxt == s[SL_BEST]) ++nxt;
         s[SL_OUT] = nxt;
     }
-    MTIP_HIP_CHECK(c, hipMemcpy(c->d_slot, slots.data(), slots.size() * sizeof(int), hipMemcpyHostToDevice));
+    MTIP_HIP_CHECK(c, mtip_copy(c, c->d_slot, slots.data(), slots.size() * sizeof(int), hipMemcpyHostToDevice));
     c->fixed_valid = false;
     return MTIP_OK;
 }
@@ -775,7 +777,7 @@ int mtip_shrinkwrap(mtip_ctx* c, double sigma, double threshold, double error_li
     // G_sigma(q) = sigma sqrt(2 pi) exp(-2 pi^2 sigma^2 q^4)   (mathLibrary.py:616-624, sic: q^4)
     std::vector<double> q(c->N), gq(c->N);
     MTIP_HIP_CHECK(c, hipStreamSynchronize(c->stream));
-    MTIP_HIP_CHECK(c, hipMemcpy(q.data(), c->d_q, c->N * sizeof(double), hipMemcpyDeviceToHost));
+    MTIP_HIP_CHECK(c, mtip_copy(c, q.data(), c->d_q, c->N * sizeof(double), hipMemcpyDeviceToHost));
     const double pi = 3.14159265358979323846;
     const double a = 1.0 / (2.0 * sigma * sigma);
     for (int i = 0; i < c->N; ++i) {
@@ -784,7 +786,7 @@ int mtip_shrinkwrap(mtip_ctx* c, double sigma, double threshold, double error_li
     }
     // own buffer: d_fixed may hold the *_non_FXS amplitudes, which survive support updates (reconstruct.py:898-904)
     double* d_gq = c->d_gq;
-    MTIP_HIP_CHECK(c, hipMemcpy(d_gq, gq.data(), c->N * sizeof(double), hipMemcpyHostToDevice));
+    MTIP_HIP_CHECK(c, mtip_copy(c, d_gq, gq.data(), c->N * sizeof(double), hipMemcpyHostToDevice));
     InvEpilogue scale, store;
     scale.mode = EPI_SCALE_SHELL;
     scale.shell_scale = d_gq;
@@ -800,7 +802,7 @@ int mtip_shrinkwrap(mtip_ctx* c, double sigma, double threshold, double error_li
     if (enforced) {
         std::vector<int> slots((size_t)c->B * SL_N);
         MTIP_HIP_CHECK(c, hipStreamSynchronize(c->stream));
-        MTIP_HIP_CHECK(c, hipMemcpy(slots.data(), c->d_slot, slots.size() * sizeof(int), hipMemcpyDeviceToHost));
+        MTIP_HIP_CHECK(c, mtip_copy(c, slots.data(), c->d_slot, slots.size() * sizeof(int), hipMemcpyDeviceToHost));
         for (int b = 0; b < c->B; ++b) enforced[b] = (uint8_t)slots[(size_t)b * SL_N + SL_ENFORCE];
     }
     return MTIP_OK;
@@ -812,9 +814,9 @@ int mtip_begin_sub_loop(mtip_ctx* c) {
     // reconstruct.py:859, 866: `hist` is read from the state and latest_intensity reset at the top of every sub-loop call
     std::vector<int> slots((size_t)c->B * SL_N);
     MTIP_HIP_CHECK(c, hipStreamSynchronize(c->stream));
-    MTIP_HIP_CHECK(c, hipMemcpy(slots.data(), c->d_slot, slots.size() * sizeof(int), hipMemcpyDeviceToHost));
+    MTIP_HIP_CHECK(c, mtip_copy(c, slots.data(), c->d_slot, slots.size() * sizeof(int), hipMemcpyDeviceToHost));
     for (int b = 0; b < c->B; ++b) slots[(size_t)b * SL_N + SL_HIST] = slots[(size_t)b * SL_N + SL_CUR];
-    MTIP_HIP_CHECK(c, hipMemcpy(c->d_slot, slots.data(), slots.size() * sizeof(int), hipMemcpyHostToDevice));
+    MTIP_HIP_CHECK(c, mtip_copy(c, c->d_slot, slots.data(), slots.size() * sizeof(int), hipMemcpyHostToDevice));
     c->fixed_valid = false;
     return MTIP_OK;
 }
@@ -832,7 +834,7 @@ int mtip_refresh_reciprocal_density(mtip_ctx* c) {
     // best pair.
     std::vector<int> slots((size_t)c->B * SL_N);
     MTIP_HIP_CHECK(c, hipStreamSynchronize(c->stream));
-    MTIP_HIP_CHECK(c, hipMemcpy(slots.data(), c->d_slot, slots.size() * sizeof(int), hipMemcpyDeviceToHost));
+    MTIP_HIP_CHECK(c, mtip_copy(c, slots.data(), c->d_slot, slots.size() * sizeof(int), hipMemcpyDeviceToHost));
     InvEpilogue store;
     ft_pipeline(c, c->d_rho, SL_CUR, c->d_T1, 0, MTIP_PRE_NONE, store, c->d_c[0], c->d_c[1]);
     for (int b = 0; b < c->B; ++b) {
@@ -853,7 +855,7 @@ int mtip_refresh_reciprocal_density(mtip_ctx* c) {
         s[SL_OUT] = f;
     }
     MTIP_HIP_CHECK(c, hipStreamSynchronize(c->stream));
-    MTIP_HIP_CHECK(c, hipMemcpy(c->d_slot, slots.data(), slots.size() * sizeof(int), hipMemcpyHostToDevice));
+    MTIP_HIP_CHECK(c, mtip_copy(c, c->d_slot, slots.data(), slots.size() * sizeof(int), hipMemcpyHostToDevice));
     return post_launch(c, "mtip_refresh_reciprocal_density");
 }
 
@@ -873,13 +875,13 @@ int mtip_last_deg2_invariant(mtip_ctx* c, int batch, mtip_cdouble* Bl) {
     launch_sht_forward(c, c->d_T1, c->d_c[2], MTIP_PRE_SQUARE);
     launch_deg2(c, c->d_c[2], c->d_Bl);
     MTIP_HIP_CHECK(c, hipStreamSynchronize(c->stream));
-    MTIP_HIP_CHECK(c, hipMemcpy(Bl, c->d_Bl + (size_t)batch * per, per * sizeof(double2), hipMemcpyDeviceToHost));
+    MTIP_HIP_CHECK(c, mtip_copy(c, Bl, c->d_Bl + (size_t)batch * per, per * sizeof(double2), hipMemcpyDeviceToHost));
     return post_launch(c, "mtip_last_deg2_invariant");
 }
 
 // ---- single operators on host arrays ---------------------------------------------------------------------
-#define H2D(dst, src, n) MTIP_HIP_CHECK(c, hipMemcpy((dst), (src), (n), hipMemcpyHostToDevice))
-#define D2H(dst, src, n) MTIP_HIP_CHECK(c, hipMemcpy((dst), (src), (n), hipMemcpyDeviceToHost))
+#define H2D(dst, src, n) MTIP_HIP_CHECK(c, mtip_copy(c, (dst), (src), (n), hipMemcpyHostToDevice))
+#define D2H(dst, src, n) MTIP_HIP_CHECK(c, mtip_copy(c, (dst), (src), (n), hipMemcpyDeviceToHost))
 #define SYNC() MTIP_HIP_CHECK(c, hipStreamSynchronize(c->stream))
 
 int mtip_op_sht_forward(mtip_ctx* c, const mtip_cdouble* grid, mtip_cdouble* coeff, int prologue) {
@@ -1028,13 +1030,13 @@ int mtip_op_apply_matrix(mtip_ctx* c, const double* matrix, const double* vects,
     if (!r) r = dev_alloc(c, &dx, (size_t)nc * nv);
     if (!r) r = dev_alloc(c, &dy, (size_t)nr * nv);
     if (!r) {
-        hipError_t e = hipMemcpy(dM, matrix, (size_t)nr * nc * sizeof(double), hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemcpy(dx, vects, (size_t)nc * nv * sizeof(double), hipMemcpyHostToDevice);
+        hipError_t e = mtip_copy(c, dM, matrix, (size_t)nr * nc * sizeof(double), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = mtip_copy(c, dx, vects, (size_t)nc * nv * sizeof(double), hipMemcpyHostToDevice);
         if (e == hipSuccess) {
             launch_apply_matrix(c, dM, dx, dy, nr, nc, nv);
             e = hipStreamSynchronize(c->stream);
         }
-        if (e == hipSuccess) e = hipMemcpy(out, dy, (size_t)nr * nv * sizeof(double), hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = mtip_copy(c, out, dy, (size_t)nr * nv * sizeof(double), hipMemcpyDeviceToHost);
         if (e != hipSuccess) {
             c->err = std::string("apply_matrix: ") + hipGetErrorString(e);
             r = MTIP_EHIP;
@@ -1068,9 +1070,9 @@ int mtip_debug_jacobi_sweeps(mtip_ctx* c, int32_t* out) {
     if (!out) return MTIP_EINVAL;
     (void)hipSetDevice(c->device);
     MTIP_HIP_CHECK(c, hipStreamSynchronize(c->stream));
-    MTIP_HIP_CHECK(c, hipMemcpy(out, c->d_sweeps, (size_t)c->B * (c->L + 1) * sizeof(int), hipMemcpyDeviceToHost));
+    MTIP_HIP_CHECK(c, mtip_copy(c, out, c->d_sweeps, (size_t)c->B * (c->L + 1) * sizeof(int), hipMemcpyDeviceToHost));
     int gave_up = 0;
-    MTIP_HIP_CHECK(c, hipMemcpy(&gave_up, c->d_conc_err, sizeof(int), hipMemcpyDeviceToHost));
+    MTIP_HIP_CHECK(c, mtip_copy(c, &gave_up, c->d_conc_err, sizeof(int), hipMemcpyDeviceToHost));
     if (gave_up != 0) FAIL(c, MTIP_EHIP, "polar factor: a concurrent V_r replay workgroup gave up waiting for its rotation log");
     return MTIP_OK;
 }
@@ -1098,9 +1100,9 @@ int mtip_debug_polar_timing(mtip_ctx* c, int64_t* out) {
     if (!c->d_polar_dbg) {                       // first call: switch the timers on (the next projections fill them)
         int r = dev_alloc(c, &c->d_polar_dbg, n);
         if (r) return r;
-        MTIP_HIP_CHECK(c, hipMemset(c->d_polar_dbg, 0, n * sizeof(long long)));
+        MTIP_HIP_CHECK(c, hipMemsetAsync(c->d_polar_dbg, 0, n * sizeof(long long), c->stream));
     }
-    if (out) MTIP_HIP_CHECK(c, hipMemcpy(out, c->d_polar_dbg, n * sizeof(long long), hipMemcpyDeviceToHost));
+    if (out) MTIP_HIP_CHECK(c, mtip_copy(c, out, c->d_polar_dbg, n * sizeof(long long), hipMemcpyDeviceToHost));
     return MTIP_OK;
 }
 
