@@ -392,14 +392,25 @@ def wigner_d(l, betas):
     """d^l_mn(beta) = <l m| exp(-i beta J_y) |l n>, (len(betas), 2l+1, 2l+1), m, n = -l..l, from the eigen-decomposition of
     J_y (unitary by construction).  The reference gets these from pysofft (``soft_plugin.py:30-36``, ``genWigAll``)."""
     betas = np.atleast_1d(np.asarray(betas, dtype=float))
-    m = np.arange(-l, l)
-    c = 0.5 * np.sqrt(l * (l + 1) - m * (m + 1))
-    jy = np.zeros((2 * l + 1, 2 * l + 1), complex)
-    idx = np.arange(2 * l)
-    jy[idx + 1, idx] = -1j * c
-    jy[idx, idx + 1] = 1j * c
-    w, v = np.linalg.eigh(jy)
+    w, v = _jy_eig(l)
     return np.ascontiguousarray(np.einsum('ik,bk,jk->bij', v, np.exp(-1j * betas[:, None] * w[None, :]), v.conj()).real)
+
+
+_JY_EIG = {}
+
+
+def _jy_eig(l):
+    """eigen-decomposition of J_y in the |l m> basis (depends on l only: kept, every rotation of coefficients asks for it)"""
+    hit = _JY_EIG.get(l)
+    if hit is None:
+        m = np.arange(-l, l)
+        c = 0.5 * np.sqrt(l * (l + 1) - m * (m + 1))
+        jy = np.zeros((2 * l + 1, 2 * l + 1), complex)
+        idx = np.arange(2 * l)
+        jy[idx + 1, idx] = -1j * c
+        jy[idx, idx + 1] = 1j * c
+        hit = _JY_EIG[l] = np.linalg.eigh(jy)
+    return hit
 
 
 def euler_grid(bw):
