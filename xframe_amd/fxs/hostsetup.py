@@ -47,8 +47,23 @@ def radial_grids(max_q, n, kappa, mode='midpoint'):
     raise NotImplementedError(f'fourier_transform.type {mode!r} is not supported (midpoint, trapz)')
 
 
+_HANKEL_W = {}
+
+
 def hankel_raw_weights(l_max, n, kappa, mode='midpoint'):
-    """real (L+1, Np, N) array indexed [l, p, k] (summation index p, output index k)."""
+    """real (L+1, Np, N) array indexed [l, p, k] (summation index p, output index k); read only (the engines of one worker
+    share it: 0.06 s of Bessel evaluations at 128 x L32)."""
+    key = (int(l_max), int(n), float(kappa), mode)
+    if key not in _HANKEL_W:
+        if len(_HANKEL_W) >= 4:
+            _HANKEL_W.pop(next(iter(_HANKEL_W)))
+        w = _hankel_raw_weights(l_max, n, kappa, mode)
+        w.setflags(write=False)
+        _HANKEL_W[key] = w
+    return _HANKEL_W[key]
+
+
+def _hankel_raw_weights(l_max, n, kappa, mode='midpoint'):
     ls = np.arange(l_max + 1)
     if mode == 'midpoint':
         ps = np.arange(n) + 0.5
