@@ -153,8 +153,10 @@ class LinearRamp:
 
 # ---------------------------------------------------------------------------------------------- reciprocal projection data
 def _regrid(values, old, new, interpolation):
-    return griddata(old[:, None], values, new[:, None], method=interpolation, fill_value=0.0,
-                    rescale=False).reshape(len(new))
+    """the reference's 1-D regridding call (fxs_Projections.py:639-676); `values` may hold several columns (len(old), k): the
+    spline of every column is the one a call per column gives, in one scipy call instead of k"""
+    out = griddata(old[:, None], values, new[:, None], method=interpolation, fill_value=0.0, rescale=False)
+    return out.reshape((len(new),) + np.shape(values)[1:])
 
 
 class ReciprocalSetup:
@@ -185,7 +187,7 @@ class ReciprocalSetup:
             m = np.asarray(dpm[oid])
             if m.ndim < 2:
                 m = m[:, None]
-            pm[oid] = np.stack([_regrid(m[:, c], q_d, self.qs, interp) for c in range(m.shape[1])], axis=1).astype(complex)
+            pm[oid] = _regrid(m, q_d, self.qs, interp).astype(complex)
         self.full_projection_matrices = [pm.get(l, np.zeros((n, min(n, 2 * l + 1)), complex)) for l in range(max_order + 1)]
         # modify_projection_matrices, 679-714
         proj = {oid: m.copy() for oid, m in pm.items()}
