@@ -1,6 +1,10 @@
 #!/bin/bash
 set -e
-timeout -k 10 400 python scripts/bench_worker.py 8 3 2>&1 | tail -5 | tee gpurun_out/r2_worker_end_to_end.txt
-timeout -k 10 400 python scripts/bench_average.py 128 32 8 2>&1 | tail -3 | tee gpurun_out/r2_avg2.txt
-timeout -k 10 900 python -m pytest tests -m gpu -x -q > gpurun_out/r2_final_gpu_tests.log 2>&1 || { tail -30 gpurun_out/r2_final_gpu_tests.log; exit 1; }
-tail -2 gpurun_out/r2_final_gpu_tests.log
+out=gpurun_out/r2_stagger.txt
+: > $out
+for st in 0 150 250 350 0 250; do
+  for args in "--steps 600 --warmup 20" "--steps 20 --warmup 5"; do
+    v=$(timeout -k 10 150 python bench.py $args --stagger-us $st --no-cpu-baseline | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(round(d['value']), round(d['ms_per_step'],3), {k: round(v['avg_ms']*1e3,1) for k,v in d['kernel_families_ms'].items()})")
+    echo "stagger=$st $args  $v" | tee -a $out
+  done
+done
