@@ -14,7 +14,10 @@
  *   - host buffers are caller-owned, C-contiguous; complex128 = interleaved (re,im) doubles
  *     (numpy complex128); masks are uint8 (numpy bool); device memory is library-owned;
  *   - a ctx is bound to one device and one hipStream_t; it is not thread-safe; several ctxs may
- *     be used concurrently (one per GPU / per process);
+ *     be used concurrently (one per GPU / per process, or several per GPU from different host threads);
+ *     the stream is created hipStreamNonBlocking: it does NOT synchronise with the null stream, so a caller's own
+ *     null-stream work is not ordered against a ctx's kernels (call mtip_synchronize); every entry point that moves
+ *     data to or from the host waits for the ctx's own stream itself and returns with the copy complete;
  *   - array shapes: grid  (n_batch, Nq, n_theta, n_phi);  coeff 'direct' (n_batch, Nq, (L+1)^2)
  *     with index l(l+1)+m  (`xframe/externalLibraries/shtns_plugin.py:24,105-114,250-261`).
  */
