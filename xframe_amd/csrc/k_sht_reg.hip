@@ -544,18 +544,22 @@ __global__ void __launch_bounds__(SW_THREADS) k_sht_inv_wide(const double2* __re
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nw = blockDim.x >> 6;
     const int nth = ntl >> 1;                       // theta pairs of this workgroup, first one j0
     const int j0 = split * nth;
-    const int jj = lane & 31, sgn = lane >> 5;
+    const int jj = lane & 31, half_id = lane >> 5;
     const int n_chunks = (nth + 31) >> 5;
-    const int n_items = (L + 1) * n_chunks;
+    // an item = (pair of orders m = 2p, 2p + 1; chunk of 32 thetas): lanes 0-31 run the recurrence of m = 2p for their theta, lanes
+    // 32-63 that of m = 2p + 1, and every lane accumulates the rows of +m AND -m (P_lm is the same for both)
+    const int n_mp = (L + 2) >> 1;
+    const int n_items = n_mp * n_chunks;
     // start values P_mm, P_m+1,m of the first item: in flight while the tables are staged
     double pmm_n = 0.0, pm1_n = 0.0;
     {
         const int i = wave;
         if (i < n_items) {
-            const int m = i / n_chunks, ch = i - m * n_chunks;
+            const int mp = i / n_chunks, ch = i - mp * n_chunks;
+            const int m = min(2 * mp + half_id, L);
             const int j = ch * 32 + jj;
             const int jc = j0 + (j < nth ? j : nth - 1);
-            const double* pcol = P + (size_t)poff[m] * nt + jc;
+            const double* pcol = P + (size_t)(m * (L + 1) - m * (m - 1) / 2) * nt + jc;
             pmm_n = pcol[0];
             pm1_n = m < L ? pcol[nt] : 0.0;
         }
@@ -592,86 +596,106 @@ __global__ void __launch_bounds__(SW_THREADS) k_sht_inv_wide(const double2* __re
     for (int kk = 0;; ++kk) {
         const int i = kk * nw + ((kk & 1) ? nw - 1 - wave : wave);
         if (i >= n_items) break;
-        const int m = i / n_chunks, ch = i - m * n_chunks;
+        const int mp = i / n_chunks, ch = i - mp * n_chunks;
+        const int m_a = 2 * mp;                                  // the smaller order of the pair: sets the trip count of the wave
+        const bool m_ok = m_a + half_id <= L;
+        const int m = min(m_a + half_id, L);                     // this lane's order (clamped: an odd L + 1 has no partner)
         const int j = ch * 32 + jj;
-        const bool act = (j < nth) && !(sgn == 1 && m == 0);
+        const bool act = (j < nth) && m_ok;
         const int jc = j0 + (j < nth ? j : nth - 1);
         const double x = cost[jc];
         double p2 = pmm_n, p1 = pm1_n;
         {   // prefetch the start values of this wave's next item
             const int i2 = (kk + 1) * nw + (((kk + 1) & 1) ? nw - 1 - wave : wave);
             if (i2 < n_items) {
-                const int m2 = i2 / n_chunks, ch2 = i2 - m2 * n_chunks;
+                const int mp2 = i2 / n_chunks, ch2 = i2 - mp2 * n_chunks;
+                const int m2 = min(2 * mp2 + half_id, L);
                 const int j2 = ch2 * 32 + jj;
                 const int jc2 = j0 + (j2 < nth ? j2 : nth - 1);
-                const double* pcol = P + (size_t)poff[m2] * nt + jc2;
+                const double* pcol = P + (size_t)(m2 * (L + 1) - m2 * (m2 - 1) / 2) * nt + jc2;
                 pmm_n = pcol[0];
                 pm1_n = m2 < L ? pcol[nt] : 0.0;
             }
         }
-        const int ms = sgn ? -m : m;
-        const double2* cc = cl + ms;
-        const double2* abm = ABs + poff[m] - m;              // abm[l]
-        double2 E, O = make_double2(0.0, 0.0);
+        const double2* cp = cl + m;                              // c_l,+m at cp[l (l + 1)]
+        const double2* cm = cl - m;                              // c_l,-m
+        const double2* abm = ABs + (m * (L + 1) - m * (m - 1) / 2) - m;   // abm[l]
+        double2 Ep, Em, Op = make_double2(0.0, 0.0), Om = make_double2(0.0, 0.0);
         {
-            const double2 ce = cc[m * (m + 1)];
-            E = make_double2(p2 * ce.x, p2 * ce.y);
+            const double2 a = cp[m * (m + 1)], b = cm[m * (m + 1)];
+            Ep = make_double2(p2 * a.x, p2 * a.y);
+            Em = make_double2(p2 * b.x, p2 * b.y);
         }
         if (m < L) {
-            const double2 co = cc[(m + 1) * (m + 2)];
-            O = make_double2(p1 * co.x, p1 * co.y);
+            const double2 a = cp[(m + 1) * (m + 2)], b = cm[(m + 1) * (m + 2)];
+            Op = make_double2(p1 * a.x, p1 * a.y);
+            Om = make_double2(p1 * b.x, p1 * b.y);
         }
-        int l = m + 2;
         // The recurrence is a dependent chain and there are only two waves per SIMD: with the operands read at the top of
         // each iteration an LDS round trip per iteration was most of the loop.  Two operand sets, A and B, alternate; a set is
-        // requested before the other one is used (clamped indices, branch-free) and the empty asm pins it there.
-        double2 Aab0, Aab1, Ace, Aco, Bab0, Bab1, Bce, Bco;
-#define LEG_LOAD(S, lq_)                                       \
-        {                                                      \
-            const int q_ = max(min((lq_), L - 1), 0);          \
-            S##ab0 = abm[q_];                                  \
-            S##ab1 = abm[q_ + 1];                              \
-            S##ce = cc[q_ * (q_ + 1)];                         \
-            S##co = cc[min((q_ + 1) * (q_ + 2), L * (L + 1))]; \
+        // requested before the other one is used (clamped indices, branch-free) and the empty asm pins it there.  The wave runs
+        // the iterations of its smaller order; a lane whose order is one larger sits out the last one when its l runs out.
+        int l = m + 2;                                           // per lane
+        const int n_it = m_a + 2 <= L ? (L - m_a - 1) >> 1 : 0;  // double steps of the wave (uniform)
+        double2 Aab0, Aab1, Acp, Aop, Acm, Aom, Bab0, Bab1, Bcp, Bop, Bcm, Bom;
+#define LEG_LOAD(S, lq_)                                             \
+        {                                                            \
+            const int q_ = max(min((lq_), L - 1), 0);                \
+            const int o_ = min((q_ + 1) * (q_ + 2), L * (L + 1));    \
+            S##ab0 = abm[q_];                                        \
+            S##ab1 = abm[q_ + 1];                                    \
+            S##cp = cp[q_ * (q_ + 1)];                               \
+            S##op = cp[o_];                                          \
+            S##cm = cm[q_ * (q_ + 1)];                               \
+            S##om = cm[o_];                                          \
         }
-#define LEG_STEP(S)                                                   \
-        {                                                             \
-            const double pa = S##ab0.x * (x * p1 - S##ab0.y * p2);    \
-            const double pb = S##ab1.x * (x * pa - S##ab1.y * p1);    \
-            E.x = fma(pa, S##ce.x, E.x); E.y = fma(pa, S##ce.y, E.y); \
-            O.x = fma(pb, S##co.x, O.x); O.y = fma(pb, S##co.y, O.y); \
-            p2 = pa;                                                  \
-            p1 = pb;                                                  \
+#define LEG_STEP(S)                                                         \
+        if (l + 1 <= L) {                                                   \
+            const double pa = S##ab0.x * (x * p1 - S##ab0.y * p2);          \
+            const double pb = S##ab1.x * (x * pa - S##ab1.y * p1);          \
+            Ep.x = fma(pa, S##cp.x, Ep.x); Ep.y = fma(pa, S##cp.y, Ep.y);   \
+            Op.x = fma(pb, S##op.x, Op.x); Op.y = fma(pb, S##op.y, Op.y);   \
+            Em.x = fma(pa, S##cm.x, Em.x); Em.y = fma(pa, S##cm.y, Em.y);   \
+            Om.x = fma(pb, S##om.x, Om.x); Om.y = fma(pb, S##om.y, Om.y);   \
+            p2 = pa;                                                        \
+            p1 = pb;                                                        \
+            l += 2;                                                         \
         }
 #define LEG_PIN(S)                                                  \
         MTIP_PIN_VGPRS4(S##ab0.x, S##ab0.y, S##ab1.x, S##ab1.y)     \
-        MTIP_PIN_VGPRS4(S##ce.x, S##ce.y, S##co.x, S##co.y)
+        MTIP_PIN_VGPRS4(S##cp.x, S##cp.y, S##op.x, S##op.y)         \
+        MTIP_PIN_VGPRS4(S##cm.x, S##cm.y, S##om.x, S##om.y)
         LEG_LOAD(A, l)
-        while (l + 1 <= L) {
+        for (int it = 0; it < n_it;) {
             LEG_LOAD(B, l + 2)
             LEG_STEP(A)
             LEG_PIN(B)
-            l += 2;
-            if (l + 1 > L) break;
+            if (++it >= n_it) break;
             LEG_LOAD(A, l + 2)
             LEG_STEP(B)
             LEG_PIN(A)
-            l += 2;
+            ++it;
         }
 #undef LEG_LOAD
 #undef LEG_STEP
 #undef LEG_PIN
         if (l <= L) {
             const double2 ab0 = abm[l];
-            const double2 ce = cc[l * (l + 1)];
+            const double2 a = cp[l * (l + 1)], b = cm[l * (l + 1)];
             const double pa = ab0.x * (x * p1 - ab0.y * p2);
-            E.x = fma(pa, ce.x, E.x); E.y = fma(pa, ce.y, E.y);
+            Ep.x = fma(pa, a.x, Ep.x); Ep.y = fma(pa, a.y, Ep.y);
+            Em.x = fma(pa, b.x, Em.x); Em.y = fma(pa, b.y, Em.y);
         }
         if (act) {
-            const double sg = (sgn && (m & 1)) ? -1.0 : 1.0;       // Y_l,-m = (-1)^m conj(Y_lm)
-            double2* g_n = Gs + (size_t)(2 * j) * nm + L + ms;
-            g_n[0] = make_double2(sg * (E.x + O.x), sg * (E.y + O.y));
-            g_n[nm] = make_double2(sg * (E.x - O.x), sg * (E.y - O.y));
+            double2* g_p = Gs + (size_t)(2 * j) * nm + L + m;
+            g_p[0] = make_double2(Ep.x + Op.x, Ep.y + Op.y);
+            g_p[nm] = make_double2(Ep.x - Op.x, Ep.y - Op.y);
+            if (m > 0) {
+                const double sg = (m & 1) ? -1.0 : 1.0;            // Y_l,-m = (-1)^m conj(Y_lm)
+                double2* g_m = Gs + (size_t)(2 * j) * nm + L - m;
+                g_m[0] = make_double2(sg * (Em.x + Om.x), sg * (Em.y + Om.y));
+                g_m[nm] = make_double2(sg * (Em.x - Om.x), sg * (Em.y - Om.y));
+            }
         }
     }
     __syncthreads();
