@@ -620,6 +620,9 @@ def check_config4_worker(lib_path=None, cfg=4, n_restarts=8, n_workers=3, n_hio=
         w = R.ProjectWorker(o, data, seeds=seeds, lib_path=lib_path)
         res, _ = w.run()
         assert len(res) == n_restarts and len(w.mtip_instances) == workers
+        groups = w.results['stats']['groups']                     # where the run spent its time, per engine group
+        assert len(groups) == workers and sum(g['restarts'] for g in groups) == n_restarts
+        assert all(g[k] >= 0 for g in groups for k in ('engine_seconds', 'setup_seconds', 'loop_seconds', 'output_seconds'))
         results[workers] = res
         engine = w.mtip_instances[0].engine
         if workers == n_workers:
