@@ -355,8 +355,8 @@ class ProjectWorker:
             # GPU.n_gpu_workers (reference: number of GPU daemon processes, reconstruct.py:104) = restart groups that run
             # concurrently on this GPU, each with its own engine / HIP stream, driven from its own host thread.  The
             # per-restart chain of a step is serial (the polar-factor kernel alone is half of it and fills half of the
-            # CUs), so 2-3 groups overlap it with the streaming kernels of the others; more than 3 serialise on the
-            # hardware queues.
+            # CUs), so 2-3 groups overlap it with the streaming kernels of the others; with more than 3 every kernel boundary
+            # gets ~40 us slower (more than four active queues of one process).
             n_eng = int(self.opt['GPU'].get('n_gpu_workers', 1) or 1)
             n_eng = max(1, min(n_eng, 3, len(mine) // 2))
             groups = [list(range(g, len(mine), n_eng)) for g in range(n_eng)]
