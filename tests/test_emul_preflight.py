@@ -15,6 +15,13 @@ EMUL_DIR = os.path.join(HERE, 'emul')
 EMUL_LIB = os.path.join(EMUL_DIR, 'libmtip_emul.so')
 
 
+@pytest.fixture(autouse=True)
+def _one_workgroup_polar_factor(monkeypatch):
+    """The concurrent V_r replay (default on the GPU) makes consumer workgroups poll for their producer: on the emulation's host
+    threads that doubles the run time of this module, so only the tests that are about it switch it on."""
+    monkeypatch.setenv('MTIP_JAC_CONC', '0')
+
+
 @pytest.fixture(scope='session')
 def emul_lib():
     r = subprocess.run(['make', '-C', EMUL_DIR, '-j6'], capture_output=True, text=True)
@@ -105,11 +112,15 @@ def test_projection_concurrent_replay(emul_lib, monkeypatch):
     while they are written (the emulation runs the blocks on real threads, so the publish / validate protocol is live);
     2l+1 up to 53: two consumer workgroups per matrix"""
     monkeypatch.setenv('MTIP_JAC_CONC', '1')
+    monkeypatch.setenv('MTIP_JAC_CONC_MIN_K', '2')           # every order split (default: the largest only)
     PC.check_projection_vs_oracle(56, 26, emul_lib, n_batch=2)
+    monkeypatch.delenv('MTIP_JAC_CONC_MIN_K')
+    PC.check_projection_vs_oracle(40, 18, emul_lib, n_batch=2)
 
 
 def test_short_trajectory_concurrent_replay(emul_lib, golden_mtip16, monkeypatch):
     monkeypatch.setenv('MTIP_JAC_CONC', '1')
+    monkeypatch.setenv('MTIP_JAC_CONC_MIN_K', '2')
     PC.check_short_trajectory_vs_oracle(golden_mtip16, emul_lib, True)
 
 

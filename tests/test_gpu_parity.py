@@ -175,7 +175,7 @@ def test_config5_properties_full_size():
 _TRAJ_SWITCHES = [('MTIP_SHT_MODE', '0'), ('MTIP_SHT_MODE', '1'), ('MTIP_SHT_WIDE', '0'), ('MTIP_FUSE_REAL', '0'),
                   ('MTIP_DEG2_SIMPLE', '1'), ('MTIP_HANKEL_SIMPLE', '1'), ('MTIP_HANKEL_WAVE_TILES', '1'),
                   ('MTIP_HANKEL_FLAT_ORDER', '1'), ('MTIP_SHT_FWD_PAIR', '0'),
-                  ('MTIP_PROJ_MFMA', '0'), ('MTIP_PROJ_FUSE', '0'), ('MTIP_JAC_CONC', '1'), ('MTIP_POLAR', 'newton')]
+                  ('MTIP_PROJ_MFMA', '0'), ('MTIP_PROJ_FUSE', '0'), ('MTIP_JAC_CONC', '0'), ('MTIP_JAC_CONC_MIN_K', '2'), ('MTIP_POLAR', 'newton')]
 
 
 @pytest.mark.parametrize('name,value', _TRAJ_SWITCHES)
@@ -188,7 +188,7 @@ def test_switch_short_trajectory_and_transforms(golden_mtip16, golden_ops, name,
     PC.check_transforms(32, 8, None, seed=5)
 
 
-@pytest.mark.parametrize('env', [{'MTIP_JAC_RESIDENT': '0'}, {'MTIP_JAC_TG': '8'}, {'MTIP_PROJ_MFMA': '0'}, {'MTIP_PROJ_FUSE': '0'}, {'MTIP_JAC_CONC': '1'},
+@pytest.mark.parametrize('env', [{'MTIP_JAC_RESIDENT': '0'}, {'MTIP_JAC_TG': '8'}, {'MTIP_PROJ_MFMA': '0'}, {'MTIP_PROJ_FUSE': '0'}, {'MTIP_JAC_CONC': '0'}, {'MTIP_JAC_CONC_MIN_K': '2'},
                                  {'MTIP_POLAR': 'newton'}, {'MTIP_POLAR': 'newton', 'MTIP_POLAR_VARIANT': '3'},
                                  {'MTIP_POLAR_ABS_TOL': '1e-14'}])
 def test_switch_projection_vs_oracle(env, monkeypatch):

@@ -377,10 +377,11 @@ struct __align__(16) JlRec {
 #define JL_NONE 0xffu
 __device__ __forceinline__ unsigned int jl_tag(int epoch) { return (unsigned int)(epoch % 32767) + 1u; }     // 1 .. 32767, never 0
 __device__ __forceinline__ unsigned int jl_hash(double cs, double wx, double wy, unsigned int meta, unsigned int slot, int epoch) {
-    unsigned int h = (unsigned int)__double2loint(cs) * 0x9E3779B1u ^ (unsigned int)__double2hiint(cs) * 0x85EBCA6Bu;
-    h ^= (unsigned int)__double2loint(wx) * 0xC2B2AE35u ^ (unsigned int)__double2hiint(wx) * 0x27D4EB2Fu;
-    h ^= (unsigned int)__double2loint(wy) * 0x165667B1u ^ (unsigned int)__double2hiint(wy) * 0xD3A2646Du;
-    h ^= meta * 0xFD7046C5u ^ slot * 0xB55A4F09u ^ (unsigned int)epoch * 0x2545F491u;
+    // a checksum, not a cipher: it has to expose a record assembled from two different writes (torn read, or the record the
+    // same slot held in an earlier call) -- a fold of all words with the slot and the call mixed in does that
+    unsigned int h = (unsigned int)__double2loint(cs) ^ ((unsigned int)__double2hiint(cs) * 3u) ^ ((unsigned int)__double2loint(wx) * 5u) ^
+                     ((unsigned int)__double2hiint(wx) * 7u) ^ ((unsigned int)__double2loint(wy) * 11u) ^ ((unsigned int)__double2hiint(wy) * 13u);
+    h ^= meta * 0x9E3779B1u + slot * 0x85EBCA6Bu + (unsigned int)epoch * 0xC2B2AE35u;
     return h ^ (h >> 15);
 }
 // agent-scope accesses: written through / read past the (per-XCD, mutually incoherent) L2
@@ -531,8 +532,18 @@ struct JacobiArgs {
 };
 
 // the workgroup of matrix (restart b, order_list[oy]); CONC: its rotation log is consumed while it is written (k_polar_conc)
+// static LDS of a Jacobi workgroup: declared once per kernel and handed to the body (k_polar_conc inlines the body twice; two
+// copies would push the launch past half a CU's LDS and halve the number of resident workgroups)
+template <int MAXT>
+struct JacShared {
+    double gmax[MAXT / 8];
+    double isig[128];
+    int perm[128];
+    int cont, keff;
+};
+
 template <int MAXR, int TG, int MAXT, bool LOGV, bool CONC>
-__device__ __forceinline__ void polar_jacobi_body(const JacobiArgs& A, int b, int oy, size_t mat) {
+__device__ __forceinline__ void polar_jacobi_body(const JacobiArgs& A, int b, int oy, size_t mat, JacShared<MAXT>& sh) {
     const double2* __restrict__ Xin_all = A.Xin_all;
     double2* __restrict__ Pn_all = A.Pn_all;
     double2* __restrict__ Vr_all = A.Vr_all;
@@ -549,11 +560,11 @@ __device__ __forceinline__ void polar_jacobi_body(const JacobiArgs& A, int b, in
     JlRec* __restrict__ log_all = A.log_all;
     int* __restrict__ log_rounds = A.log_rounds;
     HIP_DYNAMIC_SHARED(double2, sm)
-    __shared__ double s_gmax[MAXT / 8];
-    __shared__ double s_isig[128];
-    __shared__ int s_continue;
-    __shared__ int s_perm[128];
-    __shared__ int s_keff;
+    double* const s_gmax = sh.gmax;
+    double* const s_isig = sh.isig;
+    int* const s_perm = sh.perm;
+    int& s_continue = sh.cont;
+    int& s_keff = sh.keff;
     const int l = A.order_list[oy];
     if (!active[l]) {                                      // uniform per block
         if (CONC && threadIdx.x == 0)                       // (consumers of an inactive order return at once as well)
@@ -759,7 +770,8 @@ __device__ __forceinline__ void polar_jacobi_body(const JacobiArgs& A, int b, in
 // of EVERY restart is dispatched first -- these workgroups are the critical path of the launch
 template <int MAXR, int TG, int MAXT, bool LOGV>
 __global__ void __launch_bounds__(MAXT) k_polar_jacobi_lds(JacobiArgs A) {
-    polar_jacobi_body<MAXR, TG, MAXT, LOGV, false>(A, (int)blockIdx.x, (int)blockIdx.y, (size_t)blockIdx.y * gridDim.x + blockIdx.x);
+    __shared__ JacShared<MAXT> sh;
+    polar_jacobi_body<MAXR, TG, MAXT, LOGV, false>(A, (int)blockIdx.x, (int)blockIdx.y, (size_t)blockIdx.y * gridDim.x + blockIdx.x, sh);
 }
 
 // ---- V_r <- V_r R_1 R_2 ... : replay of the rotation log of k_polar_jacobi_lds<.., LOGV = true> ------------------------
@@ -929,14 +941,20 @@ __global__ void __launch_bounds__(JR_THREADS) k_jacobi_replay(const JlRec* __res
 // dispatched before any consumer; a consumer only ever waits for its producer, never the other way round, and gives up after
 // JR_POLL_LIMIT polls without progress (conc_err).  Records are validated by tag + hash, so no fence is needed anywhere.
 template <int MAXR, int TG, int MAXT>
-__global__ void __launch_bounds__(MAXT) k_polar_conc(JacobiArgs A) {
+__global__ void __launch_bounds__(MAXT) k_polar_conc(JacobiArgs A, int k_conc_min) {
     const int b = (int)blockIdx.x, oy = (int)blockIdx.y;
     const size_t mat = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
-    if (blockIdx.z == 0)
-        polar_jacobi_body<MAXR, TG, MAXT, true, true>(A, b, oy, mat);
-    else
+    // only the orders that set the duration of the launch (k_l >= k_conc_min) are split over producer + consumers; a small
+    // matrix is solved with V_r in its own workgroup as in k_polar_jacobi_lds, and has no consumers
+    const bool split = A.kl[A.order_list[oy]] >= k_conc_min;
+    __shared__ JacShared<MAXT> sh;
+    if (blockIdx.z == 0) {
+        if (split) polar_jacobi_body<MAXR, TG, MAXT, true, true>(A, b, oy, mat, sh);
+        else polar_jacobi_body<MAXR, TG, MAXT, false, false>(A, b, oy, mat, sh);
+    } else if (split) {
         jacobi_replay_body<32, MAXT, true>(A.log_all, A.log_rounds, A.Vr_all, A.kl, A.active, A.roff, A.rtot, A.warm, A.sched_ps,
                                            A.log_cap, A.order_list, b, oy, (int)blockIdx.z - 1, mat, A.epoch, A.conc_err);
+    }
 }
 
 // ---- register-tiled complex GEMMs around the polar factor ----------------------------------------------------
@@ -1669,7 +1687,8 @@ int launch_project_coefficients(mtip_ctx* c, const double2* Ilm, double2* out) {
         // row updates) when all pairs of a round still fit one workgroup, else 8
         const int tg = logv ? 16 : ((c->jac_tg == 16 && pairs_max * 16 <= JL_MAX_THREADS && nmax <= 5 * 16) ? 16 : 8);
         const size_t lds_pad = ((size_t)kmax * (div_up(nmax, tg) * tg + 1) + (logv ? 0 : (size_t)kmax * (div_up(kmax, tg) * tg + 1))) * sizeof(double2);
-        const int pad = lds_pad <= (logv ? 80 : 158) * 1024 ? 1 : 0;     // (log mode: stay below half a CU's LDS)
+        // (log mode: stay below half a CU's LDS; concurrent mode: unpadded columns, its small matrices keep V_r in the same LDS)
+        const int pad = (!conc && lds_pad <= (logv ? 80 : 158) * 1024) ? 1 : 0;
         const size_t lds_use = (pad ? lds_pad : (logv ? lds_x : lds)) + 16 * sizeof(double2);
         const bool use_sched = logv || (tg == 16 && sched_ok && c->jsched_ps * 16 <= JL_MAX_THREADS);
         int threads = (((use_sched ? c->jsched_ps : pairs_max) * tg + 63) / 64) * 64;
@@ -1725,7 +1744,15 @@ int launch_project_coefficients(mtip_ctx* c, const double2* Ilm, double2* out) {
             const size_t lds_c = ((size_t)rows_wg * (kmax | 1) + (size_t)JR_CHUNK * c->jsched_ps * 2) * sizeof(double2);
             const dim3 gc(gj.x, gj.y, 1u + (unsigned)div_up(kmax, rows_wg));
             const size_t lds_p = lds_use + (size_t)(kmax | 1) * c->jsched_ps * sizeof(int);      // X_l + the pairing table of a sweep
-            hipLaunchKernelGGL((k_polar_conc<5, 16, JL_MAX_THREADS>), gc, dim3(JL_MAX_THREADS), std::max(lds_p, lds_c), c->stream, ja);
+            const size_t lds_l = std::max(lds_p, lds_c);
+            // smallest order that is split: X_l and V_r of everything below it fit the launch's LDS together (unpadded columns)
+            int k_conc_min = 2;
+            while (k_conc_min < kmax && ((size_t)2 * (k_conc_min + 1) * ((k_conc_min + 1) | 1) + 16) * sizeof(double2) <= lds_l) ++k_conc_min;
+            // which orders to split: measured at 128 x L32 with three engines, only the largest pays (it sets the duration of the
+            // launch; every further order adds two spinning consumer workgroups that take CUs from the other engines' transforms)
+            k_conc_min = std::max(k_conc_min, c->jac_conc_min_k < 0 ? kmax : std::min(c->jac_conc_min_k, kmax));
+            c->conc_used = true;
+            hipLaunchKernelGGL((k_polar_conc<5, 16, JL_MAX_THREADS>), gc, dim3(JL_MAX_THREADS), lds_l, c->stream, ja, k_conc_min);
         } else if (logv) {
             if (nmax <= 5 * 16 && threads <= JL_MAX_THREADS) JL_LAUNCH(5, 16, JL_MAX_THREADS, true);
             else JL_LAUNCH(7, 16, 768, true);

@@ -128,6 +128,7 @@ mtip_ctx* mtip_create(const mtip_cfg* cfg, int device) {
     if (const char* e = std::getenv("MTIP_PROJ_MFMA")) c->proj_mfma = std::atoi(e) != 0;
     if (const char* e = std::getenv("MTIP_PROJ_FUSE")) c->proj_fuse = std::atoi(e) != 0;
     if (const char* e = std::getenv("MTIP_JAC_CONC")) c->jac_conc = std::atoi(e) != 0;
+    if (const char* e = std::getenv("MTIP_JAC_CONC_MIN_K")) c->jac_conc_min_k = std::atoi(e);
     if (const char* e = std::getenv("MTIP_DEG2_SIMPLE")) c->deg2_simple = std::atoi(e) != 0;
     if (const char* e = std::getenv("MTIP_HANKEL_SIMPLE")) c->hankel_simple = std::atoi(e) != 0;
     if (const char* e = std::getenv("MTIP_HANKEL_WAVE_TILES")) c->hankel_wave_tiles = std::atoi(e) != 0;
@@ -589,11 +590,21 @@ int mtip_run_async(mtip_ctx* c, int method, int ft_stab, int n_steps, const doub
     return post_launch(c, "mtip_run");
 }
 
+// after a synchronisation: did a consumer workgroup of the concurrent polar factor give up waiting for its rotation log?
+static int check_conc(mtip_ctx* c) {
+    if (!c->conc_used || c->d_conc_err == nullptr) return MTIP_OK;
+    int gave_up = 0;
+    MTIP_HIP_CHECK(c, mtip_copy(c, &gave_up, c->d_conc_err, sizeof(int), hipMemcpyDeviceToHost));
+    if (gave_up != 0) FAIL(c, MTIP_EHIP, "polar factor: a concurrent V_r replay workgroup gave up waiting for its rotation log");
+    return MTIP_OK;
+}
+
 int mtip_fetch_errors(mtip_ctx* c, int64_t first, int64_t n, double* real_err, double* deg2_err) {
     CTX_CHECK(c);
     if (first < 0 || n < 0 || first + n > c->n_steps_done) FAIL(c, MTIP_EINVAL, "step range out of bounds");
     (void)hipSetDevice(c->device);
     MTIP_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    if (int rc = check_conc(c)) return rc;
     if (real_err && n)
         MTIP_HIP_CHECK(c, mtip_copy(c, real_err, c->d_err_hist + (size_t)first * c->B, (size_t)n * c->B * sizeof(double), hipMemcpyDeviceToHost));
     if (deg2_err && n)
@@ -607,6 +618,7 @@ int mtip_fetch_main_errors(mtip_ctx* c, int64_t first, int64_t n, double* main_e
     if (first < 0 || n < 0 || first + n > c->n_steps_done || !main_err) FAIL(c, MTIP_EINVAL, "step range out of bounds / null output");
     (void)hipSetDevice(c->device);
     MTIP_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    if (int rc = check_conc(c)) return rc;
     const double* src = c->main_mode == 1 ? c->d_main_hist : c->d_err_hist;
     if (n) MTIP_HIP_CHECK(c, mtip_copy(c, main_err, src + (size_t)first * c->B, (size_t)n * c->B * sizeof(double), hipMemcpyDeviceToHost));
     return post_launch(c, "mtip_fetch_main_errors");
@@ -679,6 +691,7 @@ static int get_grid_slot(mtip_ctx* c, const double2* base, int batch, int which,
     int s = 0;
     int r = slot_of(c, batch, which == 0 ? SL_CUR : SL_BEST, &s);
     if (r) return r;
+    if (int rc = check_conc(c)) return rc;
     MTIP_HIP_CHECK(c, mtip_copy(c, out, base + ((size_t)s * c->B + batch) * c->G, c->G * sizeof(double2), hipMemcpyDeviceToHost));
     return MTIP_OK;
 }
@@ -740,6 +753,7 @@ int mtip_get_best_error(mtip_ctx* c, double* best, int64_t* n_steps_done) {
     CTX_CHECK(c);
     (void)hipSetDevice(c->device);
     MTIP_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    if (int rc = check_conc(c)) return rc;
     if (best) MTIP_HIP_CHECK(c, mtip_copy(c, best, c->d_best_err, c->B * sizeof(double), hipMemcpyDeviceToHost));
     if (n_steps_done) *n_steps_done = c->n_steps_done;
     return MTIP_OK;

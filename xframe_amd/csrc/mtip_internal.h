@@ -183,7 +183,9 @@ struct mtip_ctx {
     double2* d_Bref = nullptr;                        // (L+1, Nq, Nq) masked reference B_l
     double* d_Bnorm = nullptr;                        // (L+1)
     double* d_deg2_part = nullptr;                    // (B, L+1, (Nq/16)^2) per-tile partial sums of the B_l metric
-    bool jac_conc = false;                            // env MTIP_JAC_CONC=1: V_r of the polar factor on other CUs, concurrently (k_polar_conc)
+    int jac_conc_min_k = -1;                          // env MTIP_JAC_CONC_MIN_K: split the orders with at least this many columns (-1: the largest only)
+    bool jac_conc = true;                             // env MTIP_JAC_CONC=0: every matrix in one workgroup (no concurrent V_r replay, k_polar_conc)
+    bool conc_used = false;                           // a k_polar_conc launch has been made: d_conc_err is checked at the fetch points
     int* d_conc_err = nullptr;                        // consumers of k_polar_conc that gave up waiting (must stay 0)
     bool proj_fuse = true;                            // env MTIP_PROJ_FUSE=0: four separate projection products instead of the two fused pairs
     bool proj_mfma = true;                            // env MTIP_PROJ_MFMA=0: LDS-tiled VALU GEMMs for the projection products
