@@ -1744,13 +1744,21 @@ int launch_project_coefficients(mtip_ctx* c, const double2* Ilm, double2* out) {
             const size_t lds_c = ((size_t)rows_wg * (kmax | 1) + (size_t)JR_CHUNK * c->jsched_ps * 2) * sizeof(double2);
             const dim3 gc(gj.x, gj.y, 1u + (unsigned)div_up(kmax, rows_wg));
             const size_t lds_p = lds_use + (size_t)(kmax | 1) * c->jsched_ps * sizeof(int);      // X_l + the pairing table of a sweep
-            const size_t lds_l = std::max(lds_p, lds_c);
-            // smallest order that is split: X_l and V_r of everything below it fit the launch's LDS together (unpadded columns)
-            int k_conc_min = 2;
-            while (k_conc_min < kmax && ((size_t)2 * (k_conc_min + 1) * ((k_conc_min + 1) | 1) + 16) * sizeof(double2) <= lds_l) ++k_conc_min;
             // which orders to split: measured at 128 x L32 with three engines, only the largest pays (it sets the duration of the
             // launch; every further order adds two spinning consumer workgroups that take CUs from the other engines' transforms)
-            k_conc_min = std::max(k_conc_min, c->jac_conc_min_k < 0 ? kmax : std::min(c->jac_conc_min_k, kmax));
+            int k_conc_min = c->jac_conc_min_k < 0 ? kmax : std::max(2, std::min(c->jac_conc_min_k, kmax));
+            // the orders below it are solved with V_r in their own workgroup: X_l and V_r of the largest of them (unpadded columns)
+            // have to fit the launch's LDS
+            size_t lds_f = 0;
+            for (;;) {
+                int k_fused = 0;
+                for (int l = 0; l <= c->L; ++l)
+                    if (c->active[l] && c->kl[l] < k_conc_min) k_fused = std::max(k_fused, c->kl[l]);
+                lds_f = k_fused ? ((size_t)2 * k_fused * (k_fused | 1) + 16) * sizeof(double2) : 0;
+                if (lds_f <= 158 * 1024) break;
+                k_conc_min = k_fused;                            // does not fit: split that order as well
+            }
+            const size_t lds_l = std::max(std::max(lds_p, lds_c), lds_f);
             c->conc_used = true;
             hipLaunchKernelGGL((k_polar_conc<5, 16, JL_MAX_THREADS>), gc, dim3(JL_MAX_THREADS), lds_l, c->stream, ja, k_conc_min);
         } else if (logv) {
