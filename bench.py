@@ -335,7 +335,11 @@ def main():
                     # per pair, 32 n^3 per sweep (deflated columns are counted as if present: an upper bound of the work done)
                     flops = float((swp * (32.0 * ns ** 3)[None, :]).sum())
                     kname = 'polar (k_polar_jacobi_lds: one-sided Jacobi SVD in LDS, one workgroup per (restart, order))'
-                cus = int(min(Bp * int(active.sum()), e0_cus))
+                conc = (not newton) and os.environ.get('MTIP_JAC_CONC', '1') != '0'
+                if conc:
+                    kname = ('polar (k_polar_conc: one-sided Jacobi SVD in LDS, one workgroup per (restart, order); the V_r half of the largest '
+                             'order on two more workgroups, concurrently)')
+                cus = int(min(Bp * (int(active.sum()) + (2 if conc else 0)), e0_cus))
                 peak = cus * 4 * 32 * 2.4e9 / 1e12                                # FP64 vector: 32 flop / clk / SIMD at 2.4 GHz
                 ach = flops / (fam_ms['polar']['avg_ms'] * 1e-3) / 1e12
                 roofline = {'bound': 'fp64_valu', 'kernel': kname,
