@@ -15,13 +15,6 @@ EMUL_DIR = os.path.join(HERE, 'emul')
 EMUL_LIB = os.path.join(EMUL_DIR, 'libmtip_emul.so')
 
 
-@pytest.fixture(autouse=True)
-def _one_workgroup_polar_factor(monkeypatch):
-    """The concurrent V_r replay (default on the GPU) makes consumer workgroups poll for their producer: on the emulation's host
-    threads that doubles the run time of this module, so only the tests that are about it switch it on."""
-    monkeypatch.setenv('MTIP_JAC_CONC', '0')
-
-
 @pytest.fixture(scope='session')
 def emul_lib():
     r = subprocess.run(['make', '-C', EMUL_DIR, '-j6'], capture_output=True, text=True)
