@@ -377,12 +377,11 @@ struct __align__(16) JlRec {
 #define JL_NONE 0xffu
 __device__ __forceinline__ unsigned int jl_tag(int epoch) { return (unsigned int)(epoch % 32767) + 1u; }     // 1 .. 32767, never 0
 __device__ __forceinline__ unsigned int jl_hash(double cs, double wx, double wy, unsigned int meta, unsigned int slot, int epoch) {
-    // a checksum, not a cipher: it has to expose a record assembled from two different writes (torn read, or the record the
-    // same slot held in an earlier call) -- a fold of all words with the slot and the call mixed in does that
-    unsigned int h = (unsigned int)__double2loint(cs) ^ ((unsigned int)__double2hiint(cs) * 3u) ^ ((unsigned int)__double2loint(wx) * 5u) ^
-                     ((unsigned int)__double2hiint(wx) * 7u) ^ ((unsigned int)__double2loint(wy) * 11u) ^ ((unsigned int)__double2hiint(wy) * 13u);
-    h ^= meta * 0x9E3779B1u + slot * 0x85EBCA6Bu + (unsigned int)epoch * 0xC2B2AE35u;
-    return h ^ (h >> 15);
+    // a checksum, not a cipher: it has to expose a record assembled from two different writes (a torn read, or the record the
+    // same slot held in an earlier call): a stale word changes the XOR unless it equals the new one; slot and call are mixed in
+    return (unsigned int)__double2loint(cs) ^ (unsigned int)__double2hiint(cs) ^ (unsigned int)__double2loint(wx) ^
+           (unsigned int)__double2hiint(wx) ^ (unsigned int)__double2loint(wy) ^ (unsigned int)__double2hiint(wy) ^ meta ^
+           (slot * 0x9E3779B1u + (unsigned int)epoch * 0x85EBCA6Bu);
 }
 // agent-scope accesses: written through / read past the (per-XCD, mutually incoherent) L2
 __device__ __forceinline__ void st_agent(unsigned long long* p, unsigned long long v) {
