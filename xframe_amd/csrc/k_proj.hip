@@ -782,7 +782,7 @@ __global__ void __launch_bounds__(MAXT) k_polar_jacobi_lds(JacobiArgs A) {
 #define JR_THREADS 256
 #define JR_RPL 2
 #define JR_CHUNK 16
-#define JR_POLL_LIMIT 200000        // concurrent mode: polls (~2 us each) without a new round before a consumer gives up
+#define JR_POLL_LIMIT 2000000       // concurrent mode: polls (~2 us each, i.e. seconds) without a new round before a consumer gives up
 
 // NT threads; CONC: the log is being written by the Jacobi workgroup of the same launch (k_polar_conc) -- rounds are taken as
 // their records become valid (tag + hash, agent-scope loads), the end is the producer's round count in log_rounds
