@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU box: concurrent V_r replay A/B (default split: the largest order) + parity of the 128 x L32 trajectory
 set -e
-timeout -k 10 500 python scripts/debug_conc_trajectory.py 2>&1 | tail -5 | tee gpurun_out/r2_conc_debug.txt
+timeout -k 10 500 python tests/tools/debug_conc_trajectory.py 2>&1 | tail -5 | tee gpurun_out/r2_conc_debug.txt
 out=gpurun_out/r2_jac_conc9.txt
 : > $out
 for f in 1 0 1 0; do

@@ -7,7 +7,7 @@ reference's `average` worker; it is printed for information):
 usage (GPU box): python scripts/convergence_vs_oracle.py [config=3] [oracle_restarts=1]"""
 import os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 np.seterr(all='ignore')
 from xframe_amd.fxs import synthetic as S, hostsetup as hs, reconstruct as R

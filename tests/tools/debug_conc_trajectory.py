@@ -1,3 +1,5 @@
+"""Checker (test infrastructure, uses the oracle): the 128 x L32 short trajectory against the oracle under the polar-factor modes --
+MTIP_JAC_CONC 0 / 1, every order split, serial rotation log.  Run on the GPU box: python tests/tools/debug_conc_trajectory.py"""
 import os, sys
 sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
 import numpy as np
