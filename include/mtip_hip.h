@@ -167,6 +167,11 @@ int mtip_op_hankel(mtip_ctx* ctx, const mtip_cdouble* coeff_in, mtip_cdouble* co
 int mtip_op_fourier_transform(mtip_ctx* ctx, const mtip_cdouble* grid_in, mtip_cdouble* grid_out, int inverse);
 /* approximate_unknowns + mtip_projection (fxs_Projections.py:752-767, 832-872) on 'direct' coefficients */
 int mtip_op_project_coefficients(mtip_ctx* ctx, const mtip_cdouble* Ilm, mtip_cdouble* Ilm_projected);
+/* the same for coefficients of a REAL intensity, I_{l,-m} = (-1)^m conj(I_{l,m}) -- what the phasing loop always passes
+ * (reconstruct.py:866-870: SHT of |F|^2).  Only the m >= 0 half is read.  With real projection matrices (the reference's
+ * are: fxs_invariant_tools.py:1255, 1207) the polar factors are then computed in real arithmetic; any other case takes the
+ * general path of mtip_op_project_coefficients.  Same result as that function to rounding. */
+int mtip_op_project_real_intensity(mtip_ctx* ctx, const mtip_cdouble* Ilm, mtip_cdouble* Ilm_projected);
 /* mtip_projection with caller-supplied unknowns (fxs_Projections.py:832-849, 866-871; registry operator
  * 'mtip_projection(Ilm, unknowns)', reconstruct.py:391): U = per restart the concatenation over l = 0..L of the
  * row-major (min(2l+1, Nq), 2l+1) blocks, i.e. the layout mtip_get_unknowns reads order by order */

@@ -452,6 +452,44 @@ def check_projection_vs_oracle(N, L, lib_path=None, n_batch=2, seed=1):
     e.close()
 
 
+def check_projection_real_vs_oracle(N, L, lib_path=None, n_batch=2, seed=1, reciprocal_opt=None):
+    """The real-arithmetic form of the projection (k_projr.hip: real V_l, coefficients of a real intensity) against the
+    oracle's complex numpy-SVD route (fxs_Projections.py:752-767, 832-871): projected coefficients, unknowns, and the
+    general (complex) kernel on the same input; second call = warm start."""
+    from oracle.fourier import FourierPair
+    from oracle.sht import SHT
+    from helpers import OracleTransforms
+    sht = SHT(L)
+    fpd = FourierPair(sht, N, S.data_cutoff(N), 2.0)
+    data, _ = S.make_invariants(OracleTransforms(fpd), N, L)
+    assert all(np.all(np.asarray(p).imag == 0) for p in data['data_projection_matrices'])
+    opt = golden_settings(N, L, {'projections': {'reciprocal': reciprocal_opt}} if reciprocal_opt else None)
+    e = Engine(opt, data, n_batch=n_batch, lib_path=lib_path)
+    om = OM.MTIP(opt, data)
+    rng = np.random.default_rng(seed)
+    for rep in range(3):                                   # later calls: warm start from the previous V_r
+        grid = rng.uniform(0.0, 1.0, (n_batch, N, sht.n_theta, sht.n_phi)) * rng.uniform(0.5, 2.0, (n_batch, N, 1, 1))
+        Ilm = np.stack([np.concatenate(sht.forward_l(g.astype(complex)), axis=1) for g in grid])
+        proj = e.project_coefficients(Ilm, real_intensity=True)
+        unk_hip = [e.unknowns(b) for b in range(n_batch)]
+        proj_c = e.project_coefficients(Ilm)
+        for b in range(n_batch):
+            Il = [Ilm[b][:, l * l:(l + 1) ** 2] for l in range(L + 1)]
+            unk = om.rp.approximate_unknowns(Il)
+            ref = np.concatenate(om.rp.mtip_projection(Il, unk), axis=1)
+            assert rel_l2(proj[b], ref) < TOL_SHT, (rep, b, rel_l2(proj[b], ref))
+            assert rel_l2(proj[b], proj_c[b]) < TOL_SHT, (rep, b)
+            for i, l in enumerate(om.rp.used_orders.values()):
+                # compared through V_l U_l (the unknowns themselves are only defined up to the null space of V_l)
+                V = om.rp.projection_matrices[l]
+                if np.abs(V).max() == 0:
+                    continue
+                assert rel_l2(V @ unk_hip[b][l], V @ unk[i]) < TOL_SHT, (rep, b, l)
+    sw = e.jacobi_sweeps() if hasattr(e, 'jacobi_sweeps') else None
+    e.close()
+    return sw
+
+
 def check_config_trajectory_vs_oracle(cfg, lib_path=None, fused=True, n_hio=10, n_er=10):
     """BASELINE config sizes the oracle still walks in seconds (config 2: 64 x L16): n_hio HIO + SW + n_er ER ft_stab
     steps of the product worker against the oracle's phasing loop on the same synthetic invariants and the same seeded

@@ -159,6 +159,13 @@ def test_extract_vs_numpy(emul_lib):
     PC.check_extract_vs_numpy(emul_lib, N=12, L=4)
 
 
+@pytest.mark.parametrize('N,L,ropt', [(16, 4, None), (24, 10, None), (16, 4, {'odd_orders_to_0': False, 'use_averaged_intensity': False}),
+                                      (16, 4, {'used_order_ids': np.arange(3)})])
+def test_projection_real_vs_oracle(emul_lib, N, L, ropt):
+    """the real-arithmetic projection kernel (k_projr.hip) on the emulator"""
+    PC.check_projection_real_vs_oracle(N, L, emul_lib, n_batch=1, reciprocal_opt=ropt)
+
+
 def test_wide_projection_matrices(emul_lib):
     """k_l = Nq < 2l+1 (the reference's integration test uses 8 radial points with max_order 15,
     tests/test_fxs_integration.py:326-355): polar factor of a wide matrix, compared through V_l U_l."""

@@ -99,6 +99,19 @@ def test_projection_vs_oracle_sizes(N, L):
     PC.check_projection_vs_oracle(N, L)
 
 
+@pytest.mark.parametrize('N,L', [(16, 4), (40, 18), (66, 32), (128, 32), (100, 48)])
+def test_projection_real_vs_oracle(N, L):
+    """k_rproj (real V_l, coefficients of a real intensity: what the phasing loop runs) against the oracle's complex SVD route
+    and against the general complex kernel; (128, 32): the benchmark's matrices, (100, 48): config 5's 97 x 97 (768 threads,
+    pairing table read from L2)"""
+    PC.check_projection_real_vs_oracle(N, L)
+
+
+@pytest.mark.parametrize('ropt', [{'odd_orders_to_0': False}, {'use_averaged_intensity': False}, {'used_order_ids': np.arange(3)}])
+def test_projection_real_option_variants(ropt):
+    PC.check_projection_real_vs_oracle(24, 10, reciprocal_opt=ropt)
+
+
 @pytest.mark.parametrize('N,L', [(40, 18), (66, 32), (72, 34)])
 def test_projection_vs_oracle_newton_polar(N, L, monkeypatch):
     """MTIP_POLAR=newton: scaled-Newton polar factor (k_polar.hip) with one row slot (2l+1 <= 37), with the benchmark's

@@ -1,0 +1,647 @@
+// Reciprocal-space projection for REAL projection matrices (rows a8, a9 of SURVEY section 8), one kernel per call.
+//   approximate_unknowns  xframe/projects/fxs/projectLibrary/fxs_Projections.py:752-767   U_l = u @ vh of svd(V_l^+ D^2 I_l)
+//   mtip_projection       fxs_Projections.py:832-849, 866-871                             I'_l[mask] = (V_l U_l)[mask], l = 0 rules
+//
+// The reference's V_l are real: B_l is made real before its eigen-decomposition (fxs_invariant_tools.py:1255, 1114-1141,
+// scipy eigh of a real symmetric matrix) and stored `astype(complex)` (1207).  I_lm are the coefficients of the REAL
+// intensity |F|^2, so I_{l,-m} = (-1)^m conj(I_{l,m}).  Then M = V_l^T D^2 I_l (k x (2l+1), complex) is unitarily equivalent
+// to a REAL matrix: with the unitary T that maps the column pair (m, -m) to (sqrt2 Re, sqrt2 Im) of column m,
+//   M~ = M T,   M~[:, rho'] = sum_q V[q, :] q^2 I~[q, rho'],   I~[q, .] = (Re I_l0, 0, sqrt2 Re I_l1, sqrt2 Im I_l1, ...)
+// (rho' = 2m + part; the slot rho' = 1, "Im I_l0", is identically zero and kept so that (Re, Im) pairs sit in lane pairs),
+// and polar(M) = polar(M~) T^+ exactly: the polar factor is unique and T unitary.  Everything is real arithmetic:
+// a third of the flops of the complex one-sided Jacobi and half its LDS, and the four products around it are real GEMMs.
+//
+// One workgroup per (restart, slot); a slot is a short list of orders solved one after the other (host-packed so that every
+// slot costs about as much as the largest order alone: 9 workgroups per restart at L = 32 instead of 18 CU-filling ones).
+// Per order, all in LDS:
+//   A  X~^T[j][rho'] = sum_q (q^2 V)[q][j] I~[q][rho']         f64 MFMA, fragments straight from L2
+//   W  warm start: X~ <- X~ V_r(previous step)                  f64 MFMA from LDS (rows of X~ transform independently)
+//   J  one-sided Jacobi on the columns of X~ (n' x k) and V_r  (resident-column ordering, schedule of k_proj.hip)
+//   U  U~^T[rho'][i] = sum_c X~[rho'][c] / sigma_c V_r[i][c]    (-> complex U_l for the unknowns output)
+//   E  I~'[q][rho'] = sum_i V[q][i] U~^T[rho'][i] -> I'_{l,+-m}(q) on the masked shells, in place on the coefficients
+#include "mtip_internal.h"
+#include "k_jacobi.h"
+
+#define RP_MAX_THREADS 768
+#define RP_SLACK 128            // doubles behind the matrices: predicated-off lanes of the last row slot still form addresses
+#define RP_ACC 7                // 16 x 16 output tiles a wave may hold across a barrier (in-place products)
+
+struct RpShared {
+    double gmax[RP_MAX_THREADS / 16];
+    double isig[128];
+    int perm[128];
+    int cont, keff;
+    double red[RP_MAX_THREADS / 64];
+};
+
+// rotation [a b] <- [a b] [[c, w], [-w, c]] that annihilates gamma = a.b (smaller angle); false: already orthogonal
+__device__ __forceinline__ bool rp_params(double alpha, double beta, double g, bool valid, double tabs2, double S, bool& big,
+                                          double& cs, double& w) {
+    const double g2 = g * g;
+    const double ab = alpha * beta;
+    if (!(valid && g2 > (JAC_TOL * JAC_TOL) * ab && g2 > tabs2 * fmax(alpha, beta) * S && g2 > 0.0)) return false;
+    big = big || (g2 > (JL_EARLY * JL_EARLY) * ab);
+    // d = (beta - alpha)/2, h = sqrt(d^2 + g^2):  c^2 = (1 + |d|/h)/2,  w = sign(d) g / (2 h c)
+    const double d = 0.5 * (beta - alpha);
+    const double ih = fast_rsqrt(fma(d, d, g2));
+    const double c2 = fma(0.5 * fabs(d), ih, 0.5);
+    const double rc = fast_rsqrt(c2);
+    cs = c2 * rc;
+    w = ((d >= 0.0 ? 0.5 : -0.5) * ih * rc) * g;
+    return true;
+}
+
+// One sweep in the resident-column ordering (see jl_sweep_resident in k_proj.hip): 16 lanes per column pair, NR row slots per
+// lane for X~ and for V_r; the resident column of a group stays in registers over a phase, the mover goes through LDS.
+template <int NR>
+__device__ __forceinline__ void rp_sweep(double* Xs, double* Vs, int ns, int ks, int t, int group, const int* tab, int n_rounds,
+                                         int ps, const int* s_perm, bool xl_ok, bool vl_ok, double tabs2, double S, bool& big) {
+    double rx[NR], rv[NR];
+#pragma unroll
+    for (int u = 0; u < NR; ++u) {
+        rx[u] = 0.0;
+        rv[u] = 0.0;
+    }
+    int cur = -1;
+    bool dirty = false;
+    int e_next = (group < ps && n_rounds > 0) ? tab[group] : 0;
+    int pr_next = s_perm[(e_next & JS_ACTIVE) ? (e_next & 255) : 0], pm_next = s_perm[(e_next & JS_ACTIVE) ? ((e_next >> 8) & 255) : 0];
+    for (int r = 0; r < n_rounds; ++r) {
+        const int e = e_next;
+        const int pr = pr_next, pm = pm_next;
+        if (r + 1 < n_rounds && group < ps) e_next = tab[(size_t)(r + 1) * ps + group];
+        const bool act = (e & JS_ACTIVE) != 0;
+        const int res = act ? (e & 255) : 0;
+        double* xh = Xs + (size_t)pr * ns + t;
+        double* vh = Vs + (size_t)pr * ks + t;
+        double* xm = Xs + (size_t)pm * ns + t;
+        double* vm = Vs + (size_t)pm * ks + t;
+        double mx[NR], mv[NR];
+#pragma unroll
+        for (int u = 0; u < NR; ++u) {
+            mx[u] = 0.0;
+            mv[u] = 0.0;
+        }
+        if (act) {
+#pragma unroll
+            for (int u = 0; u < NR; ++u) {
+                mx[u] = xm[u * 16];
+                mv[u] = vm[u * 16];
+            }
+            if (res != cur) {
+#pragma unroll
+                for (int u = 0; u < NR; ++u) {
+                    rx[u] = xh[u * 16];
+                    rv[u] = vh[u * 16];
+                }
+                if (!xl_ok) rx[NR - 1] = 0.0;
+                cur = res;
+                dirty = false;
+            }
+            if (!xl_ok) mx[NR - 1] = 0.0;
+        }
+        double alpha = 0.0, beta = 0.0, g = 0.0, zero = 0.0;
+#pragma unroll
+        for (int u = 0; u < NR; ++u) {
+            alpha = fma(rx[u], rx[u], alpha);
+            beta = fma(mx[u], mx[u], beta);
+            g = fma(rx[u], mx[u], g);
+        }
+        group_sum4<16>(alpha, beta, g, zero);          // (run by every group, active or not: uniform control flow around DPP)
+        double cs = 1.0, w = 0.0;
+        const bool rot = rp_params(alpha, beta, g, act, tabs2, S, big, cs, w);
+        if (rot) {
+#pragma unroll
+            for (int u = 0; u < NR; ++u) {
+                const double a = rx[u], bq = mx[u];
+                rx[u] = fma(-w, bq, cs * a);
+                const double bn = fma(w, a, cs * bq);
+                if (u < NR - 1 || xl_ok) xm[u * 16] = bn;
+            }
+#pragma unroll
+            for (int u = 0; u < NR; ++u) {
+                const double a = rv[u], bq = mv[u];
+                rv[u] = fma(-w, bq, cs * a);
+                const double bn = fma(w, a, cs * bq);
+                if (u < NR - 1 || vl_ok) vm[u * 16] = bn;
+            }
+            dirty = true;
+        }
+        if (act && (e & JS_WB)) {                      // someone else takes this column next round
+            if (dirty) {
+#pragma unroll
+                for (int u = 0; u < NR; ++u) {
+                    if (u < NR - 1 || xl_ok) xh[u * 16] = rx[u];
+                    if (u < NR - 1 || vl_ok) vh[u * 16] = rv[u];
+                }
+            }
+            cur = -1;
+        }
+        pr_next = s_perm[(e_next & JS_ACTIVE) ? (e_next & 255) : 0];
+        pm_next = s_perm[(e_next & JS_ACTIVE) ? ((e_next >> 8) & 255) : 0];
+        __syncthreads();
+    }
+}
+
+struct RProjArgs {
+    double* coef;                 // (B, N, nlm) complex128 coefficients viewed as doubles; projected in place
+    const double* DV;             // per order at voff[l]: (N x k) row-major, q^2 V_l[q][j]
+    const double* Vt;             // per order at voff[l]: (k x N) row-major, V_l[q][i] transposed
+    double* Vr;                   // (B, utot) right singular vectors, column-major k x k per order at uoff[l] (warm start)
+    double2* U;                   // (B, xtot) complex unknowns U_l (k x (2l+1) row-major) at xoff[l]: the output dict's fxs_unknowns
+    const uint8_t* rmask;         // (L+1, N)
+    const int *kl, *voff, *uoff, *xoff;
+    const int* slots;             // (n_slots, slot_len): order | kind << 8, -1 = none
+    int slot_len;
+    const int *sched, *sched_off, *sched_rounds;
+    int sched_ps, tab_in_lds;
+    int N, L, nlm, utot, xtot, warm;
+    double tabs2, inv_sqrt_np;
+    int* sweeps_out;
+};
+
+enum { RP_SOLVE = 0, RP_ZERO = 1, RP_L0 = 2 };
+
+// acc = sum_{kk < K} A(row, kk) B(kk, col) for one 16 x 16 tile; v_mfma_f64_16x16x4: A[i = lane & 15][kk = lane >> 4],
+// B[kk = lane >> 4][j = lane & 15], D reg r = D[(lane >> 4) + 4 r][lane & 15].  A / B return 0 outside their ranges.
+template <int UNR, class FA, class FB>
+__device__ __forceinline__ v4f64 rp_tile(int K, FA A, FB Bf, int lane) {
+    const int li = lane & 15, lk = lane >> 4;
+    v4f64 acc = v4f64{0.0, 0.0, 0.0, 0.0};
+    for (int k0 = 0; k0 < K; k0 += 4 * UNR) {
+        double a[UNR], bb[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int kk = k0 + 4 * u + lk;
+            a[u] = A(li, kk);
+            bb[u] = Bf(kk, li);
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], bb[u], acc, 0, 0, 0);
+    }
+    return acc;
+}
+
+// value of the partner lane (lane ^ 1): the (Re, Im) parts of one m sit in neighbouring lanes
+__device__ __forceinline__ double rp_partner(double v) { return dpp_mov<0xB1>(v); }
+
+// the active order l of restart b: products, Jacobi, apply
+template <int DUMMY>
+__device__ __forceinline__ void rp_solve(const RProjArgs& A, int b, int l, RpShared& sh, double* sm) {
+    const int tid = threadIdx.x, nthreads = blockDim.x;
+    const int lane = tid & 63, wave = tid >> 6, nwaves = nthreads >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int N = A.N, k = A.kl[l], n = 2 * l + 1, n2 = 2 * l + 2;
+    const int nr = (n2 + 15) >> 4;                       // row slots per lane (the same for the k rows of V_r: k = 2l+1)
+    const int ns = n2 | 1, ks = k | 1;                   // odd column strides
+    double* Xs = sm;
+    double* Vs = sm + (size_t)k * ns;
+    int* s_tab = reinterpret_cast<int*>(Vs + (size_t)k * ks + RP_SLACK);
+    const double* DV = A.DV + A.voff[l];
+    const double* Vt = A.Vt + A.voff[l];
+    double* coef = A.coef + ((size_t)b * N * A.nlm + (size_t)l * (l + 1)) * 2;    // (Re, Im) of m = 0 on shell 0
+    const size_t cstride = (size_t)A.nlm * 2;                                   // doubles between shells
+    double* Vr = A.Vr + (size_t)b * A.utot + A.uoff[l];
+    const int ntm_k = (k + 15) >> 4, ntn = (n2 + 15) >> 4;
+    // ---- A: X~^T[j][rho'] = sum_q DV[q][j] I~[q][rho'] -> Xs[j * ns + rho'] ------------------------------------------
+    for (int tile = wave; tile < ntm_k * ntn; tile += nwaves) {
+        const int tm = tile / ntn, tn = tile - tm * ntn;
+        const int j = tm * 16 + li, rho = tn * 16 + li;
+        const bool j_ok = j < k, rho_ok = rho < n2;
+        const double* ap = DV + (j_ok ? j : 0);
+        const double* bp = coef + (rho_ok ? rho : 0);
+        const v4f64 acc = rp_tile<8>(N, [&](int, int q) { const double v = ap[(size_t)(q < N ? q : 0) * k]; return (j_ok && q < N) ? v : 0.0; },
+                                     [&](int q, int) { const double v = bp[(size_t)(q < N ? q : 0) * cstride]; return (rho_ok && q < N) ? v : 0.0; }, lane);
+        const double f = rho == 1 ? 0.0 : (rho >= 2 ? 1.4142135623730951 : 1.0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int jj = tm * 16 + lk + 4 * r;
+            if (jj < k && rho_ok) Xs[(size_t)jj * ns + rho] = f * acc[r];
+        }
+    }
+    // V_r: the previous step's right singular vectors (warm start) or the identity
+    for (int e = tid; e < k * ks; e += nthreads) {
+        const int cc = e / ks, i = e - cc * ks;
+        double v = 0.0;
+        if (i < k) v = A.warm ? Vr[(size_t)cc * k + i] : (cc == i ? 1.0 : 0.0);
+        Vs[e] = v;
+    }
+    __syncthreads();
+    // ---- W: X~ <- X~ V_r:  D[c][rho'] = sum_j V_r[j][c] X~[rho'][j]  (held in registers until every wave has read X~) --
+    if (A.warm) {
+        v4f64 acc[RP_ACC];
+#pragma unroll
+        for (int u = 0; u < RP_ACC; ++u) {
+            const int tile = wave + u * nwaves;
+            acc[u] = v4f64{0.0, 0.0, 0.0, 0.0};
+            if (tile < ntm_k * ntn) {
+                const int tm = tile / ntn, tn = tile - tm * ntn;
+                const int cc = tm * 16 + li, rho = tn * 16 + li;
+                const bool c_ok = cc < k, rho_ok = rho < n2;
+                const double* ap = Vs + (size_t)(c_ok ? cc : 0) * ks;
+                const double* bp = Xs + (rho_ok ? rho : 0);
+                acc[u] = rp_tile<4>(k, [&](int, int jx) { const double v = ap[jx < k ? jx : 0]; return (c_ok && jx < k) ? v : 0.0; },
+                                    [&](int jx, int) { const double v = bp[(size_t)(jx < k ? jx : 0) * ns]; return (rho_ok && jx < k) ? v : 0.0; }, lane);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < RP_ACC; ++u) {
+            const int tile = wave + u * nwaves;
+            if (tile < ntm_k * ntn) {
+                const int tm = tile / ntn, tn = tile - tm * ntn;
+                const int rho = tn * 16 + li;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int cc = tm * 16 + lk + 4 * r;
+                    if (cc < k && rho < n2) Xs[(size_t)cc * ns + rho] = acc[u][r];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // ---- J: one-sided Jacobi sweeps ------------------------------------------------------------------------------------
+    const int ngroups = nthreads >> 4;
+    const int group = tid >> 4, t = tid & 15;
+    const bool xl_ok = t + (nr - 1) * 16 < n2, vl_ok = t + (nr - 1) * 16 < k;
+    double S = 0.0;
+    if (k > 1) {
+        int tab_ke = -1;
+        for (int sweep = 0; sweep < JAC_MAX_SWEEPS; ++sweep) {
+            // column norms; deflation of numerical-zero columns (k_proj.hip: X is numerically rank deficient once the
+            // density has a support) and compaction of the tournament to the columns that are left
+            double Sl = 0.0;
+            for (int cc0 = 0; cc0 < k; cc0 += ngroups) {
+                const int cc = cc0 + group;
+                double s2 = 0.0;
+                if (cc < k)
+                    for (int u = 0; u < nr; ++u)
+                        if (t + u * 16 < n2) {
+                            const double x = Xs[(size_t)cc * ns + t + u * 16];
+                            s2 = fma(x, x, s2);
+                        }
+                s2 = group_sum<16>(s2);
+                if (cc < k && t == 0) sh.isig[cc] = s2;
+                Sl = fmax(Sl, s2);
+            }
+            if (t == 0) sh.gmax[group] = Sl;
+            __syncthreads();
+            S = 0.0;
+            for (int gq = 0; gq < ngroups; ++gq) S = fmax(S, sh.gmax[gq]);
+            for (int cc0 = 0; cc0 < k; cc0 += ngroups) {
+                const int cc = cc0 + group;
+                if (cc < k && sh.isig[cc] <= (JAC_DEFLATE * JAC_DEFLATE) * S && sh.isig[cc] > 0.0)
+                    for (int u = 0; u < nr; ++u)
+                        if (t + u * 16 < n2) Xs[(size_t)cc * ns + t + u * 16] = 0.0;
+            }
+            if (tid < 64) {                                    // wave 0: ballot + prefix popcount (k <= 128)
+                const double thr = (JAC_DEFLATE * JAC_DEFLATE) * S;
+                const bool a0 = tid < k && sh.isig[tid] > thr;
+                const bool a1 = tid + 64 < k && sh.isig[tid + 64] > thr;
+                const unsigned long long m0 = __ballot(a0), m1 = __ballot(a1);
+                const unsigned long long below = (1ull << tid) - 1ull;
+                if (a0) sh.perm[__popcll(m0 & below)] = tid;
+                if (a1) sh.perm[__popcll(m0) + __popcll(m1 & below)] = tid + 64;
+                if (tid == 0) sh.keff = __popcll(m0) + __popcll(m1);
+            }
+            __syncthreads();
+            const int ke = sh.keff;
+            bool big = false;
+            if (ke >= 2) {
+                const int* tab = A.sched + A.sched_off[ke];
+                const int nrd = A.sched_rounds[ke];
+                if (A.tab_in_lds) {                            // the pairing table of this column count, staged once
+                    if (tab_ke != ke) {
+                        for (int e = tid; e < nrd * A.sched_ps; e += nthreads) s_tab[e] = tab[e];
+                        tab_ke = ke;
+                        __syncthreads();
+                    }
+                    tab = s_tab;
+                }
+#define RP_SWEEP(NR) rp_sweep<NR>(Xs, Vs, ns, ks, t, group, tab, nrd, A.sched_ps, sh.perm, xl_ok, vl_ok, A.tabs2, S, big)
+                switch (nr) {
+                case 1: RP_SWEEP(1); break;
+                case 2: RP_SWEEP(2); break;
+                case 3: RP_SWEEP(3); break;
+                case 4: RP_SWEEP(4); break;
+                case 5: RP_SWEEP(5); break;
+                case 6: RP_SWEEP(6); break;
+                default: RP_SWEEP(7); break;
+                }
+#undef RP_SWEEP
+            }
+            if (t == 0) sh.gmax[group] = big ? 1.0 : 0.0;
+            __syncthreads();
+            if (tid == 0) {
+                double m = 0.0;
+                for (int gq = 0; gq < ngroups; ++gq) m = fmax(m, sh.gmax[gq]);
+                sh.cont = (m > 0.0) ? 1 : 0;                   // quadratic convergence: see JL_EARLY
+                A.sweeps_out[b * (A.L + 1) + l] = (sweep + 1) | (ke << 8);
+            }
+            __syncthreads();
+            const int cont = sh.cont;
+            __syncthreads();
+            if (!cont) break;
+        }
+    } else if (tid == 0) {
+        A.sweeps_out[b * (A.L + 1) + l] = 0 | (k << 8);
+    }
+    // ---- sigma_c; V_r for the next call -----------------------------------------------------------------------------------
+    for (int cc0 = 0; cc0 < k; cc0 += ngroups) {               // uniform trip count: DPP sums need the whole group
+        const int cc = cc0 + group;
+        double s2 = 0.0;
+        if (cc < k)
+            for (int u = 0; u < nr; ++u)
+                if (t + u * 16 < n2) {
+                    const double x = Xs[(size_t)cc * ns + t + u * 16];
+                    s2 = fma(x, x, s2);
+                }
+        s2 = group_sum<16>(s2);
+        if (cc < k && t == 0) sh.isig[cc] = s2 > 1e-300 ? 1.0 / sqrt(s2) : 0.0;
+    }
+    for (int e = tid; e < k * k; e += nthreads) {
+        const int cc = e / k, i = e - cc * k;
+        Vr[e] = Vs[(size_t)cc * ks + i];
+    }
+    __syncthreads();
+    // ---- U: U~^T[rho'][i] = sum_c (X~[rho'][c] / sigma_c) V_r[i][c]:  D[i][rho'] -> Xs[i * ns + rho'], complex U_l -> A.U ----
+    {
+        double2* Uo = A.U + (size_t)b * A.xtot + A.xoff[l];
+        v4f64 acc[RP_ACC];
+#pragma unroll
+        for (int u = 0; u < RP_ACC; ++u) {
+            const int tile = wave + u * nwaves;
+            acc[u] = v4f64{0.0, 0.0, 0.0, 0.0};
+            if (tile < ntm_k * ntn) {
+                const int tm = tile / ntn, tn = tile - tm * ntn;
+                const int i = tm * 16 + li, rho = tn * 16 + li;
+                const bool i_ok = i < k, rho_ok = rho < n2;
+                const double* ap = Vs + (i_ok ? i : 0);
+                const double* bp = Xs + (rho_ok ? rho : 0);
+                acc[u] = rp_tile<4>(k, [&](int, int cx) { const double v = ap[(size_t)(cx < k ? cx : 0) * ks]; return (i_ok && cx < k) ? v : 0.0; },
+                                    [&](int cx, int) {
+                                        const int cq = cx < k ? cx : 0;
+                                        const double v = bp[(size_t)cq * ns] * sh.isig[cq];
+                                        return (rho_ok && cx < k) ? v : 0.0;
+                                    }, lane);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < RP_ACC; ++u) {
+            const int tile = wave + u * nwaves;
+            const bool t_ok = tile < ntm_k * ntn;
+            const int tm = t_ok ? tile / ntn : 0, tn = t_ok ? tile - tm * ntn : 0;
+            const int rho = tn * 16 + li, m = rho >> 1;
+            const double sg = (m & 1) ? -1.0 : 1.0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = tm * 16 + lk + 4 * r;
+                const double v = acc[u][r];
+                const double p = rp_partner(v);                  // (every lane: uniform control flow around DPP)
+                if (t_ok && i < k && rho < n2) {
+                    Xs[(size_t)i * ns + rho] = v;
+                    // U[i][l + m] = (re + i im) / sqrt2,  U[i][l - m] = (-1)^m conj(.),  U[i][l] = re
+                    if (!(rho & 1)) {
+                        Uo[(size_t)i * n + l + m] = m ? make_double2(0.7071067811865476 * v, 0.7071067811865476 * p) : make_double2(v, 0.0);
+                    } else if (m) {
+                        Uo[(size_t)i * n + l - m] = make_double2(sg * 0.7071067811865476 * p, -sg * 0.7071067811865476 * v);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // ---- E: I~'[q][rho'] = sum_i V[q][i] U~^T[rho'][i] -> I'_{l, +-m}(q) on the masked shells ----------------------------------
+    {
+        const int ntq = (N + 15) >> 4;
+        const uint8_t* rm = A.rmask + (size_t)l * N;
+        for (int tile = wave; tile < ntq * ntn; tile += nwaves) {
+            const int tm = tile / ntn, tn = tile - tm * ntn;
+            const int q = tm * 16 + li, rho = tn * 16 + li;
+            const bool q_ok = q < N, rho_ok = rho < n2;
+            const double* ap = Vt + (q_ok ? q : 0);
+            const double* bp = Xs + (rho_ok ? rho : 0);
+            const v4f64 acc = rp_tile<4>(k, [&](int, int ix) { const double v = ap[(size_t)(ix < k ? ix : 0) * N]; return (q_ok && ix < k) ? v : 0.0; },
+                                         [&](int ix, int) { const double v = bp[(size_t)(ix < k ? ix : 0) * ns]; return (rho_ok && ix < k) ? v : 0.0; }, lane);
+            const int m = rho >> 1;
+            const double sg = (m & 1) ? -1.0 : 1.0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int qq = tm * 16 + lk + 4 * r;
+                const double v = acc[r];
+                const double p = rp_partner(v);
+                if (qq < N && rho_ok && rm[qq]) {
+                    double2* dst = reinterpret_cast<double2*>(coef + (size_t)qq * cstride);     // I_{l,0}(qq)
+                    if (!(rho & 1)) {
+                        dst[m] = m ? make_double2(0.7071067811865476 * v, 0.7071067811865476 * p) : make_double2(v, 0.0);
+                    } else if (m) {
+                        dst[-m] = make_double2(sg * 0.7071067811865476 * p, -sg * 0.7071067811865476 * v);
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();                                           // LDS is reused by the next order of the slot
+}
+
+// grid = (restart, slot); slots are listed heaviest first, the restart index runs fastest: the workgroups that set the
+// duration of the launch are dispatched first
+__global__ void __launch_bounds__(RP_MAX_THREADS) k_rproj(RProjArgs A) {
+    HIP_DYNAMIC_SHARED(double, sm)
+    __shared__ RpShared sh;
+    const int b = (int)blockIdx.x;
+    const int tid = threadIdx.x, nthreads = blockDim.x;
+    for (int it = 0; it < A.slot_len; ++it) {
+        const int e = A.slots[(size_t)blockIdx.y * A.slot_len + it];
+        if (e < 0) break;                                      // uniform per block
+        const int l = e & 255, kind = e >> 8;
+        if (kind == RP_SOLVE) {
+            rp_solve<0>(A, b, l, sh, sm);
+        } else if (kind == RP_ZERO) {
+            // used order with V_l = 0 (odd_orders_to_0): I'_l = 0 on the masked shells, its unknowns stay 0
+            const int n = 2 * l + 1;
+            for (int x = tid; x < A.N * n; x += nthreads) {
+                const int q = x / n, mm = x - q * n;
+                if (A.rmask[(size_t)l * A.N + q])
+                    reinterpret_cast<double2*>(A.coef)[((size_t)b * A.N + q) * A.nlm + (size_t)l * l + mm] = make_double2(0.0, 0.0);
+            }
+        } else {
+            // l = 0 (fxs_Projections.py:840, 870): unknown = sign of V_0^T D^2 Re I_00, I'_00 = V_0 on the masked shells, all / sqrt(N_p)
+            const double* DV = A.DV + A.voff[0];
+            const double* Vt = A.Vt + A.voff[0];
+            double2* c0 = reinterpret_cast<double2*>(A.coef) + (size_t)b * A.N * A.nlm;
+            double x = 0.0;
+            for (int q = tid; q < A.N; q += nthreads) x = fma(DV[(size_t)q * A.kl[0]], c0[(size_t)q * A.nlm].x, x);
+            for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+            if ((tid & 63) == 0) sh.red[tid >> 6] = x;
+            __syncthreads();
+            if (tid == 0) {
+                double s = 0.0;
+                for (int wv = 0; wv < (nthreads >> 6); ++wv) s += sh.red[wv];
+                const double s2 = s * s;
+                A.U[(size_t)b * A.xtot + A.xoff[0]] = make_double2(s2 > 1e-300 ? s / sqrt(s2) : 0.0, 0.0);
+                A.sweeps_out[b * (A.L + 1)] = 0 | (1 << 8);
+            }
+            for (int q = tid; q < A.N; q += nthreads) {
+                const double2 v = A.rmask[q] ? make_double2(Vt[q], 0.0) : c0[(size_t)q * A.nlm];
+                c0[(size_t)q * A.nlm] = cscale(v, A.inv_sqrt_np);
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// ---- host side --------------------------------------------------------------------------------------------------------
+// every solved order square (k_l = 2l+1), V_l real, 2l+2 <= 7 row slots of 16, the schedule and the matrices fit
+bool rproj_supported(mtip_ctx* c) {
+    if (!c->proj_real) return false;
+    int kmax = 0;
+    for (int l = 0; l <= c->L; ++l) {
+        if (!c->used[l]) continue;
+        if (!c->v_real[l]) return false;
+        if (c->active[l] && l > 0) {
+            if (c->kl[l] != 2 * l + 1) return false;
+            kmax = std::max(kmax, c->kl[l]);
+        }
+    }
+    if (kmax > 111) return false;
+    if (kmax >= 2) {
+        if (build_jacobi_schedule(c, kmax) != MTIP_OK) return false;
+        if (c->jsched_ps * 16 > RP_MAX_THREADS) return false;
+        const size_t lds = ((size_t)kmax * ((kmax + 1) | 1) + (size_t)kmax * (kmax | 1) + RP_SLACK) * sizeof(double);
+        if (lds + sizeof(RpShared) + 256 > 160 * 1024) return false;
+    }
+    return true;
+}
+
+// cost model of one order inside a slot: rounds ~ k, a round ~ constant + rows
+static double rp_cost(int k) { return (double)k * (40.0 + k); }
+
+static int build_rproj_tables(mtip_ctx* c) {
+    if (c->d_rp_slots != nullptr) return MTIP_OK;
+    const int L = c->L, N = c->N;
+    // real tables: q^2 V (N x k) and V^T (k x N) per order, from the host copy of V
+    std::vector<double> q(N);
+    if (mtip_copy(c, q.data(), c->d_q, N * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return MTIP_EHIP;
+    std::vector<double> DV((size_t)c->vtot, 0.0), Vt((size_t)c->vtot, 0.0);
+    for (int l = 0; l <= L; ++l) {
+        const int k = c->kl[l];
+        const double2* V = c->h_V.data() + c->voff[l];
+        for (int qi = 0; qi < N; ++qi)
+            for (int j = 0; j < k; ++j) {
+                DV[(size_t)c->voff[l] + (size_t)qi * k + j] = q[qi] * q[qi] * V[(size_t)qi * k + j].x;
+                Vt[(size_t)c->voff[l] + (size_t)j * N + qi] = V[(size_t)qi * k + j].x;
+            }
+    }
+    // slots: solved orders by first-fit decreasing into bins of the heaviest order's cost, then the cheap items
+    std::vector<int> solve;
+    for (int l = L; l >= 1; --l)
+        if (c->active[l]) solve.push_back(l);
+    std::stable_sort(solve.begin(), solve.end(), [&](int x, int y) { return c->kl[x] > c->kl[y]; });
+    std::vector<std::vector<int>> slots;
+    std::vector<double> load;
+    const double cap = solve.empty() ? 1.0 : rp_cost(c->kl[solve[0]]) * 1.02;
+    const int slot_len = 8;
+    for (int l : solve) {
+        const double w = rp_cost(c->kl[l]);
+        size_t s = 0;
+        for (; s < slots.size(); ++s)
+            if (load[s] + w <= cap && (int)slots[s].size() < slot_len - 2) break;
+        if (s == slots.size()) {
+            slots.emplace_back();
+            load.push_back(0.0);
+        }
+        slots[s].push_back(l | (RP_SOLVE << 8));
+        load[s] += w;
+    }
+    std::vector<int> cheap;
+    if (c->used[0]) cheap.push_back(0 | (RP_L0 << 8));
+    for (int l = 1; l <= L; ++l)
+        if (c->used[l] && !c->active[l]) cheap.push_back(l | (RP_ZERO << 8));
+    if (slots.empty()) {
+        slots.emplace_back();
+        load.push_back(0.0);
+    }
+    {
+        // cheap items go to the lightest slots, several per slot; more slots are opened when the lists are full
+        size_t s = slots.size() - 1;
+        for (int item : cheap) {
+            size_t tries = 0;
+            while ((int)slots[s].size() >= slot_len && tries < slots.size()) {
+                s = s == 0 ? slots.size() - 1 : s - 1;
+                ++tries;
+            }
+            if ((int)slots[s].size() >= slot_len) {
+                slots.emplace_back();
+                load.push_back(0.0);
+                s = slots.size() - 1;
+            }
+            slots[s].push_back(item);
+            s = s == 0 ? slots.size() - 1 : s - 1;
+        }
+    }
+    std::vector<int> flat(slots.size() * slot_len, -1);
+    for (size_t s = 0; s < slots.size(); ++s)
+        for (size_t i = 0; i < slots[s].size(); ++i) flat[s * slot_len + i] = slots[s][i];
+    if (hipMalloc((void**)&c->d_rp_DV, DV.size() * sizeof(double)) != hipSuccess ||
+        hipMalloc((void**)&c->d_rp_Vt, Vt.size() * sizeof(double)) != hipSuccess ||
+        hipMalloc((void**)&c->d_rp_slots, flat.size() * sizeof(int)) != hipSuccess)
+        return MTIP_ENOMEM;
+    (void)mtip_copy(c, c->d_rp_DV, DV.data(), DV.size() * sizeof(double), hipMemcpyHostToDevice);
+    (void)mtip_copy(c, c->d_rp_Vt, Vt.data(), Vt.size() * sizeof(double), hipMemcpyHostToDevice);
+    (void)mtip_copy(c, c->d_rp_slots, flat.data(), flat.size() * sizeof(int), hipMemcpyHostToDevice);
+    c->rp_n_slots = (int)slots.size();
+    c->rp_slot_len = slot_len;
+    return MTIP_OK;
+}
+
+void free_rproj_tables(mtip_ctx* c) {
+    if (c->d_rp_slots == nullptr && c->d_rp_DV == nullptr) return;
+    (void)hipStreamSynchronize(c->stream);
+    if (c->d_rp_DV) (void)hipFree(c->d_rp_DV);
+    if (c->d_rp_Vt) (void)hipFree(c->d_rp_Vt);
+    if (c->d_rp_slots) (void)hipFree(c->d_rp_slots);
+    c->d_rp_DV = nullptr;
+    c->d_rp_Vt = nullptr;
+    c->d_rp_slots = nullptr;
+}
+
+// in place on `coef` (the caller has copied I_lm there when its output is a different buffer)
+int launch_rproj(mtip_ctx* c, double2* coef) {
+    if (int rc = build_rproj_tables(c)) {
+        c->err = "real projection tables: out of device memory";
+        return rc;
+    }
+    int kmax = 1;
+    for (int l = 1; l <= c->L; ++l)
+        if (c->active[l]) kmax = std::max(kmax, c->kl[l]);
+    RProjArgs a;
+    a.coef = reinterpret_cast<double*>(coef);
+    a.DV = c->d_rp_DV; a.Vt = c->d_rp_Vt;
+    a.Vr = reinterpret_cast<double*>(c->d_Vr);
+    a.U = c->d_U;
+    a.rmask = c->d_rmask;
+    a.kl = c->d_kl; a.voff = c->d_voff; a.uoff = c->d_uoff; a.xoff = c->d_xoff;
+    a.slots = c->d_rp_slots; a.slot_len = c->rp_slot_len;
+    a.sched = c->d_jsched; a.sched_off = c->d_jsched_off; a.sched_rounds = c->d_jsched_rounds;
+    a.sched_ps = std::max(c->jsched_ps, 1);
+    a.N = c->N; a.L = c->L; a.nlm = c->nlm; a.utot = c->utot; a.xtot = c->xtot;
+    // cold start every 64 calls bounds the accumulated rounding drift of the carried V_r
+    a.warm = (c->vr_kind == 2 && (c->proj_calls % 64) != 0) ? 1 : 0;
+    a.tabs2 = c->polar_abs_tol * c->polar_abs_tol;
+    a.inv_sqrt_np = 1.0 / std::sqrt(c->n_particles);
+    a.sweeps_out = c->d_sweeps;
+    const size_t mat = ((size_t)kmax * ((kmax + 1) | 1) + (size_t)kmax * (kmax | 1) + RP_SLACK) * sizeof(double);
+    const size_t tab = (size_t)(kmax | 1) * a.sched_ps * sizeof(int);
+    // the pairing table of a sweep in LDS when it fits beside the matrices of half a CU, else read from L2 one round ahead
+    a.tab_in_lds = (kmax >= 2 && mat + tab + sizeof(RpShared) + 256 <= 80 * 1024) ? 1 : 0;
+    const size_t lds = mat + (a.tab_in_lds ? tab : 0);
+    int threads = std::max(256, ((kmax >= 2 ? c->jsched_ps : 1) * 16 + 63) / 64 * 64);
+    threads = std::min(threads, RP_MAX_THREADS);
+    ProfScope pp(c, "polar");                                    // (the whole projection is this one kernel)
+    hipLaunchKernelGGL(k_rproj, dim3((unsigned)c->B, (unsigned)c->rp_n_slots), dim3((unsigned)threads), lds, c->stream, a);
+    c->vr_kind = 2;
+    c->proj_calls += 1;
+    return MTIP_OK;
+}

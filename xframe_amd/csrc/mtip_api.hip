@@ -57,7 +57,8 @@ void mtip_destroy(mtip_ctx* c) {
                     c->d_xoff, c->d_uoff, c->d_V, c->d_rmask, c->d_Bref, c->d_Bnorm, c->d_deg2_part, c->d_S0, c->d_sup, c->d_err_wr,
                     c->d_err_wt, c->d_rho, c->d_Fp, c->d_slot, c->d_best_err, c->d_last_err, c->d_op_err, c->d_gq, c->d_polar_dbg, c->d_so3_d, c->d_so3_tw, c->d_so3_T, c->d_so3_S, c->d_so3_P, c->d_so3_D, c->d_so3_C, c->d_err_hist, c->d_main_hist,
                     c->d_deg2_hist, c->d_F, c->d_T1, c->d_T2, c->d_fixed, c->d_g, c->d_c[0], c->d_c[1], c->d_c[2],
-                    c->d_c[3], c->d_c[4], c->d_c[5], c->d_X, c->d_Vr, c->d_U, c->d_partial, c->d_minmax, c->d_Bl};
+                    c->d_c[3], c->d_c[4], c->d_c[5], c->d_X, c->d_Vr, c->d_U, c->d_partial, c->d_minmax, c->d_Bl,
+                    c->d_rp_DV, c->d_rp_Vt, c->d_rp_slots};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : c->prof_events) (void)hipEventDestroy(e);
@@ -157,6 +158,8 @@ mtip_ctx* mtip_create(const mtip_cfg* cfg, int device) {
     c->xoff.assign(L + 2, 0);
     c->uoff.assign(L + 2, 0);
     c->have_V.assign(L + 1, 0);
+    c->v_real.assign(L + 1, 1);
+    if (const char* e = std::getenv("MTIP_PROJ_REAL")) c->proj_real = std::atoi(e) != 0;
     for (int l = 0; l <= L; ++l) {
         const int n = 2 * l + 1, k = std::min(n, N);
         c->kl[l] = k;                               // default; mtip_set_projection_matrix may give a smaller k_l
@@ -176,6 +179,7 @@ mtip_ctx* mtip_create(const mtip_cfg* cfg, int device) {
     A(dev_alloc(c, &c->d_xoff, L + 2));
     A(dev_alloc(c, &c->d_uoff, L + 2));
     A(dev_alloc(c, &c->d_V, (size_t)c->vtot));
+    c->h_V.assign((size_t)c->vtot, make_double2(0.0, 0.0));
     A(dev_alloc(c, &c->d_rmask, (size_t)(L + 1) * N));
     A(dev_alloc(c, &c->d_Bref, (size_t)(L + 1) * N * N));
     A(dev_alloc(c, &c->d_Bnorm, L + 1));
@@ -315,12 +319,18 @@ int mtip_set_projection_matrix(mtip_ctx* c, int l, const mtip_cdouble* V, int k_
         for (int q = 0; q < c->N; ++q)
             for (int i = 0; i < k_l; ++i) tmp[(size_t)q * kmax + i] = make_double2(V[(size_t)q * k_l + i].re, V[(size_t)q * k_l + i].im);
     MTIP_HIP_CHECK(c, mtip_copy(c, c->d_V + c->voff[l], tmp.data(), tmp.size() * sizeof(double2), hipMemcpyHostToDevice));
+    std::copy(tmp.begin(), tmp.end(), c->h_V.begin() + c->voff[l]);
+    free_rproj_tables(c);                                // tables and slot lists of the real projection depend on V_l / used
+    bool is_real = true;
+    for (const double2& v : tmp) is_real = is_real && v.y == 0.0;
+    c->v_real[l] = is_real ? 1 : 0;
     if (radial_mask) MTIP_HIP_CHECK(c, mtip_copy(c, c->d_rmask + (size_t)l * c->N, radial_mask, c->N, hipMemcpyHostToDevice));
     c->used[l] = used ? 1 : 0;
     bool nonzero = false;
     for (const double2& v : tmp) nonzero = nonzero || v.x != 0.0 || v.y != 0.0;
     c->active[l] = (used && nonzero) ? 1 : 0;          // V_l == 0 (odd_orders_to_0): U_l stays 0, nothing to solve
     c->vr_valid = false;
+    c->vr_kind = 0;
     MTIP_HIP_CHECK(c, mtip_copy(c, c->d_used, c->used.data(), (c->L + 1) * sizeof(int), hipMemcpyHostToDevice));
     MTIP_HIP_CHECK(c, mtip_copy(c, c->d_active, c->active.data(), (c->L + 1) * sizeof(int), hipMemcpyHostToDevice));
     MTIP_HIP_CHECK(c, hipMemsetAsync(c->d_U, 0, (size_t)c->B * c->xtot * sizeof(double2), c->stream));
@@ -488,7 +498,7 @@ static int enqueue_step(mtip_ctx* c, int method, int ft_stab, double beta) {
         // 2-3 I_lm = SHT(|F|^2);  4-5 projection;  6-7 I' = iSHT, F' = F sqrt(I'/I) -> Fp[out]
         launch_sht_forward(c, c->d_F, cc[2], MTIP_PRE_SQUARE);
         if (c->deg2_enable) launch_deg2_metric(c, cc[2], c->d_deg2_hist + (size_t)c->n_steps_done * c->B * (c->L + 1));
-        const int rp = launch_project_coefficients(c, cc[2], cc[2]);          // in place: I_lm is not needed afterwards
+        const int rp = launch_project_coefficients(c, cc[2], cc[2], true);    // in place: I_lm is not needed afterwards; SHT of the real |F|^2
         if (rp != MTIP_OK) return rp;
         InvEpilogue mod;
         mod.mode = EPI_MODULUS;
@@ -680,6 +690,7 @@ int mtip_init_state(mtip_ctx* c) {
     c->n_steps_done = 0;
     c->fixed_valid = false;
     c->vr_valid = false;                 // a fresh reconstruction does not warm-start its polar factors
+    c->vr_kind = 0;
     c->proj_calls = 0;
     c->state_ready = true;
     return post_launch(c, "mtip_init_state");
@@ -953,7 +964,7 @@ int mtip_op_fourier_transform(mtip_ctx* c, const mtip_cdouble* in, mtip_cdouble*
     return post_launch(c, "mtip_op_fourier_transform");
 }
 
-int mtip_op_project_coefficients(mtip_ctx* c, const mtip_cdouble* Ilm, mtip_cdouble* out) {
+static int op_project(mtip_ctx* c, const mtip_cdouble* Ilm, mtip_cdouble* out, bool real_intensity) {
     CTX_CHECK(c);
     if (!c->have_radial) FAIL(c, MTIP_ESTATE, "mtip_set_radial_grid has not been called");
     for (int l = 0; l <= c->L; ++l)
@@ -962,12 +973,16 @@ int mtip_op_project_coefficients(mtip_ctx* c, const mtip_cdouble* Ilm, mtip_cdou
     (void)hipSetDevice(c->device);
     SYNC();
     H2D(c->d_c[2], Ilm, (size_t)c->B * c->C * sizeof(double2));
-    const int rp = launch_project_coefficients(c, c->d_c[2], c->d_c[3]);
+    const int rp = launch_project_coefficients(c, c->d_c[2], c->d_c[3], real_intensity);
     if (rp != MTIP_OK) return rp;
     SYNC();
     D2H(out, c->d_c[3], (size_t)c->B * c->C * sizeof(double2));
     return post_launch(c, "mtip_op_project_coefficients");
 }
+
+int mtip_op_project_coefficients(mtip_ctx* c, const mtip_cdouble* Ilm, mtip_cdouble* out) { return op_project(c, Ilm, out, false); }
+
+int mtip_op_project_real_intensity(mtip_ctx* c, const mtip_cdouble* Ilm, mtip_cdouble* out) { return op_project(c, Ilm, out, true); }
 
 int mtip_op_apply_unknowns(mtip_ctx* c, const mtip_cdouble* Ilm, const mtip_cdouble* U, mtip_cdouble* out) {
     CTX_CHECK(c);
@@ -979,6 +994,7 @@ int mtip_op_apply_unknowns(mtip_ctx* c, const mtip_cdouble* Ilm, const mtip_cdou
     H2D(c->d_c[2], Ilm, (size_t)c->B * c->C * sizeof(double2));
     H2D(c->d_U, U, (size_t)c->B * c->xtot * sizeof(double2));
     c->vr_valid = false;                     // d_U no longer belongs to the carried right singular vectors
+    c->vr_kind = 0;
     const int rp = launch_apply_unknowns(c, c->d_c[2], c->d_c[3]);
     if (rp != MTIP_OK) return rp;
     SYNC();

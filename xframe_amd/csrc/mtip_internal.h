@@ -169,7 +169,14 @@ struct mtip_ctx {
     std::vector<int> kl, used, active, voff, xoff, uoff;     // host copies (active = used and V_l != 0)
     int* d_active = nullptr;
     int* d_sweeps = nullptr;                          // (B, L+1) Jacobi sweeps of the last projection (diagnostic)
-    bool vr_valid = false;                            // d_Vr holds right singular vectors of the previous call
+    bool vr_valid = false;                            // d_Vr holds (complex) right singular vectors of the previous call
+    int vr_kind = 0;                                  // 2: d_Vr holds the REAL right singular vectors of the previous k_rproj call
+    bool proj_real = true;                            // env MTIP_PROJ_REAL=0: never take the real form of the projection (k_projr.hip)
+    std::vector<char> v_real;                         // per order: V_l has no imaginary part
+    std::vector<double2> h_V;                         // host copy of the concatenated V_l (tables of the real projection)
+    double *d_rp_DV = nullptr, *d_rp_Vt = nullptr;    // q^2 V_l (N x k) and V_l^T (k x N), real, at voff[l]
+    int* d_rp_slots = nullptr;                        // (rp_n_slots, rp_slot_len) order | kind << 8 lists of the k_rproj workgroups
+    int rp_n_slots = 0, rp_slot_len = 0;
     long long proj_calls = 0;
     double polar_abs_tol = 0.0;                       // 0 = purely relative Jacobi criterion (env MTIP_POLAR_ABS_TOL)
     int *d_kl = nullptr, *d_used = nullptr, *d_voff = nullptr, *d_xoff = nullptr, *d_uoff = nullptr;
@@ -266,7 +273,12 @@ int build_jacobi_schedule(mtip_ctx* c, int kmax);    // k_proj.hip: resident-col
 int build_hankel_tiles(mtip_ctx* c);
 void launch_coeff_diff(mtip_ctx* c, const double2* a, const double2* b, double2* out);
 // reciprocal projection
-int launch_project_coefficients(mtip_ctx* c, const double2* Ilm, double2* out);   // MTIP_OK or an error code (c->err set)
+// real_intensity: the caller guarantees I_{l,-m} = (-1)^m conj(I_{l,m}) (coefficients of a real grid, as in the phasing
+// loop): with real V_l the projection then takes its real form (k_projr.hip)
+int launch_project_coefficients(mtip_ctx* c, const double2* Ilm, double2* out, bool real_intensity = false);   // MTIP_OK or an error code (c->err set)
+bool rproj_supported(mtip_ctx* c);                    // k_projr.hip
+int launch_rproj(mtip_ctx* c, double2* coef);         // in place
+void free_rproj_tables(mtip_ctx* c);
 int launch_apply_unknowns(mtip_ctx* c, const double2* Ilm, double2* out);
 bool polar_newton_supported(const mtip_ctx* c);       // k_polar.hip: all active X_l square and at most 80 x 80
 int launch_polar_newton(mtip_ctx* c);                 // c->d_X (column-major X_l) -> c->d_U (U_l), scaled Newton iteration           // I'_l = V_l U_l with the U_l in c->d_U

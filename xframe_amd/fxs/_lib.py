@@ -70,6 +70,7 @@ _SIGNATURES = {
     'mtip_op_hankel': (C.c_int, [c_void, c_void, c_void, C.c_int]),
     'mtip_op_fourier_transform': (C.c_int, [c_void, c_void, c_void, C.c_int]),
     'mtip_op_project_coefficients': (C.c_int, [c_void, c_void, c_void]),
+    'mtip_op_project_real_intensity': (C.c_int, [c_void, c_void, c_void]),
     'mtip_op_apply_unknowns': (C.c_int, [c_void, c_void, c_void, c_void]),
     'mtip_op_modulus_replacement': (C.c_int, [c_void, c_void, c_void, c_void]),
     'mtip_op_real_space_update': (C.c_int, [c_void, c_void, c_void, C.c_int, C.c_double, c_void, c_void]),

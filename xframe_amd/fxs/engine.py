@@ -175,10 +175,13 @@ class Engine:
         self._ck(self.lib.mtip_op_fourier_transform(self.ctx, _lib.ptr(g), _lib.ptr(out), int(inverse)))
         return out
 
-    def project_coefficients(self, Ilm):
+    def project_coefficients(self, Ilm, real_intensity=False):
+        """approximate_unknowns + mtip_projection.  real_intensity: the coefficients are those of a real grid (as in the
+        phasing loop, SHT of |F|^2); only their m >= 0 half is read and real projection matrices take the real-arithmetic kernel."""
         c = self._bcoef(Ilm)
         out = np.empty_like(c)
-        self._ck(self.lib.mtip_op_project_coefficients(self.ctx, _lib.ptr(c), _lib.ptr(out)))
+        fn = self.lib.mtip_op_project_real_intensity if real_intensity else self.lib.mtip_op_project_coefficients
+        self._ck(fn(self.ctx, _lib.ptr(c), _lib.ptr(out)))
         return out
 
     def apply_unknowns(self, Ilm, unknowns):

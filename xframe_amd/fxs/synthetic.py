@@ -56,8 +56,10 @@ def invariants_from_intensity_coefficients(Ilm, data_radial_points, max_order, e
     bls = []
     for l in range(max_order + 1):
         Il = np.asarray(Ilm[l])
-        B = (Il @ Il.conj().T) / 4.0                       # stored convention: (V/2)(V/2)^+
-        bls.append((B + B.conj().T) / 2)
+        # real, as the reference makes it before the eigen-decomposition (fxs_invariant_tools.py:1255: B_l of a real
+        # intensity is real, sum over +-m pairs): the projection matrices are then real, as the reference's are (1207)
+        B = (Il @ Il.conj().T).real / 4.0                  # stored convention: (V/2)(V/2)^+
+        bls.append((B + B.T) / 2)
     if eigh is not None:
         all_w, all_v = eigh(np.stack(bls))
     for l in range(max_order + 1):
