@@ -153,6 +153,9 @@ static void run_block(Worker* w, int n, dim3 bidx, size_t smem_bytes) {
     b_idx = bidx;
     dyn_smem = w->smem;
     std::memset(w->smem, 0xA5, smem_bytes);          // LDS is uninitialised on a GPU
+    // the hardware drops LDS stores beyond the workgroup's allocation (and returns 0 for loads): a canary behind the requested
+    // bytes catches such stores here, where they would otherwise land in the slack of the 160 KiB buffer unnoticed
+    std::memset(w->smem + smem_bytes, 0x5C, DYN_SMEM_GUARD);
     for (int i = 0; i < n; ++i) {
         Fiber& f = w->fibers[i];
         getcontext(&f.ctx);
@@ -186,6 +189,12 @@ static void run_block(Worker* w, int n, dim3 bidx, size_t smem_bytes) {
             std::abort();
         }
     }
+    for (size_t i = smem_bytes; i < smem_bytes + DYN_SMEM_GUARD; ++i)
+        if (w->smem[i] != 0x5C) {
+            std::fprintf(stderr, "emul: block (%u,%u,%u) stored to dynamic LDS at byte %zu, beyond its allocation of %zu bytes\n",
+                         bidx.x, bidx.y, bidx.z, i, smem_bytes);
+            std::abort();
+        }
 }
 
 static std::mutex launch_mutex;
@@ -214,7 +223,7 @@ void launch(dim3 grid, dim3 block, size_t smem, const std::function<void()>& bod
     static std::vector<Worker*> pool;                 // persistent: fiber stacks are reused across launches
     while ((int)pool.size() < nw) {
         Worker* w = new Worker();
-        w->smem = (unsigned char*)aligned_alloc(64, DYN_SMEM_MAX);
+        w->smem = (unsigned char*)aligned_alloc(64, DYN_SMEM_MAX + DYN_SMEM_GUARD);
         pool.push_back(w);
     }
     auto work = [&](int id) {

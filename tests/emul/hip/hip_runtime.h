@@ -50,6 +50,7 @@ namespace emul {
 // (ucontext) that yield at __syncthreads() / wave collectives.  Deterministic and fast enough for CI.
 constexpr int WAVE = 64;
 constexpr size_t DYN_SMEM_MAX = 160 * 1024;
+constexpr size_t DYN_SMEM_GUARD = 16 * 1024;    // canary behind a block's dynamic LDS (stores beyond the allocation abort)
 struct alignas(16) WaveBuf { double d[WAVE * 4]; long long i[WAVE]; };
 struct Worker;
 extern thread_local Worker* W;

@@ -470,15 +470,16 @@ def check_projection_real_vs_oracle(N, L, lib_path=None, n_batch=2, seed=1, reci
     for rep in range(3):                                   # later calls: warm start from the previous V_r
         grid = rng.uniform(0.0, 1.0, (n_batch, N, sht.n_theta, sht.n_phi)) * rng.uniform(0.5, 2.0, (n_batch, N, 1, 1))
         Ilm = np.stack([np.concatenate(sht.forward_l(g.astype(complex)), axis=1) for g in grid])
+        # (the general kernel first, and only once: the real kernel's later calls then warm-start from its own V_r)
+        proj_c = e.project_coefficients(Ilm) if rep == 0 else None
         proj = e.project_coefficients(Ilm, real_intensity=True)
         unk_hip = [e.unknowns(b) for b in range(n_batch)]
-        proj_c = e.project_coefficients(Ilm)
         for b in range(n_batch):
             Il = [Ilm[b][:, l * l:(l + 1) ** 2] for l in range(L + 1)]
             unk = om.rp.approximate_unknowns(Il)
             ref = np.concatenate(om.rp.mtip_projection(Il, unk), axis=1)
             assert rel_l2(proj[b], ref) < TOL_SHT, (rep, b, rel_l2(proj[b], ref))
-            assert rel_l2(proj[b], proj_c[b]) < TOL_SHT, (rep, b)
+            assert proj_c is None or rel_l2(proj[b], proj_c[b]) < TOL_SHT, (rep, b)
             for i, l in enumerate(om.rp.used_orders.values()):
                 # compared through V_l U_l (the unknowns themselves are only defined up to the null space of V_l)
                 V = om.rp.projection_matrices[l]

@@ -1505,6 +1505,7 @@ int build_jacobi_schedule(mtip_ctx* c, int kmax) {
     (void)mtip_copy(c, c->d_jsched_rounds, nrd.data(), nrd.size() * sizeof(int), hipMemcpyHostToDevice);
     c->jsched_kmax = kmax;
     c->jsched_ps = ps;
+    c->jsched_nrd = nrd;                                         // host copy: rounds per sweep by column count
     return MTIP_OK;
 }
 
@@ -1670,7 +1671,9 @@ int launch_project_coefficients(mtip_ctx* c, const double2* Ilm, double2* out, b
             constexpr int rows_wg = 2 * JR_RPL * (JL_MAX_THREADS / 64);
             const size_t lds_c = ((size_t)rows_wg * (kmax | 1) + (size_t)JR_CHUNK * c->jsched_ps * 2) * sizeof(double2);
             const dim3 gc(gj.x, gj.y, 1u + (unsigned)div_up(kmax, rows_wg));
-            const size_t lds_p = lds_use + (size_t)(kmax | 1) * c->jsched_ps * sizeof(int);      // X_l + the pairing table of a sweep
+            int nrd_max = 1;                                     // (the divide-and-conquer schedule has more rounds than columns: 70 at k = 65)
+            for (int ke = 2; ke <= kmax; ++ke) nrd_max = std::max(nrd_max, c->jsched_nrd[ke]);
+            const size_t lds_p = lds_use + (size_t)nrd_max * c->jsched_ps * sizeof(int);         // X_l + the pairing table of a sweep
             // which orders to split: measured at 128 x L32 with three engines, only the largest pays (it sets the duration of the
             // launch; every further order adds two spinning consumer workgroups that take CUs from the other engines' transforms)
             int k_conc_min = c->jac_conc_min_k < 0 ? kmax : std::max(2, std::min(c->jac_conc_min_k, kmax));

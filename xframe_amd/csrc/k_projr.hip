@@ -154,7 +154,7 @@ struct RProjArgs {
     const int* slots;             // (n_slots, slot_len): order | kind << 8, -1 = none
     int slot_len;
     const int *sched, *sched_off, *sched_rounds;
-    int sched_ps, tab_in_lds;
+    int sched_ps;
     int N, L, nlm, utot, xtot, warm;
     double tabs2, inv_sqrt_np;
     int* sweeps_out;
@@ -308,25 +308,25 @@ __device__ __forceinline__ void rp_solve(const RProjArgs& A, int b, int l, RpSha
             const int ke = sh.keff;
             bool big = false;
             if (ke >= 2) {
-                const int* tab = A.sched + A.sched_off[ke];
+                const int* gtab = A.sched + A.sched_off[ke];
                 const int nrd = A.sched_rounds[ke];
-                if (A.tab_in_lds) {                            // the pairing table of this column count, staged once
-                    if (tab_ke != ke) {
-                        for (int e = tid; e < nrd * A.sched_ps; e += nthreads) s_tab[e] = tab[e];
-                        tab_ke = ke;
-                        __syncthreads();
-                    }
-                    tab = s_tab;
+                // up to 5 row slots (k <= 79) the pairing table of this column count is staged in LDS, once per column count
+                // (the launcher sizes the allocation for it); beyond, the matrices fill the CU and it is read from L2 one
+                // round ahead.  Separate call sites: the table pointer keeps its address space (no flat loads).
+                if (nr <= 5 && tab_ke != ke) {
+                    for (int e = tid; e < nrd * A.sched_ps; e += nthreads) s_tab[e] = gtab[e];
+                    tab_ke = ke;
+                    __syncthreads();
                 }
-#define RP_SWEEP(NR) rp_sweep<NR>(Xs, Vs, ns, ks, t, group, tab, nrd, A.sched_ps, sh.perm, xl_ok, vl_ok, A.tabs2, S, big)
+#define RP_SWEEP(NR, TAB) rp_sweep<NR>(Xs, Vs, ns, ks, t, group, TAB, nrd, A.sched_ps, sh.perm, xl_ok, vl_ok, A.tabs2, S, big)
                 switch (nr) {
-                case 1: RP_SWEEP(1); break;
-                case 2: RP_SWEEP(2); break;
-                case 3: RP_SWEEP(3); break;
-                case 4: RP_SWEEP(4); break;
-                case 5: RP_SWEEP(5); break;
-                case 6: RP_SWEEP(6); break;
-                default: RP_SWEEP(7); break;
+                case 1: RP_SWEEP(1, s_tab); break;
+                case 2: RP_SWEEP(2, s_tab); break;
+                case 3: RP_SWEEP(3, s_tab); break;
+                case 4: RP_SWEEP(4, s_tab); break;
+                case 5: RP_SWEEP(5, s_tab); break;
+                case 6: RP_SWEEP(6, gtab); break;
+                default: RP_SWEEP(7, gtab); break;
                 }
 #undef RP_SWEEP
             }
@@ -633,10 +633,11 @@ int launch_rproj(mtip_ctx* c, double2* coef) {
     a.inv_sqrt_np = 1.0 / std::sqrt(c->n_particles);
     a.sweeps_out = c->d_sweeps;
     const size_t mat = ((size_t)kmax * ((kmax + 1) | 1) + (size_t)kmax * (kmax | 1) + RP_SLACK) * sizeof(double);
-    const size_t tab = (size_t)(kmax | 1) * a.sched_ps * sizeof(int);
-    // the pairing table of a sweep in LDS when it fits beside the matrices of half a CU, else read from L2 one round ahead
-    a.tab_in_lds = (kmax >= 2 && mat + tab + sizeof(RpShared) + 256 <= 80 * 1024) ? 1 : 0;
-    const size_t lds = mat + (a.tab_in_lds ? tab : 0);
+    int nrd_max = 1;                                             // the schedule has more rounds than columns (70 at k = 65)
+    for (int ke = 2; ke <= kmax && ke < (int)c->jsched_nrd.size(); ++ke) nrd_max = std::max(nrd_max, c->jsched_nrd[ke]);
+    const size_t tab = (size_t)nrd_max * a.sched_ps * sizeof(int);
+    // the pairing table of a sweep is staged in LDS up to 5 row slots (k_l <= 79), see rp_solve
+    const size_t lds = mat + ((kmax + 1 + 15) / 16 <= 5 ? tab : 0);       // row slots of the largest order: 2l+2 = k+1 rows
     int threads = std::max(256, ((kmax >= 2 ? c->jsched_ps : 1) * 16 + 63) / 64 * 64);
     threads = std::min(threads, RP_MAX_THREADS);
     ProfScope pp(c, "polar");                                    // (the whole projection is this one kernel)
