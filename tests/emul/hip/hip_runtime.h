@@ -181,6 +181,7 @@ static inline unsigned atomicAdd(unsigned* p, unsigned v) {
     unsigned o = *p; *p = o + v; return o;
 }
 static inline long long clock64() { return 0; }
+static inline unsigned __builtin_amdgcn_s_getreg(int) { return 0u; }
 static inline void __threadfence() { std::atomic_thread_fence(std::memory_order_seq_cst); }
 static inline void __threadfence_block() { std::atomic_thread_fence(std::memory_order_seq_cst); }
 static inline void __builtin_amdgcn_s_sleep(int) { emul::fiber_yield(); }

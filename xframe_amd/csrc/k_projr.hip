@@ -24,7 +24,7 @@
 
 #define RP_MAX_THREADS 768
 #define RP_SLACK 128            // doubles behind the matrices: predicated-off lanes of the last row slot still form addresses
-#define RP_ACC 7                // 16 x 16 output tiles a wave may hold across a barrier (in-place products)
+#define RP_ACC 5                // 16 x 16 output tiles a wave works on at a time (and may hold across a barrier: in-place products)
 
 struct RpShared {
     double gmax[RP_MAX_THREADS / 16];
@@ -53,9 +53,19 @@ __device__ __forceinline__ bool rp_params(double alpha, double beta, double g, b
 
 // One sweep in the resident-column ordering (see jl_sweep_resident in k_proj.hip): 16 lanes per column pair, NR row slots per
 // lane for X~ and for V_r; the resident column of a group stays in registers over a phase, the mover goes through LDS.
-template <int NR>
+// TIMED (diagnostic instance, mtip_debug_polar_timing): cycles of the segments of a round summed into tacc[0..4]
+// (operands arrived | Gram sums + lane sums | rotation parameters | rotations + stores | barrier)
+template <int NR, bool TIMED = false>
 __device__ __forceinline__ void rp_sweep(double* Xs, double* Vs, int ns, int ks, int t, int group, const int* tab, int n_rounds,
-                                         int ps, const int* s_perm, bool xl_ok, bool vl_ok, double tabs2, double S, bool& big) {
+                                         int ps, const int* s_perm, bool xl_ok, bool vl_ok, double tabs2, double S, bool& big,
+                                         long long* tacc = nullptr) {
+    long long tq = 0;
+#define RP_SEG(I)                            \
+    if (TIMED) {                             \
+        const long long tn_ = clock64();     \
+        tacc[I] += tn_ - tq;                 \
+        tq = tn_;                            \
+    }
     double rx[NR], rv[NR];
 #pragma unroll
     for (int u = 0; u < NR; ++u) {
@@ -66,6 +76,7 @@ __device__ __forceinline__ void rp_sweep(double* Xs, double* Vs, int ns, int ks,
     bool dirty = false;
     int e_next = (group < ps && n_rounds > 0) ? tab[group] : 0;
     int pr_next = s_perm[(e_next & JS_ACTIVE) ? (e_next & 255) : 0], pm_next = s_perm[(e_next & JS_ACTIVE) ? ((e_next >> 8) & 255) : 0];
+    if (TIMED) tq = clock64();
     for (int r = 0; r < n_rounds; ++r) {
         const int e = e_next;
         const int pr = pr_next, pm = pm_next;
@@ -100,6 +111,13 @@ __device__ __forceinline__ void rp_sweep(double* Xs, double* Vs, int ns, int ks,
             }
             if (!xl_ok) mx[NR - 1] = 0.0;
         }
+        if (TIMED) {
+            double sink = 0.0;
+#pragma unroll
+            for (int u = 0; u < NR; ++u) sink += mx[u] + mv[u] + rx[u];
+            asm volatile("" ::"v"(sink));                      // operands have arrived
+        }
+        RP_SEG(0)
         double alpha = 0.0, beta = 0.0, g = 0.0, zero = 0.0;
 #pragma unroll
         for (int u = 0; u < NR; ++u) {
@@ -108,8 +126,12 @@ __device__ __forceinline__ void rp_sweep(double* Xs, double* Vs, int ns, int ks,
             g = fma(rx[u], mx[u], g);
         }
         group_sum4<16>(alpha, beta, g, zero);          // (run by every group, active or not: uniform control flow around DPP)
+        if (TIMED) asm volatile("" ::"v"(alpha), "v"(beta), "v"(g));
+        RP_SEG(1)
         double cs = 1.0, w = 0.0;
         const bool rot = rp_params(alpha, beta, g, act, tabs2, S, big, cs, w);
+        if (TIMED) asm volatile("" ::"v"(cs), "v"(w));
+        RP_SEG(2)
         if (rot) {
 #pragma unroll
             for (int u = 0; u < NR; ++u) {
@@ -139,8 +161,11 @@ __device__ __forceinline__ void rp_sweep(double* Xs, double* Vs, int ns, int ks,
         }
         pr_next = s_perm[(e_next & JS_ACTIVE) ? (e_next & 255) : 0];
         pm_next = s_perm[(e_next & JS_ACTIVE) ? ((e_next >> 8) & 255) : 0];
+        RP_SEG(3)
         __syncthreads();
+        RP_SEG(4)
     }
+#undef RP_SEG
 }
 
 struct RProjArgs {
@@ -158,35 +183,74 @@ struct RProjArgs {
     int N, L, nlm, utot, xtot, warm;
     double tabs2, inv_sqrt_np;
     int* sweeps_out;
+    long long* dbg;               // mtip_debug_polar_timing: 32 slots per (restart, order): cycles of the phases A, W, J, U, E of wave 0,
+                                  // rounds, start and end s_memtime, hardware id (nullptr: off)
 };
 
 enum { RP_SOLVE = 0, RP_ZERO = 1, RP_L0 = 2 };
 
-// acc = sum_{kk < K} A(row, kk) B(kk, col) for one 16 x 16 tile; v_mfma_f64_16x16x4: A[i = lane & 15][kk = lane >> 4],
-// B[kk = lane >> 4][j = lane & 15], D reg r = D[(lane >> 4) + 4 r][lane & 15].  A / B return 0 outside their ranges.
-template <int UNR, class FA, class FB>
-__device__ __forceinline__ v4f64 rp_tile(int K, FA A, FB Bf, int lane) {
-    const int li = lane & 15, lk = lane >> 4;
-    v4f64 acc = v4f64{0.0, 0.0, 0.0, 0.0};
-    for (int k0 = 0; k0 < K; k0 += 4 * UNR) {
-        double a[UNR], bb[UNR];
+// acc[u] = sum_{kk < K} A_u[row][kk] B_u[kk][col] for the nu <= T 16 x 16 tiles of this wave; v_mfma_f64_16x16x4:
+// A[i = lane & 15][kk = lane >> 4], B[kk = lane >> 4][j = lane & 15], D reg r = D[(lane >> 4) + 4 r][lane & 15].  pa[u] / pb[u] point
+// at inner index 0 of this lane's row of A_u / column of B_u, consecutive inner indices sa / sb doubles apart.  The operands of
+// a chunk of UNR inner steps are requested for ALL tiles first (T * UNR * 2 values in flight), then multiplied: independent
+// accumulators back to back on the matrix pipe while the partner wave of the SIMD loads.  No branches and no selects on the
+// loads (a `cond ? load : 0` compiles to an exec-masked block with a full wait at its join): rows and columns outside the
+// matrices are clamped by the caller -- they only reach outputs that are never stored -- and the inner indices beyond K are
+// clamped to K - 1 and multiplied by zero.
+template <int T, int UNR>
+__device__ __forceinline__ void rp_tiles(v4f64 (&acc)[T], const double* const (&pa)[T], int sa, const double* const (&pb)[T], int sb,
+                                         int K, int lk, int nu) {
 #pragma unroll
-        for (int u = 0; u < UNR; ++u) {
-            const int kk = k0 + 4 * u + lk;
-            a[u] = A(li, kk);
-            bb[u] = Bf(kk, li);
-        }
+    for (int u = 0; u < T; ++u) acc[u] = v4f64{0.0, 0.0, 0.0, 0.0};
+    const int Kfull = K - (K % (4 * UNR));
+    for (int k0 = 0; k0 < Kfull; k0 += 4 * UNR) {
+        double a[T][UNR], bb[T][UNR];
 #pragma unroll
-        for (int u = 0; u < UNR; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], bb[u], acc, 0, 0, 0);
+        for (int u = 0; u < T; ++u)
+            if (u < nu) {
+#pragma unroll
+                for (int x = 0; x < UNR; ++x) {
+                    const int kk = k0 + 4 * x + lk;
+                    a[u][x] = pa[u][kk * sa];
+                    bb[u][x] = pb[u][kk * sb];
+                }
+            }
+#pragma unroll
+        for (int u = 0; u < T; ++u)
+            if (u < nu) {
+#pragma unroll
+                for (int x = 0; x < UNR; ++x) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][x], bb[u][x], acc[u], 0, 0, 0);
+            }
     }
-    return acc;
+    if (Kfull < K) {                                         // (uniform) tail: up to UNR masked steps
+        double a[T][UNR], bb[T][UNR];
+#pragma unroll
+        for (int u = 0; u < T; ++u)
+            if (u < nu) {
+#pragma unroll
+                for (int x = 0; x < UNR; ++x) {
+                    const int kk = Kfull + 4 * x + lk;
+                    const int kq = kk < K ? kk : K - 1;
+                    a[u][x] = pa[u][kq * sa] * (kk < K ? 1.0 : 0.0);
+                    bb[u][x] = pb[u][kq * sb];
+                }
+            }
+#pragma unroll
+        for (int u = 0; u < T; ++u)
+            if (u < nu) {
+#pragma unroll
+                for (int x = 0; x < UNR; ++x)
+                    if (Kfull + 4 * x < K) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][x], bb[u][x], acc[u], 0, 0, 0);
+            }
+    }
 }
 
 // value of the partner lane (lane ^ 1): the (Re, Im) parts of one m sit in neighbouring lanes
 __device__ __forceinline__ double rp_partner(double v) { return dpp_mov<0xB1>(v); }
 
-// the active order l of restart b: products, Jacobi, apply
-template <int DUMMY>
+// the active order l of restart b: products, Jacobi, apply.  UNR: inner steps of the products requested at a time (register budget
+// of the launch bound: 4 with two waves per SIMD, 2 with three)
+template <int UNR>
 __device__ __forceinline__ void rp_solve(const RProjArgs& A, int b, int l, RpShared& sh, double* sm) {
     const int tid = threadIdx.x, nthreads = blockDim.x;
     const int lane = tid & 63, wave = tid >> 6, nwaves = nthreads >> 6;
@@ -203,20 +267,52 @@ __device__ __forceinline__ void rp_solve(const RProjArgs& A, int b, int l, RpSha
     const size_t cstride = (size_t)A.nlm * 2;                                   // doubles between shells
     double* Vr = A.Vr + (size_t)b * A.utot + A.uoff[l];
     const int ntm_k = (k + 15) >> 4, ntn = (n2 + 15) >> 4;
+    long long* dbg = A.dbg ? A.dbg + ((size_t)b * (A.L + 1) + l) * 32 : nullptr;
+    long long t0 = 0, t1 = 0;
+    long long n_rounds_done = 0;
+    if (dbg) t0 = clock64();
+#define RP_STAMP(SLOT)                                  \
+    if (dbg) {                                          \
+        t1 = clock64();                                 \
+        if (tid == 0) dbg[SLOT] = t1 - t0;              \
+        t0 = t1;                                        \
+    }
+    if (dbg && tid < 22) dbg[10 + tid] = 0;
+    if (dbg && tid == 0) {
+        dbg[6] = t0;
+        dbg[8] = (long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));      // HW_ID
+    }
     // ---- A: X~^T[j][rho'] = sum_q DV[q][j] I~[q][rho'] -> Xs[j * ns + rho'] ------------------------------------------
-    for (int tile = wave; tile < ntm_k * ntn; tile += nwaves) {
-        const int tm = tile / ntn, tn = tile - tm * ntn;
-        const int j = tm * 16 + li, rho = tn * 16 + li;
-        const bool j_ok = j < k, rho_ok = rho < n2;
-        const double* ap = DV + (j_ok ? j : 0);
-        const double* bp = coef + (rho_ok ? rho : 0);
-        const v4f64 acc = rp_tile<8>(N, [&](int, int q) { const double v = ap[(size_t)(q < N ? q : 0) * k]; return (j_ok && q < N) ? v : 0.0; },
-                                     [&](int q, int) { const double v = bp[(size_t)(q < N ? q : 0) * cstride]; return (rho_ok && q < N) ? v : 0.0; }, lane);
-        const double f = rho == 1 ? 0.0 : (rho >= 2 ? 1.4142135623730951 : 1.0);
+    // (q^2 V)[q][j]: q stride k;  I~[q][rho']: q stride = one shell of coefficients
+    for (int base = 0; base < ntm_k * ntn; base += nwaves * RP_ACC) {
+        v4f64 acc[RP_ACC];
+        const double *pa[RP_ACC], *pb[RP_ACC];
+        int nu = 0;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int jj = tm * 16 + lk + 4 * r;
-            if (jj < k && rho_ok) Xs[(size_t)jj * ns + rho] = f * acc[r];
+        for (int u = 0; u < RP_ACC; ++u) {
+            const int tile = base + wave + u * nwaves;
+            const bool ok = tile < ntm_k * ntn;
+            const int tq = ok ? tile : 0;
+            const int tm = tq / ntn, tn = tq - tm * ntn;
+            const int j = tm * 16 + li, rho = tn * 16 + li;
+            pa[u] = DV + (j < k ? j : k - 1);
+            pb[u] = coef + (rho < n2 ? rho : n2 - 1);
+            if (ok) nu = u + 1;
+        }
+        rp_tiles<RP_ACC, UNR>(acc, pa, k, pb, (int)cstride, N, lk, nu);
+#pragma unroll
+        for (int u = 0; u < RP_ACC; ++u) {
+            const int tile = base + wave + u * nwaves;
+            if (tile < ntm_k * ntn) {
+                const int tm = tile / ntn, tn = tile - tm * ntn;
+                const int rho = tn * 16 + li;
+                const double f = rho == 1 ? 0.0 : (rho >= 2 ? 1.4142135623730951 : 1.0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int jj = tm * 16 + lk + 4 * r;
+                    if (jj < k && rho < n2) Xs[(size_t)jj * ns + rho] = f * acc[u][r];
+                }
+            }
         }
     }
     // V_r: the previous step's right singular vectors (warm start) or the identity
@@ -227,22 +323,26 @@ __device__ __forceinline__ void rp_solve(const RProjArgs& A, int b, int l, RpSha
         Vs[e] = v;
     }
     __syncthreads();
+    RP_STAMP(0)
     // ---- W: X~ <- X~ V_r:  D[c][rho'] = sum_j V_r[j][c] X~[rho'][j]  (held in registers until every wave has read X~) --
     if (A.warm) {
+        // V_r[j][c] = Vs[c * ks + j]: j stride 1;  X~[rho'][j] = Xs[j * ns + rho']: j stride ns
         v4f64 acc[RP_ACC];
+        {
+            const double *pa[RP_ACC], *pb[RP_ACC];
+            int nu = 0;
 #pragma unroll
-        for (int u = 0; u < RP_ACC; ++u) {
-            const int tile = wave + u * nwaves;
-            acc[u] = v4f64{0.0, 0.0, 0.0, 0.0};
-            if (tile < ntm_k * ntn) {
-                const int tm = tile / ntn, tn = tile - tm * ntn;
+            for (int u = 0; u < RP_ACC; ++u) {
+                const int tile = wave + u * nwaves;
+                const bool ok = tile < ntm_k * ntn;
+                const int tq = ok ? tile : 0;
+                const int tm = tq / ntn, tn = tq - tm * ntn;
                 const int cc = tm * 16 + li, rho = tn * 16 + li;
-                const bool c_ok = cc < k, rho_ok = rho < n2;
-                const double* ap = Vs + (size_t)(c_ok ? cc : 0) * ks;
-                const double* bp = Xs + (rho_ok ? rho : 0);
-                acc[u] = rp_tile<4>(k, [&](int, int jx) { const double v = ap[jx < k ? jx : 0]; return (c_ok && jx < k) ? v : 0.0; },
-                                    [&](int jx, int) { const double v = bp[(size_t)(jx < k ? jx : 0) * ns]; return (rho_ok && jx < k) ? v : 0.0; }, lane);
+                pa[u] = Vs + (cc < k ? cc : k - 1) * ks;
+                pb[u] = Xs + (rho < n2 ? rho : n2 - 1);
+                if (ok) nu = u + 1;
             }
+            rp_tiles<RP_ACC, UNR>(acc, pa, 1, pb, ns, k, lk, nu);
         }
         __syncthreads();
 #pragma unroll
@@ -260,6 +360,7 @@ __device__ __forceinline__ void rp_solve(const RProjArgs& A, int b, int l, RpSha
         }
         __syncthreads();
     }
+    RP_STAMP(1)
     // ---- J: one-sided Jacobi sweeps ------------------------------------------------------------------------------------
     const int ngroups = nthreads >> 4;
     const int group = tid >> 4, t = tid & 15;
@@ -319,6 +420,16 @@ __device__ __forceinline__ void rp_solve(const RProjArgs& A, int b, int l, RpSha
                     __syncthreads();
                 }
 #define RP_SWEEP(NR, TAB) rp_sweep<NR>(Xs, Vs, ns, ks, t, group, TAB, nrd, A.sched_ps, sh.perm, xl_ok, vl_ok, A.tabs2, S, big)
+                if (dbg != nullptr && nr == 5) {                 // diagnostic instance with segment timers (one wave reports)
+                    long long tacc[5] = {0, 0, 0, 0, 0};
+                    rp_sweep<5, true>(Xs, Vs, ns, ks, t, group, s_tab, nrd, A.sched_ps, sh.perm, xl_ok, vl_ok, A.tabs2, S, big, tacc);
+                    if ((tid & 63) == 0 && (tid >> 6) < 8) {   // per wave: busy, barrier wait; wave 0 also the segments
+                        dbg[10 + (tid >> 6)] += tacc[0] + tacc[1] + tacc[2] + tacc[3];
+                        dbg[18 + (tid >> 6)] += tacc[4];
+                        if (tid == 0)
+                            for (int i = 0; i < 4; ++i) dbg[26 + i] += tacc[i];
+                    }
+                } else
                 switch (nr) {
                 case 1: RP_SWEEP(1, s_tab); break;
                 case 2: RP_SWEEP(2, s_tab); break;
@@ -329,6 +440,7 @@ __device__ __forceinline__ void rp_solve(const RProjArgs& A, int b, int l, RpSha
                 default: RP_SWEEP(7, gtab); break;
                 }
 #undef RP_SWEEP
+                n_rounds_done += nrd;
             }
             if (t == 0) sh.gmax[group] = big ? 1.0 : 0.0;
             __syncthreads();
@@ -346,6 +458,7 @@ __device__ __forceinline__ void rp_solve(const RProjArgs& A, int b, int l, RpSha
     } else if (tid == 0) {
         A.sweeps_out[b * (A.L + 1) + l] = 0 | (k << 8);
     }
+    RP_STAMP(2)
     // ---- sigma_c; V_r for the next call -----------------------------------------------------------------------------------
     for (int cc0 = 0; cc0 < k; cc0 += ngroups) {               // uniform trip count: DPP sums need the whole group
         const int cc = cc0 + group;
@@ -364,27 +477,29 @@ __device__ __forceinline__ void rp_solve(const RProjArgs& A, int b, int l, RpSha
         Vr[e] = Vs[(size_t)cc * ks + i];
     }
     __syncthreads();
+    // columns of X~ <- left singular vectors W / sigma (numerical-zero columns: 0)
+    for (int e = tid; e < k * ns; e += nthreads) Xs[e] *= sh.isig[e / ns];
+    __syncthreads();
     // ---- U: U~^T[rho'][i] = sum_c (X~[rho'][c] / sigma_c) V_r[i][c]:  D[i][rho'] -> Xs[i * ns + rho'], complex U_l -> A.U ----
     {
         double2* Uo = A.U + (size_t)b * A.xtot + A.xoff[l];
+        // V_r[i][c] = Vs[c * ks + i]: c stride ks;  (X~ / sigma)[rho'][c] = Xs[c * ns + rho']: c stride ns
         v4f64 acc[RP_ACC];
+        {
+            const double *pa[RP_ACC], *pb[RP_ACC];
+            int nu = 0;
 #pragma unroll
-        for (int u = 0; u < RP_ACC; ++u) {
-            const int tile = wave + u * nwaves;
-            acc[u] = v4f64{0.0, 0.0, 0.0, 0.0};
-            if (tile < ntm_k * ntn) {
-                const int tm = tile / ntn, tn = tile - tm * ntn;
+            for (int u = 0; u < RP_ACC; ++u) {
+                const int tile = wave + u * nwaves;
+                const bool ok = tile < ntm_k * ntn;
+                const int tq = ok ? tile : 0;
+                const int tm = tq / ntn, tn = tq - tm * ntn;
                 const int i = tm * 16 + li, rho = tn * 16 + li;
-                const bool i_ok = i < k, rho_ok = rho < n2;
-                const double* ap = Vs + (i_ok ? i : 0);
-                const double* bp = Xs + (rho_ok ? rho : 0);
-                acc[u] = rp_tile<4>(k, [&](int, int cx) { const double v = ap[(size_t)(cx < k ? cx : 0) * ks]; return (i_ok && cx < k) ? v : 0.0; },
-                                    [&](int cx, int) {
-                                        const int cq = cx < k ? cx : 0;
-                                        const double v = bp[(size_t)cq * ns] * sh.isig[cq];
-                                        return (rho_ok && cx < k) ? v : 0.0;
-                                    }, lane);
+                pa[u] = Vs + (i < k ? i : k - 1);
+                pb[u] = Xs + (rho < n2 ? rho : n2 - 1);
+                if (ok) nu = u + 1;
             }
+            rp_tiles<RP_ACC, UNR>(acc, pa, ks, pb, ns, k, lk, nu);
         }
         __syncthreads();
 #pragma unroll
@@ -412,42 +527,66 @@ __device__ __forceinline__ void rp_solve(const RProjArgs& A, int b, int l, RpSha
         }
         __syncthreads();
     }
+    RP_STAMP(3)
     // ---- E: I~'[q][rho'] = sum_i V[q][i] U~^T[rho'][i] -> I'_{l, +-m}(q) on the masked shells ----------------------------------
     {
         const int ntq = (N + 15) >> 4;
         const uint8_t* rm = A.rmask + (size_t)l * N;
-        for (int tile = wave; tile < ntq * ntn; tile += nwaves) {
-            const int tm = tile / ntn, tn = tile - tm * ntn;
-            const int q = tm * 16 + li, rho = tn * 16 + li;
-            const bool q_ok = q < N, rho_ok = rho < n2;
-            const double* ap = Vt + (q_ok ? q : 0);
-            const double* bp = Xs + (rho_ok ? rho : 0);
-            const v4f64 acc = rp_tile<4>(k, [&](int, int ix) { const double v = ap[(size_t)(ix < k ? ix : 0) * N]; return (q_ok && ix < k) ? v : 0.0; },
-                                         [&](int ix, int) { const double v = bp[(size_t)(ix < k ? ix : 0) * ns]; return (rho_ok && ix < k) ? v : 0.0; }, lane);
-            const int m = rho >> 1;
-            const double sg = (m & 1) ? -1.0 : 1.0;
+        // V[q][i] = Vt[i * N + q]: i stride N;  U~^T[rho'][i] = Xs[i * ns + rho']: i stride ns
+        for (int base = 0; base < ntq * ntn; base += nwaves * RP_ACC) {
+            v4f64 acc[RP_ACC];
+            const double *pa[RP_ACC], *pb[RP_ACC];
+            int nu = 0;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int qq = tm * 16 + lk + 4 * r;
-                const double v = acc[r];
-                const double p = rp_partner(v);
-                if (qq < N && rho_ok && rm[qq]) {
-                    double2* dst = reinterpret_cast<double2*>(coef + (size_t)qq * cstride);     // I_{l,0}(qq)
-                    if (!(rho & 1)) {
-                        dst[m] = m ? make_double2(0.7071067811865476 * v, 0.7071067811865476 * p) : make_double2(v, 0.0);
-                    } else if (m) {
-                        dst[-m] = make_double2(sg * 0.7071067811865476 * p, -sg * 0.7071067811865476 * v);
+            for (int u = 0; u < RP_ACC; ++u) {
+                const int tile = base + wave + u * nwaves;
+                const bool ok = tile < ntq * ntn;
+                const int tq = ok ? tile : 0;
+                const int tm = tq / ntn, tn = tq - tm * ntn;
+                const int q = tm * 16 + li, rho = tn * 16 + li;
+                pa[u] = Vt + (q < N ? q : N - 1);
+                pb[u] = Xs + (rho < n2 ? rho : n2 - 1);
+                if (ok) nu = u + 1;
+            }
+            rp_tiles<RP_ACC, UNR>(acc, pa, N, pb, ns, k, lk, nu);
+#pragma unroll
+            for (int u = 0; u < RP_ACC; ++u) {
+                const int tile = base + wave + u * nwaves;
+                const bool t_ok = tile < ntq * ntn;
+                const int tq = t_ok ? tile : 0;
+                const int tm = tq / ntn, tn = tq - tm * ntn;
+                const int rho = tn * 16 + li, m = rho >> 1;
+                const double sg = (m & 1) ? -1.0 : 1.0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int qq = tm * 16 + lk + 4 * r;
+                    const double v = acc[u][r];
+                    const double p = rp_partner(v);              // (every lane: uniform control flow around DPP)
+                    if (t_ok && qq < N && rho < n2 && rm[qq]) {
+                        double2* dst = reinterpret_cast<double2*>(coef + (size_t)qq * cstride);     // I_{l,0}(qq)
+                        if (!(rho & 1)) {
+                            dst[m] = m ? make_double2(0.7071067811865476 * v, 0.7071067811865476 * p) : make_double2(v, 0.0);
+                        } else if (m) {
+                            dst[-m] = make_double2(sg * 0.7071067811865476 * p, -sg * 0.7071067811865476 * v);
+                        }
                     }
                 }
             }
         }
     }
     __syncthreads();                                           // LDS is reused by the next order of the slot
+    RP_STAMP(4)
+    if (dbg && tid == 0) {
+        dbg[5] = n_rounds_done;
+        dbg[7] = t1;
+    }
+#undef RP_STAMP
 }
 
 // grid = (restart, slot); slots are listed heaviest first, the restart index runs fastest: the workgroups that set the
 // duration of the launch are dispatched first
-__global__ void __launch_bounds__(RP_MAX_THREADS) k_rproj(RProjArgs A) {
+template <int MAXT, int UNR>
+__global__ void __launch_bounds__(MAXT) k_rproj(RProjArgs A) {
     HIP_DYNAMIC_SHARED(double, sm)
     __shared__ RpShared sh;
     const int b = (int)blockIdx.x;
@@ -457,7 +596,7 @@ __global__ void __launch_bounds__(RP_MAX_THREADS) k_rproj(RProjArgs A) {
         if (e < 0) break;                                      // uniform per block
         const int l = e & 255, kind = e >> 8;
         if (kind == RP_SOLVE) {
-            rp_solve<0>(A, b, l, sh, sm);
+            rp_solve<UNR>(A, b, l, sh, sm);
         } else if (kind == RP_ZERO) {
             // used order with V_l = 0 (odd_orders_to_0): I'_l = 0 on the masked shells, its unknowns stay 0
             const int n = 2 * l + 1;
@@ -509,6 +648,9 @@ bool rproj_supported(mtip_ctx* c) {
     if (kmax >= 2) {
         if (build_jacobi_schedule(c, kmax) != MTIP_OK) return false;
         if (c->jsched_ps * 16 > RP_MAX_THREADS) return false;
+        // the in-place products hold all their 16 x 16 tiles in registers across a barrier: RP_ACC per wave
+        const int waves = std::max(256, (c->jsched_ps * 16 + 63) / 64 * 64) / 64, nt16 = (kmax + 1 + 15) / 16;
+        if (div_up(nt16 * nt16, waves) > RP_ACC) return false;
         const size_t lds = ((size_t)kmax * ((kmax + 1) | 1) + (size_t)kmax * (kmax | 1) + RP_SLACK) * sizeof(double);
         if (lds + sizeof(RpShared) + 256 > 160 * 1024) return false;
     }
@@ -632,6 +774,7 @@ int launch_rproj(mtip_ctx* c, double2* coef) {
     a.tabs2 = c->polar_abs_tol * c->polar_abs_tol;
     a.inv_sqrt_np = 1.0 / std::sqrt(c->n_particles);
     a.sweeps_out = c->d_sweeps;
+    a.dbg = c->d_polar_dbg;
     const size_t mat = ((size_t)kmax * ((kmax + 1) | 1) + (size_t)kmax * (kmax | 1) + RP_SLACK) * sizeof(double);
     int nrd_max = 1;                                             // the schedule has more rounds than columns (70 at k = 65)
     for (int ke = 2; ke <= kmax && ke < (int)c->jsched_nrd.size(); ++ke) nrd_max = std::max(nrd_max, c->jsched_nrd[ke]);
@@ -641,7 +784,11 @@ int launch_rproj(mtip_ctx* c, double2* coef) {
     int threads = std::max(256, ((kmax >= 2 ? c->jsched_ps : 1) * 16 + 63) / 64 * 64);
     threads = std::min(threads, RP_MAX_THREADS);
     ProfScope pp(c, "polar");                                    // (the whole projection is this one kernel)
-    hipLaunchKernelGGL(k_rproj, dim3((unsigned)c->B, (unsigned)c->rp_n_slots), dim3((unsigned)threads), lds, c->stream, a);
+    // up to 512 threads: two waves per SIMD, 256 registers each; the 97-column orders of config 5 need 768 (three waves per SIMD)
+    if (threads <= 512)
+        hipLaunchKernelGGL((k_rproj<512, 2>), dim3((unsigned)c->B, (unsigned)c->rp_n_slots), dim3((unsigned)threads), lds, c->stream, a);
+    else
+        hipLaunchKernelGGL((k_rproj<RP_MAX_THREADS, 1>), dim3((unsigned)c->B, (unsigned)c->rp_n_slots), dim3((unsigned)threads), lds, c->stream, a);
     c->vr_kind = 2;
     c->proj_calls += 1;
     return MTIP_OK;
