@@ -51,6 +51,7 @@ for b in range(min(B, 1)):
         t = out[b, l]
         if t[10:30].any():
             r = max(t[5], 1)
-            print('b %d l %2d per round: busy per wave %s | barrier wait per wave %s | wave 0: operands + Gram %d, lane sums %d, parameters %d, rotations + stores %d' % (
-                b, l, (t[10:18] // r).tolist(), (t[18:26] // r).tolist(), t[26] // r, t[27] // r, t[28] // r, t[29] // r))
+            print('b %d l %2d per round: busy per wave %s | LDS drain + barrier per wave %s' % (b, l, (t[10:18] // r).tolist(), (t[18:26] // r).tolist()))
+            names = 'operands | Gram | lane sums | parameters | rotations + stores issued | LDS drain | barrier'
+            print('      wave 0: %s = %s;   wave 5: %s' % (names, (t[26:33] // r).tolist(), (t[33:40] // r).tolist()))
 e.close()

@@ -168,6 +168,116 @@ __device__ __forceinline__ void rp_sweep(double* Xs, double* Vs, int ns, int ks,
 #undef RP_SEG
 }
 
+// ---- the same sweep without branches: zero-padded columns ---------------------------------------------------------------------
+// A round of rp_sweep is bound by the NUMBER of instructions a wave issues (one per ~4 cycles, whatever their kind), and two
+// thirds of them were not arithmetic: exec-mask regions around every predicate (inactive group, last row slot, rotation or not,
+// write-back), zero initialisations, address arithmetic through the column permutation.  Up to 5 row slots (k <= 79) the matrices
+// are laid out so that none of that is needed:
+//   * X~ and V_r share one column stride NS = 16 NR + 1 and V_r sits a compile-time distance behind X~ (16 NR columns): every
+//     access of a round is `ds_read / ds_write base + immediate`, base = column offset from the table + lane;
+//   * rows beyond the matrix are zero and stay zero under rotations: no predicate on the last row slot;
+//   * column 16 NR - 1 is all zero: the groups without a pair in a round "rotate" it with itself (identity, zeros written back);
+//   * the pairing table is translated once per sweep into {resident offset << 2 | write-back << 1 | load, mover offset} (through
+//     the compaction of the deflated columns), flags made self-contained: a resident is written back before an idle round;
+//   * a pair that is orthogonal already takes the identity rotation through the same instructions.
+#define RP_PAD_MAX_NR 5
+__device__ __forceinline__ constexpr int rp_pad_ns(int nr) { return 16 * nr + 1; }
+__device__ __forceinline__ constexpr int rp_pad_voff(int nr) { return 16 * nr * (16 * nr + 1); }     // doubles from X~ to V_r
+
+template <int NR, bool TIMED = false>
+__device__ __forceinline__ void rp_sweep_pad(double* xt /* X~ + lane of the group */, const int2* tab, int n_rounds, int ngroups,
+                                             int group, double tabs2, double S, bool& big, long long* tacc = nullptr) {
+    constexpr int VOFF = rp_pad_voff(NR);
+    long long tq = 0;
+#define RP_SEG(I)                            \
+    if (TIMED) {                             \
+        const long long tn_ = clock64();     \
+        tacc[I] += tn_ - tq;                 \
+        tq = tn_;                            \
+    }
+    double rx[NR], rv[NR];
+#pragma unroll
+    for (int u = 0; u < NR; ++u) {
+        rx[u] = 0.0;
+        rv[u] = 0.0;
+    }
+    int2 e_next = tab[group];
+    if (TIMED) tq = clock64();
+    for (int r = 0; r < n_rounds; ++r) {
+        const int2 e = e_next;
+        if (r + 1 < n_rounds) e_next = tab[(r + 1) * ngroups + group];     // in flight during the round
+        double* xr = xt + (e.x >> 2);
+        double* xm = xt + e.y;
+        double mx[NR], mv[NR];
+#pragma unroll
+        for (int u = 0; u < NR; ++u) {
+            mx[u] = xm[u * 16];
+            mv[u] = xm[VOFF + u * 16];
+        }
+        if (e.x & 1) {                                           // a new resident for this group
+#pragma unroll
+            for (int u = 0; u < NR; ++u) {
+                rx[u] = xr[u * 16];
+                rv[u] = xr[VOFF + u * 16];
+            }
+        }
+        if (TIMED) asm volatile("" : "+v"(mx[0]), "+v"(mx[NR - 1]), "+v"(mv[NR - 1]), "+v"(rx[NR - 1]));
+        RP_SEG(0)
+        double alpha = 0.0, beta = 0.0, g = 0.0, zero = 0.0;
+#pragma unroll
+        for (int u = 0; u < NR; ++u) {
+            alpha = fma(rx[u], rx[u], alpha);
+            beta = fma(mx[u], mx[u], beta);
+            g = fma(rx[u], mx[u], g);
+        }
+        if (TIMED) asm volatile("" : "+v"(alpha), "+v"(beta), "+v"(g));
+        RP_SEG(1)
+        group_sum4<16>(alpha, beta, g, zero);
+        if (TIMED) asm volatile("" : "+v"(alpha), "+v"(beta), "+v"(g));
+        RP_SEG(2)
+        // rotation [a b] <- [a b] [[c, w], [-w, c]] (see rp_params), the identity for a pair that is orthogonal already
+        const double g2 = g * g, ab = alpha * beta;
+        const bool rot = g2 > (JAC_TOL * JAC_TOL) * ab && g2 > tabs2 * fmax(alpha, beta) * S && g2 > 0.0;
+        big = big || (rot && g2 > (JL_EARLY * JL_EARLY) * ab);
+        const double d = 0.5 * (beta - alpha);
+        const double h2 = fma(d, d, g2);
+        const double ih = fast_rsqrt(rot ? h2 : 1.0);
+        const double c2 = fma(0.5 * fabs(d), ih, 0.5);
+        const double rc = fast_rsqrt(c2);
+        const double cs = rot ? c2 * rc : 1.0;
+        const double w = rot ? ((d >= 0.0 ? 0.5 : -0.5) * ih * rc) * g : 0.0;
+        if (TIMED) asm volatile("" : "+v"(mx[0]) : "v"(cs), "v"(w));
+        RP_SEG(3)
+#pragma unroll
+        for (int u = 0; u < NR; ++u) {
+            const double a = rx[u], bq = mx[u];
+            rx[u] = fma(-w, bq, cs * a);
+            xm[u * 16] = fma(w, a, cs * bq);
+        }
+#pragma unroll
+        for (int u = 0; u < NR; ++u) {
+            const double a = rv[u], bq = mv[u];
+            rv[u] = fma(-w, bq, cs * a);
+            xm[VOFF + u * 16] = fma(w, a, cs * bq);
+        }
+        if (e.x & 2) {                                           // someone else takes the resident next round
+#pragma unroll
+            for (int u = 0; u < NR; ++u) {
+                xr[u * 16] = rx[u];
+                xr[VOFF + u * 16] = rv[u];
+            }
+        }
+        RP_SEG(4)
+        if (TIMED) {
+            MTIP_WAIT_LDS();
+            RP_SEG(5)
+        }
+        __syncthreads();
+        RP_SEG(6)
+    }
+#undef RP_SEG
+}
+
 struct RProjArgs {
     double* coef;                 // (B, N, nlm) complex128 coefficients viewed as doubles; projected in place
     const double* DV;             // per order at voff[l]: (N x k) row-major, q^2 V_l[q][j]
@@ -179,7 +289,7 @@ struct RProjArgs {
     const int* slots;             // (n_slots, slot_len): order | kind << 8, -1 = none
     int slot_len;
     const int *sched, *sched_off, *sched_rounds;
-    int sched_ps;
+    int sched_ps, tab_ints;       // tab_ints: ints reserved in LDS for the raw pairing table (even)
     int N, L, nlm, utot, xtot, warm;
     double tabs2, inv_sqrt_np;
     int* sweeps_out;
@@ -250,17 +360,22 @@ __device__ __forceinline__ double rp_partner(double v) { return dpp_mov<0xB1>(v)
 
 // the active order l of restart b: products, Jacobi, apply.  UNR: inner steps of the products requested at a time (register budget
 // of the launch bound: 4 with two waves per SIMD, 2 with three)
-template <int UNR>
+template <int UNR, bool BIG>
 __device__ __forceinline__ void rp_solve(const RProjArgs& A, int b, int l, RpShared& sh, double* sm) {
     const int tid = threadIdx.x, nthreads = blockDim.x;
     const int lane = tid & 63, wave = tid >> 6, nwaves = nthreads >> 6;
     const int li = lane & 15, lk = lane >> 4;
     const int N = A.N, k = A.kl[l], n = 2 * l + 1, n2 = 2 * l + 2;
     const int nr = (n2 + 15) >> 4;                       // row slots per lane (the same for the k rows of V_r: k = 2l+1)
-    const int ns = n2 | 1, ks = k | 1;                   // odd column strides
+    // up to RP_PAD_MAX_NR row slots: zero-padded columns, one stride, V_r a fixed distance behind X~ (rp_sweep_pad); beyond
+    // (config 5) the matrices fill the CU: tight columns, predicates on the last row slot (rp_sweep)
+    const bool pad = nr <= RP_PAD_MAX_NR;
+    const int ns = pad ? rp_pad_ns(nr) : (n2 | 1), ks = pad ? ns : (k | 1);      // odd column strides
     double* Xs = sm;
-    double* Vs = sm + (size_t)k * ns;
-    int* s_tab = reinterpret_cast<int*>(Vs + (size_t)k * ks + RP_SLACK);
+    double* Vs = sm + (pad ? (size_t)rp_pad_voff(nr) : (size_t)k * ns);
+    // behind the matrices: the pairing table of the current column count (raw, and translated per sweep in pad mode)
+    int* s_tab = reinterpret_cast<int*>(sm + (pad ? 2 * (size_t)rp_pad_voff(nr) : (size_t)k * ns + (size_t)k * ks) + RP_SLACK);
+    int2* s_tab2 = reinterpret_cast<int2*>(s_tab + A.tab_ints);
     const double* DV = A.DV + A.voff[l];
     const double* Vt = A.Vt + A.voff[l];
     double* coef = A.coef + ((size_t)b * N * A.nlm + (size_t)l * (l + 1)) * 2;    // (Re, Im) of m = 0 on shell 0
@@ -277,10 +392,14 @@ __device__ __forceinline__ void rp_solve(const RProjArgs& A, int b, int l, RpSha
         if (tid == 0) dbg[SLOT] = t1 - t0;              \
         t0 = t1;                                        \
     }
-    if (dbg && tid < 22) dbg[10 + tid] = 0;
+    if (dbg && tid < 30) dbg[10 + tid] = 0;
     if (dbg && tid == 0) {
         dbg[6] = t0;
         dbg[8] = (long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));      // HW_ID
+    }
+    if (pad) {                                           // zero padding (rows beyond the matrices, unused columns) once
+        for (int e = tid; e < 2 * rp_pad_voff(nr); e += nthreads) Xs[e] = 0.0;
+        __syncthreads();
     }
     // ---- A: X~^T[j][rho'] = sum_q DV[q][j] I~[q][rho'] -> Xs[j * ns + rho'] ------------------------------------------
     // (q^2 V)[q][j]: q stride k;  I~[q][rho']: q stride = one shell of coefficients
@@ -320,7 +439,7 @@ __device__ __forceinline__ void rp_solve(const RProjArgs& A, int b, int l, RpSha
         const int cc = e / ks, i = e - cc * ks;
         double v = 0.0;
         if (i < k) v = A.warm ? Vr[(size_t)cc * k + i] : (cc == i ? 1.0 : 0.0);
-        Vs[e] = v;
+        if (i < k || !pad) Vs[e] = v;
     }
     __syncthreads();
     RP_STAMP(0)
@@ -411,35 +530,56 @@ __device__ __forceinline__ void rp_solve(const RProjArgs& A, int b, int l, RpSha
             if (ke >= 2) {
                 const int* gtab = A.sched + A.sched_off[ke];
                 const int nrd = A.sched_rounds[ke];
-                // up to 5 row slots (k <= 79) the pairing table of this column count is staged in LDS, once per column count
-                // (the launcher sizes the allocation for it); beyond, the matrices fill the CU and it is read from L2 one
-                // round ahead.  Separate call sites: the table pointer keeps its address space (no flat loads).
-                if (nr <= 5 && tab_ke != ke) {
-                    for (int e = tid; e < nrd * A.sched_ps; e += nthreads) s_tab[e] = gtab[e];
-                    tab_ke = ke;
-                    __syncthreads();
-                }
-#define RP_SWEEP(NR, TAB) rp_sweep<NR>(Xs, Vs, ns, ks, t, group, TAB, nrd, A.sched_ps, sh.perm, xl_ok, vl_ok, A.tabs2, S, big)
-                if (dbg != nullptr && nr == 5) {                 // diagnostic instance with segment timers (one wave reports)
-                    long long tacc[5] = {0, 0, 0, 0, 0};
-                    rp_sweep<5, true>(Xs, Vs, ns, ks, t, group, s_tab, nrd, A.sched_ps, sh.perm, xl_ok, vl_ok, A.tabs2, S, big, tacc);
-                    if ((tid & 63) == 0 && (tid >> 6) < 8) {   // per wave: busy, barrier wait; wave 0 also the segments
-                        dbg[10 + (tid >> 6)] += tacc[0] + tacc[1] + tacc[2] + tacc[3];
-                        dbg[18 + (tid >> 6)] += tacc[4];
-                        if (tid == 0)
-                            for (int i = 0; i < 4; ++i) dbg[26 + i] += tacc[i];
+                if (pad) {
+                    // the raw pairing table of this column count in LDS once, translated for rp_sweep_pad every sweep (the
+                    // compaction of the deflated columns may have changed): offsets of the resident / mover columns, flags
+                    if (tab_ke != ke) {
+                        for (int e = tid; e < nrd * A.sched_ps; e += nthreads) s_tab[e] = gtab[e];
+                        tab_ke = ke;
+                        __syncthreads();
                     }
-                } else
-                switch (nr) {
-                case 1: RP_SWEEP(1, s_tab); break;
-                case 2: RP_SWEEP(2, s_tab); break;
-                case 3: RP_SWEEP(3, s_tab); break;
-                case 4: RP_SWEEP(4, s_tab); break;
-                case 5: RP_SWEEP(5, s_tab); break;
-                case 6: RP_SWEEP(6, gtab); break;
-                default: RP_SWEEP(7, gtab); break;
+                    const int ps = A.sched_ps;
+                    const int dummy = (16 * nr - 1) * ns;        // the all-zero column
+                    for (int e = tid; e < nrd * ngroups; e += nthreads) {
+                        const int r = e / ngroups, gq = e - r * ngroups;
+                        const int raw = gq < ps ? s_tab[r * ps + gq] : 0;
+                        int x = (dummy << 2) | 1, y = dummy;
+                        if (raw & JS_ACTIVE) {
+                            const int prev = r > 0 ? s_tab[(r - 1) * ps + gq] : 0;
+                            const int next = r + 1 < nrd ? s_tab[(r + 1) * ps + gq] : 0;
+                            // a resident stays in registers only from one active round to the next one with the same resident
+                            const int load = (!(prev & JS_ACTIVE) || (prev & JS_WB) || (prev & 255) != (raw & 255)) ? 1 : 0;
+                            const int wb = ((raw & JS_WB) || !(next & JS_ACTIVE)) ? 2 : 0;
+                            x = ((sh.perm[raw & 255] * ns) << 2) | wb | load;
+                            y = sh.perm[(raw >> 8) & 255] * ns;
+                        }
+                        s_tab2[e] = make_int2(x, y);
+                    }
+                    __syncthreads();
+                    double* xt = Xs + t;
+                    if (dbg != nullptr && nr == 5) {             // diagnostic instance with segment timers
+                        long long tacc[7] = {0, 0, 0, 0, 0, 0, 0};
+                        rp_sweep_pad<5, true>(xt, s_tab2, nrd, ngroups, group, A.tabs2, S, big, tacc);
+                        if ((tid & 63) == 0 && (tid >> 6) < 8) {   // per wave: busy, LDS drain + barrier; wave 0 and 5 also the segments
+                            dbg[10 + (tid >> 6)] += tacc[0] + tacc[1] + tacc[2] + tacc[3] + tacc[4];
+                            dbg[18 + (tid >> 6)] += tacc[5] + tacc[6];
+                            if (tid == 0 || tid == 320)
+                                for (int i = 0; i < 7; ++i) dbg[(tid ? 33 : 26) + i] += tacc[i];
+                        }
+                    } else {
+                        switch (nr) {
+                        case 1: rp_sweep_pad<1>(xt, s_tab2, nrd, ngroups, group, A.tabs2, S, big); break;
+                        case 2: rp_sweep_pad<2>(xt, s_tab2, nrd, ngroups, group, A.tabs2, S, big); break;
+                        case 3: rp_sweep_pad<3>(xt, s_tab2, nrd, ngroups, group, A.tabs2, S, big); break;
+                        case 4: rp_sweep_pad<4>(xt, s_tab2, nrd, ngroups, group, A.tabs2, S, big); break;
+                        default: rp_sweep_pad<5>(xt, s_tab2, nrd, ngroups, group, A.tabs2, S, big); break;
+                        }
+                    }
+                } else if (BIG) {
+                    // 6 or 7 row slots: the table is read from L2 one round ahead
+                    if (nr == 6) rp_sweep<6>(Xs, Vs, ns, ks, t, group, gtab, nrd, A.sched_ps, sh.perm, xl_ok, vl_ok, A.tabs2, S, big);
+                    else rp_sweep<7>(Xs, Vs, ns, ks, t, group, gtab, nrd, A.sched_ps, sh.perm, xl_ok, vl_ok, A.tabs2, S, big);
                 }
-#undef RP_SWEEP
                 n_rounds_done += nrd;
             }
             if (t == 0) sh.gmax[group] = big ? 1.0 : 0.0;
@@ -585,7 +725,7 @@ __device__ __forceinline__ void rp_solve(const RProjArgs& A, int b, int l, RpSha
 
 // grid = (restart, slot); slots are listed heaviest first, the restart index runs fastest: the workgroups that set the
 // duration of the launch are dispatched first
-template <int MAXT, int UNR>
+template <int MAXT, int UNR, bool BIG>
 __global__ void __launch_bounds__(MAXT) k_rproj(RProjArgs A) {
     HIP_DYNAMIC_SHARED(double, sm)
     __shared__ RpShared sh;
@@ -596,7 +736,7 @@ __global__ void __launch_bounds__(MAXT) k_rproj(RProjArgs A) {
         if (e < 0) break;                                      // uniform per block
         const int l = e & 255, kind = e >> 8;
         if (kind == RP_SOLVE) {
-            rp_solve<UNR>(A, b, l, sh, sm);
+            rp_solve<UNR, BIG>(A, b, l, sh, sm);
         } else if (kind == RP_ZERO) {
             // used order with V_l = 0 (odd_orders_to_0): I'_l = 0 on the masked shells, its unknowns stay 0
             const int n = 2 * l + 1;
@@ -632,6 +772,36 @@ __global__ void __launch_bounds__(MAXT) k_rproj(RProjArgs A) {
 }
 
 // ---- host side --------------------------------------------------------------------------------------------------------
+// threads and dynamic LDS of a k_rproj launch.  LDS: the largest order's matrices -- padded layout up to RP_PAD_MAX_NR row
+// slots, behind them the raw pairing table and its per-sweep translation (one int2 per round and group); tight layout beyond
+// (table read from L2) -- whichever needs more; tab_ints = ints reserved for the raw table
+static size_t rp_launch_geometry(const mtip_ctx* c, int* threads_out, int* tab_ints_out) {
+    int kpad = 0, kbig = 0;
+    for (int l = 1; l <= c->L; ++l) {
+        if (!c->active[l]) continue;
+        if ((c->kl[l] + 1 + 15) / 16 <= RP_PAD_MAX_NR) kpad = std::max(kpad, c->kl[l]);
+        else kbig = std::max(kbig, c->kl[l]);
+    }
+    const int kmax = std::max(kpad, kbig);
+    const int ps = kmax >= 2 ? std::max(c->jsched_ps, 1) : 1;
+    int threads = std::max(256, (ps * 16 + 63) / 64 * 64);
+    size_t lds = RP_SLACK * sizeof(double);
+    int tab_ints = 0;
+    if (kpad >= 2) {
+        int nrd = 1;                                             // (the schedule has more rounds than columns: 70 at k = 65)
+        for (int ke = 2; ke <= kpad && ke < (int)c->jsched_nrd.size(); ++ke) nrd = std::max(nrd, c->jsched_nrd[ke]);
+        tab_ints = (nrd * ps + 1) & ~1;
+        const size_t nr = (kpad + 1 + 15) / 16;
+        lds = (2 * 16 * nr * (16 * nr + 1) + RP_SLACK) * sizeof(double) + (size_t)tab_ints * sizeof(int) +
+              (size_t)nrd * (threads / 16) * sizeof(int2);
+    }
+    if (kbig >= 2)
+        lds = std::max(lds, ((size_t)kbig * ((kbig + 1) | 1) + (size_t)kbig * (kbig | 1) + RP_SLACK) * sizeof(double));
+    if (threads_out) *threads_out = threads;
+    if (tab_ints_out) *tab_ints_out = tab_ints;
+    return lds;
+}
+
 // every solved order square (k_l = 2l+1), V_l real, 2l+2 <= 7 row slots of 16, the schedule and the matrices fit
 bool rproj_supported(mtip_ctx* c) {
     if (!c->proj_real) return false;
@@ -647,12 +817,13 @@ bool rproj_supported(mtip_ctx* c) {
     if (kmax > 111) return false;
     if (kmax >= 2) {
         if (build_jacobi_schedule(c, kmax) != MTIP_OK) return false;
-        if (c->jsched_ps * 16 > RP_MAX_THREADS) return false;
-        // the in-place products hold all their 16 x 16 tiles in registers across a barrier: RP_ACC per wave
-        const int waves = std::max(256, (c->jsched_ps * 16 + 63) / 64 * 64) / 64, nt16 = (kmax + 1 + 15) / 16;
-        if (div_up(nt16 * nt16, waves) > RP_ACC) return false;
-        const size_t lds = ((size_t)kmax * ((kmax + 1) | 1) + (size_t)kmax * (kmax | 1) + RP_SLACK) * sizeof(double);
+        int threads = 0;
+        const size_t lds = rp_launch_geometry(c, &threads, nullptr);
+        if (threads > RP_MAX_THREADS) return false;
         if (lds + sizeof(RpShared) + 256 > 160 * 1024) return false;
+        // the in-place products hold all their 16 x 16 tiles in registers across a barrier: RP_ACC per wave
+        const int nt16 = (kmax + 1 + 15) / 16;
+        if (div_up(nt16 * nt16, threads / 64) > RP_ACC) return false;
     }
     return true;
 }
@@ -775,20 +946,14 @@ int launch_rproj(mtip_ctx* c, double2* coef) {
     a.inv_sqrt_np = 1.0 / std::sqrt(c->n_particles);
     a.sweeps_out = c->d_sweeps;
     a.dbg = c->d_polar_dbg;
-    const size_t mat = ((size_t)kmax * ((kmax + 1) | 1) + (size_t)kmax * (kmax | 1) + RP_SLACK) * sizeof(double);
-    int nrd_max = 1;                                             // the schedule has more rounds than columns (70 at k = 65)
-    for (int ke = 2; ke <= kmax && ke < (int)c->jsched_nrd.size(); ++ke) nrd_max = std::max(nrd_max, c->jsched_nrd[ke]);
-    const size_t tab = (size_t)nrd_max * a.sched_ps * sizeof(int);
-    // the pairing table of a sweep is staged in LDS up to 5 row slots (k_l <= 79), see rp_solve
-    const size_t lds = mat + ((kmax + 1 + 15) / 16 <= 5 ? tab : 0);       // row slots of the largest order: 2l+2 = k+1 rows
-    int threads = std::max(256, ((kmax >= 2 ? c->jsched_ps : 1) * 16 + 63) / 64 * 64);
-    threads = std::min(threads, RP_MAX_THREADS);
+    int threads = 256;
+    const size_t lds = rp_launch_geometry(c, &threads, &a.tab_ints);
     ProfScope pp(c, "polar");                                    // (the whole projection is this one kernel)
     // up to 512 threads: two waves per SIMD, 256 registers each; the 97-column orders of config 5 need 768 (three waves per SIMD)
     if (threads <= 512)
-        hipLaunchKernelGGL((k_rproj<512, 2>), dim3((unsigned)c->B, (unsigned)c->rp_n_slots), dim3((unsigned)threads), lds, c->stream, a);
+        hipLaunchKernelGGL((k_rproj<512, 2, false>), dim3((unsigned)c->B, (unsigned)c->rp_n_slots), dim3((unsigned)threads), lds, c->stream, a);
     else
-        hipLaunchKernelGGL((k_rproj<RP_MAX_THREADS, 1>), dim3((unsigned)c->B, (unsigned)c->rp_n_slots), dim3((unsigned)threads), lds, c->stream, a);
+        hipLaunchKernelGGL((k_rproj<RP_MAX_THREADS, 1, true>), dim3((unsigned)c->B, (unsigned)c->rp_n_slots), dim3((unsigned)threads), lds, c->stream, a);
     c->vr_kind = 2;
     c->proj_calls += 1;
     return MTIP_OK;

@@ -12,6 +12,10 @@
 #ifndef MTIP_PIN_VGPRS4
 #define MTIP_PIN_VGPRS4(a, b, c, d) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
 #endif
+// all LDS operations of this wave have completed (diagnostic timers: separates the store drain from the barrier wait)
+#ifndef MTIP_WAIT_LDS
+#define MTIP_WAIT_LDS() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#endif
 
 
 typedef double v4f64 __attribute__((vector_size(32)));   // accumulator of v_mfma_f64_16x16x4_f64
