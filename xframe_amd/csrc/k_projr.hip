@@ -312,46 +312,38 @@ __device__ __forceinline__ void rp_tiles(v4f64 (&acc)[T], const double* const (&
                                          int K, int lk, int nu) {
 #pragma unroll
     for (int u = 0; u < T; ++u) acc[u] = v4f64{0.0, 0.0, 0.0, 0.0};
-    const int Kfull = K - (K % (4 * UNR));
-    for (int k0 = 0; k0 < Kfull; k0 += 4 * UNR) {
-        double a[T][UNR], bb[T][UNR];
+    // two register sets: the operands of the next chunk are requested before the current chunk is multiplied (the two waves of a
+    // SIMD run this in lock step after a barrier: without the prefetch both load, then both queue on the matrix pipe)
+    double a0[T][UNR], b0[T][UNR], a1[T][UNR], b1[T][UNR];
+    const int n_chunks = (K + 4 * UNR - 1) / (4 * UNR);
+    auto request = [&](int ch, double (&a)[T][UNR], double (&bb)[T][UNR]) {
+        const int k0 = ch * 4 * UNR;
 #pragma unroll
         for (int u = 0; u < T; ++u)
             if (u < nu) {
 #pragma unroll
                 for (int x = 0; x < UNR; ++x) {
                     const int kk = k0 + 4 * x + lk;
-                    a[u][x] = pa[u][kk * sa];
-                    bb[u][x] = pb[u][kk * sb];
-                }
-            }
-#pragma unroll
-        for (int u = 0; u < T; ++u)
-            if (u < nu) {
-#pragma unroll
-                for (int x = 0; x < UNR; ++x) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][x], bb[u][x], acc[u], 0, 0, 0);
-            }
-    }
-    if (Kfull < K) {                                         // (uniform) tail: up to UNR masked steps
-        double a[T][UNR], bb[T][UNR];
-#pragma unroll
-        for (int u = 0; u < T; ++u)
-            if (u < nu) {
-#pragma unroll
-                for (int x = 0; x < UNR; ++x) {
-                    const int kk = Kfull + 4 * x + lk;
-                    const int kq = kk < K ? kk : K - 1;
-                    a[u][x] = pa[u][kq * sa] * (kk < K ? 1.0 : 0.0);
+                    const int kq = kk < K ? kk : K - 1;              // beyond K (last chunk, or a request past the end): clamped, times zero
+                    const double m = kk < K ? 1.0 : 0.0;
+                    a[u][x] = pa[u][kq * sa] * m;
                     bb[u][x] = pb[u][kq * sb];
                 }
             }
+    };
+    auto multiply = [&](const double (&a)[T][UNR], const double (&bb)[T][UNR]) {
 #pragma unroll
-        for (int u = 0; u < T; ++u)
-            if (u < nu) {
+        for (int x = 0; x < UNR; ++x)
 #pragma unroll
-                for (int x = 0; x < UNR; ++x)
-                    if (Kfull + 4 * x < K) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][x], bb[u][x], acc[u], 0, 0, 0);
-            }
+            for (int u = 0; u < T; ++u)
+                if (u < nu) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][x], bb[u][x], acc[u], 0, 0, 0);
+    };
+    request(0, a0, b0);
+    for (int ch = 0; ch < n_chunks; ch += 2) {
+        request(ch + 1, a1, b1);                                 // (past the end: zeros)
+        multiply(a0, b0);
+        if (ch + 2 < n_chunks) request(ch + 2, a0, b0);
+        if (ch + 1 < n_chunks) multiply(a1, b1);
     }
 }
 
@@ -363,7 +355,9 @@ __device__ __forceinline__ double rp_partner(double v) { return dpp_mov<0xB1>(v)
 template <int UNR, bool BIG>
 __device__ __forceinline__ void rp_solve(const RProjArgs& A, int b, int l, RpShared& sh, double* sm) {
     const int tid = threadIdx.x, nthreads = blockDim.x;
-    const int lane = tid & 63, wave = tid >> 6, nwaves = nthreads >> 6;
+    // (the wave index through readfirstlane: everything derived from it -- tile lists, tile counts -- is then scalar, and the
+    // guards around the products are branches, not exec-mask regions with a full wait at every join)
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = nthreads >> 6;
     const int li = lane & 15, lk = lane >> 4;
     const int N = A.N, k = A.kl[l], n = 2 * l + 1, n2 = 2 * l + 2;
     const int nr = (n2 + 15) >> 4;                       // row slots per lane (the same for the k rows of V_r: k = 2l+1)
