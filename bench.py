@@ -320,48 +320,48 @@ def main():
                 tops['proj_gemms'] = {'total_ms': fam_ms['proj']['total_ms'] - fam_ms['polar']['total_ms']}
             top = max(tops, key=lambda k: tops[k]['total_ms'])
             if top == 'polar':
-                swp = np.asarray(e0.jacobi_sweeps(), dtype=float)                  # (Bp, L+1): sweeps / iterations of the last call
+                swp = np.asarray(e0.jacobi_sweeps(), dtype=float)                  # (Bp, L+1): sweeps of the last call
                 ns = 2 * np.arange(L + 1) + 1
                 active = swp.mean(0) > 0
-                newton = os.environ.get('MTIP_POLAR', 'jacobi') == 'newton'
-                if newton:
-                    # one Newton iteration = one in-place complex Gauss-Jordan inverse (n^3 complex multiply-adds = 8 n^3 flop)
-                    # + the update (4 n^2)
-                    flops = float((swp * (8.0 * ns ** 3 + 4.0 * ns ** 2)[None, :]).sum())
-                    kname = 'polar (k_polar_newton: scaled Newton polar factor, Gauss-Jordan inverse)'
+                real = (os.environ.get('MTIP_PROJ_REAL', '1') != '0'
+                        and all(np.all(np.asarray(p).imag == 0) for p in data['data_projection_matrices']))
+                if real:
+                    # k_rproj, real arithmetic.  One sweep of the one-sided Jacobi = n (n - 1) / 2 column pairs, each 6 n flop for the
+                    # three Gram sums and 6 flop per row for the rotation of the two X~ columns (n rows) and of the two V_r columns
+                    # (n rows): 18 n per pair, 9 n^3 per sweep (deflated columns counted as present: an upper bound); the four
+                    # products of an order (X~, warm start, U, apply) 2 n^2 (2 N + 2 n) flop
+                    per_sweep, prod = 9.0 * ns ** 3, 2.0 * ns ** 2 * (2.0 * N + 2.0 * ns) * active
+                    kname = ('polar (k_rproj: the whole reciprocal projection in real arithmetic -- four f64 MFMA products and the '
+                             'one-sided Jacobi SVD in LDS, one workgroup per (restart, slot of orders))')
+                    slots = 9 if L == 32 else int(active.sum())                    # workgroups per restart (host-packed slots)
                 else:
-                    # one sweep of the one-sided Jacobi SVD = n (n - 1) / 2 column pairs, each 16 n flop for the Gram sums and
-                    # 24 flop per row for the rotation of the two X_l columns (n rows) and of the two V_r columns (n rows): 64 n
-                    # per pair, 32 n^3 per sweep (deflated columns are counted as if present: an upper bound of the work done)
-                    flops = float((swp * (32.0 * ns ** 3)[None, :]).sum())
-                    kname = 'polar (k_polar_jacobi_lds: one-sided Jacobi SVD in LDS, one workgroup per (restart, order))'
-                conc = (not newton) and os.environ.get('MTIP_JAC_CONC', '1') != '0'
-                if conc:
-                    kname = ('polar (k_polar_conc: one-sided Jacobi SVD in LDS, one workgroup per (restart, order); the V_r half of the largest '
-                             'order on two more workgroups, concurrently)')
-                cus = int(min(Bp * (int(active.sum()) + (2 if conc else 0)), e0_cus))
-                peak = cus * 4 * 32 * 2.4e9 / 1e12                                # FP64 vector: 32 flop / clk / SIMD at 2.4 GHz
+                    # complex one-sided Jacobi: 16 n flop for the Gram sums and 24 flop per row for the rotations: 32 n^3 per sweep
+                    per_sweep, prod = 32.0 * ns ** 3, 0.0 * ns
+                    kname = 'polar (k_polar_jacobi_lds: complex one-sided Jacobi SVD in LDS, one workgroup per (restart, order))'
+                    slots = int(active.sum())
+                flops = float((swp * per_sweep[None, :] + prod[None, :]).sum())
+                cus = int(min(Bp * slots, e0_cus))
+                peak_cu = 4 * 32 * 2.4e9 / 1e12                                   # FP64 vector: 32 flop / clk / SIMD at 2.4 GHz
                 ach = flops / (fam_ms['polar']['avg_ms'] * 1e-3) / 1e12
+                crit = float(swp[:, -1].max() * per_sweep[-1] + prod[-1])
                 roofline = {'bound': 'fp64_valu', 'kernel': kname,
-                            'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak, 'traffic': None,
-                            'cus_used': cus, 'cus_total': e0_cus, 'avg_launch_ms': fam_ms['polar']['avg_ms'],
+                            'achieved': ach, 'peak': e0_cus * peak_cu, 'unit': 'TFLOP/s', 'frac': ach / (e0_cus * peak_cu), 'traffic': None,
+                            'cus_used': cus, 'cus_total': e0_cus, 'frac_of_cus_used': ach / (cus * peak_cu),
+                            'avg_launch_ms': fam_ms['polar']['avg_ms'],
                             'algorithmic_flops_per_launch': flops, 'restarts_per_launch': Bp,
-                            'sweeps_or_iterations_restart0': [int(x) for x in swp[0]],
+                            'sweeps_restart0': [int(x) for x in swp[0]],
                             'share_of_step': fam_ms['polar']['total_ms'] / sum(v['total_ms'] for v in tops.values()),
                             # the launch lasts as long as its largest matrix (l = L, one CU): that matrix against one CU's peak
-                            'critical_matrix': {'n': int(ns[-1]), 'flops': float(swp[:, -1].max() * (8.0 * ns[-1] ** 3 + 4.0 * ns[-1] ** 2 if newton
-                                                                                               else 32.0 * ns[-1] ** 3)),
-                                                'peak_one_cu': 4 * 32 * 2.4e9 / 1e12,
-                                                'frac_one_cu': float(swp[:, -1].max() * (8.0 * ns[-1] ** 3 + 4.0 * ns[-1] ** 2 if newton
-                                                                                    else 32.0 * ns[-1] ** 3))
-                                                / (fam_ms['polar']['avg_ms'] * 1e-3) / (4 * 32 * 2.4e9)},
+                            'critical_matrix': {'n': int(ns[-1]), 'flops': crit, 'peak_one_cu': peak_cu,
+                                                'frac_one_cu': crit / (fam_ms['polar']['avg_ms'] * 1e-3) / 1e12 / peak_cu},
                             'hbm_family': hbm_roof,
                             'note': 'dominant kernel by hipEvent time over the timed region on the stream of engine 0; not an HBM or '
-                                    'MFMA kernel: bound by FP64 vector issue and the latency of its dependent chain inside one CU '
-                                    'per matrix; peak = FP64 vector rate of the CUs the launch occupies (one workgroup per '
-                                    'matrix); flops from the sweep / iteration counts of the last timed call; hbm_family = the '
-                                    'dominant HBM-bound kernel family against 8 TB/s, traffic = FETCH_SIZE x 2 + WRITE_SIZE of '
-                                    'profiles/pmc_traffic.json when collected at this batch size'}
+                                    'MFMA kernel: a chain of dependent Jacobi rounds inside one CU per matrix (LDS exchange, lane sums, '
+                                    'rotation parameters, barrier; in-kernel timers: profiles/r03_rproj_round_timers.txt); peak = FP64 '
+                                    'vector rate of the whole chip, frac_of_cus_used = against the CUs the launch occupies; flops '
+                                    'from the sweep counts of the last timed call; hbm_family = the dominant HBM-bound kernel '
+                                    'family against 8 TB/s, traffic = FETCH_SIZE x 2 + WRITE_SIZE of profiles/pmc_traffic.json '
+                                    'when collected at this batch size'}
             else:
                 roofline = dict(hbm_roof)
                 roofline['share_of_step'] = fam_ms[dom]['total_ms'] / sum(v['total_ms'] for v in tops.values())

@@ -217,9 +217,10 @@ int mtip_profile_reset(mtip_ctx* ctx);
 /* diagnostic of the last polar-factor solve, (n_batch, L+1) int32: bits 0-7 Jacobi sweeps used, bits 8+ the
  * number of columns of X_l that were still non-zero (not deflated) in the final sweep */
 int mtip_debug_jacobi_sweeps(mtip_ctx* ctx, int32_t* out);
-/* diagnostic: phase timers of the Newton polar-factor kernel, (n_batch, L+1, 8 waves, 4) int64 shader cycles of the last
- * projection: producing records, waiting for records, applying them, whole kernel.  The first call (out may be NULL)
- * switches the timers on. */
+/* diagnostic: in-kernel timers of the real projection kernel (k_rproj), (n_batch, L+1, 32) int64 s_memtime ticks of the last
+ * projection per (restart, order): [0..4] phases X~ product, warm start, Jacobi, U, apply; [5] rounds; [6], [7] start / end;
+ * [8] hardware id; [10..17] busy and [18..25] LDS drain + barrier per wave and [26..32] the segments of a round of wave 0
+ * (summed over the rounds; largest order of L = 32 only).  The first call (out may be NULL) switches the timers on. */
 int mtip_debug_polar_timing(mtip_ctx* ctx, int64_t* out);
 /* diagnostic: enqueue a one-workgroup kernel that spins for `microseconds` on the context's stream (asynchronous).  Used to
  * check that the streams of several engines of one process really execute side by side (HIP maps streams onto a limited

@@ -41,11 +41,3 @@ def rel_l2(a, b):
     n = np.linalg.norm(b.ravel())
     d = np.linalg.norm((a - b).ravel())
     return d / n if n > 0 else d
-
-
-@pytest.fixture(autouse=True)
-def _emulation_defaults(request, monkeypatch):
-    """CPU tests run the kernels on the fiber emulation: the concurrent V_r replay (default on the GPU) makes consumer workgroups
-    poll for their producer there, which costs minutes over the suite -- off unless a test is about it (it sets the variable itself)."""
-    if request.node.get_closest_marker('gpu') is None and 'MTIP_JAC_CONC' not in os.environ:
-        monkeypatch.setenv('MTIP_JAC_CONC', '0')

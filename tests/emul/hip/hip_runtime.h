@@ -141,6 +141,30 @@ static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int, i
     else { std::fprintf(stderr, "emul: unsupported dpp ctrl 0x%x\n", ctrl); std::abort(); }
     return __shfl(src, from, 64);
 }
+// v_permlane16_swap_b32 / v_permlane32_swap_b32 (gfx950), semantics measured on the MI355X (scripts/microbench/permlane_swap.hip):
+// (vdst_old A, src0_old B) -> {vdst_new, src0_new}; rows of 16 lanes: 16: {[A0 B0 A2 B2], [A1 B1 A3 B3]}, 32: {[A0 A1 B0 B1], [A2 A3 B2 B3]}
+struct emul_u2 {
+    unsigned v[2];
+    unsigned operator[](int i) const { return v[i]; }
+};
+static inline emul_u2 __builtin_amdgcn_permlane16_swap(unsigned a, unsigned b, bool, bool) {
+    const int l = emul::lane(), row = l >> 4, col = l & 15;
+    // vdst_new row r: even r -> A[r], odd r -> B[r - 1];  src0_new row r: even r -> A[r + 1], odd r -> B[r]
+    const unsigned a_from0 = __shfl(a, (row & ~1) * 16 + col, 64), b_from0 = __shfl(b, (row & ~1) * 16 + col, 64);
+    const unsigned a_from1 = __shfl(a, (row | 1) * 16 + col, 64), b_from1 = __shfl(b, (row | 1) * 16 + col, 64);
+    emul_u2 r;
+    r.v[0] = (row & 1) ? b_from0 : a_from0;
+    r.v[1] = (row & 1) ? b_from1 : a_from1;
+    return r;
+}
+static inline emul_u2 __builtin_amdgcn_permlane32_swap(unsigned a, unsigned b, bool, bool) {
+    const int l = emul::lane(), half = l >> 5, col = l & 31;
+    const unsigned a_lo = __shfl(a, col, 64), a_hi = __shfl(a, 32 + col, 64), b_lo = __shfl(b, col, 64), b_hi = __shfl(b, 32 + col, 64);
+    emul_u2 r;
+    r.v[0] = half ? b_lo : a_lo;
+    r.v[1] = half ? b_hi : a_hi;
+    return r;
+}
 // wave-uniform lane reads (the lane index is uniform in the kernels: an SGPR on the GPU)
 static inline int __builtin_amdgcn_readlane(int v, int src_lane) { return __shfl(v, src_lane, 64); }
 #define MTIP_PIN_VGPRS4(a, b, c, d)      // register-scheduling fence of the device build: nothing to do on the host

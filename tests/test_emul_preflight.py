@@ -85,36 +85,9 @@ def test_sw_center_vs_oracle(emul_lib, golden_mtip16, fused):
     PC.check_sw_center_trajectory_vs_oracle(golden_mtip16, emul_lib, fused)
 
 
-@pytest.mark.parametrize('N,L', [(70, 34), (86, 42)])
-def test_projection_rotation_log_sizes(emul_lib, N, L, monkeypatch):
-    """Polar factor with the rotation log (X_l only in LDS, V_r replayed row-wise): k = 69 takes 34 slots per round
-    (64 lanes per row in the replay), k = 85 the 7-row-slot / 768-thread Jacobi variant that config 5 uses (the log is
-    automatic there; forced at the smaller size, where X_l and V_r would still share the LDS)."""
-    monkeypatch.setenv('MTIP_JAC_REPLAY', '2')
-    PC.check_projection_vs_oracle(N, L, emul_lib, n_batch=1)
-
-
-@pytest.mark.parametrize('fused', [False, True])
-def test_short_trajectory_rotation_log(emul_lib, golden_mtip16, fused, monkeypatch):
-    monkeypatch.setenv('MTIP_JAC_REPLAY', '2')
-    PC.check_short_trajectory_vs_oracle(golden_mtip16, emul_lib, fused)
-
-
-def test_projection_concurrent_replay(emul_lib, monkeypatch):
-    """k_polar_conc: the Jacobi workgroups publish their rotations, other workgroups of the same launch apply them to V_r
-    while they are written (the emulation runs the blocks on real threads, so the publish / validate protocol is live);
-    2l+1 up to 53: two consumer workgroups per matrix"""
-    monkeypatch.setenv('MTIP_JAC_CONC', '1')
-    monkeypatch.setenv('MTIP_JAC_CONC_MIN_K', '2')           # every order split (default: the largest only)
-    PC.check_projection_vs_oracle(56, 26, emul_lib, n_batch=2)
-    monkeypatch.delenv('MTIP_JAC_CONC_MIN_K')
-    PC.check_projection_vs_oracle(40, 18, emul_lib, n_batch=2)
-
-
-def test_short_trajectory_concurrent_replay(emul_lib, golden_mtip16, monkeypatch):
-    monkeypatch.setenv('MTIP_JAC_CONC', '1')
-    monkeypatch.setenv('MTIP_JAC_CONC_MIN_K', '2')
-    PC.check_short_trajectory_vs_oracle(golden_mtip16, emul_lib, True)
+def test_projection_general_kernels_large(emul_lib):
+    """the general (complex) projection at 2l+1 = 69: X_l and V_r still share one CU's LDS (unpadded columns)"""
+    PC.check_projection_vs_oracle(70, 34, emul_lib, n_batch=1)
 
 
 @pytest.mark.parametrize('kind', ['bump', 'low_resolution_autocorrelation'])
@@ -129,19 +102,6 @@ def test_apply_unknowns_operator(emul_lib, golden_mtip16):
 def test_worker_engines_vs_single_and_oracle(emul_lib):
     """the config-4 worker case of the GPU suite at a toy size: 4 restarts on 2 engines"""
     PC.check_config4_worker(emul_lib, cfg=1, n_restarts=4, n_workers=2, n_hio=3, n_er=2, oracle_restarts=(0, 1), sizes=(12, 4))
-
-
-@pytest.mark.parametrize('N,L', [(20, 9), (36, 16)])
-def test_projection_newton_polar_sizes(emul_lib, N, L, monkeypatch):
-    """MTIP_POLAR=newton: scaled-Newton polar factor (k_polar.hip, 2 / 4 / 8 columns per wave) against the oracle's numpy SVD
-    route (the 65 x 65 case, two row slots, runs on the GPU)."""
-    monkeypatch.setenv('MTIP_POLAR', 'newton')
-    PC.check_projection_vs_oracle(N, L, emul_lib, n_batch=1)
-
-
-def test_short_trajectory_newton_polar(emul_lib, golden_mtip16, monkeypatch):
-    monkeypatch.setenv('MTIP_POLAR', 'newton')
-    PC.check_short_trajectory_vs_oracle(golden_mtip16, emul_lib, True)
 
 
 @pytest.mark.parametrize('name', PC.VARIANT_NAMES)

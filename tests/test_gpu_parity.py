@@ -93,9 +93,9 @@ def test_config2_trajectory_vs_oracle(fused):
 
 @pytest.mark.parametrize('N,L', [(40, 18), (66, 32), (96, 44)])
 def test_projection_vs_oracle_sizes(N, L):
-    """(40, 18): LDS Jacobi with 3 row slots and odd/even k mixes; (66, 32): the benchmark's 65 x 65 matrices; (96, 44): X_l
-    and V_r (2l+1 = 89) do not share one CU's LDS -> X_l-only Jacobi with the rotation log + row-wise V_r replay (the path
-    config 5, L = 48, takes)."""
+    """the general (complex) projection kernels on random coefficients without any symmetry -- (40, 18): LDS Jacobi with 3 row
+    slots and odd/even k mixes; (66, 32): 65 x 65 matrices; (96, 44): X_l and V_r (2l+1 = 89, complex) do not share one CU's
+    LDS -> the global-memory Jacobi fallback"""
     PC.check_projection_vs_oracle(N, L)
 
 
@@ -110,22 +110,6 @@ def test_projection_real_vs_oracle(N, L):
 @pytest.mark.parametrize('ropt', [{'odd_orders_to_0': False}, {'use_averaged_intensity': False}, {'used_order_ids': np.arange(3)}])
 def test_projection_real_option_variants(ropt):
     PC.check_projection_real_vs_oracle(24, 10, reciprocal_opt=ropt)
-
-
-@pytest.mark.parametrize('N,L', [(40, 18), (66, 32), (72, 34)])
-def test_projection_vs_oracle_newton_polar(N, L, monkeypatch):
-    """MTIP_POLAR=newton: scaled-Newton polar factor (k_polar.hip) with one row slot (2l+1 <= 37), with the benchmark's
-    65 x 65 matrices and with the largest size it takes (69 x 69, two row slots, nine columns per wave)"""
-    monkeypatch.setenv('MTIP_POLAR', 'newton')
-    PC.check_projection_vs_oracle(N, L)
-
-
-@pytest.mark.parametrize('N,L,mode', [(40, 18, '2'), (72, 34, '2'), (96, 44, '0')])
-def test_projection_vs_oracle_jacobi_modes(N, L, mode, monkeypatch):
-    """Same projection with the other Jacobi path forced: rotation log at sizes that would run fused
-    (32 / 64 lanes per V_r row in the replay), and the global-memory fallback at the large size."""
-    monkeypatch.setenv('MTIP_JAC_REPLAY', mode)
-    PC.check_projection_vs_oracle(N, L)
 
 
 def test_config3_short_trajectory_vs_oracle():
@@ -188,7 +172,7 @@ def test_config5_properties_full_size():
 _TRAJ_SWITCHES = [('MTIP_SHT_MODE', '0'), ('MTIP_SHT_MODE', '1'), ('MTIP_SHT_WIDE', '0'), ('MTIP_FUSE_REAL', '0'),
                   ('MTIP_DEG2_SIMPLE', '1'), ('MTIP_HANKEL_SIMPLE', '1'), ('MTIP_HANKEL_WAVE_TILES', '1'),
                   ('MTIP_HANKEL_FLAT_ORDER', '1'), ('MTIP_SHT_FWD_PAIR', '0'),
-                  ('MTIP_PROJ_MFMA', '0'), ('MTIP_PROJ_FUSE', '0'), ('MTIP_JAC_CONC', '0'), ('MTIP_JAC_CONC_MIN_K', '2'), ('MTIP_POLAR', 'newton')]
+                  ('MTIP_PROJ_FUSE', '0'), ('MTIP_PROJ_REAL', '0')]
 
 
 @pytest.mark.parametrize('name,value', _TRAJ_SWITCHES)
@@ -201,9 +185,7 @@ def test_switch_short_trajectory_and_transforms(golden_mtip16, golden_ops, name,
     PC.check_transforms(32, 8, None, seed=5)
 
 
-@pytest.mark.parametrize('env', [{'MTIP_JAC_RESIDENT': '0'}, {'MTIP_JAC_TG': '8'}, {'MTIP_PROJ_MFMA': '0'}, {'MTIP_PROJ_FUSE': '0'}, {'MTIP_JAC_CONC': '0'}, {'MTIP_JAC_CONC_MIN_K': '2'},
-                                 {'MTIP_POLAR': 'newton'}, {'MTIP_POLAR': 'newton', 'MTIP_POLAR_VARIANT': '3'},
-                                 {'MTIP_POLAR_ABS_TOL': '1e-14'}])
+@pytest.mark.parametrize('env', [{'MTIP_JAC_RESIDENT': '0'}, {'MTIP_JAC_TG': '8'}, {'MTIP_PROJ_FUSE': '0'}, {'MTIP_POLAR_ABS_TOL': '1e-14'}])
 def test_switch_projection_vs_oracle(env, monkeypatch):
     """polar-factor / projection-GEMM switches at a size with several row slots (2l+1 up to 37)"""
     for k, v in env.items():

@@ -286,43 +286,15 @@ __device__ __forceinline__ void jl_pair_generic(double2* xi, double2* xj, double
 // resident must be written back because another group needs it next) is precomputed on the host for every
 // column count (build_jacobi_schedule) and verified there.
 
-// One rotation of the log that k_jacobi_replay applies to V_r: columns (pr, pm) <- (pr, pm) [[c, conj(w)], [-w, c]].
-// meta = pr | pm << 8 | tag << 16 (pr = 0xff: nothing to do in this (round, group) slot; tag: see jl_tag), hash = jl_hash of the
-// record -- the concurrent consumer (k_polar_conc) takes a record only when tag and hash fit its slot and call, whatever
-// order the producer's stores become visible in.
-struct __align__(16) JlRec {
-    double cs, wx, wy;
-    unsigned int meta, hash;
-};
-#define JL_NONE 0xffu
-__device__ __forceinline__ unsigned int jl_tag(int epoch) { return (unsigned int)(epoch % 32767) + 1u; }     // 1 .. 32767, never 0
-__device__ __forceinline__ unsigned int jl_hash(double cs, double wx, double wy, unsigned int meta, unsigned int slot, int epoch) {
-    // a checksum, not a cipher: it has to expose a record assembled from two different writes (a torn read, or the record the
-    // same slot held in an earlier call): a stale word changes the XOR unless it equals the new one; slot and call are mixed in
-    return (unsigned int)__double2loint(cs) ^ (unsigned int)__double2hiint(cs) ^ (unsigned int)__double2loint(wx) ^
-           (unsigned int)__double2hiint(wx) ^ (unsigned int)__double2loint(wy) ^ (unsigned int)__double2hiint(wy) ^ meta ^
-           (slot * 0x9E3779B1u + (unsigned int)epoch * 0x85EBCA6Bu);
-}
-// agent-scope accesses: written through / read past the (per-XCD, mutually incoherent) L2
-__device__ __forceinline__ void st_agent(unsigned long long* p, unsigned long long v) {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ unsigned long long ld_agent(const unsigned long long* p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// WITHV = false: V_r is not touched here; the rotation of every (round, group) slot is appended to `log` instead
-// (slot = round * ps + group) and replayed on V_r by k_jacobi_replay, which spreads the rows of V_r over the chip.
-template <int NR, int TG, bool WITHV, bool CONC>
+template <int NR, int TG>
 __device__ __forceinline__ void jl_sweep_resident(double2* Xs, double2* Vs, int ns, int ks, int t, int group,
                                                   const int* __restrict__ tab, int n_rounds, int ps, const int* s_perm,
-                                                  bool xl_ok, bool vl_ok, double tabs2, double S, bool& big,
-                                                  JlRec* __restrict__ log, int slot0, int epoch) {
-    double2 rx[NR], rv[WITHV ? NR : 1];
+                                                  bool xl_ok, bool vl_ok, double tabs2, double S, bool& big) {
+    double2 rx[NR], rv[NR];
 #pragma unroll
     for (int u = 0; u < NR; ++u) rx[u] = make_double2(0.0, 0.0);
 #pragma unroll
-    for (int u = 0; u < (WITHV ? NR : 1); ++u) rv[u] = make_double2(0.0, 0.0);
+    for (int u = 0; u < NR; ++u) rv[u] = make_double2(0.0, 0.0);
     int cur = -1;                                            // compact index of the resident column
     bool dirty = false;
     // table entry and physical columns (through s_perm) of a round are resolved during the previous round
@@ -339,7 +311,7 @@ __device__ __forceinline__ void jl_sweep_resident(double2* Xs, double2* Vs, int 
         double2* vh = Vs + (size_t)pr * ks + t;
         double2* xm = Xs + (size_t)pm * ns + t;
         double2* vm = Vs + (size_t)pm * ks + t;
-        double2 mx[NR], mv[WITHV ? NR : 1];
+        double2 mx[NR], mv[NR];
 #pragma unroll
         for (int u = 0; u < NR; ++u) mx[u] = make_double2(0.0, 0.0);
         if (act) {
@@ -349,7 +321,7 @@ __device__ __forceinline__ void jl_sweep_resident(double2* Xs, double2* Vs, int 
 #pragma unroll
                 for (int u = 0; u < NR; ++u) {
                     rx[u] = xh[u * TG];
-                    if (WITHV) rv[u] = vh[u * TG];
+                    rv[u] = vh[u * TG];
                 }
                 if (!xl_ok) rx[NR - 1] = make_double2(0.0, 0.0);
                 cur = res;
@@ -370,29 +342,9 @@ __device__ __forceinline__ void jl_sweep_resident(double2* Xs, double2* Vs, int 
         double cs = 1.0;
         double2 w = make_double2(0.0, 0.0);
         const bool rot = jl_params(alpha, beta, gr, gi, act, tabs2, S, big, cs, w);
-        if (!WITHV && t == 0 && group < ps) {
-            const unsigned int slot = (unsigned int)(slot0 + r * ps + group);
-            const unsigned int meta = (rot ? (unsigned int)pr : JL_NONE) | ((unsigned int)pm << 8) | (jl_tag(epoch) << 16);
-            const unsigned int hash = jl_hash(cs, w.x, w.y, meta, slot, epoch);
-            JlRec* dst = log + (size_t)r * ps + group;
-            if (CONC) {                                          // published to a workgroup that runs at the same time
-                unsigned long long* d8 = reinterpret_cast<unsigned long long*>(dst);
-                st_agent(d8, (unsigned long long)__double_as_longlong(cs));
-                st_agent(d8 + 1, (unsigned long long)__double_as_longlong(w.x));
-                st_agent(d8 + 2, (unsigned long long)__double_as_longlong(w.y));
-                st_agent(d8 + 3, (unsigned long long)meta | ((unsigned long long)hash << 32));
-            } else {
-                JlRec rec;
-                rec.cs = cs; rec.wx = w.x; rec.wy = w.y;
-                rec.meta = meta; rec.hash = hash;
-                *dst = rec;
-            }
-        }
         if (rot) {
-            if (WITHV) {
 #pragma unroll
-                for (int u = 0; u < NR; ++u) mv[u] = vm[u * TG];
-            }
+            for (int u = 0; u < NR; ++u) mv[u] = vm[u * TG];
 #pragma unroll
             for (int u = 0; u < NR; ++u) {
                 double2 an, bn;
@@ -400,14 +352,12 @@ __device__ __forceinline__ void jl_sweep_resident(double2* Xs, double2* Vs, int 
                 rx[u] = an;
                 if (u < NR - 1 || xl_ok) xm[u * TG] = bn;
             }
-            if (WITHV) {
 #pragma unroll
-                for (int u = 0; u < NR; ++u) {
-                    double2 an, bn;
-                    jl_rotate(cs, w, rv[u], mv[u], an, bn);
-                    rv[u] = an;
-                    if (u < NR - 1 || vl_ok) vm[u * TG] = bn;
-                }
+            for (int u = 0; u < NR; ++u) {
+                double2 an, bn;
+                jl_rotate(cs, w, rv[u], mv[u], an, bn);
+                rv[u] = an;
+                if (u < NR - 1 || vl_ok) vm[u * TG] = bn;
             }
             dirty = true;
         }
@@ -416,7 +366,7 @@ __device__ __forceinline__ void jl_sweep_resident(double2* Xs, double2* Vs, int 
 #pragma unroll
                 for (int u = 0; u < NR; ++u) {
                     if (u < NR - 1 || xl_ok) xh[u * TG] = rx[u];
-                    if (WITHV && (u < NR - 1 || vl_ok)) vh[u * TG] = rv[u];
+                    if (u < NR - 1 || vl_ok) vh[u * TG] = rv[u];
                 }
             }
             cur = -1;
@@ -444,15 +394,9 @@ struct JacobiArgs {
     const int *sched, *sched_off, *sched_rounds;
     int sched_ps;
     const int* order_list;
-    JlRec* log_all;
-    int* log_rounds;
-    int log_cap, epoch;
-    int* conc_err;                     // concurrent replay: consumers that gave up waiting (must stay 0)
 };
 
-// the workgroup of matrix (restart b, order_list[oy]); CONC: its rotation log is consumed while it is written (k_polar_conc)
-// static LDS of a Jacobi workgroup: declared once per kernel and handed to the body (k_polar_conc inlines the body twice; two
-// copies would push the launch past half a CU's LDS and halve the number of resident workgroups)
+// static LDS of a Jacobi workgroup
 template <int MAXT>
 struct JacShared {
     double gmax[MAXT / 8];
@@ -461,8 +405,9 @@ struct JacShared {
     int cont, keff;
 };
 
-template <int MAXR, int TG, int MAXT, bool LOGV, bool CONC>
-__device__ __forceinline__ void polar_jacobi_body(const JacobiArgs& A, int b, int oy, size_t mat, JacShared<MAXT>& sh) {
+// the workgroup of matrix (restart b, order_list[oy])
+template <int MAXR, int TG, int MAXT>
+__device__ __forceinline__ void polar_jacobi_body(const JacobiArgs& A, int b, int oy, JacShared<MAXT>& sh) {
     const double2* __restrict__ Xin_all = A.Xin_all;
     double2* __restrict__ Pn_all = A.Pn_all;
     double2* __restrict__ Vr_all = A.Vr_all;
@@ -470,14 +415,12 @@ __device__ __forceinline__ void polar_jacobi_body(const JacobiArgs& A, int b, in
     const int* __restrict__ active = A.active;
     const int* __restrict__ xoff = A.xoff;
     const int* __restrict__ roff = A.roff;
-    const int xtot = A.xtot, rtot = A.rtot, L = A.L, warm = A.warm, pad = A.pad, sched_ps = A.sched_ps, log_cap = A.log_cap;
+    const int xtot = A.xtot, rtot = A.rtot, L = A.L, warm = A.warm, pad = A.pad, sched_ps = A.sched_ps;
     const double tabs2 = A.tabs2;
     int* __restrict__ sweeps_out = A.sweeps_out;
     const int* __restrict__ sched = A.sched;
     const int* __restrict__ sched_off = A.sched_off;
     const int* __restrict__ sched_rounds = A.sched_rounds;
-    JlRec* __restrict__ log_all = A.log_all;
-    int* __restrict__ log_rounds = A.log_rounds;
     HIP_DYNAMIC_SHARED(double2, sm)
     double* const s_gmax = sh.gmax;
     double* const s_isig = sh.isig;
@@ -485,11 +428,7 @@ __device__ __forceinline__ void polar_jacobi_body(const JacobiArgs& A, int b, in
     int& s_continue = sh.cont;
     int& s_keff = sh.keff;
     const int l = A.order_list[oy];
-    if (!active[l]) {                                      // uniform per block
-        if (CONC && threadIdx.x == 0)                       // (consumers of an inactive order return at once as well)
-            __hip_atomic_store(log_rounds + mat, (int)(jl_tag(A.epoch) << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return;
-    }
+    if (!active[l]) return;                                // uniform per block
     const int k = kl[l], n = 2 * l + 1;
     const int nr = (n + TG - 1) / TG, kr = (k + TG - 1) / TG;   // rows per lane
     // column strides: odd; padded to whole lane-groups of rows when LDS allows (pad), else row predicates
@@ -504,15 +443,12 @@ __device__ __forceinline__ void polar_jacobi_body(const JacobiArgs& A, int b, in
         const int cc = e / ns, r = e - cc * ns;
         Xs[e] = r < n ? Xin[(size_t)cc * n + r] : make_double2(0.0, 0.0);
     }
-    for (int e = tid; e < (LOGV ? 0 : k * ks); e += blockDim.x) {
+    for (int e = tid; e < k * ks; e += blockDim.x) {
         const int cc = e / ks, i = e - cc * ks;
         double2 v = make_double2(0.0, 0.0);
         if (i < k) v = warm ? Vr[(size_t)cc * k + i] : make_double2(cc == i ? 1.0 : 0.0, 0.0);
         Vs[e] = v;
     }
-    // LOGV: rotations of this matrix go to its slice of the log, lr = slots (rounds) written so far
-    JlRec* log = LOGV ? log_all + mat * (size_t)log_cap * sched_ps : nullptr;
-    int lr = 0;
     __syncthreads();
     const int ngroups = blockDim.x / TG;
     const int group = tid / TG, t = tid - group * TG;
@@ -566,16 +502,13 @@ __device__ __forceinline__ void polar_jacobi_body(const JacobiArgs& A, int b, in
             const int per_group = (pairs + ngroups - 1) / ngroups;
             bool big = false;                                  // some pair of this group was above the early-exit level
             // resident-column ordering when it applies (16-lane groups, equal row counts, enough groups)
-            // (LOGV launches are only made when this holds for every active order)
             constexpr int RMAX = (TG == 16 && MAXR >= 7) ? 7 : 5;
             const bool resident = TG == 16 && sched != nullptr && nr == kr && nr <= RMAX && sched_ps <= ngroups;
             if (resident) {
                 const bool xl_ok = pad || t + (nr - 1) * TG < n, vl_ok = pad || t + (kr - 1) * TG < k;
                 const int* tab = sched + sched_off[ke];
-                int nrd = sched_rounds[ke];
-                if (LOGV && lr + nrd > log_cap) nrd = 0;       // log full (never with JAC_MAX_SWEEPS sweeps sized in)
-                JlRec* lg = LOGV ? log + (size_t)lr * sched_ps : nullptr;
-#define JL_SWEEP_T(NR, TAB) jl_sweep_resident<NR, TG, !LOGV, CONC>(Xs, Vs, ns, ks, t, group, TAB, nrd, sched_ps, s_perm, xl_ok, vl_ok, tabs2, S, big, lg, lr * sched_ps, A.epoch)
+                const int nrd = sched_rounds[ke];
+#define JL_SWEEP_T(NR, TAB) jl_sweep_resident<NR, TG>(Xs, Vs, ns, ks, t, group, TAB, nrd, sched_ps, s_perm, xl_ok, vl_ok, tabs2, S, big)
 #define JL_SWEEP_ALL(TAB)                              \
                 switch (nr) {                              \
                 case 1: JL_SWEEP_T(1, TAB); break;         \
@@ -586,21 +519,11 @@ __device__ __forceinline__ void polar_jacobi_body(const JacobiArgs& A, int b, in
                 case 6: JL_SWEEP_T((RMAX >= 7 ? 6 : 1), TAB); break;   \
                 default: JL_SWEEP_T((RMAX >= 7 ? 7 : 1), TAB); break;  \
                 }
-                if (CONC) {
-                    // the pairing table of this sweep in LDS (where V_r would be): a global load per round would make every
-                    // round wait, through the shared vmcnt counter, for the written-through log records of the round before
-                    int* s_tab = reinterpret_cast<int*>(sm + (size_t)k * ns);
-                    for (int e = tid; e < nrd * sched_ps; e += blockDim.x) s_tab[e] = tab[e];
-                    __syncthreads();
-                    JL_SWEEP_ALL(s_tab)
-                } else {
-                    JL_SWEEP_ALL(tab)
-                }
+                JL_SWEEP_ALL(tab)
 #undef JL_SWEEP_ALL
 #undef JL_SWEEP_T
-                lr += nrd;
             }
-            for (int r = 0; r < ((resident || LOGV) ? 0 : rounds); ++r) {
+            for (int r = 0; r < (resident ? 0 : rounds); ++r) {
                 for (int it = 0; it < per_group; ++it) {
                     const int pi = group + it * ngroups;
                     int ci = 0, cj = 0;
@@ -675,226 +598,23 @@ __device__ __forceinline__ void polar_jacobi_body(const JacobiArgs& A, int b, in
         const int cc = e / n, r = e - cc * n;
         Pn[e] = cscale(Xs[(size_t)cc * ns + r], s_isig[cc]);
     }
-    for (int e = tid; e < (LOGV ? 0 : k * k); e += blockDim.x) {
+    for (int e = tid; e < k * k; e += blockDim.x) {
         const int cc = e / k, i = e - cc * k;
         Vr[e] = Vs[(size_t)cc * ks + i];
-    }
-    if (LOGV && tid == 0) {
-        if (CONC) __hip_atomic_store(log_rounds + mat, (int)((jl_tag(A.epoch) << 16) | (unsigned int)lr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else log_rounds[mat] = lr;
     }
 }
 
 // grid = (restart, rank of the order among the active ones): the restart index runs fastest, so the heaviest order
 // of EVERY restart is dispatched first -- these workgroups are the critical path of the launch
-template <int MAXR, int TG, int MAXT, bool LOGV>
+template <int MAXR, int TG, int MAXT>
 __global__ void __launch_bounds__(MAXT) k_polar_jacobi_lds(JacobiArgs A) {
     __shared__ JacShared<MAXT> sh;
-    polar_jacobi_body<MAXR, TG, MAXT, LOGV, false>(A, (int)blockIdx.x, (int)blockIdx.y, (size_t)blockIdx.y * gridDim.x + blockIdx.x, sh);
+    polar_jacobi_body<MAXR, TG, MAXT>(A, (int)blockIdx.x, (int)blockIdx.y, sh);
 }
 
-// ---- V_r <- V_r R_1 R_2 ... : replay of the rotation log of k_polar_jacobi_lds<.., LOGV = true> ------------------------
-// Every row of V_r transforms on its own, so one matrix is spread over several workgroups (JR_ROWS rows each), and
-// inside a workgroup over waves that never have to meet: a wave owns 64 / G rows x JR_RPL, lane = (row, slot of the
-// round); the rotations of one round touch disjoint columns and LDS operations of a wave complete in order, so rounds
-// follow each other without a barrier.  The log is staged through LDS in chunks of JR_CHUNK rounds (double buffered:
-// the next chunk is in flight in registers while the current one is applied).
-#define JR_THREADS 256
-#define JR_RPL 2
-#define JR_CHUNK 16
-#define JR_POLL_LIMIT 2000000       // concurrent mode: polls (~2 us each, i.e. seconds) without a new round before a consumer gives up
-
-// NT threads; CONC: the log is being written by the Jacobi workgroup of the same launch (k_polar_conc) -- rounds are taken as
-// their records become valid (tag + hash, agent-scope loads), the end is the producer's round count in log_rounds
-template <int G, int NT, bool CONC>                         // G lanes per row: 32 (slots per round <= 32) or 64
-__device__ __forceinline__ void jacobi_replay_body(const JlRec* __restrict__ log_all, int* __restrict__ log_rounds,
-                                                   double2* __restrict__ Vr_all, const int* __restrict__ kl,
-                                                   const int* __restrict__ active, const int* __restrict__ roff, int rtot,
-                                                   int warm, int ps, int log_cap, const int* __restrict__ order_list, int b,
-                                                   int oy, int zrow, size_t mat, int epoch, int* __restrict__ conc_err) {
-    constexpr int ROWS_W = (64 / G) * JR_RPL;               // rows of a wave
-    constexpr int ROWS = ROWS_W * (NT / 64);                // rows of a workgroup
-    HIP_DYNAMIC_SHARED(double2, sm)
-    __shared__ int s_total, s_first_bad;
-    const int l = order_list[oy];
-    if (!active[l]) return;
-    const int k = kl[l];
-    const int row0 = zrow * ROWS;
-    if (row0 >= k) return;
-    const int ks = k | 1;                                   // odd row stride
-    double2* Vl = sm;                                       // ROWS x ks (row-major: a rotation works inside a row)
-    uint4* Ls = reinterpret_cast<uint4*>(sm + (size_t)ROWS * ks);   // 2 x JR_CHUNK x ps records (2 x uint4 each)
-    const uint4* lsrc = reinterpret_cast<const uint4*>(log_all + mat * (size_t)log_cap * ps);
-    double2* Vr = Vr_all + (size_t)b * rtot + roff[l];      // column-major: Vr[col * k + row]
-    const int tid = threadIdx.x;
-    const int nrow = min(ROWS, k - row0);
-    for (int e = tid; e < ROWS * k; e += NT) {
-        const int cc = e / ROWS, i = e - cc * ROWS;
-        double2 v = make_double2(0.0, 0.0);
-        if (i < nrow) v = warm ? Vr[(size_t)cc * k + row0 + i] : make_double2(cc == row0 + i ? 1.0 : 0.0, 0.0);
-        Vl[(size_t)i * ks + cc] = v;
-    }
-    const int per_chunk = JR_CHUNK * ps * 2;                // uint4 per chunk
-    constexpr int NLD = (2 * JR_CHUNK * 64 + NT - 1) / NT;  // chunk loads of a thread (per_chunk <= NLD * NT, ps <= 64)
-    const int lane = tid & 63, wave = tid >> 6;
-    const int g = lane % G, rw = lane / G;
-    double2* vrow[JR_RPL];
-#pragma unroll
-    for (int u = 0; u < JR_RPL; ++u) vrow[u] = Vl + (size_t)(wave * ROWS_W + rw * JR_RPL + u) * ks;
-    // the rotations of `rounds` rounds staged at lc: a wave owns whole rows, LDS is in order within a wave -> no barrier per round
-    auto apply = [&](const uint4* lc, int rounds) {
-        for (int r = 0; r < rounds; ++r) {
-            if (g < ps) {
-                const uint4 q0 = lc[(r * ps + g) * 2], q1 = lc[(r * ps + g) * 2 + 1];
-                const int pr = (int)(q1.z & 0xffu), pm = (int)((q1.z >> 8) & 0xffu);
-                if (pr != (int)JL_NONE) {
-                    const double cs = __hiloint2double((int)q0.y, (int)q0.x);
-                    const double2 w = make_double2(__hiloint2double((int)q0.w, (int)q0.z), __hiloint2double((int)q1.y, (int)q1.x));
-#pragma unroll
-                    for (int u = 0; u < JR_RPL; ++u) {
-                        double2 an, bn;
-                        jl_rotate(cs, w, vrow[u][pr], vrow[u][pm], an, bn);
-                        vrow[u][pr] = an;
-                        vrow[u][pm] = bn;
-                    }
-                }
-            }
-            __builtin_amdgcn_wave_barrier();                 // (scheduling fence only: LDS is in order within a wave)
-        }
-    };
-    if (!CONC) {
-        const int total = log_rounds[mat];
-        uint4 nxt[NLD];
-        const int n_chunks = (total + JR_CHUNK - 1) / JR_CHUNK;
-        auto fetch = [&](int ch) {
-            const size_t base = (size_t)ch * per_chunk;
-            const size_t lim = (size_t)total * ps * 2;
-#pragma unroll
-            for (int u = 0; u < NLD; ++u) {
-                const int e = tid + u * NT;
-                nxt[u] = (e < per_chunk && base + e < lim) ? lsrc[base + e] : make_uint4(0u, 0u, 0u, 0u);
-            }
-        };
-        auto stash = [&](int buf) {
-#pragma unroll
-            for (int u = 0; u < NLD; ++u) {
-                const int e = tid + u * NT;
-                if (e < per_chunk) Ls[(size_t)buf * per_chunk + e] = nxt[u];
-            }
-        };
-        if (n_chunks > 0) fetch(0);
-        for (int ch = 0; ch < n_chunks; ++ch) {
-            stash(ch & 1);
-            __syncthreads();                                     // chunk ch visible; chunk ch - 1 (other buffer) is done with
-            if (ch + 1 < n_chunks) fetch(ch + 1);
-            apply(Ls + (size_t)(ch & 1) * per_chunk, min(JR_CHUNK, total - ch * JR_CHUNK));
-        }
-    } else {
-        const unsigned int tag = jl_tag(epoch);
-        int r0 = 0, polls = 0;
-        for (;;) {
-            if (tid == 0) {
-                const int d = __hip_atomic_load(log_rounds + mat, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                s_total = (((unsigned int)d >> 16) == tag) ? (d & 0xffff) : -1;     // the producer's last word
-                s_first_bad = JR_CHUNK;
-            }
-            __syncthreads();
-            const int total = s_total;
-            if (total >= 0 && r0 >= total) break;
-            const int want = total >= 0 ? min(JR_CHUNK, total - r0) : JR_CHUNK;
-            // records of rounds r0 .. r0 + want - 1, read past the L2; every thread checks the records it loaded the second half of
-            const unsigned long long* src8 = reinterpret_cast<const unsigned long long*>(lsrc + (size_t)r0 * ps * 2);
-#pragma unroll
-            for (int u = 0; u < NLD; ++u) {
-                const int e = tid + u * NT;                      // uint4 piece: record e >> 1, half e & 1
-                if (e < want * ps * 2) {
-                    const unsigned long long a0 = ld_agent(src8 + 2 * (size_t)e), a1 = ld_agent(src8 + 2 * (size_t)e + 1);
-                    Ls[e] = make_uint4((unsigned int)a0, (unsigned int)(a0 >> 32), (unsigned int)a1, (unsigned int)(a1 >> 32));
-                }
-            }
-            __syncthreads();
-            for (int rec = tid; rec < want * ps; rec += NT) {
-                const uint4 q0 = Ls[2 * rec], q1 = Ls[2 * rec + 1];
-                const double cs = __hiloint2double((int)q0.y, (int)q0.x), wx = __hiloint2double((int)q0.w, (int)q0.z);
-                const double wy = __hiloint2double((int)q1.y, (int)q1.x);
-                const bool ok = (q1.z >> 16) == tag && q1.w == jl_hash(cs, wx, wy, q1.z, (unsigned int)(r0 * ps + rec), epoch);
-                if (!ok) atomicMin(&s_first_bad, rec / ps);
-            }
-            __syncthreads();
-            const int nv = min(s_first_bad, want);               // leading rounds whose records have all arrived
-            if (nv == 0) {
-                if (++polls > JR_POLL_LIMIT) {                   // never seen; the host reports it (results are wrong then)
-                    if (tid == 0) atomicAdd(conc_err, 1);
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(20);
-            } else {
-                polls = 0;
-                apply(Ls, nv);
-                r0 += nv;
-            }
-            __syncthreads();                                     // Ls, s_total and s_first_bad are rewritten
-        }
-    }
-    __syncthreads();
-    for (int e = tid; e < ROWS * k; e += NT) {
-        const int cc = e / ROWS, i = e - cc * ROWS;
-        if (i < nrow) Vr[(size_t)cc * k + row0 + i] = Vl[(size_t)i * ks + cc];
-    }
-}
-
-template <int G>
-__global__ void __launch_bounds__(JR_THREADS) k_jacobi_replay(const JlRec* __restrict__ log_all, int* __restrict__ log_rounds,
-                                                              double2* __restrict__ Vr_all, const int* __restrict__ kl,
-                                                              const int* __restrict__ active, const int* __restrict__ roff,
-                                                              int rtot, int warm, int ps, int log_cap,
-                                                              const int* __restrict__ order_list) {
-    jacobi_replay_body<G, JR_THREADS, false>(log_all, log_rounds, Vr_all, kl, active, roff, rtot, warm, ps, log_cap, order_list,
-                                             (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z,
-                                             (size_t)blockIdx.y * gridDim.x + blockIdx.x, 0, nullptr);
-}
-
-// The polar factor on more than one CU per matrix: grid z = 0 is the Jacobi workgroup of matrix (x, y) -- X_l only, every
-// rotation published to its log -- and z = 1 .. are workgroups that apply the log to their rows of V_r WHILE it is written
-// (on other CUs; rows of V_r transform independently).  The producers have the lowest workgroup ids, so they are all
-// dispatched before any consumer; a consumer only ever waits for its producer, never the other way round, and gives up after
-// JR_POLL_LIMIT polls without progress (conc_err).  Records are validated by tag + hash, so no fence is needed anywhere.
-template <int MAXR, int TG, int MAXT>
-__global__ void __launch_bounds__(MAXT) k_polar_conc(JacobiArgs A, int k_conc_min) {
-    const int b = (int)blockIdx.x, oy = (int)blockIdx.y;
-    const size_t mat = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
-    // only the orders that set the duration of the launch (k_l >= k_conc_min) are split over producer + consumers; a small
-    // matrix is solved with V_r in its own workgroup as in k_polar_jacobi_lds, and has no consumers
-    const bool split = A.kl[A.order_list[oy]] >= k_conc_min;
-    __shared__ JacShared<MAXT> sh;
-    if (blockIdx.z == 0) {
-        if (split) polar_jacobi_body<MAXR, TG, MAXT, true, true>(A, b, oy, mat, sh);
-        else polar_jacobi_body<MAXR, TG, MAXT, false, false>(A, b, oy, mat, sh);
-    } else if (split) {
-        jacobi_replay_body<32, MAXT, true>(A.log_all, A.log_rounds, A.Vr_all, A.kl, A.active, A.roff, A.rtot, A.warm, A.sched_ps,
-                                           A.log_cap, A.order_list, b, oy, (int)blockIdx.z - 1, mat, A.epoch, A.conc_err);
-    }
-}
-
-// ---- register-tiled complex GEMMs around the polar factor ----------------------------------------------------
-// The four products of the projection (X_l = I_l^+ D^2 V_l, the warm start X_l V_r, U_l = V_r Pn^+ and
-// I'_l = V_l U_l) are small batched complex GEMMs (<= 128 x 65 x 65 per (restart, l)), 285 MFLOP per call in all:
-// they have to be spread over the whole chip (one (restart, l = 32) product alone is 14 us of one CU's FP64 peak) and
-// must not re-read their operands per output element (32 bytes per complex FMA from L2 otherwise).  Tile = 33 x 33
-// outputs (2l+1 <= 65 -> two tiles, 1.5 % padding), 11 x 11 threads with 3 x 3 outputs each, inner extent in chunks
-// of 8 through LDS, the operands of the next two chunks in flight in registers while the current one is multiplied.  A
-// tile is shared by PG_KS = 4 thread sets that take the inner indices round robin and add their partial sums in a fixed
-// order at the end: a launch has only a few hundred tiles, and one 2-wave set per tile leaves the LDS latency of every
-// inner step exposed (2-3 waves per CU).
-#define PG_T 11                 // threads per tile edge
-#define PG_R 3                  // outputs per thread and edge
-#define PG_TM (PG_T * PG_R)     // tile edge (33)
-#define PG_TK 8
-// thread sets that share a tile (template parameter KS: set s multiplies the inner indices kk = s (mod KS)); threads per
-// workgroup and staged elements per thread and operand follow from it
-#define PG_NT(KS) ((KS) == 1 ? 128 : 512)
-#define PG_LDN(KS) ((PG_TM * PG_TK + PG_NT(KS) - 1) / PG_NT(KS))
-
+// ---- the four complex products around the polar factor -------------------------------------------------------------
+// X_l = I_l^+ D^2 V_l, the warm start X_l V_r, U_l = V_r Pn^+ and I'_l = V_l U_l are small batched complex GEMMs
+// (<= 128 x 65 x 65 per (restart, l)) on the f64 matrix cores (k_proj_mfma and the fused pairs k_proj_xw / k_proj_ua below).
 struct ProjGemmArgs {
     const double2* Ilm;
     const double2* V;
@@ -970,156 +690,9 @@ struct ProjGemm {
     }
 };
 
-// The grid is the compact list of (order, tile) pairs that exist (host-built, `tiles`): a dense
-// (max tiles) x (L+1) x B grid is mostly workgroups that return at once, and dispatching them costs more than the
-// products (measured: 1056 workgroups of 8 waves start over 34 us).
-template <int OP, int PG_KS>
-__global__ void __launch_bounds__(PG_NT(PG_KS)) k_proj_gemm(ProjGemmArgs a, const int* __restrict__ tiles) {
-    typedef ProjGemm<OP> G;
-    constexpr int LD = PG_TM + 1;
-    constexpr int PG_THREADS = PG_NT(PG_KS);
-    constexpr int PG_LD = PG_LDN(PG_KS);
-    __shared__ double2 As[2][PG_TK][LD];
-    __shared__ double2 Bs[2][PG_TK][LD];
-    const int tinfo = tiles[blockIdx.x];
-    const int l = tinfo & 255, tile_m = (tinfo >> 8) & 255, tile_n = tinfo >> 16;
-    const int b = blockIdx.y;
-    const bool prod = G::has_product(a, l);
-    if (!prod && OP != PG_APPLY) return;
-    int M, Nn, K;
-    PgView A, Bv;
-    G::setup(a, b, l, M, Nn, K, A, Bv);
-    const int k = a.kl[l], n = 2 * l + 1, xo = a.xoff[l];
-    const int m0 = tile_m * PG_TM, n0 = tile_n * PG_TM;
-    if (m0 >= M || n0 >= Nn) return;                         // block-uniform
-    const int tid = threadIdx.x;
-    const int ks = tid / (PG_T * PG_T);                      // inner-index set of this thread (set PG_KS: staging only)
-    const int wt = tid - ks * (PG_T * PG_T);
-    const int ty = wt / PG_T, tx = wt - ty * PG_T;
-    const bool worker = ks < PG_KS;
-    double2 acc[PG_R][PG_R];
-#pragma unroll
-    for (int i = 0; i < PG_R; ++i)
-#pragma unroll
-        for (int j = 0; j < PG_R; ++j) acc[i][j] = make_double2(0.0, 0.0);
-    if (prod) {
-        // staging slots of this thread: element e = tid + u * PG_THREADS of the PG_TM x PG_TK operand chunks
-        int am[PG_LD], ak[PG_LD], bn[PG_LD], bk[PG_LD];
-#pragma unroll
-        for (int u = 0; u < PG_LD; ++u) {
-            const int e = tid + u * PG_THREADS;
-            if (G::A_M_FAST) { ak[u] = e / PG_TM; am[u] = e - ak[u] * PG_TM; }
-            else { am[u] = e / PG_TK; ak[u] = e - am[u] * PG_TK; }
-            if (G::B_N_FAST) { bk[u] = e / PG_TM; bn[u] = e - bk[u] * PG_TM; }
-            else { bn[u] = e / PG_TK; bk[u] = e - bn[u] * PG_TK; }
-            if (e >= PG_TM * PG_TK) { am[u] = PG_TM; bn[u] = PG_TM; ak[u] = 0; bk[u] = 0; }    // no such slot
-        }
-        // two register sets: the operands of the next TWO chunks are in flight while one is multiplied (a dependent
-        // global round trip costs ~2.5 k cycles here, the multiply of a chunk ~1 k)
-        double2 ra0[PG_LD], rb0[PG_LD], ra1[PG_LD], rb1[PG_LD];
-        // branch-free: clamped addresses, every load is issued, out-of-range elements are zeroed by a select -- so the
-        // compiler can count the loads in flight and wait only for the older set
-        auto request = [&](int k0, double2 (&ra)[PG_LD], double2 (&rb)[PG_LD]) {
-#pragma unroll
-            for (int u = 0; u < PG_LD; ++u) {
-                const bool a_ok = am[u] < PG_TM && m0 + am[u] < M && k0 + ak[u] < K;
-                const bool b_ok = bn[u] < PG_TM && n0 + bn[u] < Nn && k0 + bk[u] < K;
-                const int ma = a_ok ? m0 + am[u] : 0, ka = a_ok ? k0 + ak[u] : 0;
-                const int nb = b_ok ? n0 + bn[u] : 0, kb = b_ok ? k0 + bk[u] : 0;
-                double2 va = A.base[(size_t)ma * A.si + (size_t)ka * A.sj];
-                double2 vb = Bv.base[(size_t)kb * Bv.si + (size_t)nb * Bv.sj];
-                if (OP == PG_X) {
-                    const double qq = a.q[ka];
-                    va = make_double2(qq * qq * va.x, -qq * qq * va.y);
-                }
-                if (G::B_CONJ) vb.y = -vb.y;
-                ra[u] = a_ok ? va : make_double2(0.0, 0.0);
-                rb[u] = b_ok ? vb : make_double2(0.0, 0.0);
-            }
-        };
-        auto deposit = [&](int buf, const double2 (&ra)[PG_LD], const double2 (&rb)[PG_LD]) {
-#pragma unroll
-            for (int u = 0; u < PG_LD; ++u) {
-                if (am[u] < PG_TM) {
-                    As[buf][ak[u]][am[u]] = ra[u];
-                    Bs[buf][bk[u]][bn[u]] = rb[u];
-                }
-            }
-        };
-        auto multiply = [&](int buf) {
-            if (worker) {
-#pragma unroll
-                for (int kq = 0; kq < PG_TK / PG_KS; ++kq) {
-                    const int kk = kq * PG_KS + ks;
-                    double2 av[PG_R], bv[PG_R];
-#pragma unroll
-                    for (int i = 0; i < PG_R; ++i) {
-                        av[i] = As[buf][kk][ty * PG_R + i];
-                        bv[i] = Bs[buf][kk][tx * PG_R + i];
-                    }
-#pragma unroll
-                    for (int i = 0; i < PG_R; ++i)
-#pragma unroll
-                        for (int j = 0; j < PG_R; ++j) {
-                            acc[i][j].x = fma(av[i].x, bv[j].x, acc[i][j].x);
-                            acc[i][j].x = fma(-av[i].y, bv[j].y, acc[i][j].x);
-                            acc[i][j].y = fma(av[i].x, bv[j].y, acc[i][j].y);
-                            acc[i][j].y = fma(av[i].y, bv[j].x, acc[i][j].y);
-                        }
-                }
-            }
-        };
-        const int n_chunks = (K + PG_TK - 1) / PG_TK;
-        request(0, ra0, rb0);
-        request(PG_TK, ra1, rb1);                              // (requests beyond K load nothing new: clamped, zeroed)
-        deposit(0, ra0, rb0);
-        request(2 * PG_TK, ra0, rb0);
-        __syncthreads();
-        for (int i = 0; i < n_chunks; i += 2) {
-            // chunk i from buffer 0; chunk i+1 (set 1) goes to buffer 1; then set 1 asks for chunk i+3
-            multiply(0);
-            deposit(1, ra1, rb1);
-            __syncthreads();
-            request((i + 3) * PG_TK, ra1, rb1);
-            // chunk i+1 from buffer 1 (zeros beyond K); chunk i+2 (set 0) goes to buffer 0; then set 0 asks for chunk i+4
-            multiply(1);
-            deposit(0, ra0, rb0);
-            __syncthreads();
-            request((i + 4) * PG_TK, ra0, rb0);
-        }
-    }
-    // partial sums of the sets 1..PG_KS-1 through LDS, added by set 0 in a fixed order (bitwise reproducible)
-    __shared__ double2 part[PG_KS > 1 ? PG_KS - 1 : 1][PG_KS > 1 ? PG_T * PG_T : 1][PG_R * PG_R + 1];
-    if (prod && PG_KS > 1) {
-        if (worker && ks > 0) {
-#pragma unroll
-            for (int i = 0; i < PG_R; ++i)
-#pragma unroll
-                for (int j = 0; j < PG_R; ++j) part[ks - 1][wt][i * PG_R + j] = acc[i][j];
-        }
-        __syncthreads();
-        if (ks == 0) {
-#pragma unroll
-            for (int s2 = 0; s2 < PG_KS - 1; ++s2)
-#pragma unroll
-                for (int i = 0; i < PG_R; ++i)
-#pragma unroll
-                    for (int j = 0; j < PG_R; ++j) acc[i][j] = cadd(acc[i][j], part[s2][wt][i * PG_R + j]);
-        }
-    }
-    if (ks == 0) {
-#pragma unroll
-        for (int i = 0; i < PG_R; ++i)
-#pragma unroll
-            for (int j = 0; j < PG_R; ++j) {
-                const int mm = m0 + ty * PG_R + i, nn = n0 + tx * PG_R + j;
-                if (mm < M && nn < Nn) G::store(a, b, l, k, n, xo, mm, nn, acc[i][j]);
-            }
-    }
-}
-
-// ---- the same four products on the f64 matrix cores ------------------------------------------------------------
-// They are GEMMs, so they can run on v_mfma_f64_16x16x4 with the fragments read straight from global memory (no LDS,
+// ---- the four products on the f64 matrix cores ------------------------------------------------------------
+// The grid is the compact list of (order, tile) pairs that exist (host-built, `tiles`): a dense (max tiles) x (L+1) x B grid is
+// mostly workgroups that return at once, and dispatching them costs more than the products.  They are GEMMs, so they run on v_mfma_f64_16x16x4 with the fragments read straight from global memory (no LDS,
 // no barriers): a wave owns one 16 x 16 complex output tile (two accumulators), the four waves of a workgroup share
 // the row tile.  Complex as real: with A read as rows [re, im, ...] over the inner index (K = 2 x inner extent),
 //   Re C = sum_K A[i][K] B1[K][j],  B1[(k,re)] = Re B, B1[(k,im)] = -Im B;   Im C = sum_K A[i][K] B2[K][j],
@@ -1370,8 +943,7 @@ __global__ void __launch_bounds__(PF_THREADS) k_proj_ua(ProjGemmArgs a, double2*
 // tile lists of the four products (order | tile_m << 8 | tile_n << 16), heavy orders first
 static int build_proj_tiles(mtip_ctx* c) {
     if (c->d_pg_tiles[0] != nullptr) return MTIP_OK;
-    const int tm_edge = c->proj_mfma ? 16 : PG_TM;               // MFMA: 16 x (4 x 16) per workgroup; VALU: 33 x 33
-    const int tn_edge = c->proj_mfma ? 64 : PG_TM;
+    const int tm_edge = 16, tn_edge = 64;                        // 16 x (4 x 16) outputs per workgroup
     for (int op = 0; op < 4; ++op) {
         std::vector<int> t;
         for (int l = c->L; l >= 0; --l) {
@@ -1407,15 +979,8 @@ static int build_proj_tiles(mtip_ctx* c) {
 
 template <int OP>
 static void launch_proj_gemm(mtip_ctx* c, const ProjGemmArgs& a) {
-    // I'_l = V_l U_l has 4-8 tiles per order and all orders to write: enough workgroups already, one thread set per tile
-    if (c->proj_mfma) {
-        hipLaunchKernelGGL(k_proj_mfma<OP>, dim3((unsigned)c->n_pg_tiles[OP], (unsigned)c->B), dim3(256), 0, c->stream, a,
-                           (const int*)c->d_pg_tiles[OP]);
-        return;
-    }
-    constexpr int KS = (OP == PG_APPLY) ? 1 : 4;
-    hipLaunchKernelGGL((k_proj_gemm<OP, KS>), dim3((unsigned)c->n_pg_tiles[OP], (unsigned)c->B), dim3(PG_NT(KS)), 0, c->stream,
-                       a, (const int*)c->d_pg_tiles[OP]);
+    hipLaunchKernelGGL(k_proj_mfma<OP>, dim3((unsigned)c->n_pg_tiles[OP], (unsigned)c->B), dim3(256), 0, c->stream, a,
+                       (const int*)c->d_pg_tiles[OP]);
 }
 
 // Divide-and-conquer pairing schedule for every column count 2..kmax (see jl_sweep_resident).  Entry
@@ -1549,11 +1114,12 @@ int launch_project_coefficients(mtip_ctx* c, const double2* Ilm, double2* out, b
         c->vr_valid = false;
         return launch_rproj(c, out);
     }
+    // general case (complex V_l, or coefficients without the symmetry of a real intensity): complex one-sided Jacobi between
+    // the fused product pairs
     c->vr_kind = 0;
-    int max_kn = 1, kmax = 1, nmax = 1;
+    int kmax = 1, nmax = 1;
     for (int l = 0; l <= c->L; ++l) {
         if (!c->active[l]) continue;
-        max_kn = std::max(max_kn, c->kl[l] * (2 * l + 1));
         kmax = std::max(kmax, c->kl[l]);
         nmax = std::max(nmax, 2 * l + 1);
     }
@@ -1563,39 +1129,11 @@ int launch_project_coefficients(mtip_ctx* c, const double2* Ilm, double2* out, b
         c->err = "projection tile lists: out of device memory";
         return MTIP_ENOMEM;
     }
-    // fused pairs (k_proj_xw, k_proj_ua) on the MFMA path when X_l fits the 8 waves of k_proj_xw
-    const bool fuse = c->proj_fuse && c->proj_mfma && kmax <= 16 * (PF_THREADS / 64);
-    if (polar_newton_supported(c)) {
-        launch_proj_gemm<PG_X>(c, ga);
-        // square X_l: polar factor by the scaled Newton iteration (k_polar.hip), U_l written directly
-        int rn;
-        {
-            ProfScope pp(c, "polar");                            // the polar-factor kernel alone (nested in "proj")
-            rn = launch_polar_newton(c);
-        }
-        if (rn != MTIP_OK) return rn;
-        c->vr_valid = false;
-        c->proj_calls += 1;
-        return launch_apply_unknowns(c, Ilm, out);
-    }
+    // fused pairs (k_proj_xw, k_proj_ua) when X_l fits the 8 waves of k_proj_xw
+    const bool fuse = c->proj_fuse && kmax <= 16 * (PF_THREADS / 64);
     const size_t lds = ((size_t)kmax * (nmax | 1) + (size_t)kmax * (kmax | 1)) * sizeof(double2);   // unpadded minimum
-    // Rotation-log mode: only X_l lives in the LDS of the Jacobi workgroup, V_r is updated afterwards by k_jacobi_replay
-    // (rows spread over the chip).  Needs the resident ordering for every active order (square X_l, 16-lane groups).
-    bool square = true;
-    for (int l = 0; l <= c->L; ++l)
-        if (c->active[l] && c->kl[l] != 2 * l + 1) square = false;
     const bool sched_ok = c->jac_resident && kmax <= 255 && kmax >= 2 && build_jacobi_schedule(c, kmax) == MTIP_OK;
-    const size_t lds_x = (size_t)kmax * (nmax | 1) * sizeof(double2);
-    // Measured at k = 65 (fits either way): X-only Jacobi 497 us + replay 232 us against 572 us with V_r in the same
-    // workgroup, so the log is used where X_l and V_r do not fit one CU's LDS together (2l+1 > 71: config 5, 3 x faster
-    // than the global-memory fallback there) unless MTIP_JAC_REPLAY=2 forces it.
-    // Concurrent replay (k_polar_conc): X-only Jacobi workgroups and, in the same launch, workgroups on other CUs that apply the
-    // rotation log to V_r while it is being written
-    const bool conc = c->jac_conc && c->jac_tg == 16 && square && sched_ok && nmax <= 5 * 16 && c->jsched_ps <= 32 &&
-                      c->jsched_ps * 16 <= JL_MAX_THREADS && lds_x + 16 * sizeof(double2) <= 80 * 1024;
-    const bool logv = conc || (c->jac_replay > 0 && (c->jac_replay > 1 || lds > 158 * 1024) && c->jac_tg == 16 && square && sched_ok &&
-                               nmax <= 7 * 16 && c->jsched_ps <= 48 && lds_x + 16 * sizeof(double2) <= 158 * 1024);
-    const bool lds_path = logv || lds <= 158 * 1024;
+    const bool lds_path = lds <= 158 * 1024;                    // X_l and V_r of the largest order share one CU's LDS (2l+1 <= 71)
     // cold start every 64 calls bounds the accumulated rounding drift of the carried V_r
     const int warm = (lds_path && c->vr_valid && (c->proj_calls % 64) != 0) ? 1 : 0;
     if (!(fuse && warm)) launch_proj_gemm<PG_X>(c, ga);         // (fused warm start: X_l never leaves the workgroups of k_proj_xw)
@@ -1611,16 +1149,14 @@ int launch_project_coefficients(mtip_ctx* c, const double2* Ilm, double2* out, b
             src = c->d_U;
         }
         const int pairs_max = kmax / 2;                         // valid pairs per round (odd k: dummy pair skipped)
-        // 16 lanes per pair (two waves per SIMD at k = 65: one wave's rotation parameters overlap the other's
-        // row updates) when all pairs of a round still fit one workgroup, else 8
-        const int tg = logv ? 16 : ((c->jac_tg == 16 && pairs_max * 16 <= JL_MAX_THREADS && nmax <= 5 * 16) ? 16 : 8);
-        const size_t lds_pad = ((size_t)kmax * (div_up(nmax, tg) * tg + 1) + (logv ? 0 : (size_t)kmax * (div_up(kmax, tg) * tg + 1))) * sizeof(double2);
-        // (log mode: stay below half a CU's LDS; concurrent mode: unpadded columns, its small matrices keep V_r in the same LDS)
-        const int pad = (!conc && lds_pad <= (logv ? 80 : 158) * 1024) ? 1 : 0;
-        const size_t lds_use = (pad ? lds_pad : (logv ? lds_x : lds)) + 16 * sizeof(double2);
-        const bool use_sched = logv || (tg == 16 && sched_ok && c->jsched_ps * 16 <= JL_MAX_THREADS);
+        // 16 lanes per pair when all pairs of a round still fit one workgroup, else 8
+        const int tg = (c->jac_tg == 16 && pairs_max * 16 <= JL_MAX_THREADS && nmax <= 5 * 16) ? 16 : 8;
+        const size_t lds_pad = ((size_t)kmax * (div_up(nmax, tg) * tg + 1) + (size_t)kmax * (div_up(kmax, tg) * tg + 1)) * sizeof(double2);
+        const int pad = lds_pad <= 158 * 1024 ? 1 : 0;
+        const size_t lds_use = (pad ? lds_pad : lds) + 16 * sizeof(double2);
+        const bool use_sched = tg == 16 && sched_ok && c->jsched_ps * 16 <= JL_MAX_THREADS;
         int threads = (((use_sched ? c->jsched_ps : pairs_max) * tg + 63) / 64) * 64;
-        threads = std::min(std::max(threads, 64), logv ? 768 : JL_MAX_THREADS);
+        threads = std::min(std::max(threads, 64), JL_MAX_THREADS);
         if (c->d_jorder == nullptr) {                           // active orders, heaviest (largest k_l) first
             std::vector<int> ord;
             for (int l = 0; l <= c->L; ++l)
@@ -1634,24 +1170,9 @@ int launch_project_coefficients(mtip_ctx* c, const double2* Ilm, double2* out, b
             }
             (void)mtip_copy(c, c->d_jorder, ord.data(), ord.size() * sizeof(int), hipMemcpyHostToDevice);
         }
+        // the launch's LDS must hold the padded (or tight) X_l and V_r of EVERY active order: they are sized by the largest
+        // k_l and 2l+1 above, which bound every order's
         const dim3 gj((unsigned)c->B, (unsigned)std::max(c->n_jorder, 1));
-        const int log_cap = JAC_MAX_SWEEPS * (kmax | 1);        // rounds: at most k (odd k) or k - 1 per sweep
-        if (logv && (c->d_jlog == nullptr || c->jlog_cap != log_cap || c->jlog_ps != c->jsched_ps || c->jlog_nmat != (size_t)gj.x * gj.y)) {
-            if (c->d_jlog) (void)hipFree(c->d_jlog);
-            if (c->d_jlog_rounds) (void)hipFree(c->d_jlog_rounds);
-            c->d_jlog = nullptr; c->d_jlog_rounds = nullptr;
-            const size_t nmat = (size_t)gj.x * gj.y;
-            if (hipMalloc((void**)&c->d_jlog, nmat * log_cap * c->jsched_ps * sizeof(JlRec)) != hipSuccess ||
-                hipMalloc((void**)&c->d_jlog_rounds, nmat * sizeof(int)) != hipSuccess) {
-                c->err = "rotation log: out of device memory";
-                return MTIP_ENOMEM;
-            }
-            (void)hipMemsetAsync(c->d_jlog_rounds, 0, nmat * sizeof(int), c->stream);
-            (void)hipMemsetAsync(c->d_jlog, 0, nmat * log_cap * c->jsched_ps * sizeof(JlRec), c->stream);
-            c->jlog_cap = log_cap;
-            c->jlog_nmat = nmat;
-            c->jlog_ps = c->jsched_ps;
-        }
         JacobiArgs ja;
         ja.Xin_all = src; ja.Pn_all = c->d_X; ja.Vr_all = c->d_Vr;
         ja.kl = c->d_kl; ja.active = c->d_active; ja.xoff = c->d_xoff; ja.roff = c->d_uoff;
@@ -1660,56 +1181,13 @@ int launch_project_coefficients(mtip_ctx* c, const double2* Ilm, double2* out, b
         ja.sweeps_out = c->d_sweeps; ja.pad = pad;
         ja.sched = use_sched ? (const int*)c->d_jsched : (const int*)nullptr;
         ja.sched_off = c->d_jsched_off; ja.sched_rounds = c->d_jsched_rounds; ja.sched_ps = c->jsched_ps;
-        ja.order_list = c->d_jorder; ja.log_all = (JlRec*)c->d_jlog; ja.log_rounds = c->d_jlog_rounds;
-        ja.log_cap = log_cap; ja.epoch = (int)(c->proj_calls & 0x3fffffff); ja.conc_err = c->d_conc_err;
-#define JL_LAUNCH(MAXR, TG, MAXT, LOGV) \
-    hipLaunchKernelGGL((k_polar_jacobi_lds<MAXR, TG, MAXT, LOGV>), gj, dim3(threads), lds_use, c->stream, ja)
+        ja.order_list = c->d_jorder;
         {
-        ProfScope pp(c, "polar");                                // the polar-factor kernels alone (nested in "proj")
-        if (conc) {
-            // Jacobi workgroups (z = 0) and the workgroups that replay their logs on V_r at the same time (z >= 1), one launch
-            constexpr int rows_wg = 2 * JR_RPL * (JL_MAX_THREADS / 64);
-            const size_t lds_c = ((size_t)rows_wg * (kmax | 1) + (size_t)JR_CHUNK * c->jsched_ps * 2) * sizeof(double2);
-            const dim3 gc(gj.x, gj.y, 1u + (unsigned)div_up(kmax, rows_wg));
-            int nrd_max = 1;                                     // (the divide-and-conquer schedule has more rounds than columns: 70 at k = 65)
-            for (int ke = 2; ke <= kmax; ++ke) nrd_max = std::max(nrd_max, c->jsched_nrd[ke]);
-            const size_t lds_p = lds_use + (size_t)nrd_max * c->jsched_ps * sizeof(int);         // X_l + the pairing table of a sweep
-            // which orders to split: measured at 128 x L32 with three engines, only the largest pays (it sets the duration of the
-            // launch; every further order adds two spinning consumer workgroups that take CUs from the other engines' transforms)
-            int k_conc_min = c->jac_conc_min_k < 0 ? kmax : std::max(2, std::min(c->jac_conc_min_k, kmax));
-            // the orders below it are solved with V_r in their own workgroup: X_l and V_r of the largest of them (unpadded columns)
-            // have to fit the launch's LDS
-            size_t lds_f = 0;
-            for (;;) {
-                int k_fused = 0;
-                for (int l = 0; l <= c->L; ++l)
-                    if (c->active[l] && c->kl[l] < k_conc_min) k_fused = std::max(k_fused, c->kl[l]);
-                lds_f = k_fused ? ((size_t)2 * k_fused * (k_fused | 1) + 16) * sizeof(double2) : 0;
-                if (lds_f <= 158 * 1024) break;
-                k_conc_min = k_fused;                            // does not fit: split that order as well
-            }
-            const size_t lds_l = std::max(std::max(lds_p, lds_c), lds_f);
-            c->conc_used = true;
-            hipLaunchKernelGGL((k_polar_conc<5, 16, JL_MAX_THREADS>), gc, dim3(JL_MAX_THREADS), lds_l, c->stream, ja, k_conc_min);
-        } else if (logv) {
-            if (nmax <= 5 * 16 && threads <= JL_MAX_THREADS) JL_LAUNCH(5, 16, JL_MAX_THREADS, true);
-            else JL_LAUNCH(7, 16, 768, true);
-            const int ps = c->jsched_ps;
-            const int rows_wg = (ps <= 32 ? 2 : 1) * JR_RPL * (JR_THREADS / 64);
-            const size_t lds_r = ((size_t)rows_wg * (kmax | 1) + 2 * (size_t)JR_CHUNK * ps * 2) * sizeof(double2);
-            const dim3 gr(gj.x, gj.y, (unsigned)div_up(kmax, rows_wg));
-#define JR_LAUNCH(G)                                                                                                     \
-    hipLaunchKernelGGL((k_jacobi_replay<G>), gr, dim3(JR_THREADS), lds_r, c->stream, (const JlRec*)c->d_jlog,           \
-                       c->d_jlog_rounds, c->d_Vr, (const int*)c->d_kl, (const int*)c->d_active,             \
-                       (const int*)c->d_uoff, c->utot, warm, ps, log_cap, (const int*)c->d_jorder)
-            if (ps <= 32) JR_LAUNCH(32);
-            else JR_LAUNCH(64);
-#undef JR_LAUNCH
-        } else if (tg == 16) JL_LAUNCH(5, 16, JL_MAX_THREADS, false);
-        else if (nmax <= 9 * 8) JL_LAUNCH(9, 8, JL_MAX_THREADS, false);
-        else JL_LAUNCH(16, 8, JL_MAX_THREADS, false);
+            ProfScope pp(c, "polar");                            // the polar-factor kernel alone (nested in "proj")
+            if (tg == 16) hipLaunchKernelGGL((k_polar_jacobi_lds<5, 16, JL_MAX_THREADS>), gj, dim3(threads), lds_use, c->stream, ja);
+            else if (nmax <= 9 * 8) hipLaunchKernelGGL((k_polar_jacobi_lds<9, 8, JL_MAX_THREADS>), gj, dim3(threads), lds_use, c->stream, ja);
+            else hipLaunchKernelGGL((k_polar_jacobi_lds<16, 8, JL_MAX_THREADS>), gj, dim3(threads), lds_use, c->stream, ja);
         }
-#undef JL_LAUNCH
         c->vr_valid = true;
         c->proj_calls += 1;
         if (fuse) {
@@ -1724,9 +1202,13 @@ int launch_project_coefficients(mtip_ctx* c, const double2* Ilm, double2* out, b
         ga.dst = c->d_U;
         launch_proj_gemm<PG_U>(c, ga);
     } else {
+        // X_l and V_r do not share a CU's LDS (complex 2l+1 > 71): global-memory Jacobi, cold start
+        ProfScope pp(c, "polar");
         hipLaunchKernelGGL(k_polar_jacobi, dim3((unsigned)(c->L + 1), (unsigned)c->B), dim3(256), 0, c->stream, c->d_X,
                            c->d_Vr, c->d_U, (const int*)c->d_kl, (const int*)c->d_active, (const int*)c->d_xoff,
                            (const int*)c->d_uoff, c->xtot, c->utot);
+        c->vr_valid = false;
+        c->proj_calls += 1;
     }
     // I'_l = V_l U_l in place on the coefficient buffer; a separate output first receives a copy of I_l
     if (out != Ilm)

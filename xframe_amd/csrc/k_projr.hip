@@ -22,9 +22,9 @@
 #include "mtip_internal.h"
 #include "k_jacobi.h"
 
-#define RP_MAX_THREADS 768
+#define RP_MAX_THREADS 1024
 #define RP_SLACK 128            // doubles behind the matrices: predicated-off lanes of the last row slot still form addresses
-#define RP_ACC 5                // 16 x 16 output tiles a wave works on at a time (and may hold across a barrier: in-place products)
+#define RP_ACC_MAX 5            // 16 x 16 output tiles a wave works on at a time (and holds across a barrier: in-place products)
 
 struct RpShared {
     double gmax[RP_MAX_THREADS / 16];
@@ -32,6 +32,7 @@ struct RpShared {
     int perm[128];
     int cont, keff;
     double red[RP_MAX_THREADS / 64];
+    int pad_;
 };
 
 // rotation [a b] <- [a b] [[c, w], [-w, c]] that annihilates gamma = a.b (smaller angle); false: already orthogonal
@@ -180,14 +181,45 @@ __device__ __forceinline__ void rp_sweep(double* Xs, double* Vs, int ns, int ks,
 //   * the pairing table is translated once per sweep into {resident offset << 2 | write-back << 1 | load, mover offset} (through
 //     the compaction of the deflated columns), flags made self-contained: a resident is written back before an idle round;
 //   * a pair that is orthogonal already takes the identity rotation through the same instructions.
+// nc = blocks of 16 columns (= row slots of 16 rows: 2l+2 <= 16 nc); TG = lanes per column pair (16, or 32: twice the waves
+// per round with shorter chains each, conflict-free 32-lane column reads; up to 32 pairs = 1024 threads)
 #define RP_PAD_MAX_NR 5
-__device__ __forceinline__ constexpr int rp_pad_ns(int nr) { return 16 * nr + 1; }
-__device__ __forceinline__ constexpr int rp_pad_voff(int nr) { return 16 * nr * (16 * nr + 1); }     // doubles from X~ to V_r
+__host__ __device__ __forceinline__ constexpr int rp_pad_nrt(int nc, int tg) { return (16 * nc + tg - 1) / tg; }      // row slots per lane
+__host__ __device__ __forceinline__ constexpr int rp_pad_ns(int nc, int tg) { return rp_pad_nrt(nc, tg) * tg + 1; }   // column stride (odd)
+__host__ __device__ __forceinline__ constexpr int rp_pad_voff(int nc, int tg) { return 16 * nc * rp_pad_ns(nc, tg); } // doubles from X~ to V_r
 
-template <int NR, bool TIMED = false>
+// value of the same lane in the neighbouring row of 16 lanes (row ^ 1): v_permlane16_swap (gfx950) exchanges the odd rows of its
+// first operand with the even rows of its second
+__device__ __forceinline__ double rp_xrow(double v) {
+    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);      // {[r0 r0 r2 r2], [r1 r1 r3 r3]}
+    const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    const bool odd = ((threadIdx.x >> 4) & 1) != 0;
+    return __hiloint2double((int)(odd ? b[0] : b[1]), (int)(odd ? a[0] : a[1]));
+}
+// sums over the TG lanes of a pair-group, every lane receives them
+template <int TG>
+__device__ __forceinline__ void rp_sum3(double& a, double& b, double& g) {
+    double z = 0.0;
+    group_sum4<16>(a, b, g, z);
+    if (TG == 32) {
+        a += rp_xrow(a);
+        b += rp_xrow(b);
+        g += rp_xrow(g);
+    }
+}
+template <int TG>
+__device__ __forceinline__ double rp_sum1(double v) {
+    v = group_sum<16>(v);
+    if (TG == 32) v += rp_xrow(v);
+    return v;
+}
+
+template <int NC, int TG, bool TIMED = false>
 __device__ __forceinline__ void rp_sweep_pad(double* xt /* X~ + lane of the group */, const int2* tab, int n_rounds, int ngroups,
                                              int group, double tabs2, double S, bool& big, long long* tacc = nullptr) {
-    constexpr int VOFF = rp_pad_voff(NR);
+    constexpr int NR = rp_pad_nrt(NC, TG);
+    constexpr int VOFF = rp_pad_voff(NC, TG);
     long long tq = 0;
 #define RP_SEG(I)                            \
     if (TIMED) {                             \
@@ -211,19 +243,19 @@ __device__ __forceinline__ void rp_sweep_pad(double* xt /* X~ + lane of the grou
         double mx[NR], mv[NR];
 #pragma unroll
         for (int u = 0; u < NR; ++u) {
-            mx[u] = xm[u * 16];
-            mv[u] = xm[VOFF + u * 16];
+            mx[u] = xm[u * TG];
+            mv[u] = xm[VOFF + u * TG];
         }
         if (e.x & 1) {                                           // a new resident for this group
 #pragma unroll
             for (int u = 0; u < NR; ++u) {
-                rx[u] = xr[u * 16];
-                rv[u] = xr[VOFF + u * 16];
+                rx[u] = xr[u * TG];
+                rv[u] = xr[VOFF + u * TG];
             }
         }
         if (TIMED) asm volatile("" : "+v"(mx[0]), "+v"(mx[NR - 1]), "+v"(mv[NR - 1]), "+v"(rx[NR - 1]));
         RP_SEG(0)
-        double alpha = 0.0, beta = 0.0, g = 0.0, zero = 0.0;
+        double alpha = 0.0, beta = 0.0, g = 0.0;
 #pragma unroll
         for (int u = 0; u < NR; ++u) {
             alpha = fma(rx[u], rx[u], alpha);
@@ -232,7 +264,7 @@ __device__ __forceinline__ void rp_sweep_pad(double* xt /* X~ + lane of the grou
         }
         if (TIMED) asm volatile("" : "+v"(alpha), "+v"(beta), "+v"(g));
         RP_SEG(1)
-        group_sum4<16>(alpha, beta, g, zero);
+        rp_sum3<TG>(alpha, beta, g);
         if (TIMED) asm volatile("" : "+v"(alpha), "+v"(beta), "+v"(g));
         RP_SEG(2)
         // rotation [a b] <- [a b] [[c, w], [-w, c]] (see rp_params), the identity for a pair that is orthogonal already
@@ -252,19 +284,19 @@ __device__ __forceinline__ void rp_sweep_pad(double* xt /* X~ + lane of the grou
         for (int u = 0; u < NR; ++u) {
             const double a = rx[u], bq = mx[u];
             rx[u] = fma(-w, bq, cs * a);
-            xm[u * 16] = fma(w, a, cs * bq);
+            xm[u * TG] = fma(w, a, cs * bq);
         }
 #pragma unroll
         for (int u = 0; u < NR; ++u) {
             const double a = rv[u], bq = mv[u];
             rv[u] = fma(-w, bq, cs * a);
-            xm[VOFF + u * 16] = fma(w, a, cs * bq);
+            xm[VOFF + u * TG] = fma(w, a, cs * bq);
         }
         if (e.x & 2) {                                           // someone else takes the resident next round
 #pragma unroll
             for (int u = 0; u < NR; ++u) {
-                xr[u * 16] = rx[u];
-                xr[VOFF + u * 16] = rv[u];
+                xr[u * TG] = rx[u];
+                xr[VOFF + u * TG] = rv[u];
             }
         }
         RP_SEG(4)
@@ -352,7 +384,7 @@ __device__ __forceinline__ double rp_partner(double v) { return dpp_mov<0xB1>(v)
 
 // the active order l of restart b: products, Jacobi, apply.  UNR: inner steps of the products requested at a time (register budget
 // of the launch bound: 4 with two waves per SIMD, 2 with three)
-template <int UNR, bool BIG>
+template <int UNR, int RP_ACC, bool BIG, int TG>
 __device__ __forceinline__ void rp_solve(const RProjArgs& A, int b, int l, RpShared& sh, double* sm) {
     const int tid = threadIdx.x, nthreads = blockDim.x;
     // (the wave index through readfirstlane: everything derived from it -- tile lists, tile counts -- is then scalar, and the
@@ -360,15 +392,16 @@ __device__ __forceinline__ void rp_solve(const RProjArgs& A, int b, int l, RpSha
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = nthreads >> 6;
     const int li = lane & 15, lk = lane >> 4;
     const int N = A.N, k = A.kl[l], n = 2 * l + 1, n2 = 2 * l + 2;
-    const int nr = (n2 + 15) >> 4;                       // row slots per lane (the same for the k rows of V_r: k = 2l+1)
+    const int nc = (n2 + 15) >> 4;                       // blocks of 16 columns / rows
+    const int nr = TG == 16 ? nc : rp_pad_nrt(nc, TG);   // row slots per lane (the same for the k rows of V_r: k = 2l+1)
     // up to RP_PAD_MAX_NR row slots: zero-padded columns, one stride, V_r a fixed distance behind X~ (rp_sweep_pad); beyond
     // (config 5) the matrices fill the CU: tight columns, predicates on the last row slot (rp_sweep)
-    const bool pad = nr <= RP_PAD_MAX_NR;
-    const int ns = pad ? rp_pad_ns(nr) : (n2 | 1), ks = pad ? ns : (k | 1);      // odd column strides
+    const bool pad = nc <= RP_PAD_MAX_NR;
+    const int ns = pad ? rp_pad_ns(nc, TG) : (n2 | 1), ks = pad ? ns : (k | 1);      // odd column strides
     double* Xs = sm;
-    double* Vs = sm + (pad ? (size_t)rp_pad_voff(nr) : (size_t)k * ns);
+    double* Vs = sm + (pad ? (size_t)rp_pad_voff(nc, TG) : (size_t)k * ns);
     // behind the matrices: the pairing table of the current column count (raw, and translated per sweep in pad mode)
-    int* s_tab = reinterpret_cast<int*>(sm + (pad ? 2 * (size_t)rp_pad_voff(nr) : (size_t)k * ns + (size_t)k * ks) + RP_SLACK);
+    int* s_tab = reinterpret_cast<int*>(sm + (pad ? 2 * (size_t)rp_pad_voff(nc, TG) : (size_t)k * ns + (size_t)k * ks) + RP_SLACK);
     int2* s_tab2 = reinterpret_cast<int2*>(s_tab + A.tab_ints);
     const double* DV = A.DV + A.voff[l];
     const double* Vt = A.Vt + A.voff[l];
@@ -392,7 +425,7 @@ __device__ __forceinline__ void rp_solve(const RProjArgs& A, int b, int l, RpSha
         dbg[8] = (long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));      // HW_ID
     }
     if (pad) {                                           // zero padding (rows beyond the matrices, unused columns) once
-        for (int e = tid; e < 2 * rp_pad_voff(nr); e += nthreads) Xs[e] = 0.0;
+        for (int e = tid; e < 2 * rp_pad_voff(nc, TG); e += nthreads) Xs[e] = 0.0;
         __syncthreads();
     }
     // ---- A: X~^T[j][rho'] = sum_q DV[q][j] I~[q][rho'] -> Xs[j * ns + rho'] ------------------------------------------
@@ -475,9 +508,9 @@ __device__ __forceinline__ void rp_solve(const RProjArgs& A, int b, int l, RpSha
     }
     RP_STAMP(1)
     // ---- J: one-sided Jacobi sweeps ------------------------------------------------------------------------------------
-    const int ngroups = nthreads >> 4;
-    const int group = tid >> 4, t = tid & 15;
-    const bool xl_ok = t + (nr - 1) * 16 < n2, vl_ok = t + (nr - 1) * 16 < k;
+    const int ngroups = nthreads / TG;
+    const int group = tid / TG, t = tid % TG;
+    const bool xl_ok = t + (nr - 1) * TG < n2, vl_ok = t + (nr - 1) * TG < k;
     double S = 0.0;
     if (k > 1) {
         int tab_ke = -1;
@@ -490,11 +523,11 @@ __device__ __forceinline__ void rp_solve(const RProjArgs& A, int b, int l, RpSha
                 double s2 = 0.0;
                 if (cc < k)
                     for (int u = 0; u < nr; ++u)
-                        if (t + u * 16 < n2) {
-                            const double x = Xs[(size_t)cc * ns + t + u * 16];
+                        if (t + u * TG < n2) {
+                            const double x = Xs[(size_t)cc * ns + t + u * TG];
                             s2 = fma(x, x, s2);
                         }
-                s2 = group_sum<16>(s2);
+                s2 = rp_sum1<TG>(s2);
                 if (cc < k && t == 0) sh.isig[cc] = s2;
                 Sl = fmax(Sl, s2);
             }
@@ -506,7 +539,7 @@ __device__ __forceinline__ void rp_solve(const RProjArgs& A, int b, int l, RpSha
                 const int cc = cc0 + group;
                 if (cc < k && sh.isig[cc] <= (JAC_DEFLATE * JAC_DEFLATE) * S && sh.isig[cc] > 0.0)
                     for (int u = 0; u < nr; ++u)
-                        if (t + u * 16 < n2) Xs[(size_t)cc * ns + t + u * 16] = 0.0;
+                        if (t + u * TG < n2) Xs[(size_t)cc * ns + t + u * TG] = 0.0;
             }
             if (tid < 64) {                                    // wave 0: ballot + prefix popcount (k <= 128)
                 const double thr = (JAC_DEFLATE * JAC_DEFLATE) * S;
@@ -533,7 +566,7 @@ __device__ __forceinline__ void rp_solve(const RProjArgs& A, int b, int l, RpSha
                         __syncthreads();
                     }
                     const int ps = A.sched_ps;
-                    const int dummy = (16 * nr - 1) * ns;        // the all-zero column
+                    const int dummy = (16 * nc - 1) * ns;        // the all-zero column
                     for (int e = tid; e < nrd * ngroups; e += nthreads) {
                         const int r = e / ngroups, gq = e - r * ngroups;
                         const int raw = gq < ps ? s_tab[r * ps + gq] : 0;
@@ -551,9 +584,9 @@ __device__ __forceinline__ void rp_solve(const RProjArgs& A, int b, int l, RpSha
                     }
                     __syncthreads();
                     double* xt = Xs + t;
-                    if (dbg != nullptr && nr == 5) {             // diagnostic instance with segment timers
+                    if (dbg != nullptr && nc == 5) {             // diagnostic instance with segment timers
                         long long tacc[7] = {0, 0, 0, 0, 0, 0, 0};
-                        rp_sweep_pad<5, true>(xt, s_tab2, nrd, ngroups, group, A.tabs2, S, big, tacc);
+                        rp_sweep_pad<5, TG, true>(xt, s_tab2, nrd, ngroups, group, A.tabs2, S, big, tacc);
                         if ((tid & 63) == 0 && (tid >> 6) < 8) {   // per wave: busy, LDS drain + barrier; wave 0 and 5 also the segments
                             dbg[10 + (tid >> 6)] += tacc[0] + tacc[1] + tacc[2] + tacc[3] + tacc[4];
                             dbg[18 + (tid >> 6)] += tacc[5] + tacc[6];
@@ -561,12 +594,12 @@ __device__ __forceinline__ void rp_solve(const RProjArgs& A, int b, int l, RpSha
                                 for (int i = 0; i < 7; ++i) dbg[(tid ? 33 : 26) + i] += tacc[i];
                         }
                     } else {
-                        switch (nr) {
-                        case 1: rp_sweep_pad<1>(xt, s_tab2, nrd, ngroups, group, A.tabs2, S, big); break;
-                        case 2: rp_sweep_pad<2>(xt, s_tab2, nrd, ngroups, group, A.tabs2, S, big); break;
-                        case 3: rp_sweep_pad<3>(xt, s_tab2, nrd, ngroups, group, A.tabs2, S, big); break;
-                        case 4: rp_sweep_pad<4>(xt, s_tab2, nrd, ngroups, group, A.tabs2, S, big); break;
-                        default: rp_sweep_pad<5>(xt, s_tab2, nrd, ngroups, group, A.tabs2, S, big); break;
+                        switch (nc) {
+                        case 1: rp_sweep_pad<1, TG>(xt, s_tab2, nrd, ngroups, group, A.tabs2, S, big); break;
+                        case 2: rp_sweep_pad<2, TG>(xt, s_tab2, nrd, ngroups, group, A.tabs2, S, big); break;
+                        case 3: rp_sweep_pad<3, TG>(xt, s_tab2, nrd, ngroups, group, A.tabs2, S, big); break;
+                        case 4: rp_sweep_pad<4, TG>(xt, s_tab2, nrd, ngroups, group, A.tabs2, S, big); break;
+                        default: rp_sweep_pad<5, TG>(xt, s_tab2, nrd, ngroups, group, A.tabs2, S, big); break;
                         }
                     }
                 } else if (BIG) {
@@ -599,11 +632,11 @@ __device__ __forceinline__ void rp_solve(const RProjArgs& A, int b, int l, RpSha
         double s2 = 0.0;
         if (cc < k)
             for (int u = 0; u < nr; ++u)
-                if (t + u * 16 < n2) {
-                    const double x = Xs[(size_t)cc * ns + t + u * 16];
+                if (t + u * TG < n2) {
+                    const double x = Xs[(size_t)cc * ns + t + u * TG];
                     s2 = fma(x, x, s2);
                 }
-        s2 = group_sum<16>(s2);
+        s2 = rp_sum1<TG>(s2);
         if (cc < k && t == 0) sh.isig[cc] = s2 > 1e-300 ? 1.0 / sqrt(s2) : 0.0;
     }
     for (int e = tid; e < k * k; e += nthreads) {
@@ -719,7 +752,7 @@ __device__ __forceinline__ void rp_solve(const RProjArgs& A, int b, int l, RpSha
 
 // grid = (restart, slot); slots are listed heaviest first, the restart index runs fastest: the workgroups that set the
 // duration of the launch are dispatched first
-template <int MAXT, int UNR, bool BIG>
+template <int MAXT, int UNR, int ACC, bool BIG, int TG>
 __global__ void __launch_bounds__(MAXT) k_rproj(RProjArgs A) {
     HIP_DYNAMIC_SHARED(double, sm)
     __shared__ RpShared sh;
@@ -730,7 +763,7 @@ __global__ void __launch_bounds__(MAXT) k_rproj(RProjArgs A) {
         if (e < 0) break;                                      // uniform per block
         const int l = e & 255, kind = e >> 8;
         if (kind == RP_SOLVE) {
-            rp_solve<UNR, BIG>(A, b, l, sh, sm);
+            rp_solve<UNR, ACC, BIG, TG>(A, b, l, sh, sm);
         } else if (kind == RP_ZERO) {
             // used order with V_l = 0 (odd_orders_to_0): I'_l = 0 on the masked shells, its unknowns stay 0
             const int n = 2 * l + 1;
@@ -766,10 +799,15 @@ __global__ void __launch_bounds__(MAXT) k_rproj(RProjArgs A) {
 }
 
 // ---- host side --------------------------------------------------------------------------------------------------------
-// threads and dynamic LDS of a k_rproj launch.  LDS: the largest order's matrices -- padded layout up to RP_PAD_MAX_NR row
-// slots, behind them the raw pairing table and its per-sweep translation (one int2 per round and group); tight layout beyond
-// (table read from L2) -- whichever needs more; tab_ints = ints reserved for the raw table
-static size_t rp_launch_geometry(const mtip_ctx* c, int* threads_out, int* tab_ints_out) {
+// lanes per column pair, threads and dynamic LDS of a k_rproj launch.  LDS: the largest order's matrices -- padded layout up to
+// RP_PAD_MAX_NR blocks of 16 columns, behind them the raw pairing table and its per-sweep translation (one int2 per round and
+// group); tight layout beyond (table read from L2) -- whichever needs more; tab_ints = ints reserved for the raw table
+struct RpGeom {
+    int tg = 16, threads = 256, tab_ints = 0, acc = RP_ACC_MAX;
+    size_t lds = 0;
+};
+static RpGeom rp_launch_geometry(const mtip_ctx* c) {
+    RpGeom g;
     int kpad = 0, kbig = 0;
     for (int l = 1; l <= c->L; ++l) {
         if (!c->active[l]) continue;
@@ -778,22 +816,26 @@ static size_t rp_launch_geometry(const mtip_ctx* c, int* threads_out, int* tab_i
     }
     const int kmax = std::max(kpad, kbig);
     const int ps = kmax >= 2 ? std::max(c->jsched_ps, 1) : 1;
-    int threads = std::max(256, (ps * 16 + 63) / 64 * 64);
-    size_t lds = RP_SLACK * sizeof(double);
-    int tab_ints = 0;
+    // 32 lanes per pair when every order has the padded layout and all pairs of a round fit 1024 threads: four waves per SIMD
+    // with three row slots each instead of two with five
+    // (measured at k = 65: 3520 ticks per round against 2440 with 16 lanes: the youngest of four waves per SIMD starve; MTIP_RP_TG=32 selects it)
+    g.tg = (c->rp_tg == 32 && kbig == 0 && ps * 32 <= 1024 && kmax >= 34) ? 32 : 16;
+    g.threads = std::max(256, (ps * g.tg + 63) / 64 * 64);
+    g.lds = RP_SLACK * sizeof(double);
     if (kpad >= 2) {
         int nrd = 1;                                             // (the schedule has more rounds than columns: 70 at k = 65)
         for (int ke = 2; ke <= kpad && ke < (int)c->jsched_nrd.size(); ++ke) nrd = std::max(nrd, c->jsched_nrd[ke]);
-        tab_ints = (nrd * ps + 1) & ~1;
-        const size_t nr = (kpad + 1 + 15) / 16;
-        lds = (2 * 16 * nr * (16 * nr + 1) + RP_SLACK) * sizeof(double) + (size_t)tab_ints * sizeof(int) +
-              (size_t)nrd * (threads / 16) * sizeof(int2);
+        g.tab_ints = (nrd * ps + 1) & ~1;
+        const int nc = (kpad + 1 + 15) / 16;
+        g.lds = (2 * (size_t)rp_pad_voff(nc, g.tg) + RP_SLACK) * sizeof(double) + (size_t)g.tab_ints * sizeof(int) +
+                (size_t)nrd * (g.threads / g.tg) * sizeof(int2);
     }
     if (kbig >= 2)
-        lds = std::max(lds, ((size_t)kbig * ((kbig + 1) | 1) + (size_t)kbig * (kbig | 1) + RP_SLACK) * sizeof(double));
-    if (threads_out) *threads_out = threads;
-    if (tab_ints_out) *tab_ints_out = tab_ints;
-    return lds;
+        g.lds = std::max(g.lds, ((size_t)kbig * ((kbig + 1) | 1) + (size_t)kbig * (kbig | 1) + RP_SLACK) * sizeof(double));
+    // the in-place products hold all their 16 x 16 tiles in registers across a barrier
+    const int nt16 = (kmax + 1 + 15) / 16;
+    g.acc = div_up(nt16 * nt16, g.threads / 64);
+    return g;
 }
 
 // every solved order square (k_l = 2l+1), V_l real, 2l+2 <= 7 row slots of 16, the schedule and the matrices fit
@@ -811,13 +853,10 @@ bool rproj_supported(mtip_ctx* c) {
     if (kmax > 111) return false;
     if (kmax >= 2) {
         if (build_jacobi_schedule(c, kmax) != MTIP_OK) return false;
-        int threads = 0;
-        const size_t lds = rp_launch_geometry(c, &threads, nullptr);
-        if (threads > RP_MAX_THREADS) return false;
-        if (lds + sizeof(RpShared) + 256 > 160 * 1024) return false;
-        // the in-place products hold all their 16 x 16 tiles in registers across a barrier: RP_ACC per wave
-        const int nt16 = (kmax + 1 + 15) / 16;
-        if (div_up(nt16 * nt16, threads / 64) > RP_ACC) return false;
+        const RpGeom g = rp_launch_geometry(c);
+        if (g.threads > RP_MAX_THREADS) return false;
+        if (g.lds + sizeof(RpShared) + 256 > 160 * 1024) return false;
+        if (g.acc > (g.tg == 32 ? 2 : RP_ACC_MAX)) return false;
     }
     return true;
 }
@@ -940,14 +979,18 @@ int launch_rproj(mtip_ctx* c, double2* coef) {
     a.inv_sqrt_np = 1.0 / std::sqrt(c->n_particles);
     a.sweeps_out = c->d_sweeps;
     a.dbg = c->d_polar_dbg;
-    int threads = 256;
-    const size_t lds = rp_launch_geometry(c, &threads, &a.tab_ints);
+    const RpGeom g = rp_launch_geometry(c);
+    a.tab_ints = g.tab_ints;
     ProfScope pp(c, "polar");                                    // (the whole projection is this one kernel)
-    // up to 512 threads: two waves per SIMD, 256 registers each; the 97-column orders of config 5 need 768 (three waves per SIMD)
-    if (threads <= 512)
-        hipLaunchKernelGGL((k_rproj<512, 2, false>), dim3((unsigned)c->B, (unsigned)c->rp_n_slots), dim3((unsigned)threads), lds, c->stream, a);
+    const dim3 grid((unsigned)c->B, (unsigned)c->rp_n_slots), block((unsigned)g.threads);
+    // registers by launch bound: 1024 threads (32 lanes per pair) = four waves per SIMD, 128 registers; 512 = two, 256 each; 768
+    // (the 97-column orders of config 5) = three, 168 each
+    if (g.tg == 32)
+        hipLaunchKernelGGL((k_rproj<1024, 1, 2, false, 32>), grid, block, g.lds, c->stream, a);
+    else if (g.threads <= 512)
+        hipLaunchKernelGGL((k_rproj<512, 2, RP_ACC_MAX, false, 16>), grid, block, g.lds, c->stream, a);
     else
-        hipLaunchKernelGGL((k_rproj<RP_MAX_THREADS, 1, true>), dim3((unsigned)c->B, (unsigned)c->rp_n_slots), dim3((unsigned)threads), lds, c->stream, a);
+        hipLaunchKernelGGL((k_rproj<768, 1, RP_ACC_MAX, true, 16>), grid, block, g.lds, c->stream, a);
     c->vr_kind = 2;
     c->proj_calls += 1;
     return MTIP_OK;

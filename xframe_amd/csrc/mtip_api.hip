@@ -53,7 +53,7 @@ void mtip_destroy(mtip_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    void* ptrs[] = {c->d_cost, c->d_gw, c->d_P, c->d_r, c->d_q, c->d_poff, c->d_PT, c->d_AB, c->d_lmtab, c->d_twN, c->d_tw, c->d_W, c->d_htiles, c->d_htiles32, c->d_kl, c->d_used, c->d_active, c->d_sweeps, c->d_conc_err, c->d_jsched, c->d_jsched_off, c->d_jsched_rounds, c->d_jorder, c->d_jlog, c->d_jlog_rounds, c->d_pg_tiles[0], c->d_pg_tiles[1], c->d_pg_tiles[2], c->d_pg_tiles[3], c->d_pg_tiles[4], c->d_pg_tiles[5], c->d_voff,
+    void* ptrs[] = {c->d_cost, c->d_gw, c->d_P, c->d_r, c->d_q, c->d_poff, c->d_PT, c->d_AB, c->d_lmtab, c->d_twN, c->d_tw, c->d_W, c->d_htiles, c->d_htiles32, c->d_kl, c->d_used, c->d_active, c->d_sweeps, c->d_jsched, c->d_jsched_off, c->d_jsched_rounds, c->d_jorder, c->d_pg_tiles[0], c->d_pg_tiles[1], c->d_pg_tiles[2], c->d_pg_tiles[3], c->d_pg_tiles[4], c->d_pg_tiles[5], c->d_voff,
                     c->d_xoff, c->d_uoff, c->d_V, c->d_rmask, c->d_Bref, c->d_Bnorm, c->d_deg2_part, c->d_S0, c->d_sup, c->d_err_wr,
                     c->d_err_wt, c->d_rho, c->d_Fp, c->d_slot, c->d_best_err, c->d_last_err, c->d_op_err, c->d_gq, c->d_polar_dbg, c->d_so3_d, c->d_so3_tw, c->d_so3_T, c->d_so3_S, c->d_so3_P, c->d_so3_D, c->d_so3_C, c->d_err_hist, c->d_main_hist,
                     c->d_deg2_hist, c->d_F, c->d_T1, c->d_T2, c->d_fixed, c->d_g, c->d_c[0], c->d_c[1], c->d_c[2],
@@ -126,10 +126,7 @@ mtip_ctx* mtip_create(const mtip_cfg* cfg, int device) {
     A(dev_alloc(c, &c->d_PT, (size_t)(c->nt / 2 + 1) * c->npairs));
     A(dev_alloc(c, &c->d_AB, (size_t)c->npairs));
     A(dev_alloc(c, &c->d_lmtab, c->npairs));
-    if (const char* e = std::getenv("MTIP_PROJ_MFMA")) c->proj_mfma = std::atoi(e) != 0;
     if (const char* e = std::getenv("MTIP_PROJ_FUSE")) c->proj_fuse = std::atoi(e) != 0;
-    if (const char* e = std::getenv("MTIP_JAC_CONC")) c->jac_conc = std::atoi(e) != 0;
-    if (const char* e = std::getenv("MTIP_JAC_CONC_MIN_K")) c->jac_conc_min_k = std::atoi(e);
     if (const char* e = std::getenv("MTIP_DEG2_SIMPLE")) c->deg2_simple = std::atoi(e) != 0;
     if (const char* e = std::getenv("MTIP_HANKEL_SIMPLE")) c->hankel_simple = std::atoi(e) != 0;
     if (const char* e = std::getenv("MTIP_HANKEL_WAVE_TILES")) c->hankel_wave_tiles = std::atoi(e) != 0;
@@ -138,10 +135,7 @@ mtip_ctx* mtip_create(const mtip_cfg* cfg, int device) {
     if (const char* e = std::getenv("MTIP_FUSE_REAL")) c->fuse_real_update = std::atoi(e) != 0;
     if (const char* e = std::getenv("MTIP_SHT_WIDE")) c->sht_wide = std::atoi(e) != 0;
     if (const char* e = std::getenv("MTIP_JAC_RESIDENT")) c->jac_resident = std::atoi(e) != 0;
-    if (const char* e = std::getenv("MTIP_POLAR_VARIANT")) c->polar_variant = std::atoi(e);
-    if (const char* e = std::getenv("MTIP_POLAR")) c->polar_newton = std::string(e) == "newton";
     if (const char* e = std::getenv("MTIP_JAC_TG")) c->jac_tg = std::atoi(e) == 8 ? 8 : 16;
-    if (const char* e = std::getenv("MTIP_JAC_REPLAY")) c->jac_replay = std::max(0, std::min(2, std::atoi(e)));
     if (rc == MTIP_OK) rc = build_hankel_tiles(c);
     A(dev_alloc(c, &c->d_twN, c->np));
     if (const char* e = std::getenv("MTIP_SHT_MODE")) c->sht_mode = std::atoi(e);
@@ -160,6 +154,7 @@ mtip_ctx* mtip_create(const mtip_cfg* cfg, int device) {
     c->have_V.assign(L + 1, 0);
     c->v_real.assign(L + 1, 1);
     if (const char* e = std::getenv("MTIP_PROJ_REAL")) c->proj_real = std::atoi(e) != 0;
+    if (const char* e = std::getenv("MTIP_RP_TG")) c->rp_tg = std::atoi(e);
     for (int l = 0; l <= L; ++l) {
         const int n = 2 * l + 1, k = std::min(n, N);
         c->kl[l] = k;                               // default; mtip_set_projection_matrix may give a smaller k_l
@@ -174,7 +169,6 @@ mtip_ctx* mtip_create(const mtip_cfg* cfg, int device) {
     A(dev_alloc(c, &c->d_used, L + 1));
     A(dev_alloc(c, &c->d_active, L + 1));
     A(dev_alloc(c, &c->d_sweeps, (size_t)B * (L + 1)));
-    A(dev_alloc(c, &c->d_conc_err, 1));
     A(dev_alloc(c, &c->d_voff, L + 2));
     A(dev_alloc(c, &c->d_xoff, L + 2));
     A(dev_alloc(c, &c->d_uoff, L + 2));
@@ -223,7 +217,6 @@ mtip_ctx* mtip_create(const mtip_cfg* cfg, int device) {
     (void)hipMemsetAsync(c->d_used, 0, (L + 1) * sizeof(int), c->stream);
     (void)hipMemsetAsync(c->d_active, 0, (L + 1) * sizeof(int), c->stream);
     (void)hipMemsetAsync(c->d_sweeps, 0, (size_t)B * (L + 1) * sizeof(int), c->stream);
-    if (c->d_conc_err) (void)hipMemsetAsync(c->d_conc_err, 0, sizeof(int), c->stream);
     (void)hipMemsetAsync(c->d_U, 0, (size_t)B * c->xtot * sizeof(double2), c->stream);
     (void)hipMemsetAsync(c->d_X, 0, (size_t)B * c->xtot * sizeof(double2), c->stream);
     (void)hipMemsetAsync(c->d_Vr, 0, (size_t)B * c->utot * sizeof(double2), c->stream);
@@ -600,21 +593,11 @@ int mtip_run_async(mtip_ctx* c, int method, int ft_stab, int n_steps, const doub
     return post_launch(c, "mtip_run");
 }
 
-// after a synchronisation: did a consumer workgroup of the concurrent polar factor give up waiting for its rotation log?
-static int check_conc(mtip_ctx* c) {
-    if (!c->conc_used || c->d_conc_err == nullptr) return MTIP_OK;
-    int gave_up = 0;
-    MTIP_HIP_CHECK(c, mtip_copy(c, &gave_up, c->d_conc_err, sizeof(int), hipMemcpyDeviceToHost));
-    if (gave_up != 0) FAIL(c, MTIP_EHIP, "polar factor: a concurrent V_r replay workgroup gave up waiting for its rotation log");
-    return MTIP_OK;
-}
-
 int mtip_fetch_errors(mtip_ctx* c, int64_t first, int64_t n, double* real_err, double* deg2_err) {
     CTX_CHECK(c);
     if (first < 0 || n < 0 || first + n > c->n_steps_done) FAIL(c, MTIP_EINVAL, "step range out of bounds");
     (void)hipSetDevice(c->device);
     MTIP_HIP_CHECK(c, hipStreamSynchronize(c->stream));
-    if (int rc = check_conc(c)) return rc;
     if (real_err && n)
         MTIP_HIP_CHECK(c, mtip_copy(c, real_err, c->d_err_hist + (size_t)first * c->B, (size_t)n * c->B * sizeof(double), hipMemcpyDeviceToHost));
     if (deg2_err && n)
@@ -628,7 +611,6 @@ int mtip_fetch_main_errors(mtip_ctx* c, int64_t first, int64_t n, double* main_e
     if (first < 0 || n < 0 || first + n > c->n_steps_done || !main_err) FAIL(c, MTIP_EINVAL, "step range out of bounds / null output");
     (void)hipSetDevice(c->device);
     MTIP_HIP_CHECK(c, hipStreamSynchronize(c->stream));
-    if (int rc = check_conc(c)) return rc;
     const double* src = c->main_mode == 1 ? c->d_main_hist : c->d_err_hist;
     if (n) MTIP_HIP_CHECK(c, mtip_copy(c, main_err, src + (size_t)first * c->B, (size_t)n * c->B * sizeof(double), hipMemcpyDeviceToHost));
     return post_launch(c, "mtip_fetch_main_errors");
@@ -702,7 +684,6 @@ static int get_grid_slot(mtip_ctx* c, const double2* base, int batch, int which,
     int s = 0;
     int r = slot_of(c, batch, which == 0 ? SL_CUR : SL_BEST, &s);
     if (r) return r;
-    if (int rc = check_conc(c)) return rc;
     MTIP_HIP_CHECK(c, mtip_copy(c, out, base + ((size_t)s * c->B + batch) * c->G, c->G * sizeof(double2), hipMemcpyDeviceToHost));
     return MTIP_OK;
 }
@@ -764,7 +745,6 @@ int mtip_get_best_error(mtip_ctx* c, double* best, int64_t* n_steps_done) {
     CTX_CHECK(c);
     (void)hipSetDevice(c->device);
     MTIP_HIP_CHECK(c, hipStreamSynchronize(c->stream));
-    if (int rc = check_conc(c)) return rc;
     if (best) MTIP_HIP_CHECK(c, mtip_copy(c, best, c->d_best_err, c->B * sizeof(double), hipMemcpyDeviceToHost));
     if (n_steps_done) *n_steps_done = c->n_steps_done;
     return MTIP_OK;
@@ -1101,9 +1081,6 @@ int mtip_debug_jacobi_sweeps(mtip_ctx* c, int32_t* out) {
     (void)hipSetDevice(c->device);
     MTIP_HIP_CHECK(c, hipStreamSynchronize(c->stream));
     MTIP_HIP_CHECK(c, mtip_copy(c, out, c->d_sweeps, (size_t)c->B * (c->L + 1) * sizeof(int), hipMemcpyDeviceToHost));
-    int gave_up = 0;
-    MTIP_HIP_CHECK(c, mtip_copy(c, &gave_up, c->d_conc_err, sizeof(int), hipMemcpyDeviceToHost));
-    if (gave_up != 0) FAIL(c, MTIP_EHIP, "polar factor: a concurrent V_r replay workgroup gave up waiting for its rotation log");
     return MTIP_OK;
 }
 
@@ -1125,7 +1102,7 @@ int mtip_debug_spin(mtip_ctx* c, double microseconds) {
 int mtip_debug_polar_timing(mtip_ctx* c, int64_t* out) {
     CTX_CHECK(c);
     (void)hipSetDevice(c->device);
-    const size_t n = (size_t)c->B * (c->L + 1) * 8 * 4;
+    const size_t n = (size_t)c->B * (c->L + 1) * 32;
     MTIP_HIP_CHECK(c, hipStreamSynchronize(c->stream));
     if (!c->d_polar_dbg) {                       // first call: switch the timers on (the next projections fill them)
         int r = dev_alloc(c, &c->d_polar_dbg, n);

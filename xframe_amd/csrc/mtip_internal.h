@@ -153,15 +153,8 @@ struct mtip_ctx {
     int n_jorder = 0;
     int* d_pg_tiles[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // (order, tile) lists of the projection GEMMs (4, 5: fused pairs)
     int n_pg_tiles[6] = {0, 0, 0, 0, 0, 0};
-    long long* d_polar_dbg = nullptr;                 // (B, L+1, 8 waves, 4) phase timers of k_polar_newton, allocated by mtip_debug_polar_timing
-    int polar_variant = 0;                            // env MTIP_POLAR_VARIANT (A/B switches of k_polar_newton: 1 ds_bpermute pivot row, 2 spin without s_sleep)
-    bool polar_newton = false;                        // env MTIP_POLAR=newton: scaled Newton iteration (k_polar.hip) for square X_l up to 72 x 72; default: one-sided Jacobi
+    long long* d_polar_dbg = nullptr;                 // (B, L+1, 32) phase / round timers of k_rproj, allocated by mtip_debug_polar_timing
     int jac_tg = 16;                                  // env MTIP_JAC_TG=8|16: lanes per Jacobi column pair
-    int jac_replay = 1;                               // env MTIP_JAC_REPLAY: 0 never, 1 rotation log + V_r replay when X_l, V_r do not share LDS, 2 always
-    void* d_jlog = nullptr;                           // rotation log of the last Jacobi launch (matrix, round, slot)
-    int* d_jlog_rounds = nullptr;                     // rounds logged per matrix
-    int jlog_cap = 0, jlog_ps = 0;
-    size_t jlog_nmat = 0;
     bool sht_fwd_pair = true;                         // env MTIP_SHT_FWD_PAIR=0: k_sht_fwd_reg (table loads inside the accumulation loop)
     bool hankel_flat_order = false;                   // env MTIP_HANKEL_FLAT_ORDER=1: tiles in order-major sequence (not XCD-aware)
     bool hankel_wave_tiles = false;                   // env MTIP_HANKEL_WAVE_TILES=1: per-wave tiles straight from L2 (k_hankel_mfma)
@@ -177,6 +170,7 @@ struct mtip_ctx {
     bool vr_valid = false;                            // d_Vr holds (complex) right singular vectors of the previous call
     int vr_kind = 0;                                  // 2: d_Vr holds the REAL right singular vectors of the previous k_rproj call
     bool proj_real = true;                            // env MTIP_PROJ_REAL=0: never take the real form of the projection (k_projr.hip)
+    int rp_tg = 0;                                    // env MTIP_RP_TG=32: 32 lanes per column pair in k_rproj where 1024 threads hold a round (default 16; slower as measured)
     std::vector<char> v_real;                         // per order: V_l has no imaginary part
     std::vector<double2> h_V;                         // host copy of the concatenated V_l (tables of the real projection)
     double *d_rp_DV = nullptr, *d_rp_Vt = nullptr;    // q^2 V_l (N x k) and V_l^T (k x N), real, at voff[l]
@@ -195,12 +189,7 @@ struct mtip_ctx {
     double2* d_Bref = nullptr;                        // (L+1, Nq, Nq) masked reference B_l
     double* d_Bnorm = nullptr;                        // (L+1)
     double* d_deg2_part = nullptr;                    // (B, L+1, (Nq/16)^2) per-tile partial sums of the B_l metric
-    int jac_conc_min_k = -1;                          // env MTIP_JAC_CONC_MIN_K: split the orders with at least this many columns (-1: the largest only)
-    bool jac_conc = true;                             // env MTIP_JAC_CONC=0: every matrix in one workgroup (no concurrent V_r replay, k_polar_conc)
-    bool conc_used = false;                           // a k_polar_conc launch has been made: d_conc_err is checked at the fetch points
-    int* d_conc_err = nullptr;                        // consumers of k_polar_conc that gave up waiting (must stay 0)
     bool proj_fuse = true;                            // env MTIP_PROJ_FUSE=0: four separate projection products instead of the two fused pairs
-    bool proj_mfma = true;                            // env MTIP_PROJ_MFMA=0: LDS-tiled VALU GEMMs for the projection products
     bool deg2_simple = false;                         // env MTIP_DEG2_SIMPLE=1: one thread per B_l element instead of MFMA tiles
     bool bref_dirty = true;
     // real-space constraints and error metric
@@ -285,8 +274,6 @@ bool rproj_supported(mtip_ctx* c);                    // k_projr.hip
 int launch_rproj(mtip_ctx* c, double2* coef);         // in place
 void free_rproj_tables(mtip_ctx* c);
 int launch_apply_unknowns(mtip_ctx* c, const double2* Ilm, double2* out);
-bool polar_newton_supported(const mtip_ctx* c);       // k_polar.hip: all active X_l square and at most 80 x 80
-int launch_polar_newton(mtip_ctx* c);                 // c->d_X (column-major X_l) -> c->d_U (U_l), scaled Newton iteration           // I'_l = V_l U_l with the U_l in c->d_U
 void launch_deg2(mtip_ctx* c, const double2* Ilm, double2* Bl);
 void launch_deg2_metric(mtip_ctx* c, const double2* Ilm, double* out /*(B, L+1)*/);
 // elementwise / reductions
