@@ -171,7 +171,7 @@ def main():
     t_setup = time.time()
     eng_d = Engine({'grid': {'n_radial_points': N, 'max_order': L}}, None, n_batch=1, device=local_rank,
                    max_q=S.data_cutoff(N))
-    data, rho_true = S.make_invariants(eng_d, N, L, eigh=eng_d.hermitian_eig)     # simulate + extract front half on the device
+    data, rho_true = S.make_invariants(eng_d, N, L, eigh=eng_d)     # simulate + extract front half on the device
     eng_d.close()
     sizes = [B // n_eng + (1 if i < B % n_eng else 0) for i in range(n_eng)]
     engines = [Engine(opt, data, n_batch=nb, device=local_rank, fused=not a.exact) for nb in sizes]

@@ -206,6 +206,9 @@ int mtip_op_rotate_coefficients(mtip_ctx* ctx, const mtip_cdouble* coeff, const 
  * unsorted, eigvecs (n_mat, n, n) with eigenvector i of matrix k in eigvecs[k][i][:] (one eigenvector per row).  Sorting,
  * the cut to min(2l+1, Nq) pairs, clipping of negative eigenvalues and V_l = eigvecs sqrt(eigvals) are host bookkeeping. */
 int mtip_op_hermitian_eig(mtip_ctx* ctx, int n, int n_mat, const mtip_cdouble* A, double* eigvals, mtip_cdouble* eigvecs);
+/* the same for REAL symmetric matrices up to 128 x 128 (the reference makes B_l real before its eigen-decomposition,
+ * fxs_invariant_tools.py:1255, 1114-1131): LDS-resident solver, eigenvalues accurate to eps |A|_F as LAPACK's */
+int mtip_op_symmetric_eig(mtip_ctx* ctx, int n, int n_mat, const double* A, double* eigvals, double* eigvecs);
 
 /* ---- timing ----------------------------------------------------------------------------------- */
 /* average duration (ms) and launch count of kernel family `name` ("sht_fwd", "sht_inv", "hankel",

@@ -20,7 +20,7 @@ cfg = 4
 N, L = S._SIZES[cfg]
 t0 = time.perf_counter()
 eng = Engine({'grid': {'n_radial_points': N, 'max_order': L}}, None, n_batch=1, max_q=S.data_cutoff(N))
-data, _ = S.make_invariants(eng, N, L, eigh=eng.hermitian_eig)
+data, _ = S.make_invariants(eng, N, L, eigh=eng)
 eng.close()
 t1 = time.perf_counter()
 opt = ST.deep_update(ST.default_settings(), S.config_overrides(cfg))

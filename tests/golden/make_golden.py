@@ -554,8 +554,51 @@ def main_average_ops():
     print('average ops fixture:', len(out), 'arrays')
 
 
+def main_extract():
+    """tests/golden/extract_ops.npz (G15): the reference's `extract` numerics on seeded B_l -- deg2_invariant_eigenvalues
+    (fxs_invariant_tools.py:1114-1141, both sort modes), deg2_invariant_to_projection_matrices_3d (1171-1207, with and without
+    q_id_limits) and nearest_positive_semidefinite_matrix (mathLibrary.py:872-892) -- on: a rank-deficient semi-definite
+    matrix (what B_l of 2l+1 coefficients is), an indefinite one, the zero matrix, a complex Hermitian one."""
+    mods = bootstrap()
+    ml = mods['xframe.library.mathLibrary']
+    ml.shtns = ShAdapter
+    it = importlib.import_module('xframe.projects.fxs.projectLibrary.fxs_invariant_tools')
+    rng = np.random.default_rng(1515)
+    n = 12
+    A5 = rng.normal(size=(n, 5)) * np.array([3.0, 1.0, 0.3, 1e-3, 1e-6])[None, :]
+    mats = {
+        'psd_rank5': A5 @ A5.T,
+        'indefinite': (lambda M: (M + M.T) / 2)(rng.normal(size=(n, n))),
+        'zero': np.zeros((n, n)),
+        'hermitian': (lambda M: M @ M.conj().T)(rng.normal(size=(n, 4)) + 1j * rng.normal(size=(n, 4))),
+        'not_symmetric': A5 @ A5.T + 1e-3 * rng.normal(size=(n, n)),        # symmetrised by the routine itself (1122)
+    }
+    out = {'G15_names': np.array(list(mats))}
+    lim_full = np.array([[0, n], [0, n]])
+    lim_sub = np.array([[2, 10], [2, 10]])
+    for name, B in mats.items():
+        out[f'G15_{name}_B'] = B
+        for sm in (0, 1):
+            w, v = it.deg2_invariant_eigenvalues(B.copy(), sort_mode=sm)
+            out[f'G15_{name}_eigvals_s{sm}'], out[f'G15_{name}_eigvecs_s{sm}'] = np.asarray(w), np.asarray(v)
+        for order in (1, 2, 4, 7):
+            for lname, lim in (('full', lim_full), ('sub', lim_sub)):
+                for sm in (0, 1):
+                    pm, ev = it.deg2_invariant_to_projection_matrices_3d(B.copy(), lim.copy(), order, sm)
+                    out[f'G15_{name}_pm_l{order}_{lname}_s{sm}'] = np.asarray(pm)
+                    out[f'G15_{name}_ev_l{order}_{lname}_s{sm}'] = np.asarray(ev)
+        out[f'G15_{name}_psd'] = np.asarray(ml.nearest_positive_semidefinite_matrix(B.copy()))
+        out[f'G15_{name}_psd_floor'] = np.asarray(ml.nearest_positive_semidefinite_matrix(B.copy(), low_positive_eigenvalues_to_zero=True))
+    stack = np.stack([mats['psd_rank5'], mats['indefinite'], mats['zero']])
+    out['G15_stack_psd'] = np.asarray(ml.nearest_positive_semidefinite_matrix(stack.copy()))     # batched over the leading axis (858)
+    np.savez_compressed(os.path.join(HERE, 'extract_ops.npz'), **out)
+    print('extract fixture:', len(out), 'arrays')
+
+
 if __name__ == '__main__':
-    if len(sys.argv) > 1 and sys.argv[1] == 'average':
+    if len(sys.argv) > 1 and sys.argv[1] == 'extract':
+        main_extract()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'average':
         main_average_ops()
     elif len(sys.argv) > 1 and sys.argv[1] == 'variants':
         main_variants()

@@ -153,3 +153,7 @@ def test_wide_projection_matrices(emul_lib):
     for l in range(L + 1):
         assert U[l].shape == (min(2 * l + 1, N), 2 * l + 1)
     e.close()
+
+
+def test_extract_rules_golden(emul_lib):
+    PC.check_extract_rules_hip(emul_lib)

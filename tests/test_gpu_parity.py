@@ -149,6 +149,11 @@ def test_extract_vs_numpy(N, L):
     PC.check_extract_vs_numpy(None, N=N, L=L)
 
 
+def test_extract_rules_golden():
+    """G15: the product's `extract` rules on the device eigensolvers against the reference's own outputs"""
+    PC.check_extract_rules_hip(None)
+
+
 def test_config2_properties():
     PC.check_full_size_properties(2)
 

@@ -257,3 +257,11 @@ def test_G14_average_metrics():
     rs, vals = g['G14_int_rs'], g['G14_int_values']
     assert np.isclose(AV.integrate_normed(rs, vals.shape[1], vals), float(g['G14_int_normed']), rtol=1e-13)
     assert np.isclose(SphericalIntegrator(rs, vals.shape[1]).integrate_normed(vals), float(g['G14_int_normed']), rtol=1e-13)
+
+
+def test_g15_extract_rules_oracle():
+    """oracle/extract.py against the reference's own `extract` numerics (fixtures of make_golden.py extract)"""
+    import parity_cases as PC
+    from oracle import extract as OE
+    PC.check_extract_rules_golden((OE.deg2_invariant_eigenvalues, OE.deg2_invariant_to_projection_matrices_3d,
+                                   OE.nearest_positive_semidefinite_matrix), tol=1e-13)

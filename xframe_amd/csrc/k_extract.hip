@@ -199,3 +199,217 @@ extern "C" int mtip_op_hermitian_eig(mtip_ctx* c, int n, int n_mat, const mtip_c
     if (dres) (void)hipFree(dres);
     return rc;
 }
+
+// ---- real symmetric matrices up to 128 x 128: LDS-resident one-sided Jacobi (round 3) ---------------------------------------
+// The reference's B_l are real (fxs_invariant_tools.py:1255: `.real` before the eigen-decomposition; scipy eigh of a real
+// symmetric matrix, 1114-1131).  The matrix is shifted to A' = A + s 1, s = |A|_F: positive definite with condition <= 2, so the
+// one-sided Jacobi on its columns  A' V = W  has no +x / -x singular pairs, no numerical null space, and converges in a few
+// sweeps; the eigenvectors are the normalised columns of W (left = right singular vectors of a definite matrix, V is never
+// formed), the eigenvalues |W_i| - s -- accurate to eps |A|, as LAPACK's.  W lives in LDS for the whole solve (128 x 129 doubles =
+// 132 KB; the global-memory kernel above moved 390 x the matrix bytes through HBM), 16 lanes per column pair in the resident-
+// column ordering of k_proj.hip (its schedule is read from L2 one round ahead), HBM traffic = the matrix in, the vectors out.
+#include "k_jacobi.h"
+
+#define SE_MAX_N 128
+#define SE_MAX_SWEEPS 40
+// the sweeps go on until one stays below this relative off-diagonal: the shifted matrix has most of its eigenvalues in one cluster
+// (those of a rank 2l+1 matrix: all but 2l+1 equal the shift), where the convergence is not quadratic -- measured 7e-5 -> 1e-7 ->
+// 1e-11 per sweep -- so the projection kernels' early exit (JL_EARLY) would leave 1e-8
+#define SE_EARLY 1e-12
+
+template <int NR>
+__device__ __forceinline__ void se_sweep(double* Ws, int ns, int t, int group, const int* __restrict__ tab, int n_rounds, int ps,
+                                         bool l_ok, bool& big) {
+    double rx[NR];
+#pragma unroll
+    for (int u = 0; u < NR; ++u) rx[u] = 0.0;
+    int cur = -1;
+    bool dirty = false;
+    int e_next = (group < ps && n_rounds > 0) ? tab[group] : 0;
+    for (int r = 0; r < n_rounds; ++r) {
+        const int e = e_next;
+        if (r + 1 < n_rounds && group < ps) e_next = tab[(size_t)(r + 1) * ps + group];
+        const bool act = (e & JS_ACTIVE) != 0;
+        const int res = act ? (e & 255) : 0, mov = act ? ((e >> 8) & 255) : 0;
+        double* xh = Ws + (size_t)res * ns + t;
+        double* xm = Ws + (size_t)mov * ns + t;
+        double mx[NR];
+#pragma unroll
+        for (int u = 0; u < NR; ++u) mx[u] = 0.0;
+        if (act) {
+#pragma unroll
+            for (int u = 0; u < NR; ++u) mx[u] = xm[u * 16];
+            if (res != cur) {
+#pragma unroll
+                for (int u = 0; u < NR; ++u) rx[u] = xh[u * 16];
+                if (!l_ok) rx[NR - 1] = 0.0;
+                cur = res;
+                dirty = false;
+            }
+            if (!l_ok) mx[NR - 1] = 0.0;
+        }
+        double alpha = 0.0, beta = 0.0, g = 0.0, zero = 0.0;
+#pragma unroll
+        for (int u = 0; u < NR; ++u) {
+            alpha = fma(rx[u], rx[u], alpha);
+            beta = fma(mx[u], mx[u], beta);
+            g = fma(rx[u], mx[u], g);
+        }
+        group_sum4<16>(alpha, beta, g, zero);                     // (every group: uniform control flow around DPP)
+        const double g2 = g * g, ab = alpha * beta;
+        if (act && g2 > (JAC_TOL * JAC_TOL) * ab && g2 > 0.0) {
+            big = big || (g2 > (SE_EARLY * SE_EARLY) * ab);
+            const double d = 0.5 * (beta - alpha);
+            const double ih = fast_rsqrt(fma(d, d, g2));
+            const double c2 = fma(0.5 * fabs(d), ih, 0.5);
+            const double rc = fast_rsqrt(c2);
+            const double cs = c2 * rc, w = ((d >= 0.0 ? 0.5 : -0.5) * ih * rc) * g;
+#pragma unroll
+            for (int u = 0; u < NR; ++u) {
+                const double a = rx[u], bq = mx[u];
+                rx[u] = fma(-w, bq, cs * a);
+                if (u < NR - 1 || l_ok) xm[u * 16] = fma(w, a, cs * bq);
+            }
+            dirty = true;
+        }
+        if (act && (e & JS_WB)) {
+            if (dirty) {
+#pragma unroll
+                for (int u = 0; u < NR; ++u)
+                    if (u < NR - 1 || l_ok) xh[u * 16] = rx[u];
+            }
+            cur = -1;
+        }
+        __syncthreads();
+    }
+}
+
+// one workgroup per matrix; A (n_mat, n, n) real symmetric (either triangle order: it is symmetric), U (n_mat, n, n) eigenvector i
+// in U[i][:], lam (n_mat, n)
+__global__ void __launch_bounds__(1024) k_sym_eig(const double* __restrict__ A_all, double* __restrict__ U_all, double* __restrict__ lam_all,
+                                                  int n, const int* __restrict__ sched, const int* __restrict__ sched_off,
+                                                  const int* __restrict__ sched_rounds, int sched_ps, int* __restrict__ sweeps_out) {
+    HIP_DYNAMIC_SHARED(double, Ws)
+    __shared__ double s_red[16];
+    __shared__ double s_gmax[64];
+    __shared__ int s_cont;
+    const double* A = A_all + (size_t)blockIdx.x * n * n;
+    double* U = U_all + (size_t)blockIdx.x * n * n;
+    double* lam = lam_all + (size_t)blockIdx.x * n;
+    const int tid = threadIdx.x, nthreads = blockDim.x;
+    const int ns = n | 1, nr = (n + 15) >> 4;
+    // |A|_F
+    double f2 = 0.0;
+    for (int e = tid; e < n * n; e += nthreads) f2 = fma(A[e], A[e], f2);
+    for (int o = 32; o > 0; o >>= 1) f2 += __shfl_xor(f2, o, 64);
+    if ((tid & 63) == 0) s_red[tid >> 6] = f2;
+    __syncthreads();
+    double s = 0.0;
+    for (int wv = 0; wv < (nthreads >> 6); ++wv) s += s_red[wv];
+    s = sqrt(s);
+    if (!(s > 0.0)) s = 1.0;                                       // the zero matrix: eigenvalues 0, vectors e_i
+    for (int e = tid; e < n * n; e += nthreads) {
+        const int cc = e / n, r = e - cc * n;
+        Ws[(size_t)cc * ns + r] = A[e] + (cc == r ? s : 0.0);     // column cc of the symmetric matrix = its row cc
+    }
+    __syncthreads();
+    const int ngroups = nthreads >> 4, group = tid >> 4, t = tid & 15;
+    const bool l_ok = t + (nr - 1) * 16 < n;
+    int sweep = 0;
+    if (n > 1) {
+        const int* tab = sched + sched_off[n];
+        const int nrd = sched_rounds[n];
+        for (; sweep < SE_MAX_SWEEPS; ++sweep) {
+            bool big = false;
+            switch (nr) {
+            case 1: se_sweep<1>(Ws, ns, t, group, tab, nrd, sched_ps, l_ok, big); break;
+            case 2: se_sweep<2>(Ws, ns, t, group, tab, nrd, sched_ps, l_ok, big); break;
+            case 3: se_sweep<3>(Ws, ns, t, group, tab, nrd, sched_ps, l_ok, big); break;
+            case 4: se_sweep<4>(Ws, ns, t, group, tab, nrd, sched_ps, l_ok, big); break;
+            case 5: se_sweep<5>(Ws, ns, t, group, tab, nrd, sched_ps, l_ok, big); break;
+            case 6: se_sweep<6>(Ws, ns, t, group, tab, nrd, sched_ps, l_ok, big); break;
+            case 7: se_sweep<7>(Ws, ns, t, group, tab, nrd, sched_ps, l_ok, big); break;
+            default: se_sweep<8>(Ws, ns, t, group, tab, nrd, sched_ps, l_ok, big); break;
+            }
+            if (t == 0) s_gmax[group] = big ? 1.0 : 0.0;
+            __syncthreads();
+            if (tid == 0) {
+                double m = 0.0;
+                for (int gq = 0; gq < ngroups; ++gq) m = fmax(m, s_gmax[gq]);
+                s_cont = m > 0.0 ? 1 : 0;
+            }
+            __syncthreads();
+            const int cont = s_cont;
+            __syncthreads();
+            if (!cont) {
+                ++sweep;
+                break;
+            }
+        }
+    }
+    if (tid == 0 && sweeps_out) sweeps_out[blockIdx.x] = sweep;
+    // eigenvector i = W_i / |W_i|, eigenvalue |W_i| - s
+    for (int cc0 = 0; cc0 < n; cc0 += ngroups) {                   // uniform trip count: DPP sums need the whole group
+        const int cc = cc0 + group;
+        double s2 = 0.0;
+        if (cc < n)
+            for (int u = 0; u < nr; ++u)
+                if (t + u * 16 < n) {
+                    const double x = Ws[(size_t)cc * ns + t + u * 16];
+                    s2 = fma(x, x, s2);
+                }
+        s2 = group_sum<16>(s2);
+        const double sig = sqrt(s2), inv = sig > 0.0 ? 1.0 / sig : 0.0;
+        if (cc < n) {
+            if (t == 0) lam[cc] = sig - s;
+            for (int u = 0; u < nr; ++u)
+                if (t + u * 16 < n) U[(size_t)cc * n + t + u * 16] = Ws[(size_t)cc * ns + t + u * 16] * inv;
+        }
+    }
+}
+
+// eigvals (n_mat, n) unsorted, eigvecs (n_mat, n, n): eigenvector i of matrix k in eigvecs[k][i][:]
+extern "C" int mtip_op_symmetric_eig(mtip_ctx* c, int n, int n_mat, const double* A, double* eigvals, double* eigvecs) {
+    if (!c) return MTIP_EINVAL;
+    if (n < 1 || n > SE_MAX_N || n_mat < 1 || !A || !eigvals || !eigvecs) {
+        c->err = "symmetric_eig: n must be in [1, 128], n_mat >= 1, buffers not null";
+        return MTIP_EINVAL;
+    }
+    (void)hipSetDevice(c->device);
+    if (n >= 2 && build_jacobi_schedule(c, n) != MTIP_OK) {
+        c->err = "symmetric_eig: pairing schedule";
+        return MTIP_ENOMEM;
+    }
+    double *dA = nullptr, *dU = nullptr, *dl = nullptr;
+    const size_t nn = (size_t)n_mat * n * n;
+    int rc = MTIP_OK;
+    if (hipMalloc((void**)&dA, nn * sizeof(double)) != hipSuccess || hipMalloc((void**)&dU, nn * sizeof(double)) != hipSuccess ||
+        hipMalloc((void**)&dl, (size_t)n_mat * n * sizeof(double)) != hipSuccess) {
+        c->err = "symmetric_eig: out of device memory";
+        rc = MTIP_ENOMEM;
+    }
+    if (rc == MTIP_OK) {
+        hipError_t e = mtip_copy(c, dA, A, nn * sizeof(double), hipMemcpyHostToDevice);
+        if (e == hipSuccess) {
+            // all pairs of a round in one workgroup: floor(n / 2) groups of 16 lanes (the schedule's group count for n columns)
+            const int groups = std::max(n / 2, 1);
+            const int threads = std::min(1024, std::max(64, (groups * 16 + 63) / 64 * 64));
+            const size_t lds = ((size_t)n * (n | 1) + 128) * sizeof(double);
+            ProfScope ps(c, "sym_eig");
+            hipLaunchKernelGGL(k_sym_eig, dim3((unsigned)n_mat), dim3((unsigned)threads), lds, c->stream, (const double*)dA, dU, dl, n,
+                               (const int*)c->d_jsched, (const int*)c->d_jsched_off, (const int*)c->d_jsched_rounds, c->jsched_ps,
+                               n_mat <= c->B * (c->L + 1) ? c->d_sweeps : (int*)nullptr);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e == hipSuccess) e = mtip_copy(c, eigvals, dl, (size_t)n_mat * n * sizeof(double), hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = mtip_copy(c, eigvecs, dU, nn * sizeof(double), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) {
+            c->err = std::string("symmetric_eig: ") + hipGetErrorString(e);
+            rc = MTIP_EHIP;
+        }
+    }
+    if (dA) (void)hipFree(dA);
+    if (dU) (void)hipFree(dU);
+    if (dl) (void)hipFree(dl);
+    return rc;
+}

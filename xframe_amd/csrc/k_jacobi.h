@@ -76,9 +76,13 @@ __device__ __forceinline__ void group_sum4(double& v0, double& v1, double& v2, d
     const double s = p2 ? u0 : u1;
     double w = p2 ? u1 : u0;
     w += dpp_mov<0x4E>(s);
-    // across the four quads of the group
-    w += dpp_mov<0x124>(w);
+    // across the four quads of the group.  Opposite quads first (row_ror 8), then neighbours (row_ror 4): every quad then adds
+    // (W_q + W_q+2) + (W_q+1 + W_q+3) -- the same two operands in either order, so all 16 lanes end with bitwise identical sums.
+    // (Neighbours first gave the even and the odd quads differently associated sums, one ulp apart: the lanes of ONE column pair
+    // then derived different rotations for their rows -- harmless for small angles, a 1e-8 stall for the 45 degree rotations
+    // inside a cluster of equal singular values, found with k_sym_eig.)
     w += dpp_mov<0x128>(w);
+    w += dpp_mov<0x124>(w);
     // lane & 3 = p + 2 p2 holds value 2 p + p2:  quad lane 0 -> v0, 2 -> v1, 1 -> v2, 3 -> v3
     v0 = dpp_mov<0x00>(w);
     v1 = dpp_mov<0xAA>(w);

@@ -994,6 +994,8 @@ static int js_groups(int s) {
 
 // cols -> halves A (floor(s/2) residents, one group each) and B (movers); |B| rounds: group i takes B_((i + r) mod |B|),
 // so every group is busy in every round; then A and B side by side on disjoint groups (A's groups keep residents)
+int jacobi_groups(int k) { return js_groups(k); }
+
 static void js_build(const std::vector<int>& cols, int g0, int round0, int ps, std::vector<std::vector<int>>& rounds) {
     const int s = (int)cols.size();
     if (s < 2) return;

@@ -815,12 +815,13 @@ static RpGeom rp_launch_geometry(const mtip_ctx* c) {
         else kbig = std::max(kbig, c->kl[l]);
     }
     const int kmax = std::max(kpad, kbig);
-    const int ps = kmax >= 2 ? std::max(c->jsched_ps, 1) : 1;
+    const int ps = kmax >= 2 ? std::max(c->jsched_ps, 1) : 1;        // row length of the pairing table (it may have been built for more columns)
+    const int groups = kmax >= 2 ? std::max(jacobi_groups(kmax), 1) : 1; // pair-groups the largest order keeps busy
     // 32 lanes per pair when every order has the padded layout and all pairs of a round fit 1024 threads: four waves per SIMD
     // with three row slots each instead of two with five
     // (measured at k = 65: 3520 ticks per round against 2440 with 16 lanes: the youngest of four waves per SIMD starve; MTIP_RP_TG=32 selects it)
-    g.tg = (c->rp_tg == 32 && kbig == 0 && ps * 32 <= 1024 && kmax >= 34) ? 32 : 16;
-    g.threads = std::max(256, (ps * g.tg + 63) / 64 * 64);
+    g.tg = (c->rp_tg == 32 && kbig == 0 && groups * 32 <= 1024 && kmax >= 34) ? 32 : 16;
+    g.threads = std::max(256, (groups * g.tg + 63) / 64 * 64);
     g.lds = RP_SLACK * sizeof(double);
     if (kpad >= 2) {
         int nrd = 1;                                             // (the schedule has more rounds than columns: 70 at k = 65)

@@ -264,6 +264,7 @@ void launch_hankel(mtip_ctx* c, const double2* in, double2* out, int inverse);
 bool hankel_has_difference(const mtip_ctx* c);       // launch_hankel_mfma_sub is available (workgroup-tiled kernel)
 void launch_hankel_mfma_sub(mtip_ctx* c, const double2* in, const double2* in_sub, double2* out, int inverse);
 int build_jacobi_schedule(mtip_ctx* c, int kmax);    // k_proj.hip: resident-column pairing schedule, verified on the host
+int jacobi_groups(int k);                            // pair-groups a round of that schedule keeps busy for k columns (<= jsched_ps: the table's row length)
 int build_hankel_tiles(mtip_ctx* c);
 void launch_coeff_diff(mtip_ctx* c, const double2* a, const double2* b, double2* out);
 // reciprocal projection

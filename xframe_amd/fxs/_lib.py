@@ -80,6 +80,7 @@ _SIGNATURES = {
     'mtip_op_so3_correlation': (C.c_int, [c_void, c_void, c_void, C.c_int, C.c_int, c_void]),
     'mtip_op_rotate_coefficients': (C.c_int, [c_void, c_void, c_void, c_void]),
     'mtip_op_hermitian_eig': (C.c_int, [c_void, C.c_int, C.c_int, c_void, c_void, c_void]),
+    'mtip_op_symmetric_eig': (C.c_int, [c_void, C.c_int, C.c_int, c_void, c_void, c_void]),
     'mtip_profile': (C.c_int, [c_void, C.c_int]),
     'mtip_profile_get': (C.c_int, [c_void, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     'mtip_profile_reset': (C.c_int, [c_void]),

@@ -231,6 +231,16 @@ class Engine:
         eigenvectors (K, n, n) with eigenvector i in [:, :, i] (numpy.linalg.eigh's layout, reversed order)"""
         m = _lib.as_c128(mats)
         K, n = m.shape[0], m.shape[1]
+        if n <= 128 and not np.any(m.imag):
+            # real symmetric (what the reference's B_l are): LDS-resident solver
+            sym = np.ascontiguousarray((m.real + np.swapaxes(m.real, -1, -2)) / 2)
+            vals = np.empty((K, n))
+            vecs = np.empty((K, n, n))
+            self._ck(self.lib.mtip_op_symmetric_eig(self.ctx, n, K, _lib.ptr(sym), _lib.ptr(vals), _lib.ptr(vecs)))
+            order = np.argsort(vals, axis=1)[:, ::-1]
+            vals = np.take_along_axis(vals, order, axis=1)
+            vecs = np.take_along_axis(vecs, order[:, :, None], axis=1)          # rows = eigenvectors
+            return vals, np.ascontiguousarray(np.swapaxes(vecs, -1, -2)).astype(complex)
         herm = np.ascontiguousarray((m + np.conj(np.swapaxes(m, -1, -2))) / 2)
         # the kernel rotates the columns of its column-major work matrix: hand it B^T = conj(B), whose eigenvectors are the
         # conjugates of B's

@@ -49,10 +49,9 @@ def invariants_from_intensity_coefficients(Ilm, data_radial_points, max_order, e
     """I_lm (list over l of (N,2l+1)) -> the dict ``load_invariants`` would hand to the worker
     (``xframe/projects/fxs/_database_.py:566-609``).  Stored in the reference's on-disk convention:
     V_l halved (``fxs_Projections.py:710-713`` multiplies by 2), average_intensity from B_0.
-    ``eigh``: batched Hermitian eigensolver ``(K, N, N) -> (eigenvalues descending (K, N), eigenvectors (K, N, N))``, e.g.
-    ``Engine.hermitian_eig`` (the ``extract`` step on the device); default numpy."""
+    ``eigh``: an object with ``hermitian_eig`` (an Engine: the ``extract`` step on the device, reference rules in
+    ``xframe_amd.fxs.extract``); default: the same rules with numpy's eigh (fxs_invariant_tools.py:1114-1207, sort_mode 0)."""
     N = len(data_radial_points)
-    pms = np.empty(max_order + 1, dtype=object)
     bls = []
     for l in range(max_order + 1):
         Il = np.asarray(Ilm[l])
@@ -60,22 +59,12 @@ def invariants_from_intensity_coefficients(Ilm, data_radial_points, max_order, e
         # intensity is real, sum over +-m pairs): the projection matrices are then real, as the reference's are (1207)
         B = (Il @ Il.conj().T).real / 4.0                  # stored convention: (V/2)(V/2)^+
         bls.append((B + B.T) / 2)
-    if eigh is not None:
-        all_w, all_v = eigh(np.stack(bls))
+    bls = np.stack(bls)
+    from . import extract as X
+    pms_t, _ = X.deg2_invariant_to_projection_matrices(eigh, bls)
+    pms = np.empty(max_order + 1, dtype=object)
     for l in range(max_order + 1):
-        B = bls[l]
-        if eigh is not None:
-            w, v = np.array(all_w[l]), np.array(all_v[l])
-        else:
-            w, v = np.linalg.eigh(B)
-            order = np.argsort(w)[::-1]
-            w, v = w[order].real, v[:, order]
-        k = min(N, 2 * l + 1)
-        w, v = w[:k].copy(), v[:, :k].copy()
-        neg = w < 0
-        w[neg] = 0
-        v[:, neg] = 0
-        pms[l] = (v @ np.diag(np.sqrt(w))).astype(complex)
+        pms[l] = pms_t[l]
     aint = np.sqrt(np.diag(bls[0]).real / (4 * np.pi))
     return {'dimensions': 3, 'xray_wavelength': XRAY_WAVELENGTH, 'average_intensity': aint,
             'data_radial_points': np.asarray(data_radial_points), 'data_angular_points': np.zeros(1),
