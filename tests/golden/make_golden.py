@@ -595,8 +595,238 @@ def main_extract():
     print('extract fixture:', len(out), 'arrays')
 
 
+class _RecFile:
+    """a recording stand-in for h5py.File: enough of the group / dataset surface for the reference's HDF5 plugin
+    (xframe/externalLibraries/hdf5_plugin.py) to write into and to read back from; nothing touches a disk"""
+    current = None
+
+    class Attrs(dict):
+        def create(s, key, value):
+            s[key] = value
+
+    class Node:
+        def __init__(s, rec, path, kind, value=None):
+            s.rec, s.path, s.kind, s.value, s.attrs = rec, path, kind, value, _RecFile.Attrs()
+
+        def _child(s, key):
+            return (s.path.rstrip('/') + '/' + key) if s.path != '/' else '/' + key
+
+        def create_dataset(s, key, data=None):
+            n = _RecFile.Node(s.rec, s._child(key), 'dataset', np.asarray(data))
+            s.rec.nodes[n.path] = n
+            return n
+
+        def create_group(s, key):
+            n = _RecFile.Node(s.rec, s._child(key), 'group')
+            s.rec.nodes[n.path] = n
+            return n
+
+        def items(s):
+            pre = s.path.rstrip('/') + '/'
+            return [(p[len(pre):], n) for p, n in s.rec.nodes.items() if p.startswith(pre) and '/' not in p[len(pre):] and p != '/']
+
+        def __getitem__(s, idx):
+            if isinstance(idx, tuple) and idx == ():
+                v = s.value
+                return v[()] if v.shape == () else v
+            raise KeyError(idx)
+
+    def __init__(s, path, mode='r', **kw):
+        if mode == 'w' or _RecFile.current is None:
+            s.nodes = {'/': _RecFile.Node(s, '/', 'group')}
+            _RecFile.current = s
+        else:
+            s.nodes = _RecFile.current.nodes
+
+    def __enter__(s):
+        return s
+
+    def __exit__(s, *a):
+        return False
+
+    def __getitem__(s, path):
+        p = '/' + '/'.join(x for x in path.split('/') if x)      # h5py collapses repeated slashes (the plugin writes 'a//b')
+        return s.nodes[p]
+
+
+def main_io():
+    """tests/golden/io_contract.npz (G16): the on-disk contract of the fxs project without h5py --
+    (a) the dict tree the reference's worker hands to its database (reconstruct.py:160-185 post_processing) for two result
+        dicts, and what the reference's HDF5 plugin (externalLibraries/hdf5_plugin.py:29-140) writes for it into a recording
+        stand-in for h5py.File: path, kind, dtype, shape, `type` attribute of every node, and the tree its own loader reads back;
+    (b) what ProjectDB.load_invariants (_database_.py:566-609) makes of the three layouts of an invariants file.
+    The presenters (matplotlib / OpenCV plotting) are stubbed for the import; numpy 2 dropped `np.complex_`, which the plugin
+    still names (hdf5_plugin.py:117): aliased to complex128 for the run."""
+    mods = bootstrap()
+    ml = mods['xframe.library.mathLibrary']
+    ml.shtns = ShAdapter
+    import types as _t
+
+    class _Any:
+        def __init__(s, *a, **k):
+            pass
+
+        def __getattr__(s, n):
+            return _Any()
+
+        def __call__(s, *a, **k):
+            return _Any()
+
+    class AnyModule(_t.ModuleType):
+        def __getattr__(s, n):
+            if n.startswith('__'):
+                raise AttributeError(n)
+            return _Any()
+    for name in ('xframe.presenters', 'xframe.presenters.matplotlibPresenter', 'xframe.presenters.openCVPresenter'):
+        sys.modules[name] = AnyModule(name)
+    h5 = AnyModule('h5py')
+    h5.File = _RecFile
+    h5.VirtualLayout = type('VirtualLayout', (), {})
+    h5._hl = _t.SimpleNamespace(dataset=_t.SimpleNamespace(Dataset=_RecFile.Node), group=_t.SimpleNamespace(Group=_RecFile.Node))
+    sys.modules['h5py'] = h5
+    if not hasattr(np, 'complex_'):
+        np.complex_ = np.complex128
+    pl = mods['xframe.library.pythonLibrary']
+    st = mods['xframe.settings']
+    from oracle import mtip as OM
+    from xframe_amd.fxs import synthetic as S
+    # (the reference's reconstruct module reads settings.project while it is imported: the tutorial settings of the other fixtures)
+    o = OM.deep_update(OM.default_settings(), S.config_overrides(1))
+    o = OM.deep_update(o, {'grid': {'n_radial_points': 16, 'max_order': 4}, 'projections': {'reciprocal': {'used_order_ids': np.arange(5)}},
+                           'GPU': {'use': False}, 'multi_process': {'use': False}})
+    st.project = pl.DictNamespace.dict_to_dictnamespace(o)
+    plug = importlib.import_module('xframe.externalLibraries.hdf5_plugin')
+    dbm = importlib.import_module('xframe.projects.fxs._database_')
+    cwd = os.getcwd()
+    rec = importlib.import_module('xframe.projects.fxs.reconstruct')
+    os.chdir(cwd)
+    plug.HDF5_DB()                                               # registers the custom save / load routines
+    # the plugin tells datasets from groups by isinstance on h5py's classes: one Node class plays both, told apart by kind
+    _RecFile.Node.__instancecheck__ = None
+    plug.h5._hl.dataset.Dataset = type('Dataset', (), {'__instancecheck__': None})
+
+    class DS(type):
+        def __instancecheck__(cls, inst):
+            return isinstance(inst, _RecFile.Node) and inst.kind == 'dataset'
+
+    class GR(type):
+        def __instancecheck__(cls, inst):
+            return isinstance(inst, _RecFile.Node) and inst.kind == 'group'
+    plug.h5._hl.dataset.Dataset = DS('Dataset', (), {})
+    plug.h5._hl.group.Group = GR('Group', (), {})
+
+    rng = np.random.default_rng(1616)
+    N, nt, npi, L = 4, 3, 4, 2
+    shape = (N, nt, npi)
+
+    def result_dict(seed, err_last):
+        r = np.random.default_rng(seed)
+        c = lambda: r.normal(size=shape) + 1j * r.normal(size=shape)
+        grid = pl.FTGridPair(mods['xframe.library.gridLibrary'].NestedArray(r.random(shape + (3,)), 1),
+                             mods['xframe.library.gridLibrary'].NestedArray(r.random(shape + (3,)), 1))
+        return {'real_density': c(), 'last_real_density': c(), 'reciprocal_density': c(), 'last_reciprocal_density': c(),
+                'final_error': float(err_last), 'initial_density': c(), 'initial_support': r.random(shape) > 0.5,
+                'error_dict': {'main': np.array([0.5, 0.2, err_last]), 'real': {'l2_projection_diff': np.array([0.5, 0.2, err_last])},
+                               'reciprocal': {}},
+                'support_mask': r.random(shape) > 0.5, 'last_support_mask': r.random(shape) > 0.5, 'loop_iterations': 3,
+                'fxs_unknowns': [r.normal(size=(min(2 * l + 1, N), 2 * l + 1)) + 0j for l in range(L + 1)],
+                'n_particles': [1], 'n_particles_gradients': [], 'n_particles_fraction': [],
+                'grid_pair': grid, 'projection_matrices': [r.normal(size=(N, min(2 * l + 1, N))) + 0j for l in range(L + 1)],
+                'last_deg2_invariant': r.normal(size=(L + 1, N, N)) + 0j}
+
+    results = {0: result_dict(1, 0.03), 1: result_dict(2, 0.01)}
+    out = {}
+    # inputs of the test: the result dicts as plain arrays
+    for rid, rd in results.items():
+        for k, v in rd.items():
+            if k == 'grid_pair':
+                out[f'G16_res{rid}/grid_pair/real_grid'] = v.realGrid.array
+                out[f'G16_res{rid}/grid_pair/reciprocal_grid'] = v.reciprocalGrid.array
+            elif k == 'error_dict':
+                out[f'G16_res{rid}/error_dict/main'] = v['main']
+                out[f'G16_res{rid}/error_dict/real/l2_projection_diff'] = v['real']['l2_projection_diff']
+            elif isinstance(v, list):
+                for i, x in enumerate(v):
+                    out[f'G16_res{rid}/{k}/{i}'] = np.asarray(x)
+                out[f'G16_res{rid}/{k}/__len__'] = np.array(len(v))
+            else:
+                out[f'G16_res{rid}/{k}'] = np.asarray(v)
+    # (a) reference post_processing with a recording database
+    saved = {}
+    fake_db = _t.SimpleNamespace(save=lambda name, data, **kw: saved.setdefault(name, data))
+    old_db = rec.database.project if hasattr(rec.database, 'project') else None
+    rec.database.project = fake_db
+    fake_self = _t.SimpleNamespace(results={'MTIP': {k: dict(v) for k, v in results.items()}, 'stats': {'run_time': 1.5}},
+                                   mtip=_t.SimpleNamespace(load_mtip_data=lambda: ({'xray_wavelength': 1.23984},)))
+    rec.ProjectWorker.post_processing(fake_self)
+    rec.database.project = old_db
+    tree = saved['reconstructions']
+    out['G16_tree_keys'] = np.array(sorted(tree))
+    out['G16_tree_result_order'] = np.array(list(tree['reconstruction_results']))
+    plug.HDF5_DB.save('mem', tree)
+    nodes = _RecFile.current.nodes
+    paths = [p for p in nodes if p != '/']
+    out['G16_h5_paths'] = np.array(paths)
+    out['G16_h5_kinds'] = np.array([nodes[p].kind for p in paths])
+    out['G16_h5_dtypes'] = np.array([str(nodes[p].value.dtype) if nodes[p].kind == 'dataset' else '' for p in paths])
+    out['G16_h5_shapes'] = np.array([str(tuple(nodes[p].value.shape)) if nodes[p].kind == 'dataset' else '' for p in paths])
+    out['G16_h5_type_attr'] = np.array([str(nodes[p].attrs.get('type', '')) for p in paths])
+    out['G16_h5_n_ndim_attr'] = np.array([int(nodes[p].attrs.get('n_ndim', -1)) for p in paths])
+    for p in paths:
+        if nodes[p].kind == 'dataset' and nodes[p].value.dtype.kind in 'fciub':
+            out['G16_h5_value' + p] = nodes[p].value
+    back = plug.HDF5_DB.load('mem')
+
+    def flat(d, pre=''):
+        r = {}
+        for k, v in d.items():
+            if isinstance(v, dict):
+                r.update(flat(v, pre + k + '/'))
+            elif isinstance(v, (list, tuple)):
+                r[pre + k + '/__type__'] = np.array(type(v).__name__)
+                r.update(flat({str(i): x for i, x in enumerate(v)}, pre + k + '/'))
+            else:
+                r[pre + k] = np.asarray(v)
+        return r
+    fb = flat(back)
+    out['G16_back_paths'] = np.array(sorted(fb))
+    out['G16_back_dtypes'] = np.array([str(fb[k].dtype) for k in sorted(fb)])
+    # (b) load_invariants on the three layouts of an invariants file
+    pm = [rng.normal(size=(N, min(2 * l + 1, N))) + 0j for l in range(L + 1)]
+    base = {'average_intensity': rng.random(N), 'data_radial_points': np.linspace(0.1, 0.4, N), 'dimensions': 3,
+            'xray_wavelength': 1.23984, 'max_order': L, 'data_angular_points': np.zeros(1)}
+    layouts = {
+        'orders_dict': dict(base, data_projection_matrices={str(l): pm[l] for l in (2, 0, 1)}, deg_2_invariant=rng.random((L + 1, N, N))),
+        'I1I1': dict(base, data_projection_matrices={'I1I1': {str(l): pm[l] for l in range(L + 1)}}),
+        'legacy_1d_l0': dict(base, data_projection_matrices={'0': pm[0][:, 0], '1': pm[1], '2': pm[2]},
+                             data_low_resolution_intensity_coefficients=[rng.random((N, 1)) + 0j, rng.random((N, 3)) + 0j]),
+    }
+    for name, lay in layouts.items():
+        for k, v in flat(lay).items():
+            out[f'G16_inv_{name}_in/{k}'] = v
+        fake = _t.SimpleNamespace(load_direct=lambda nm, _l=lay, **kw: {k: (dict(v) if isinstance(v, dict) else v) for k, v in _l.items()})
+        d = dbm.ProjectDB.load_invariants(fake, 'invariants')
+        out[f'G16_inv_{name}_keys'] = np.array(sorted(d))
+        for l, m in enumerate(d['data_projection_matrices']):
+            out[f'G16_inv_{name}_pm{l}'] = np.asarray(m)
+        out[f'G16_inv_{name}_n_pm'] = np.array(len(d['data_projection_matrices']))
+        ai = d['average_intensity']
+        out[f'G16_inv_{name}_aint_data'] = np.asarray(ai.data)
+        out[f'G16_inv_{name}_aint_grid'] = np.asarray(ai.grid.array)
+        out[f'G16_inv_{name}_b_coeff'] = np.asarray(d['b_coeff'])
+        lr = d['data_low_resolution_intensity_coefficients']
+        out[f'G16_inv_{name}_lowres_is_bool'] = np.array(isinstance(lr, bool))
+        if not isinstance(lr, bool):
+            for i, m in enumerate(lr):
+                out[f'G16_inv_{name}_lowres{i}'] = np.asarray(m)
+    np.savez_compressed(os.path.join(HERE, 'io_contract.npz'), **out)
+    print('io contract fixture:', len(out), 'arrays;', len(paths), 'HDF5 nodes')
+
+
 if __name__ == '__main__':
-    if len(sys.argv) > 1 and sys.argv[1] == 'extract':
+    if len(sys.argv) > 1 and sys.argv[1] == 'io':
+        main_io()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'extract':
         main_extract()
     elif len(sys.argv) > 1 and sys.argv[1] == 'average':
         main_average_ops()
