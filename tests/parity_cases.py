@@ -667,6 +667,17 @@ def check_config4_worker(lib_path=None, cfg=4, n_restarts=8, n_workers=3, n_hio=
         results[workers] = res
         engine = w.mtip_instances[0].engine
         if workers == n_workers:
+            # the tree the reference's worker hands to its database, and the HDF5 layout of it (xframe_amd/fxs/io.py, f-2)
+            from xframe_amd.fxs import io as IO
+            tree = w.database_tree()
+            assert sorted(tree) == ['configuration', 'projection_matrices', 'reconstruction_results', 'stats']
+            ids = list(tree['reconstruction_results'])
+            errs = [tree['reconstruction_results'][i]['error_dict']['main'][-1] for i in ids]
+            assert errs == sorted(errs) and sorted(int(i) for i in ids) == list(range(n_restarts))
+            lay = {e['path']: e for e in IO.hdf5_layout(tree)}
+            assert lay['/configuration/internal_grid/real_grid']['type'] == 'NestedArray'
+            assert lay[f'/reconstruction_results/{ids[0]}/real_density']['dtype'] == 'complex128'
+            assert lay['/projection_matrices']['type'] in ('list', 'tuple')
             rs, shape = engine.rs, engine.shape
             ii, wr, wt = engine.rsetup.integrated_intensity, engine.int_wr, engine.int_wt
         for m in w.mtip_instances:

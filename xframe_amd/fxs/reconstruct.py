@@ -410,3 +410,24 @@ class ProjectWorker:
         order = np.argsort(errors)
         self.results['sorted_ids'] = order
         self.results['reconstruction_results'] = {str(i): res[i] for i in order}
+
+    def database_tree(self, xray_wavelength=None, reciprocity_coefficient=None):
+        """the dict tree the reference's worker hands to ``database.project.save('reconstructions', ...)`` after a run
+        (reconstruct.py:160-185), from this run's results: see xframe_amd/fxs/io.py (HDF5 layout, G16 fixtures)"""
+        from . import io as IO
+        res = self.results.get('MTIP')
+        if res is None or len(res) == 0:
+            raise RuntimeError('no results: run() first (rank 0 holds them)')
+        dicts = {}
+        for i, r in enumerate(res):
+            d = dict(r)
+            gp = d.get('grid_pair')
+            if isinstance(gp, dict):
+                d['grid_pair'] = IO.GridPair(gp['real_grid'], gp['reciprocal_grid'])
+            dicts[i] = d
+        if reciprocity_coefficient is None:                     # misk._get_reciprocity_coefficient: pi in q, or the coefficient given
+            ft = self.opt['fourier_transform']
+            reciprocity_coefficient = np.pi if ft.get('pi_in_q', False) else ft.get('reciprocity_coefficient', np.pi)
+        if xray_wavelength is None:
+            xray_wavelength = MTIP.mtip_data.get('xray_wavelength', 0.0)
+        return IO.reconstruction_tree(dicts, float(xray_wavelength), float(reciprocity_coefficient), self.results.get('stats', {}))
