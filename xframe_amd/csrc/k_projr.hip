@@ -345,23 +345,47 @@ __device__ __forceinline__ void rp_tiles(v4f64 (&acc)[T], const double* const (&
 #pragma unroll
     for (int u = 0; u < T; ++u) acc[u] = v4f64{0.0, 0.0, 0.0, 0.0};
     // two register sets: the operands of the next chunk are requested before the current chunk is multiplied (the two waves of a
-    // SIMD run this in lock step after a barrier: without the prefetch both load, then both queue on the matrix pipe)
+    // SIMD run this in lock step after a barrier: without the prefetch both load, then both queue on the matrix pipe).  Running
+    // pointers: an integer multiply per operand (inner index x run-time stride) costs as much issue time as the MFMA it feeds.
     double a0[T][UNR], b0[T][UNR], a1[T][UNR], b1[T][UNR];
-    const int n_chunks = (K + 4 * UNR - 1) / (4 * UNR);
-    auto request = [&](int ch, double (&a)[T][UNR], double (&bb)[T][UNR]) {
-        const int k0 = ch * 4 * UNR;
+    const int n_chunks = (K + 4 * UNR - 1) / (4 * UNR), n_full = K / (4 * UNR);
+    const int sa4 = 4 * sa, sb4 = 4 * sb;
+    const double *qa[T], *qb[T];
 #pragma unroll
-        for (int u = 0; u < T; ++u)
-            if (u < nu) {
+    for (int u = 0; u < T; ++u) {
+        qa[u] = pa[u] + lk * sa;
+        qb[u] = pb[u] + lk * sb;
+    }
+    int next = 0;                                                // chunk the next request loads (requests come in order)
+    auto request = [&](double (&a)[T][UNR], double (&bb)[T][UNR]) {
+        if (next < n_full) {                                     // (uniform) whole chunk: no clamps, no masks
 #pragma unroll
-                for (int x = 0; x < UNR; ++x) {
-                    const int kk = k0 + 4 * x + lk;
-                    const int kq = kk < K ? kk : K - 1;              // beyond K (last chunk, or a request past the end): clamped, times zero
-                    const double m = kk < K ? 1.0 : 0.0;
-                    a[u][x] = pa[u][kq * sa] * m;
-                    bb[u][x] = pb[u][kq * sb];
+            for (int u = 0; u < T; ++u)
+                if (u < nu) {
+#pragma unroll
+                    for (int x = 0; x < UNR; ++x) {
+                        a[u][x] = qa[u][x * sa4];
+                        bb[u][x] = qb[u][x * sb4];
+                    }
+                    qa[u] += UNR * sa4;
+                    qb[u] += UNR * sb4;
                 }
-            }
+        } else {                                                 // the last, partial chunk (inner indices beyond K: clamped, times zero) or past the end
+            const int k0 = next * 4 * UNR;
+#pragma unroll
+            for (int u = 0; u < T; ++u)
+                if (u < nu) {
+#pragma unroll
+                    for (int x = 0; x < UNR; ++x) {
+                        const bool in = k0 + 4 * x + lk < K;
+                        const int xo = in ? x : 0;               // (step 0 of the last chunk exists for the lanes that matter: clamp to it)
+                        const bool in0 = k0 + lk < K;
+                        a[u][x] = (in0 ? qa[u][xo * sa4] : 0.0) * (in ? 1.0 : 0.0);
+                        bb[u][x] = in0 ? qb[u][xo * sb4] : 0.0;
+                    }
+                }
+        }
+        ++next;
     };
     auto multiply = [&](const double (&a)[T][UNR], const double (&bb)[T][UNR]) {
 #pragma unroll
@@ -370,11 +394,11 @@ __device__ __forceinline__ void rp_tiles(v4f64 (&acc)[T], const double* const (&
             for (int u = 0; u < T; ++u)
                 if (u < nu) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][x], bb[u][x], acc[u], 0, 0, 0);
     };
-    request(0, a0, b0);
+    request(a0, b0);
     for (int ch = 0; ch < n_chunks; ch += 2) {
-        request(ch + 1, a1, b1);                                 // (past the end: zeros)
+        if (ch + 1 < n_chunks) request(a1, b1);
         multiply(a0, b0);
-        if (ch + 2 < n_chunks) request(ch + 2, a0, b0);
+        if (ch + 2 < n_chunks) request(a0, b0);
         if (ch + 1 < n_chunks) multiply(a1, b1);
     }
 }
@@ -857,7 +881,7 @@ bool rproj_supported(mtip_ctx* c) {
         const RpGeom g = rp_launch_geometry(c);
         if (g.threads > RP_MAX_THREADS) return false;
         if (g.lds + sizeof(RpShared) + 256 > 160 * 1024) return false;
-        if (g.acc > (g.tg == 32 ? 2 : RP_ACC_MAX)) return false;
+        if (g.acc > (g.tg == 32 ? 2 : (g.threads <= 512 ? 4 : RP_ACC_MAX))) return false;   // tiles per wave of the instantiations below
     }
     return true;
 }
@@ -989,7 +1013,7 @@ int launch_rproj(mtip_ctx* c, double2* coef) {
     if (g.tg == 32)
         hipLaunchKernelGGL((k_rproj<1024, 1, 2, false, 32>), grid, block, g.lds, c->stream, a);
     else if (g.threads <= 512)
-        hipLaunchKernelGGL((k_rproj<512, 2, RP_ACC_MAX, false, 16>), grid, block, g.lds, c->stream, a);
+        hipLaunchKernelGGL((k_rproj<512, 2, 4, false, 16>), grid, block, g.lds, c->stream, a);
     else
         hipLaunchKernelGGL((k_rproj<768, 1, RP_ACC_MAX, true, 16>), grid, block, g.lds, c->stream, a);
     c->vr_kind = 2;
