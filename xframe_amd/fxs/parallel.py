@@ -60,8 +60,9 @@ def gather_results(local_results, local_ids, n_total, rank, world_size, n_full=8
     1. all_gather of the per-restart scalars (last main error) -> every rank knows the global ranking;
     2. the light parts of the result dicts (scalars, error histories, unknowns: a few KB each) go to rank 0 as objects;
     3. the grid-sized arrays (densities, supports, B_l: ~7 x 16 MiB per restart at 128 x L32) travel only for the ``n_full``
-       best restarts, as tensors point to point to rank 0 (RCCL send / recv over xGMI with the nccl backend, from device
-       staging buffers; gloo on CPU in the tests).
+       best restarts, as tensors point to point to rank 0 (RCCL send / recv over xGMI with the nccl backend; gloo on CPU in the
+       tests).  The result dicts hold host arrays (the engine has already copied them back): with the nccl backend each array is
+       staged host -> device tensor -> send -> device tensor -> host on the receiver.
     Rank 0 returns an object array of all restarts -- full dicts for its own and for the selected ones, light dicts (flagged
     ``'gathered': 'light'``) for the rest; other ranks return their own results unchanged."""
     if world_size == 1:
