@@ -168,9 +168,11 @@ int mtip_op_fourier_transform(mtip_ctx* ctx, const mtip_cdouble* grid_in, mtip_c
 /* approximate_unknowns + mtip_projection (fxs_Projections.py:752-767, 832-872) on 'direct' coefficients */
 int mtip_op_project_coefficients(mtip_ctx* ctx, const mtip_cdouble* Ilm, mtip_cdouble* Ilm_projected);
 /* the same for coefficients of a REAL intensity, I_{l,-m} = (-1)^m conj(I_{l,m}) -- what the phasing loop always passes
- * (reconstruct.py:866-870: SHT of |F|^2).  Only the m >= 0 half is read.  With real projection matrices (the reference's
- * are: fxs_invariant_tools.py:1255, 1207) the polar factors are then computed in real arithmetic; any other case takes the
- * general path of mtip_op_project_coefficients.  Same result as that function to rounding. */
+ * (reconstruct.py:866-870: SHT of |F|^2).  Only the m >= 0 half is read.  With projection matrices whose imaginary part
+ * is exactly zero (eigenvectors of a real B_l, fxs_invariant_tools.py:1114-1141, 1207: what the reference's cross-correlation
+ * route gives; env MTIP_PROJ_REAL_TOL=t additionally drops imaginary parts below t max|V_l|, the rounding residue of its
+ * `density` route) the polar factors are computed in real arithmetic; any other case takes the general path of
+ * mtip_op_project_coefficients.  Same result as that function to rounding. */
 int mtip_op_project_real_intensity(mtip_ctx* ctx, const mtip_cdouble* Ilm, mtip_cdouble* Ilm_projected);
 /* mtip_projection with caller-supplied unknowns (fxs_Projections.py:832-849, 866-871; registry operator
  * 'mtip_projection(Ilm, unknowns)', reconstruct.py:391): U = per restart the concatenation over l = 0..L of the
@@ -206,8 +208,8 @@ int mtip_op_rotate_coefficients(mtip_ctx* ctx, const mtip_cdouble* coeff, const 
  * unsorted, eigvecs (n_mat, n, n) with eigenvector i of matrix k in eigvecs[k][i][:] (one eigenvector per row).  Sorting,
  * the cut to min(2l+1, Nq) pairs, clipping of negative eigenvalues and V_l = eigvecs sqrt(eigvals) are host bookkeeping. */
 int mtip_op_hermitian_eig(mtip_ctx* ctx, int n, int n_mat, const mtip_cdouble* A, double* eigvals, mtip_cdouble* eigvecs);
-/* the same for REAL symmetric matrices up to 128 x 128 (the reference makes B_l real before its eigen-decomposition,
- * fxs_invariant_tools.py:1255, 1114-1131): LDS-resident solver, eigenvalues accurate to eps |A|_F as LAPACK's */
+/* the same for REAL symmetric matrices up to 128 x 128 (B_l of a real intensity has no imaginary part; the rules of
+ * fxs_invariant_tools.py:1114-1131 stay on the host): LDS-resident solver, eigenvalues accurate to eps |A|_F as LAPACK's */
 int mtip_op_symmetric_eig(mtip_ctx* ctx, int n, int n_mat, const double* A, double* eigvals, double* eigvecs);
 
 /* ---- timing ----------------------------------------------------------------------------------- */

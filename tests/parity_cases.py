@@ -454,7 +454,7 @@ def check_projection_vs_oracle(N, L, lib_path=None, n_batch=2, seed=1):
     e.close()
 
 
-def check_projection_real_vs_oracle(N, L, lib_path=None, n_batch=2, seed=1, reciprocal_opt=None):
+def check_projection_real_vs_oracle(N, L, lib_path=None, n_batch=2, seed=1, reciprocal_opt=None, imag_residue=None):
     """The real-arithmetic form of the projection (k_projr.hip: real V_l, coefficients of a real intensity) against the
     oracle's complex numpy-SVD route (fxs_Projections.py:752-767, 832-871): projected coefficients, unknowns, and the
     general (complex) kernel on the same input; second call = warm start."""
@@ -466,7 +466,18 @@ def check_projection_real_vs_oracle(N, L, lib_path=None, n_batch=2, seed=1, reci
     data, _ = S.make_invariants(OracleTransforms(fpd), N, L)
     assert all(np.all(np.asarray(p).imag == 0) for p in data['data_projection_matrices'])
     opt = golden_settings(N, L, {'projections': {'reciprocal': reciprocal_opt}} if reciprocal_opt else None)
-    e = Engine(opt, data, n_batch=n_batch, lib_path=lib_path)
+    if imag_residue:
+        # rounding residue in Im V_l, as the reference's `density` route of extract leaves it (complex-typed B_l = Il Il^+):
+        # the real kernel is taken only under the opt-in MTIP_PROJ_REAL_TOL, which drops it
+        rng_v = np.random.default_rng(seed + 77)
+        data = dict(data)
+        data['data_projection_matrices'] = [np.asarray(p) + 1j * imag_residue * np.abs(p).max() * rng_v.normal(size=np.shape(p))
+                                            for p in data['data_projection_matrices']]
+        os.environ['MTIP_PROJ_REAL_TOL'] = str(100 * imag_residue)
+    try:
+        e = Engine(opt, data, n_batch=n_batch, lib_path=lib_path)
+    finally:
+        os.environ.pop('MTIP_PROJ_REAL_TOL', None)
     om = OM.MTIP(opt, data)
     rng = np.random.default_rng(seed)
     for rep in range(3):                                   # later calls: warm start from the previous V_r
@@ -488,6 +499,17 @@ def check_projection_real_vs_oracle(N, L, lib_path=None, n_batch=2, seed=1, reci
                 if np.abs(V).max() == 0:
                     continue
                 assert rel_l2(V @ unk_hip[b][l], V @ unk[i]) < TOL_SHT, (rep, b, l)
+    # which kernel ran: the real one reads only the m >= 0 half of the coefficients
+    junk = Ilm.copy()
+    for l in range(1, L + 1):
+        junk[:, :, l * l:l * l + l] = 1.0 + 2.0j
+    same = rel_l2(e.project_coefficients(junk, real_intensity=True), proj) < TOL_SHT
+    assert same, 'the real-arithmetic projection was expected to run'
+    if imag_residue:
+        e2 = Engine(opt, data, n_batch=n_batch, lib_path=lib_path)      # without the opt-in: the general kernels
+        assert rel_l2(e2.project_coefficients(junk, real_intensity=True), proj) > 1e-3
+        assert rel_l2(e2.project_coefficients(Ilm, real_intensity=True), proj) < TOL_SHT
+        e2.close()
     sw = e.jacobi_sweeps() if hasattr(e, 'jacobi_sweeps') else None
     e.close()
     return sw

@@ -126,6 +126,11 @@ def test_projection_real_vs_oracle(emul_lib, N, L, ropt):
     PC.check_projection_real_vs_oracle(N, L, emul_lib, n_batch=1, reciprocal_opt=ropt)
 
 
+def test_projection_real_tolerance_opt_in(emul_lib):
+    """Im V_l at rounding level (the reference's `density` route): general kernels by default, the real one under MTIP_PROJ_REAL_TOL"""
+    PC.check_projection_real_vs_oracle(16, 6, emul_lib, n_batch=1, imag_residue=1e-15)
+
+
 def test_wide_projection_matrices(emul_lib):
     """k_l = Nq < 2l+1 (the reference's integration test uses 8 radial points with max_order 15,
     tests/test_fxs_integration.py:326-355): polar factor of a wide matrix, compared through V_l U_l."""

@@ -112,6 +112,12 @@ def test_projection_real_option_variants(ropt):
     PC.check_projection_real_vs_oracle(24, 10, reciprocal_opt=ropt)
 
 
+def test_projection_real_tolerance_opt_in():
+    """Im V_l at rounding level (the reference's `density` route of extract): general kernels by default, k_rproj under the
+    opt-in MTIP_PROJ_REAL_TOL; the check tells the two apart by which half of the coefficients is read"""
+    PC.check_projection_real_vs_oracle(40, 18, imag_residue=1e-15)
+
+
 def test_config3_short_trajectory_vs_oracle():
     """128 x L32 (the benchmark size): 10 HIO + shrink-wrap + 10 ER ft_stab steps against the oracle."""
     PC.check_config_trajectory_vs_oracle(3, fused=True, n_hio=10, n_er=10)

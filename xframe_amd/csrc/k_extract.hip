@@ -201,8 +201,9 @@ extern "C" int mtip_op_hermitian_eig(mtip_ctx* c, int n, int n_mat, const mtip_c
 }
 
 // ---- real symmetric matrices up to 128 x 128: LDS-resident one-sided Jacobi (round 3) ---------------------------------------
-// The reference's B_l are real (fxs_invariant_tools.py:1255: `.real` before the eigen-decomposition; scipy eigh of a real
-// symmetric matrix, 1114-1131).  The matrix is shifted to A' = A + s 1, s = |A|_F: positive definite with condition <= 2, so the
+// B_l of a real intensity is real (the reference types it complex; its imaginary part is zero from cross-correlation data,
+// rounding residue on the `density` route of extract.py:288); the host takes this solver for matrices without imaginary part
+// (the rules of fxs_invariant_tools.py:1114-1131 on top).  The matrix is shifted to A' = A + s 1, s = |A|_F: positive definite with condition <= 2, so the
 // one-sided Jacobi on its columns  A' V = W  has no +x / -x singular pairs, no numerical null space, and converges in a few
 // sweeps; the eigenvectors are the normalised columns of W (left = right singular vectors of a definite matrix, V is never
 // formed), the eigenvalues |W_i| - s -- accurate to eps |A|, as LAPACK's.  W lives in LDS for the whole solve (128 x 129 doubles =

@@ -2,9 +2,14 @@
 //   approximate_unknowns  xframe/projects/fxs/projectLibrary/fxs_Projections.py:752-767   U_l = u @ vh of svd(V_l^+ D^2 I_l)
 //   mtip_projection       fxs_Projections.py:832-849, 866-871                             I'_l[mask] = (V_l U_l)[mask], l = 0 rules
 //
-// The reference's V_l are real: B_l is made real before its eigen-decomposition (fxs_invariant_tools.py:1255, 1114-1141,
-// scipy eigh of a real symmetric matrix) and stored `astype(complex)` (1207).  I_lm are the coefficients of the REAL
-// intensity |F|^2, so I_{l,-m} = (-1)^m conj(I_{l,m}).  Then M = V_l^T D^2 I_l (k x (2l+1), complex) is unitarily equivalent
+// B_l(q,q') = sum_m I_lm(q) conj(I_lm(q')) of a real intensity is real, so V_l = eigvecs sqrt(eigvals) of it is real
+// (fxs_invariant_tools.py:1114-1141: scipy eigh, real eigenvectors for a matrix without imaginary part; stored
+// `astype(complex)`, 1207).  The reference types B_l complex: from cross-correlation data (extract.py:136, real data through
+// real Legendre matrices, 460-515) its imaginary part is exactly zero and V_l exactly real; on the `density` route
+// (extract.py:288, `Il @ Il.T.conj()`) rounding residue remains (measured with the reference here: <= 1e-17 |B_l| at even l,
+// up to 1e-7 max|V_l| in the null-space columns of V_l) -- the host takes this kernel only when Im V_l == 0 exactly for
+// every used order (or below MTIP_PROJ_REAL_TOL when that opt-in is set), otherwise the general kernels of k_proj.hip.
+// I_lm are the coefficients of the REAL intensity |F|^2, so I_{l,-m} = (-1)^m conj(I_{l,m}).  Then M = V_l^T D^2 I_l (k x (2l+1), complex) is unitarily equivalent
 // to a REAL matrix: with the unitary T that maps the column pair (m, -m) to (sqrt2 Re, sqrt2 Im) of column m,
 //   M~ = M T,   M~[:, rho'] = sum_q V[q, :] q^2 I~[q, rho'],   I~[q, .] = (Re I_l0, 0, sqrt2 Re I_l1, sqrt2 Im I_l1, ...)
 // (rho' = 2m + part; the slot rho' = 1, "Im I_l0", is identically zero and kept so that (Re, Im) pairs sit in lane pairs),

@@ -311,6 +311,20 @@ int mtip_set_projection_matrix(mtip_ctx* c, int l, const mtip_cdouble* V, int k_
     if (V)
         for (int q = 0; q < c->N; ++q)
             for (int i = 0; i < k_l; ++i) tmp[(size_t)q * kmax + i] = make_double2(V[(size_t)q * k_l + i].re, V[(size_t)q * k_l + i].im);
+    // MTIP_PROJ_REAL_TOL = t > 0 (opt-in, default 0): imaginary parts of V_l below t * max|V_l| are rounding residue of an
+    // eigen-decomposition of a complex-typed but real-valued B_l (the reference's `density` route of extract) and are dropped,
+    // so that such matrices take the real-arithmetic projection too.  With the default only Im V_l == 0 exactly does.
+    double real_tol = 0.0;
+    if (const char* e = std::getenv("MTIP_PROJ_REAL_TOL")) real_tol = std::atof(e);
+    if (real_tol > 0.0) {
+        double vmax = 0.0, imax = 0.0;
+        for (const double2& v : tmp) {
+            vmax = std::max(vmax, std::max(std::fabs(v.x), std::fabs(v.y)));
+            imax = std::max(imax, std::fabs(v.y));
+        }
+        if (imax <= real_tol * vmax)
+            for (double2& v : tmp) v.y = 0.0;
+    }
     MTIP_HIP_CHECK(c, mtip_copy(c, c->d_V + c->voff[l], tmp.data(), tmp.size() * sizeof(double2), hipMemcpyHostToDevice));
     std::copy(tmp.begin(), tmp.end(), c->h_V.begin() + c->voff[l]);
     free_rproj_tables(c);                                // tables and slot lists of the real projection depend on V_l / used

@@ -55,8 +55,9 @@ def invariants_from_intensity_coefficients(Ilm, data_radial_points, max_order, e
     bls = []
     for l in range(max_order + 1):
         Il = np.asarray(Ilm[l])
-        # real, as the reference makes it before the eigen-decomposition (fxs_invariant_tools.py:1255: B_l of a real
-        # intensity is real, sum over +-m pairs): the projection matrices are then real, as the reference's are (1207)
+        # B_l of a real intensity is real (the +-m pairs are conjugate); `Il @ Il^+` leaves rounding residue in the
+        # imaginary part, dropped here as the reference's own B_l-from-coefficients routine does (fxs_invariant_tools.py:1255),
+        # so that the projection matrices are exactly real like those of its cross-correlation route
         B = (Il @ Il.conj().T).real / 4.0                  # stored convention: (V/2)(V/2)^+
         bls.append((B + B.T) / 2)
     bls = np.stack(bls)
