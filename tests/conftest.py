@@ -31,6 +31,11 @@ def golden_variants():
 
 
 @pytest.fixture(scope='session')
+def golden_flow():
+    return np.load(os.path.join(GOLDEN, 'average_flow.npz'))
+
+
+@pytest.fixture(scope='session')
 def golden_cfg1():
     return np.load(os.path.join(GOLDEN, 'mtip_cfg1_N32_L8.npz'))
 

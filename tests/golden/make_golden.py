@@ -823,6 +823,238 @@ def main_io():
     print('io contract fixture:', len(out), 'arrays;', len(paths), 'HDF5 nodes')
 
 
+# ---- (f-1) the reference's own averaging flow, run with a pysofft double -------------------------------------------------------
+def install_pysofft_double():
+    """``pysofft`` (the reference's SO(3) library, soft_plugin.py:5-15) is third party and absent.  This double offers the names
+    the plugin imports, on top of oracle/alignment.py: the SO(3) correlation on the (2 bw)^3 Euler grid and the rotation of
+    harmonic coefficients.  Conventions of the double (NOT checkable against pysofft here, see oracle/alignment.py):
+    ``calc_mean_C_array`` returns C indexed [beta, alpha, gamma] (what average.py:936-938 assumes when it reads the grid at
+    [argmax[1], argmax[0], argmax[2]]) and tabulated so that the angles average.py makes of the arg-max
+    (alpha -> 2 pi - alpha, gamma -> 2 pi - gamma, 939-940) are those ``rotate_coeff_multi`` needs to map the signal onto
+    the reference.  Everything the flow does AROUND these two calls is the reference's own code."""
+    from oracle import alignment as OA
+    import types as _t
+
+    def mod(name):
+        m = _t.ModuleType(name)
+        sys.modules[name] = m
+        return m
+    pk = mod('pysofft')
+    pk.__path__ = []
+    mw, wt, ww, so, ro = (mod('pysofft.' + n) for n in ('make_wiegner', 'wignerTransform', 'wignerWeights', 'soft', 'rotate'))
+    pk.make_wiegner, pk.wignerTransform, pk.wignerWeights, pk.soft, pk.rotate = mw, wt, ww, so, ro
+    for n in ('CosEvalPts', 'CosEvalPts2', 'SinEvalPts', 'SinEvalPts2', 'genWigTrans_L2'):
+        setattr(mw, n, None)
+    mw.genWigAll = lambda bw: None
+    mw.genWigAllTrans = lambda bw: None
+    mw.get_euler_angles = lambda bw: OA.euler_grid(bw)
+    wt.wigNaiveSynthesis_fftw = None
+    ww.makeweights2 = lambda bw: None
+    so.Inverse_SO3_Naive_fft_pc = so.Forward_SO3_Naive_fft_pc = so.coefLoc_so3 = so.sampLoc_so3 = None
+    so.totalCoeffs_so3 = lambda bw: (4 * bw ** 3 - bw) // 3
+
+    def calc_mean_C_array(bw, f_coeff, g_coeff, r_lo, r_hi, ml_split_ids, wigners_transposed, flag):
+        C = OA.correlation(np.asarray(g_coeff), np.asarray(f_coeff), bw - 1, [int(r_lo), int(r_hi)])      # [alpha, beta, gamma]
+        n = 2 * bw
+        flip = (-np.arange(n)) % n
+        return np.ascontiguousarray(C[flip][:, :, flip].transpose(1, 0, 2)).astype(complex)
+    so.calc_mean_C_array = calc_mean_C_array
+
+    def rotate_coeff_multi(bw, coeff, split_ids, euler_angles):
+        return OA.rotate_coeff(np.asarray(coeff), np.asarray(euler_angles, dtype=float), bw - 1)
+    ro.rotate_coeff_multi = rotate_coeff_multi
+    ro.rotate_coeff = rotate_coeff_multi
+
+
+def average_flow_inputs(name, N, L):
+    """seeded sets of reconstructions for the averaging flow; returns (list of [density, ft_density], selection errors, settings
+    overrides).  Shared by this generator and the tests (tests read the arrays from the fixture, not this function)."""
+    from oracle import alignment as OA
+    from oracle.fourier import FourierPair
+    from oracle.sht import SHT
+    from xframe_amd.fxs import synthetic as S
+    fp = FourierPair(SHT(L), N, S.data_cutoff(N), 2.0)
+    sht = fp.sht
+    rng = np.random.default_rng({'A': 1717, 'B': 1818}[name])
+    rs = fp.rs
+    th, ph = np.meshgrid(sht.theta, sht.phi, indexing='ij')
+    R = rs.max()
+
+    def blobs(n, seed):
+        r = np.random.default_rng(seed)
+        x = rs[:, None, None] * np.sin(th)[None] * np.cos(ph)[None]
+        y = rs[:, None, None] * np.sin(th)[None] * np.sin(ph)[None]
+        z = rs[:, None, None] * np.cos(th)[None] * np.ones_like(ph)[None]
+        d = np.zeros(x.shape)
+        for _ in range(n):
+            c = r.normal(size=3) * 0.22 * R
+            w = r.uniform(0.12, 0.2) * R
+            d += r.uniform(0.5, 1.5) * np.exp(-((x - c[0]) ** 2 + (y - c[1]) ** 2 + (z - c[2]) ** 2) / (2 * w * w))
+        return sht.inverse_d(sht.forward_d(d.astype(complex))).real        # band limited: rotations are then exact
+
+    base = blobs(5, 11 if name == 'A' else 12)
+    other = blobs(4, 99)
+    al, be, ga = OA.euler_grid(L + 1)
+
+    def rot(d, i, j, k):
+        return sht.inverse_d(OA.rotate_coeff(sht.forward_d(d.astype(complex)), (al[i], be[j], ga[k]), L)).real
+
+    def shifted(d, cart):
+        """translate by a (small) cartesian vector through the reciprocal phases"""
+        from oracle import projections as P
+        v = np.asarray(cart, dtype=float)
+        r = np.linalg.norm(v)
+        sph = np.array([r, np.arccos(v[2] / r), np.arctan2(v[1], v[0]) % (2 * np.pi)])
+        return fp.ift(fp.ft(d.astype(complex)) * P.shift_phases(fp.grid.reciprocal_grid(), sph)).real
+
+    def noisy(d, amp):
+        return d + amp * d.max() * rng.normal(size=d.shape)
+    if name == 'A':
+        dens = [2.0 * rot(base, 3, 2, 5),
+                noisy(rot(base, 1, 4, 2), 0.02) * 0.7,
+                base * 1.3,                                                     # the reference (lowest selection error)
+                shifted(rot(base, 6, 1, 3), [0.05 * R, -0.03 * R, 0.04 * R]),
+                fp.ift(fp.ft(rot(base, 2, 3, 1).astype(complex)).conj()).real,   # point inverted
+                other,                                                          # unrelated: fails the alignment error limit
+                noisy(rot(base, 3, 2, 5), 0.01),                                # same rotation as #0: the same grid point is hit again
+                noisy(rot(base, 5, 5, 0), 0.05)]
+        errors = np.array([0.04, 0.05, 0.01, 0.03, 0.06, 0.02, 0.07, 0.08])
+        over = {'alignment_error_limit': 0.5}
+    else:
+        dens = [rot(base, 4, 1, 1) * 0.9, base, noisy(rot(base, 2, 2, 6), 0.03), other * 1.1, noisy(rot(base, 0, 3, 3), 0.01),
+                rot(base, 7, 4, 2) * 1.7]
+        errors = np.array([0.2, 0.1, 0.3, 0.15, 0.25, 0.12])
+        over = {'alignment_error_limit': 0.2, 'center_reconstructions': False, 'pointinvert_reference': True,
+                'normalize_reconstructions': {'use': True, 'mode': 'mean'}, 'find_rotation': {'r_limit_ids': [2, N - 2]},
+                'selection': {'n_reconstructions': 3}}
+    recs = [[d.astype(complex), fp.ft(d.astype(complex))] for d in dens]
+    return recs, errors, over
+
+
+def main_average_flow():
+    """tests/golden/average_flow.npz (G17): ``ProjectWorker.run_3d`` and ``Alignment`` of the reference's average.py (359-627,
+    729-1111) run on two seeded sets of reconstructions -- centring, normalisation, reference choice, the alignment of every
+    reconstruction and of its point inverse, the error limit and the selection, the averages, the four PRTF variants, the centred
+    average -- with a pysofft double (install_pysofft_double) and the oracle's numpy SHT in the shtns slot.  Recorded: inputs,
+    settings, and everything the reference saves or decides."""
+    mods = bootstrap()
+    ml = mods['xframe.library.mathLibrary']
+    ml.shtns = ShAdapter
+    import types as _t
+
+    class _Any:
+        def __init__(s, *a, **k):
+            pass
+
+        def __getattr__(s, n):
+            return _Any()
+
+        def __call__(s, *a, **k):
+            return _Any()
+
+    class AnyModule(_t.ModuleType):
+        def __getattr__(s, n):
+            if n.startswith('__'):
+                raise AttributeError(n)
+            return _Any()
+    for name in ('xframe.presenters', 'xframe.presenters.matplotlibPresenter', 'xframe.presenters.openCVPresenter', 'shtns'):
+        sys.modules[name] = AnyModule(name)
+    install_pysofft_double()
+    pl = mods['xframe.library.pythonLibrary']
+    st = mods['xframe.settings']
+    from oracle import mtip as OM
+    from oracle.sht import SHT
+    from xframe_amd.fxs import synthetic as S
+    N, L = 12, 5
+    ro = OM.deep_update(OM.default_settings(), S.config_overrides(1))
+    ro = OM.deep_update(ro, {'grid': {'n_radial_points': N, 'max_order': L}, 'GPU': {'use': False}, 'multi_process': {'use': False}})
+    st.project = pl.DictNamespace.dict_to_dictnamespace(ro)
+    cwd = os.getcwd()
+    av = importlib.import_module('xframe.projects.fxs.average')
+    os.chdir(cwd)
+    soft_plugin = importlib.import_module('xframe.externalLibraries.soft_plugin')
+    ml.Soft = soft_plugin.Soft
+    gp = importlib.import_module('xframe.projects.fxs.projectLibrary.ft_grid_pairs')
+    htm = importlib.import_module('xframe.projects.fxs.projectLibrary.hankel_transforms')
+    av.xprint = lambda *a, **k: None
+    sh = SHT(L)
+    grid = gp.get_grid({**ro['fourier_transform'], 'dimensions': 3, **ro['grid'], 'phis': sh.phi, 'thetas': sh.theta,
+                        'max_q': S.data_cutoff(N), 'n_radial_points_from_data': N})
+    out = {'G17_N': np.array(N), 'G17_L': np.array(L), 'G17_max_q': np.array(S.data_cutoff(N)), 'G17_sets': np.array(['A', 'B'])}
+    defaults = {'center_reconstructions': True, 'multi_process': {'use': False}, 'use_masks': False,
+                'normalize_reconstructions': {'use': True, 'mode': 'max'}, 'pointinvert_reference': False,
+                'alignment_error_limit': 0.5, 'max_iterations': 1, 'find_rotation': {}, 'resolution_metrics': {'PRTF': True},
+                'average_normalization_min': 0, 'selection': {'method': 'least_error', 'n_reconstructions': 100}}
+    for sname in ('A', 'B'):
+        recs, sel_err, over = average_flow_inputs(sname, N, L)
+        o = OM.deep_update({k: (dict(v) if isinstance(v, dict) else v) for k, v in defaults.items()}, over)
+        if 'r_limit_ids' not in o['find_rotation']:
+            o['find_rotation'] = {'r_limit_ids': [0, N]}
+        st.project = pl.DictNamespace.dict_to_dictnamespace(o)
+        r_opt = pl.DictNamespace.dict_to_dictnamespace(ro)
+        r_opt.internal_grid = grid
+        saved = {}
+
+        class FakeDB:
+            def save(s, name, data, **kw):
+                saved[name] = data
+
+            def load(s, name, **kw):
+                if name == 'ft_weights':          # (the reference computes them through its multi-process module when no file exists)
+                    return {'weights': htm.calc_spherical_mid_weights(np.arange(L + 1), N, 2.0), 'posHarmOrders': np.arange(L + 1),
+                            'mode': 'midpoint'}
+                raise FileNotFoundError(name)
+        db = FakeDB()
+        av.database.project = db
+        w = av.ProjectWorker.__new__(av.ProjectWorker)
+        w.opt, w.db = st.project, db
+        w.process_factory = av.get_analysis_process_factory(db, [])
+        n = len(recs)
+        ref_arg = w.get_reference_arg(sel_err, {})
+        n_rec = o['selection']['n_reconstructions']
+        masks = [np.ones(recs[0][0].shape, bool) for _ in range(n)]
+        for i, r in enumerate(recs):
+            out[f'G17_{sname}_in{i}_real'], out[f'G17_{sname}_in{i}_recip'] = r[0].copy(), r[1].copy()
+        out[f'G17_{sname}_n'] = np.array(n)
+        out[f'G17_{sname}_selection_errors'] = sel_err
+        import json
+        out[f'G17_{sname}_settings'] = np.array(json.dumps(o))
+        res, loc = w.run_3d([[a.copy(), b.copy()] for a, b in recs], masks, r_opt, sel_err, None, ref_arg,
+                            [str(i) for i in range(n)], min(n_rec, n) if isinstance(n_rec, int) else n, [], [np.arange(n)])
+        assert 'average_results' in saved, 'post_processing failed'
+        r = saved['average_results']
+        pre = f'G17_{sname}_'
+        out[pre + 'reference_arg'] = np.array(ref_arg)
+        for k in ('real_density', 'normalized_real_density', 'reciprocal_density', 'intensity_from_densities', 'intensity_from_ft_densities'):
+            out[pre + 'average_' + k] = np.asarray(r['average'][k])
+        for k in ('real_density', 'normalized_real_density', 'reciprocal_density'):
+            out[pre + 'centered_' + k] = np.asarray(r['centered_average'][k])
+        for k, v in r['resolution_metrics'].items():
+            out[pre + 'metric_' + k] = np.asarray(v)
+        out[pre + 'average_ids'] = np.asarray(r['average_ids'])
+        out[pre + 'n_aligned'] = np.array(len(r['aligned']))
+        for k, v in r['aligned'].items():
+            out[pre + f'aligned{k}_real'], out[pre + f'aligned{k}_recip'] = np.asarray(v['real_density']), np.asarray(v['reciprocal_density'])
+        out[pre + 'scaling_factors'] = np.asarray(r['input_meta']['scaling_factors'])
+        out[pre + 'average_scaling_factors_per_file'] = np.asarray(r['input_meta']['average_scaling_factors_per_file'])
+        out[pre + 'rotation_angles'] = np.array([np.asarray(r['rotation_angles'][str(i + 1)])[-1] for i in range(n - 1)])
+        out[pre + 'rotation_metric_shape'] = np.array(np.asarray(r['rotation_metric']['1'][-1]).shape)
+        out[pre + 'alignment_errors'] = np.array(loc['errors'], dtype=float)
+        # which of (signal, point inverse) was kept: the returned dict is the one whose density gives diff_norm / diff_inverted_norm
+        refd = loc['reference_reconstruction'][0].real
+        inv = []
+        for o_ in loc['outs']:
+            d = refd - np.asarray(o_['densities'][0]).real
+            inv.append(bool(np.abs(d - o_['diff_inverted_norm']).max() < np.abs(d - o_['diff_norm']).max()))
+        out[pre + 'inverted'] = np.array(inv)
+        out[pre + 'keys'] = np.array(sorted(r))
+        out[pre + 'so3_grid'] = np.asarray(r['so3_grid'])              # (after the in-place angle flips of average.py:939-940)
+        print(sname, 'reference', ref_arg, 'errors', np.round(loc['errors'], 4), 'inverted', inv, 'averaged', len(r['aligned']),
+              'ids', r['average_ids'])
+    np.savez_compressed(os.path.join(HERE, 'average_flow.npz'), **out)
+    print('average flow fixture:', len(out), 'arrays')
+
+
 if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'io':
         main_io()
@@ -830,6 +1062,8 @@ if __name__ == '__main__':
         main_extract()
     elif len(sys.argv) > 1 and sys.argv[1] == 'average':
         main_average_ops()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'average_flow':
+        main_average_flow()
     elif len(sys.argv) > 1 and sys.argv[1] == 'variants':
         main_variants()
     else:

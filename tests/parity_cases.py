@@ -839,6 +839,66 @@ def check_average_vs_oracle(lib_path=None, N=12, L=6, n_rec=5, seed=3):
     return got
 
 
+def _average_flow_sets(golden_flow):
+    import json
+    g = golden_flow
+    N, L = int(g['G17_N']), int(g['G17_L'])
+    for s in g['G17_sets']:
+        pre = f'G17_{s}_'
+        n = int(g[pre + 'n'])
+        recs = [[g[pre + f'in{i}_real'], g[pre + f'in{i}_recip']] for i in range(n)]
+        yield str(s), pre, N, L, recs, g[pre + 'selection_errors'], json.loads(str(g[pre + 'settings']))
+
+
+def _compare_average_flow(res, g, pre, tol, aligned, angles, inverted, errors, scales):
+    """a result of the averaging flow against what the reference's own run_3d saved / decided (fixture G17)"""
+    assert int(res['reference_arg']) == int(g[pre + 'reference_arg'])
+    assert np.allclose(errors, g[pre + 'alignment_errors'], rtol=1e-6, atol=1e-12), (errors, g[pre + 'alignment_errors'])
+    assert list(inverted) == [bool(x) for x in g[pre + 'inverted']]
+    assert np.allclose(scales, g[pre + 'scaling_factors'], rtol=1e-10)
+    assert list(res['average_ids']) == [int(x) for x in g[pre + 'average_ids']]
+    assert len(aligned) == int(g[pre + 'n_aligned'])
+    for i, a in enumerate(aligned):
+        assert rel_l2(a[0], g[pre + f'aligned{i}_real']) < tol and rel_l2(a[1], g[pre + f'aligned{i}_recip']) < tol, i
+    # angles modulo 2 pi (2 pi - 0 is stored as 2 pi); compared on the circle
+    d = np.asarray(angles) - g[pre + 'rotation_angles']
+    assert np.abs(np.exp(1j * d) - 1).max() < 1e-9
+    for k in ('real_density', 'normalized_real_density', 'reciprocal_density', 'intensity_from_densities', 'intensity_from_ft_densities'):
+        assert rel_l2(res['average'][k], g[pre + 'average_' + k]) < tol, k
+    for k in ('real_density', 'normalized_real_density', 'reciprocal_density'):
+        assert rel_l2(res['centered_average'][k], g[pre + 'centered_' + k]) < tol, k
+    for k in ('PRTF', 'PRTF_from_density', 'PRTF_from_ft_density', 'PRTF_ftI'):
+        assert np.allclose(res['resolution_metrics'][k], g[pre + 'metric_' + k], rtol=1e-6, atol=1e-9), k
+        assert np.allclose(res['resolution_metrics'][k + '_std'], g[pre + 'metric_' + k + '_std'], rtol=1e-6, atol=1e-8), k
+    assert np.abs(np.exp(1j * (res['so3_grid'] - g[pre + 'so3_grid'])) - 1).max() < 1e-9          # the in-place flips, both sides
+
+
+def check_average_flow_golden_oracle(golden_flow):
+    """oracle/alignment.py against the reference's own averaging flow (fixture G17: ProjectWorker.run_3d + Alignment of the
+    imported average.py on two seeded sets, pysofft doubled on the oracle's correlation / rotation)"""
+    from oracle import alignment as OA
+    for s, pre, N, L, recs, sel_err, o in _average_flow_sets(golden_flow):
+        fp = FourierPair(SHT(L), N, float(golden_flow['G17_max_q']), 2.0)
+        res = OA.average_reconstructions(fp, recs, sel_err, o)
+        _compare_average_flow(res, golden_flow, pre, 1e-12, res['aligned'], res['rotation_angles'], res['inverted'],
+                              res['alignment_errors'], res['scaling_factors'])
+
+
+def check_average_flow_golden_hip(golden_flow, lib_path=None):
+    """the product's averaging (xframe_amd/fxs/average.py on the engine's device transforms / SO(3) correlation / rotation)
+    against the same fixture: every decision of the reference's flow and every array it saves"""
+    from xframe_amd.fxs import average as AV
+    for s, pre, N, L, recs, sel_err, o in _average_flow_sets(golden_flow):
+        e = Engine({'grid': {'n_radial_points': N, 'max_order': L}}, None, n_batch=3, lib_path=lib_path,
+                   max_q=float(golden_flow['G17_max_q']))
+        res = AV.average_reconstructions(e, recs, sel_err, o)
+        n = len(recs) - 1
+        aligned = [[res['aligned'][str(i)]['real_density'], res['aligned'][str(i)]['reciprocal_density']] for i in range(len(res['aligned']))]
+        _compare_average_flow(res, golden_flow, pre, 1e-9, aligned, [res['rotation_angles'][str(i + 1)][-1] for i in range(n)],
+                              res['inverted'], res['alignment_errors'], res['input_meta']['scaling_factors'])
+        e.close()
+
+
 def check_extract_vs_numpy(lib_path=None, N=24, L=6):
     """`extract` (fxs_invariant_tools.py:1079-1207): B_l -> V_l with the device eigensolver against numpy's eigh -- compared
     through eigenvalues and through V_l V_l^+ (eigenvectors are only defined up to phases / rotations inside degenerate

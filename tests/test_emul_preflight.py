@@ -115,6 +115,11 @@ def test_average_vs_oracle(emul_lib):
     PC.check_average_vs_oracle(emul_lib)
 
 
+def test_average_flow_golden(emul_lib, golden_flow):
+    """the product's averaging against what the reference's own run_3d / Alignment did with two seeded sets (fixture G17)"""
+    PC.check_average_flow_golden_hip(golden_flow, emul_lib)
+
+
 def test_extract_vs_numpy(emul_lib):
     PC.check_extract_vs_numpy(emul_lib, N=12, L=4)
 

@@ -149,6 +149,12 @@ def test_average_vs_oracle(N, L):
     PC.check_average_vs_oracle(None, N=N, L=L)
 
 
+def test_average_flow_golden(golden_flow):
+    """the product's averaging against what the reference's own ProjectWorker.run_3d / Alignment did with two seeded sets of
+    reconstructions (fixture G17, tests/golden/average_flow.npz): decisions, aligned pairs, averages, PRTF variants"""
+    PC.check_average_flow_golden_hip(golden_flow)
+
+
 @pytest.mark.parametrize('N,L', [(24, 6), (128, 32)])
 def test_extract_vs_numpy(N, L):
     """B_l -> V_l on the device (the `extract` step) against numpy eigh, small and at the benchmark size"""

@@ -265,3 +265,9 @@ def test_g15_extract_rules_oracle():
     from oracle import extract as OE
     PC.check_extract_rules_golden((OE.deg2_invariant_eigenvalues, OE.deg2_invariant_to_projection_matrices_3d,
                                    OE.nearest_positive_semidefinite_matrix), tol=1e-13)
+
+
+def test_g17_average_flow_oracle(golden_flow):
+    """oracle/alignment.py reproduces the reference's own averaging flow (run_3d + Alignment of the imported average.py)"""
+    import parity_cases as PC
+    PC.check_average_flow_golden_oracle(golden_flow)

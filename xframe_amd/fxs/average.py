@@ -11,7 +11,13 @@ broadcasts, and the sums of the aligned densities are all-reduced (RCCL over xGM
 ``reconstruct -> average`` pipeline that moves grid-sized data.
 
 pysofft (the reference's SO(3) library) is not available: conventions of the correlation / rotation are those of
-``oracle/alignment.py`` (see its parity note); only their composition enters the result.
+``oracle/alignment.py`` (see its parity note); only their composition enters the result.  The flow around those two calls is
+held to the reference's own ``run_3d`` / ``Alignment`` (fixture G17, tests/golden/average_flow.npz), including three things the
+reference does that change its results: ``find_rotation`` flips the angles of the Euler-grid entry it found IN PLACE
+(average.py:938-940), so a grid point found twice by one ``Alignment`` object hands out un-flipped angles the second time; the
+list of valid alignments starts with the reference while the list of their errors does not (519-524); and the averaged pair is
+centred before the metrics with a shift operator that works in place (538, fxs_Projections.py:1442), so the saved averaged
+reciprocal density and the 'PRTF' metric see the shifted one.
 """
 import numpy as np
 
@@ -59,7 +65,7 @@ class Alignment:
         self.opt = dict(DEFAULTS)
         self.opt.update(opt or {})
         self.L = engine.L
-        self.soft_grid = hs.euler_grid(self.L + 1)
+        self.soft_grid = np.stack(np.meshgrid(*hs.euler_grid(self.L + 1), indexing='ij'), -1)     # make_SO3_grid; edited in place
         self.results = {}
 
     # -- batched transforms: lists of grids -> lists, in chunks of the engine's batch size
@@ -92,17 +98,23 @@ class Alignment:
         shifted = self.ift([f * p for f, p in zip(self.ft(densities), phases)])
         return shifted, [f * p for f, p in zip(ft_densities, phases)], centers
 
-    def find_rotation(self, ref_coeff, sig_coeffs):
-        """find_rotation (920-947) for a list of signals: Euler angles maximising the mean correlation + the metric arrays"""
+    def correlations(self, ref_coeff, sig_coeffs):
+        """mean_C of find_rotation (920-935) for a list of signals, in the layout the reference reads it in: [beta, alpha, gamma],
+        tabulated at the angles whose flip is the aligning rotation (oracle/alignment.py mean_C_layout)"""
         r_lim = self.opt['find_rotation'].get('r_limit_ids', [0, self.e.N])
         r_lim = [int(r_lim[0]), int(r_lim[1])]                      # the reference reads entries 0 and 1 (soft_plugin.py:92-94)
-        al, be, ga = self.soft_grid
         Cs = self._batched(lambda c: self.e.so3_correlation(ref_coeff, c, r_lim), sig_coeffs)
-        eulers = []
-        for C in Cs:
-            a, b, g = np.unravel_index(np.argmax(C), C.shape)
-            eulers.append(np.array([al[a], be[b], ga[g]]))
-        return eulers, Cs
+        n = 2 * (self.L + 1)
+        flip = (-np.arange(n)) % n
+        return [C[flip][:, :, flip].transpose(1, 0, 2) for C in Cs]
+
+    def pick_rotation(self, mean_C):
+        """find_rotation (936-946), literally: arg-max in the reference's order, the grid entry is a VIEW and is flipped in place"""
+        am = np.unravel_index(np.argmax(mean_C), mean_C.shape)
+        euler = self.soft_grid[am[1], am[0], am[2]]
+        euler[0] = 2 * np.pi - euler[0]
+        euler[2] = 2 * np.pi - euler[2]
+        return euler
 
     def rotate(self, coeffs, eulers):
         B, out = self.e.B, []
@@ -113,35 +125,35 @@ class Alignment:
             out.extend(res[:len(cc)])
         return out
 
-    def align(self, reference, signals):
-        """rotate_signal sketch (970-975) for a list of (density, ft_density): the rotation found on the densities is applied
-        to both halves"""
-        ref_c = self.e.sht_forward(np.stack([reference] * self.e.B))[0]
-        sig_c = self.sht([s[0] for s in signals])
-        ft_c = self.sht([s[1] for s in signals])
-        eulers, Cs = self.find_rotation(ref_c, sig_c)
-        dens = self.isht(self.rotate(sig_c, eulers))
-        fts = self.isht(self.rotate(ft_c, eulers))
-        return [[d, f] for d, f in zip(dens, fts)], eulers, Cs
-
     def apply_to(self, reference, signals):
-        """alignment_routine (1089-1109) for a list of signals: each signal and its point inverse are aligned, the one with
-        the smaller difference to the reference is kept.  Returns a list of dicts like the reference's."""
+        """alignment_routine (1089-1109) for a list of signals: each signal and its point inverse are aligned (rotate_signal
+        sketch 970-975: the rotation found on the densities is applied to both halves), the one with the smaller difference to the
+        reference is kept.  Transforms, correlations and rotations run batched over all signals and their inverses; the angles are
+        picked in the reference's order (signal 0, its inverse, signal 1, ...) because picking edits the grid.  Returns a list of
+        dicts like the reference's."""
         e = self.e
         inv_d = self.ift([f.conj() for f in self.ft([s[0] for s in signals])])
-        inverted = [[d, s[1].conj()] for d, s in zip(inv_d, signals)]
+        both = [[s[0], s[1]] for s in signals] + [[d, s[1].conj()] for d, s in zip(inv_d, signals)]
+        n = len(signals)
         norm = integrate_normed(e.rs, e.n_theta, reference.real ** 2)
         norm = norm if norm != 0 else 1
-        outs = []
-        for variant in (signals, inverted):
-            aligned, eulers, Cs = self.align(reference, variant)
-            errs = [integrate_normed(e.rs, e.n_theta, (reference.real - a[0].real) ** 2) / norm for a in aligned]
-            outs.append((aligned, eulers, Cs, errs))
+        ref_c = self.e.sht_forward(np.stack([reference] * self.e.B))[0]
+        sig_c = self.sht([s[0] for s in both])
+        ft_c = self.sht([s[1] for s in both])
+        Cs = self.correlations(ref_c, sig_c)
+        eulers, at_pick = [None] * (2 * n), [None] * (2 * n)
+        for i in range(n):
+            for j in (i, n + i):
+                eulers[j] = self.pick_rotation(Cs[j])           # the view the reference stores: a later pick of the same point edits it
+                at_pick[j] = np.array(eulers[j])                # what the reference rotates with (it rotates right after the pick)
+        dens = self.isht(self.rotate(sig_c, at_pick))
+        fts = self.isht(self.rotate(ft_c, at_pick))
+        errs = [integrate_normed(e.rs, e.n_theta, (reference.real - d.real) ** 2) / norm for d in dens]
         res = []
-        for i in range(len(signals)):
-            k = 0 if outs[0][3][i] < outs[1][3][i] else 1
-            res.append({'densities': outs[k][0][i], 'errors': [outs[k][3][i]], 'rotation_angles': [outs[k][1][i]],
-                        'rotation_metrics': [outs[k][2][i]], 'inverted': bool(k)})
+        for i in range(n):
+            k = i if errs[i] < errs[n + i] else n + i
+            res.append({'densities': [dens[k], fts[k]], 'errors': [errs[k]], 'rotation_angles': [eulers[k]],
+                        'rotation_metrics': [Cs[k]], 'inverted': k >= n})
         return res
 
 
@@ -162,11 +174,14 @@ def average_reconstructions(engine, reconstructions, errors, opt=None, dist=None
     scales = np.ones(len(recs))
     if o['normalize_reconstructions']['use']:
         for i, r in enumerate(recs):
-            if np.max(r[0]).real <= 0:
-                continue
-            pos = r[0][r[0] > 0]
-            scales[i] = np.max(pos.real) if o['normalize_reconstructions']['mode'] == 'max' else np.mean(pos)
-            recs[i] = [r[0] / scales[i], r[1] / scales[i]]
+            if o['normalize_reconstructions']['mode'] == 'max':
+                if np.max(r[0]).real <= 0:
+                    continue
+                scale = np.max(r[0][r[0] > 0].real)
+            else:
+                scale = np.mean(r[0][r[0] > 0])               # (432-435: complex; only its real part reaches scaling_factors)
+            scales[i] = np.real(scale)
+            recs[i] = [r[0] / scale, r[1] / scale]
     # ---- reference: the reconstruction with the lowest error (of all ranks)
     world = dist.get_world_size() if dist is not None else 1
     rank = dist.get_rank() if dist is not None else 0
@@ -216,14 +231,20 @@ def average_reconstructions(engine, reconstructions, errors, opt=None, dist=None
     valid = [('ref', -1)] + [(rk, i) for rk, i, x in glob if x < limit]
     valid_err = [x for _, _, x in glob if x < limit]
     chosen = [valid[i] for i in np.argsort(valid_err)]
-    n_rec = o['selection'].get('n_reconstructions', 100)
+    n_rec = o['selection'].get('n_reconstructions', 'all')         # average.py:113-115: anything but an int means all
+    if not isinstance(n_rec, int) or isinstance(n_rec, bool):
+        n_rec = len(glob) + 1
     if len(chosen) >= n_rec:
         chosen = chosen[:n_rec]
     if not chosen:
         chosen = [('ref', -1)]
-    mine = [i for rk, i in chosen if rk == rank]
-    use_ref = ('ref', -1) in chosen and rank == owner
-    aligned = ([reference] if use_ref else []) + [outs[i]['densities'] for i in mine]
+    aligned = []                                           # this rank's part, in the reference's order (sorted by alignment error)
+    for rk, i in chosen:
+        if rk == 'ref':
+            if rank == owner:
+                aligned.append(reference)
+        elif rk == rank:
+            aligned.append(outs[i]['densities'])
     # ---- sums over the selected alignments (all-reduced over the ranks), then the means
     ftd = al.ft([a[0] for a in aligned]) if aligned else []
     sums = np.zeros((4,) + e.shape, complex)
@@ -245,6 +266,10 @@ def average_reconstructions(engine, reconstructions, errors, opt=None, dist=None
         count = float(n.cpu()[0])
     average = [sums[0] / count, sums[1] / count]
     I_ft, I_d = (sums[2] / count).real, (sums[3] / count).real
+    # average.py:538: the averaged pair is centred BEFORE the metrics and the reference's shift operator multiplies its argument in
+    # place (fxs_Projections.py:1442): the averaged reciprocal density that is saved and that enters 'PRTF' is the shifted one
+    cen = al.shift_to_center([average[0]], [average[1]])
+    average[1] = cen[1][0]
     ft_avg = al.ft([average[0]])[0]
     metrics = {}
     if o['resolution_metrics'].get('PRTF', False):
@@ -254,7 +279,6 @@ def average_reconstructions(engine, reconstructions, errors, opt=None, dist=None
                            ('PRTF_ftI', (ft_avg, ft_avg, np.sqrt(I_ft), np.sqrt(I_ft)))):
             p = PRTF(*args)
             metrics[name], metrics[name + '_std'] = p
-    cen = al.shift_to_center([average[0]], [average[1]])
     dmin = o.get('average_normalization_min', False)
     return {
         'average': {'real_density': average[0], 'normalized_real_density': normalize_density(average[0], dmin),
@@ -266,5 +290,7 @@ def average_reconstructions(engine, reconstructions, errors, opt=None, dist=None
         'n_averaged': int(count), 'alignment_errors': loc_err, 'reference_owner': owner, 'reference_arg': ref_arg,
         'rotation_angles': {str(i + 1): x['rotation_angles'] for i, x in enumerate(outs)},
         'inverted': [x['inverted'] for x in outs],
-        'input_meta': {'scaling_factors': scales}, 'so3_grid': np.stack(np.meshgrid(*al.soft_grid, indexing='ij'), -1),
+        # average.py:479, 520: 0 for the reference, then the position (in this rank's list without the reference) of every valid one
+        'average_ids': [0] + [i for i, x in enumerate(loc_err) if x < limit],
+        'input_meta': {'scaling_factors': scales}, 'so3_grid': al.soft_grid,
     }
