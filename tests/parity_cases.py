@@ -899,6 +899,32 @@ def check_average_flow_golden_hip(golden_flow, lib_path=None):
         e.close()
 
 
+def check_symmetric_eig(lib_path=None, n=130, K=3, seed=0):
+    """mtip_op_symmetric_eig against LAPACK on what `extract` feeds it (fxs_invariant_tools.py:1114-1131): a rank-deficient
+    semi-definite matrix (B_l of 2l+1 coefficients), an indefinite one, the zero matrix; n > 128 takes the solver that cuts the
+    columns into blocks over workgroups.  Eigenvalues to eps |A|, eigenvectors through A = V diag(w) V^T and orthonormality."""
+    e = Engine({'grid': {'n_radial_points': 8, 'max_order': 2}}, None, n_batch=1, lib_path=lib_path, max_q=1.0)
+    rng = np.random.default_rng(seed)
+    B = np.empty((K, n, n))
+    for k in range(K):
+        if k % 3 == 0:
+            A = rng.normal(size=(n, min(n, 2 * k + 7))) * np.logspace(0, -6, min(n, 2 * k + 7))[None, :]
+            B[k] = A @ A.T
+        elif k % 3 == 1:
+            M = rng.normal(size=(n, n))
+            B[k] = (M + M.T) / 2
+        else:
+            B[k] = 0
+    vals, vecs = e.hermitian_eig(B.astype(complex))
+    for k in range(K):
+        w = np.linalg.eigvalsh(B[k])[::-1]
+        scale = max(np.abs(w).max(), 1e-300)
+        assert np.abs(vals[k] - w).max() / scale < 1e-12, (k, np.abs(vals[k] - w).max() / scale)
+        assert np.linalg.norm((vecs[k] * vals[k]) @ vecs[k].conj().T - B[k]) <= 1e-12 * max(np.linalg.norm(B[k]), 1e-300), k
+        assert np.abs(vecs[k].conj().T @ vecs[k] - np.eye(n)).max() < 1e-12, k
+    e.close()
+
+
 def check_extract_vs_numpy(lib_path=None, N=24, L=6):
     """`extract` (fxs_invariant_tools.py:1079-1207): B_l -> V_l with the device eigensolver against numpy's eigh -- compared
     through eigenvalues and through V_l V_l^+ (eigenvectors are only defined up to phases / rotations inside degenerate

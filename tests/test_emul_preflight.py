@@ -120,6 +120,11 @@ def test_average_flow_golden(emul_lib, golden_flow):
     PC.check_average_flow_golden_hip(golden_flow, emul_lib)
 
 
+def test_symmetric_eig_blocked(emul_lib):
+    """n > 128: column blocks over workgroups (k_sym_eig_block), 5 blocks -> an empty sixth pads the tournament"""
+    PC.check_symmetric_eig(emul_lib, n=130, K=3)
+
+
 def test_extract_vs_numpy(emul_lib):
     PC.check_extract_vs_numpy(emul_lib, N=12, L=4)
 

@@ -155,6 +155,13 @@ def test_average_flow_golden(golden_flow):
     PC.check_average_flow_golden_hip(golden_flow)
 
 
+@pytest.mark.parametrize('n,K', [(100, 6), (128, 33), (130, 5), (200, 7), (256, 49), (288, 4)])
+def test_symmetric_eig(n, K):
+    """the eigensolvers of `extract` against LAPACK: LDS-resident up to 128, column blocks over workgroups up to 288
+    ((256, 49) = config 5's B_l)"""
+    PC.check_symmetric_eig(None, n=n, K=K)
+
+
 @pytest.mark.parametrize('N,L', [(24, 6), (128, 32)])
 def test_extract_vs_numpy(N, L):
     """B_l -> V_l on the device (the `extract` step) against numpy eigh, small and at the benchmark size"""

@@ -369,15 +369,180 @@ __global__ void __launch_bounds__(1024) k_sym_eig(const double* __restrict__ A_a
     }
 }
 
+// ---- 128 < n <= 288: the same one-sided Jacobi, blocked over workgroups -----------------------------------------------------
+// The matrix no longer fits one CU's LDS (256 x 257 doubles = 514 KB).  Its columns are cut into blocks of SB_BW = 32; a workgroup
+// takes a PAIR of blocks (64 columns x n rows <= 148 KB of LDS), runs one full sweep of the resident-column ordering over those 64
+// columns (se_sweep, rows zero padded to whole 16-lane chunks) and writes them back; the block pairs of an outer round (round-robin
+// tournament over the blocks: every two blocks meet once per outer sweep) are disjoint, so one launch does n_mat x blocks/2 of them
+// side by side, and the launch boundary is the global synchronisation.  49 matrices of 256 x 256 (config 5): 196 workgroups per
+// launch, 7 launches per outer sweep.  HBM traffic per launch: every matrix once in, once out.
+#define SB_BW 32
+#define SB_MAX_N 288
+#define SB_MAX_OUTER 30
+
+__global__ void __launch_bounds__(1024) k_sym_eig_shift(const double* __restrict__ A_all, double* __restrict__ W_all, double* __restrict__ shift,
+                                                        int n) {
+    __shared__ double s_red[16];
+    const double* A = A_all + (size_t)blockIdx.x * n * n;
+    double* W = W_all + (size_t)blockIdx.x * n * n;
+    const int tid = threadIdx.x, nthreads = blockDim.x;
+    double f2 = 0.0;
+    for (int e = tid; e < n * n; e += nthreads) f2 = fma(A[e], A[e], f2);
+    for (int o = 32; o > 0; o >>= 1) f2 += __shfl_xor(f2, o, 64);
+    if ((tid & 63) == 0) s_red[tid >> 6] = f2;
+    __syncthreads();
+    double s = 0.0;
+    for (int wv = 0; wv < (nthreads >> 6); ++wv) s += s_red[wv];
+    s = sqrt(s);
+    if (!(s > 0.0)) s = 1.0;
+    if (tid == 0) shift[blockIdx.x] = s;
+    for (int e = tid; e < n * n; e += nthreads) {
+        const int cc = e / n, r = e - cc * n;
+        W[e] = A[e] + (cc == r ? s : 0.0);                          // column cc of the symmetric matrix = its row cc
+    }
+}
+
+// one workgroup per (matrix, block pair of this outer round); W (n_mat, n columns, n rows); 2 SB_BW groups of 16 lanes
+template <int NR>
+__global__ void __launch_bounds__(SB_BW * 16) k_sym_eig_block(double* __restrict__ W_all, int n, const int2* __restrict__ pairs, int n_pairs,
+                                                              const int* __restrict__ tab, int nrd, int sched_ps, int* __restrict__ flags) {
+    HIP_DYNAMIC_SHARED(double, Ws)
+    constexpr int ns = NR * 16 + 1;
+    const int mat = blockIdx.x / n_pairs;
+    const int2 pr = pairs[blockIdx.x - mat * n_pairs];
+    double* W = W_all + (size_t)mat * n * n;
+    const int tid = threadIdx.x, group = tid >> 4, t = tid & 15;
+    // columns of the two blocks -> LDS (a block beyond the matrix, or the columns past n of the last one: zero columns, which no
+    // rotation touches -- the Gram element with a zero column is 0)
+    for (int lc = group; lc < 2 * SB_BW; lc += SB_BW) {
+        const int gc = (lc < SB_BW ? pr.x : pr.y) * SB_BW + (lc & (SB_BW - 1));
+        const bool have = gc < n && (lc < SB_BW ? pr.x : pr.y) >= 0;
+#pragma unroll
+        for (int u = 0; u < NR; ++u) {
+            const int r = t + u * 16;
+            Ws[(size_t)lc * ns + r] = (have && r < n) ? W[(size_t)gc * n + r] : 0.0;
+        }
+    }
+    __syncthreads();
+    bool big = false;
+    se_sweep<NR>(Ws, ns, t, group, tab, nrd, sched_ps, true, big);
+    if (big && t == 0) atomicAdd(flags + mat, 1);
+    for (int lc = group; lc < 2 * SB_BW; lc += SB_BW) {
+        const int gc = (lc < SB_BW ? pr.x : pr.y) * SB_BW + (lc & (SB_BW - 1));
+        if (gc < n && (lc < SB_BW ? pr.x : pr.y) >= 0) {
+#pragma unroll
+            for (int u = 0; u < NR; ++u) {
+                const int r = t + u * 16;
+                if (r < n) W[(size_t)gc * n + r] = Ws[(size_t)lc * ns + r];
+            }
+        }
+    }
+}
+
+// eigenvector i = W_i / |W_i|, eigenvalue |W_i| - s; one workgroup per matrix, 16 lanes per column
+__global__ void __launch_bounds__(1024) k_sym_eig_finish(const double* __restrict__ W_all, const double* __restrict__ shift,
+                                                         double* __restrict__ U_all, double* __restrict__ lam_all, int n) {
+    const double* W = W_all + (size_t)blockIdx.x * n * n;
+    double* U = U_all + (size_t)blockIdx.x * n * n;
+    const double s = shift[blockIdx.x];
+    const int ngroups = blockDim.x >> 4, group = threadIdx.x >> 4, t = threadIdx.x & 15;
+    for (int cc0 = 0; cc0 < n; cc0 += ngroups) {                   // uniform trip count: DPP sums need the whole group
+        const int cc = cc0 + group;
+        double s2 = 0.0;
+        if (cc < n)
+            for (int r = t; r < n; r += 16) s2 = fma(W[(size_t)cc * n + r], W[(size_t)cc * n + r], s2);
+        s2 = group_sum<16>(s2);
+        const double sig = sqrt(s2), inv = sig > 0.0 ? 1.0 / sig : 0.0;
+        if (cc < n) {
+            if (t == 0) lam_all[(size_t)blockIdx.x * n + cc] = sig - s;
+            for (int r = t; r < n; r += 16) U[(size_t)cc * n + r] = W[(size_t)cc * n + r] * inv;
+        }
+    }
+}
+
+template <int NR>
+static void launch_sym_eig_block(mtip_ctx* c, double* dW, int n, const int2* d_pairs, int n_pairs, int n_mat, int* d_flags) {
+    const size_t lds = (size_t)2 * SB_BW * (NR * 16 + 1) * sizeof(double);
+    hipLaunchKernelGGL((k_sym_eig_block<NR>), dim3((unsigned)(n_mat * n_pairs)), dim3(SB_BW * 16), lds, c->stream, dW, n, d_pairs, n_pairs,
+                       (const int*)(c->d_jsched) + c->jsched_off_h[2 * SB_BW], c->jsched_nrd[2 * SB_BW], c->jsched_ps, d_flags);
+}
+
+// n in (128, 288]: blocked solve; dA, dU, dl device buffers as in mtip_op_symmetric_eig.  Returns the outer sweeps done (< 0: error).
+static int sym_eig_blocked(mtip_ctx* c, int n, int n_mat, const double* dA, double* dU, double* dl) {
+    const int nb = (n + SB_BW - 1) / SB_BW, nbe = nb + (nb & 1);                 // blocks, padded to an even count (-1 = empty block)
+    const int n_pairs = nbe / 2, n_rounds = nbe - 1;
+    std::vector<int2> pairs;
+    for (int r = 0; r < n_rounds; ++r) {                                          // circle method: block nbe-1 stays, the others rotate
+        pairs.push_back(make_int2(nbe - 1 < nb ? nbe - 1 : -1, r));
+        for (int k = 1; k < n_pairs; ++k) pairs.push_back(make_int2((r + k) % (nbe - 1), (r - k + nbe - 1) % (nbe - 1)));
+    }
+    {   // every two blocks meet exactly once per outer sweep
+        std::vector<char> met((size_t)nbe * nbe, 0);
+        for (size_t i = 0; i < pairs.size(); ++i) {
+            const int x = pairs[i].x < 0 ? nbe - 1 : pairs[i].x, y = pairs[i].y;
+            if (x == y || met[(size_t)x * nbe + y]) return -1;
+            met[(size_t)x * nbe + y] = met[(size_t)y * nbe + x] = 1;
+        }
+        if ((int)pairs.size() != n_rounds * n_pairs) return -1;
+    }
+    for (auto& pr : pairs)                                                        // the kept (first) block in .x must exist
+        if (pr.x < 0) std::swap(pr.x, pr.y);
+    int2* d_pairs = nullptr;
+    int* d_flags = nullptr;
+    double *dW = nullptr, *d_shift = nullptr;
+    int rc = 0;
+    if (hipMalloc((void**)&d_pairs, pairs.size() * sizeof(int2)) != hipSuccess || hipMalloc((void**)&d_flags, (size_t)n_mat * sizeof(int)) != hipSuccess ||
+        hipMalloc((void**)&dW, (size_t)n_mat * n * n * sizeof(double)) != hipSuccess || hipMalloc((void**)&d_shift, (size_t)n_mat * sizeof(double)) != hipSuccess)
+        rc = -2;
+    if (rc == 0 && mtip_copy(c, d_pairs, pairs.data(), pairs.size() * sizeof(int2), hipMemcpyHostToDevice) != hipSuccess) rc = -3;
+    if (rc == 0) {
+        hipLaunchKernelGGL(k_sym_eig_shift, dim3((unsigned)n_mat), dim3(1024), 0, c->stream, dA, dW, d_shift, n);
+        const int nr = (n + 15) / 16;
+        std::vector<int> flags(n_mat);
+        int outer = 0;
+        for (; outer < SB_MAX_OUTER; ++outer) {
+            (void)hipMemsetAsync(d_flags, 0, (size_t)n_mat * sizeof(int), c->stream);
+            for (int r = 0; r < n_rounds; ++r) {
+                const int2* pp = d_pairs + (size_t)r * n_pairs;
+                if (nr <= 10) launch_sym_eig_block<10>(c, dW, n, pp, n_pairs, n_mat, d_flags);
+                else if (nr <= 12) launch_sym_eig_block<12>(c, dW, n, pp, n_pairs, n_mat, d_flags);
+                else if (nr <= 14) launch_sym_eig_block<14>(c, dW, n, pp, n_pairs, n_mat, d_flags);
+                else if (nr <= 16) launch_sym_eig_block<16>(c, dW, n, pp, n_pairs, n_mat, d_flags);
+                else launch_sym_eig_block<18>(c, dW, n, pp, n_pairs, n_mat, d_flags);
+            }
+            if (mtip_copy(c, flags.data(), d_flags, (size_t)n_mat * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) {
+                rc = -3;
+                break;
+            }
+            bool any = false;
+            for (int f : flags) any = any || f != 0;
+            if (!any) {
+                ++outer;
+                break;
+            }
+        }
+        if (rc == 0) {
+            hipLaunchKernelGGL(k_sym_eig_finish, dim3((unsigned)n_mat), dim3(1024), 0, c->stream, (const double*)dW, (const double*)d_shift, dU, dl, n);
+            rc = outer;
+        }
+    }
+    (void)hipStreamSynchronize(c->stream);
+    if (d_pairs) (void)hipFree(d_pairs);
+    if (d_flags) (void)hipFree(d_flags);
+    if (dW) (void)hipFree(dW);
+    if (d_shift) (void)hipFree(d_shift);
+    return rc;
+}
+
 // eigvals (n_mat, n) unsorted, eigvecs (n_mat, n, n): eigenvector i of matrix k in eigvecs[k][i][:]
 extern "C" int mtip_op_symmetric_eig(mtip_ctx* c, int n, int n_mat, const double* A, double* eigvals, double* eigvecs) {
     if (!c) return MTIP_EINVAL;
-    if (n < 1 || n > SE_MAX_N || n_mat < 1 || !A || !eigvals || !eigvecs) {
-        c->err = "symmetric_eig: n must be in [1, 128], n_mat >= 1, buffers not null";
+    if (n < 1 || n > SB_MAX_N || n_mat < 1 || !A || !eigvals || !eigvecs) {
+        c->err = "symmetric_eig: n must be in [1, 288], n_mat >= 1, buffers not null";
         return MTIP_EINVAL;
     }
     (void)hipSetDevice(c->device);
-    if (n >= 2 && build_jacobi_schedule(c, n) != MTIP_OK) {
+    if (n >= 2 && build_jacobi_schedule(c, n > SE_MAX_N ? 2 * SB_BW : n) != MTIP_OK) {
         c->err = "symmetric_eig: pairing schedule";
         return MTIP_ENOMEM;
     }
@@ -391,7 +556,16 @@ extern "C" int mtip_op_symmetric_eig(mtip_ctx* c, int n, int n_mat, const double
     }
     if (rc == MTIP_OK) {
         hipError_t e = mtip_copy(c, dA, A, nn * sizeof(double), hipMemcpyHostToDevice);
-        if (e == hipSuccess) {
+        if (e == hipSuccess && n > SE_MAX_N) {
+            ProfScope ps(c, "sym_eig");
+            const int outer = sym_eig_blocked(c, n, n_mat, dA, dU, dl);
+            if (outer < 0) {
+                c->err = "symmetric_eig: blocked solve failed (device memory or block schedule)";
+                rc = MTIP_EHIP;
+            } else if (c->d_sweeps != nullptr) {
+                (void)mtip_copy(c, c->d_sweeps, &outer, sizeof(int), hipMemcpyHostToDevice);
+            }
+        } else if (e == hipSuccess) {
             // all pairs of a round in one workgroup: floor(n / 2) groups of 16 lanes (the schedule's group count for n columns)
             const int groups = std::max(n / 2, 1);
             const int threads = std::min(1024, std::max(64, (groups * 16 + 63) / 64 * 64));
@@ -402,7 +576,7 @@ extern "C" int mtip_op_symmetric_eig(mtip_ctx* c, int n, int n_mat, const double
                                n_mat <= c->B * (c->L + 1) ? c->d_sweeps : (int*)nullptr);
         }
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-        if (e == hipSuccess) e = mtip_copy(c, eigvals, dl, (size_t)n_mat * n * sizeof(double), hipMemcpyDeviceToHost);
+        if (e == hipSuccess && rc == MTIP_OK) e = mtip_copy(c, eigvals, dl, (size_t)n_mat * n * sizeof(double), hipMemcpyDeviceToHost);
         if (e == hipSuccess) e = mtip_copy(c, eigvecs, dU, nn * sizeof(double), hipMemcpyDeviceToHost);
         if (e != hipSuccess) {
             c->err = std::string("symmetric_eig: ") + hipGetErrorString(e);

@@ -1073,6 +1073,7 @@ int build_jacobi_schedule(mtip_ctx* c, int kmax) {
     c->jsched_kmax = kmax;
     c->jsched_ps = ps;
     c->jsched_nrd = nrd;                                         // host copy: rounds per sweep by column count
+    c->jsched_off_h = off;
     return MTIP_OK;
 }
 

@@ -231,8 +231,8 @@ class Engine:
         eigenvectors (K, n, n) with eigenvector i in [:, :, i] (numpy.linalg.eigh's layout, reversed order)"""
         m = _lib.as_c128(mats)
         K, n = m.shape[0], m.shape[1]
-        if n <= 128 and not np.any(m.imag):
-            # real symmetric (what the reference's B_l are): LDS-resident solver
+        if n <= 288 and not np.any(m.imag):
+            # real symmetric (B_l of a real intensity): LDS-resident solver up to 128, column blocks over workgroups up to 288
             sym = np.ascontiguousarray((m.real + np.swapaxes(m.real, -1, -2)) / 2)
             vals = np.empty((K, n))
             vecs = np.empty((K, n, n))
