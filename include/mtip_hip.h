@@ -159,8 +159,10 @@ int mtip_refresh_reciprocal_density(mtip_ctx* ctx);
 /* B_l = I_l I_l^+ of FT(latest rho) (reconstruct.py:757-765, 992-993), (L+1, Nq, Nq) complex */
 int mtip_last_deg2_invariant(mtip_ctx* ctx, int batch, mtip_cdouble* Bl);
 
-/* ---- single operators on host arrays (parity tests; the operator registry of
- *      reconstruct.py:370,391,445,485).  All arrays carry the leading n_batch dimension. ------------ */
+/* ---- single operators (parity tests; the operator registry of reconstruct.py:370,391,445,485; the
+ *      averaging of f-1).  All arrays carry the leading n_batch dimension.  The caller's buffers may be
+ *      host memory or memory of the context's device (unified addressing decides the copy): the
+ *      averaging keeps its batch in HBM between these calls. ---------------------------------------- */
 int mtip_op_sht_forward(mtip_ctx* ctx, const mtip_cdouble* grid, mtip_cdouble* coeff, int prologue);
 int mtip_op_sht_inverse(mtip_ctx* ctx, const mtip_cdouble* coeff, mtip_cdouble* grid);
 int mtip_op_hankel(mtip_ctx* ctx, const mtip_cdouble* coeff_in, mtip_cdouble* coeff_out, int inverse);
@@ -202,6 +204,16 @@ int mtip_op_so3_correlation(mtip_ctx* ctx, const mtip_cdouble* ref, const mtip_c
 /* f_lm -> sum_n D^l_mn f_ln on every shell (soft.rotate_coeff, soft_plugin.py:64-79): D (n_batch, sum_l (2l+1)^2) Wigner
  * matrices in the table layout above (one rotation per restart) */
 int mtip_op_rotate_coefficients(mtip_ctx* ctx, const mtip_cdouble* coeff, const mtip_cdouble* D, mtip_cdouble* out);
+/* find_rotation (average.py:920-947): the correlation and, per restart, its arg-max in the order the reference reads it in --
+ * arg[b] = i_beta nb^2 + i_alpha nb + i_gamma of its np.argmax over mean_C (indexed [beta, alpha, gamma], tabulated at the angles
+ * whose flip alpha -> 2 pi - alpha, gamma -> 2 pi - gamma is the aligning rotation; first maximum wins), vmax[b] the maximum;
+ * C (B, nb, nb, nb) as mtip_op_so3_correlation returns it, or NULL */
+int mtip_op_so3_find_rotation(mtip_ctx* ctx, const mtip_cdouble* ref, const mtip_cdouble* sig, int r_lo, int r_hi, int64_t* arg,
+                              double* vmax, double* C);
+/* rotate (average.py:948-960) by Euler angles (alpha[b], beta of grid sample beta_index[b], gamma[b]) -- what find_rotation hands
+ * out; D^l_mn is built on the device from the Wigner table (host arrays of B entries) */
+int mtip_op_rotate_coefficients_grid(mtip_ctx* ctx, const mtip_cdouble* coeff, const int32_t* beta_index, const double* alpha,
+                                     const double* gamma, mtip_cdouble* out);
 
 /* ---- upstream step `extract`: B_l -> V_l (fxs_invariant_tools.py:1079-1131, 1171-1207) -------------------------------
  * eigen-decomposition of n_mat Hermitian n x n matrices A (row-major, only their Hermitian part matters): eigvals (n_mat, n)

@@ -39,14 +39,30 @@ for i in range(R):
 F = e.fourier_transform(np.stack(recs))
 recs = [(recs[i], F[i]) for i in range(R)]
 opt = {'alignment_error_limit': 0.5, 'find_rotation': {'r_limit_ids': [0, N]}}
-for rep in range(2):                                  # the first call builds the Wigner tables and uploads them
-    t0 = time.perf_counter()
-    got = AV.average_reconstructions(e, recs, errs, opt)
-    t1 = time.perf_counter()
-    print(f'average_reconstructions: {R} reconstructions at {N} x L{L}, Euler grid {2 * L + 2}^3: {1e3 * (t1 - t0):.1f} ms wall '
-          f'({"first call, incl. Wigner-d tables" if rep == 0 else "second call"}); reference {got["reference_arg"]}, '
+import torch                                          # noqa: E402
+
+
+def timed(label, inputs, o, reps=3):
+    best = None
+    for rep in range(reps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        got = AV.average_reconstructions(e, inputs, errs, o)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if rep == 0:
+            print(f'{label}: first call {1e3 * dt:.1f} ms', end='')
+        best = dt if best is None else min(best, dt)
+    print(f', best of the next {reps - 1}: {1e3 * best:.1f} ms wall; reference {got["reference_arg"]}, '
           f'alignment errors {np.array2string(np.asarray(got["alignment_errors"]), precision=2)}')
-t0 = time.perf_counter()
-C = e.so3_correlation(coeff, rot)
-t1 = time.perf_counter()
-print(f'so3_correlation alone ({R} correlations, host arrays in and out): {1e3 * (t1 - t0):.1f} ms; output {C.nbytes / 1e6:.1f} MB')
+    return got
+
+
+print(f'average_reconstructions: {R} reconstructions at {N} x L{L}, Euler grid {2 * L + 2}^3')
+timed('host arrays in, every array of the result on the host (incl. aligned pairs and rotation metrics)', recs, opt)
+dv = e.torch_device()
+recs_dev = [(torch.from_numpy(a).to(dv), torch.from_numpy(b).to(dv)) for a, b in recs]
+timed('device tensors in (as a reconstruct worker on the same GPU hands them over), full result on the host', recs_dev, opt)
+timed('device tensors in, aligned pairs and rotation metrics stay on the device, averages and metrics on the host', recs_dev,
+      dict(opt, keep_on_device=True))
+timed('the same without keeping the rotation metrics', recs_dev, dict(opt, keep_on_device=True, keep_rotation_metrics=False))

@@ -99,7 +99,91 @@ __global__ void __launch_bounds__(256) k_rotate_coeff(const double2* __restrict_
     }
 }
 
+// D^l_mn = e^{-i m alpha} d^l_mn(beta_bi) e^{-i n gamma} from the device's Wigner table, for rotations whose beta is a grid sample
+// (what find_rotation hands out): one workgroup per (order, restart)
+__global__ void __launch_bounds__(256) k_so3_build_D(const double* __restrict__ dtab, const int* __restrict__ beta_idx,
+                                                     const double* __restrict__ alpha, const double* __restrict__ gamma,
+                                                     double2* __restrict__ D, int ntab) {
+    const int l = blockIdx.x, b = blockIdx.y, n = 2 * l + 1;
+    const int off = l * (4 * l * l - 1) / 3;
+    const double a = alpha[b], g = gamma[b];
+    const double* d = dtab + (size_t)beta_idx[b] * ntab + off;
+    for (int e = threadIdx.x; e < n * n; e += blockDim.x) {
+        const int m = e / n - l, nn = e % n - l;
+        double sn, cs;
+        sincos(-(m * a + nn * g), &sn, &cs);
+        D[(size_t)b * ntab + off + e] = make_double2(d[e] * cs, d[e] * sn);
+    }
+}
+
+// arg-max of the correlation in the order the reference reads it in (average.py:936-940: [beta, alpha, gamma], tabulated at
+// the angles whose flip alpha -> 2 pi - alpha, gamma -> 2 pi - gamma is the aligning rotation -- oracle/alignment.py
+// mean_C_layout): the key of element C[j][bi][k] is bi nb^2 + ((-j) mod nb) nb + ((-k) mod nb); the first maximum in that order
+// wins, as numpy's argmax does.  One workgroup per restart.
+__global__ void __launch_bounds__(1024) k_so3_argmax(const double* __restrict__ C, int nb, long long* __restrict__ arg, double* __restrict__ vmax) {
+    __shared__ double s_v[16];
+    __shared__ long long s_k[16];
+    const int b = blockIdx.x;
+    const double* Cb = C + (size_t)b * nb * nb * nb;
+    double best = -HUGE_VAL;
+    long long key = 0x7fffffffffffffffLL;
+    for (int e = threadIdx.x; e < nb * nb * nb; e += blockDim.x) {
+        const int j = e / (nb * nb), bi = (e / nb) % nb, k = e % nb;
+        const long long kk = (long long)bi * nb * nb + (long long)((nb - j) % nb) * nb + (nb - k) % nb;
+        const double v = Cb[e];
+        if (v > best || (v == best && kk < key)) {
+            best = v;
+            key = kk;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const double v2 = __shfl_xor(best, o, 64);
+        const long long k2 = __shfl_xor(key, o, 64);
+        if (v2 > best || (v2 == best && k2 < key)) {
+            best = v2;
+            key = k2;
+        }
+    }
+    if ((threadIdx.x & 63) == 0) {
+        s_v[threadIdx.x >> 6] = best;
+        s_k[threadIdx.x >> 6] = key;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int wv = 1; wv < (int)(blockDim.x >> 6); ++wv)
+            if (s_v[wv] > best || (s_v[wv] == best && s_k[wv] < key)) {
+                best = s_v[wv];
+                key = s_k[wv];
+            }
+        arg[b] = key;
+        vmax[b] = best;
+    }
+}
+
 static int so3_ntab(int L) { return (L + 1) * (2 * L + 1) * (2 * L + 3) / 3; }
+
+// enqueue + wait: C of (ref, sig) into d_so3_C
+static int so3_correlate(mtip_ctx* c, const mtip_cdouble* ref, const mtip_cdouble* sig, int r_lo, int r_hi) {
+    const int nb = 2 * c->so3_bw, ntab = so3_ntab(c->L);
+    MTIP_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    MTIP_HIP_CHECK(c, mtip_copy(c, c->d_c[0], ref, c->C * sizeof(double2), hipMemcpyHostToDevice));
+    MTIP_HIP_CHECK(c, mtip_copy(c, c->d_c[1], sig, (size_t)c->B * c->C * sizeof(double2), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_so3_T, dim3((unsigned)(c->L + 1), (unsigned)c->B), dim3(256), 0, c->stream, (const double2*)c->d_c[0],
+                       (const double2*)c->d_c[1], c->d_so3_T, c->N, c->nlm, ntab, r_lo, r_hi);
+    hipLaunchKernelGGL(k_so3_S, dim3((unsigned)nb, (unsigned)c->B), dim3(256), 0, c->stream, (const double2*)c->d_so3_T,
+                       (const double*)c->d_so3_d, c->d_so3_S, c->L, ntab);
+    hipLaunchKernelGGL(k_so3_P, dim3((unsigned)nb, (unsigned)c->B), dim3(256), 0, c->stream, (const double2*)c->d_so3_S,
+                       (const double2*)c->d_so3_tw, c->d_so3_P, c->L);
+    hipLaunchKernelGGL(k_so3_C, dim3((unsigned)nb, (unsigned)c->B), dim3(256), 0, c->stream, (const double2*)c->d_so3_P,
+                       (const double2*)c->d_so3_tw, c->d_so3_C, c->L);
+    MTIP_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        c->err = std::string("so3 correlation: ") + hipGetErrorString(e);
+        return MTIP_EHIP;
+    }
+    return MTIP_OK;
+}
 
 extern "C" {
 
@@ -142,23 +226,79 @@ int mtip_op_so3_correlation(mtip_ctx* c, const mtip_cdouble* ref, const mtip_cdo
         return MTIP_EINVAL;
     }
     (void)hipSetDevice(c->device);
-    const int nb = 2 * c->so3_bw, ntab = so3_ntab(c->L);
-    MTIP_HIP_CHECK(c, hipStreamSynchronize(c->stream));
-    MTIP_HIP_CHECK(c, mtip_copy(c, c->d_c[0], ref, c->C * sizeof(double2), hipMemcpyHostToDevice));
-    MTIP_HIP_CHECK(c, mtip_copy(c, c->d_c[1], sig, (size_t)c->B * c->C * sizeof(double2), hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_so3_T, dim3((unsigned)(c->L + 1), (unsigned)c->B), dim3(256), 0, c->stream, (const double2*)c->d_c[0],
-                       (const double2*)c->d_c[1], c->d_so3_T, c->N, c->nlm, ntab, r_lo, r_hi);
-    hipLaunchKernelGGL(k_so3_S, dim3((unsigned)nb, (unsigned)c->B), dim3(256), 0, c->stream, (const double2*)c->d_so3_T,
-                       (const double*)c->d_so3_d, c->d_so3_S, c->L, ntab);
-    hipLaunchKernelGGL(k_so3_P, dim3((unsigned)nb, (unsigned)c->B), dim3(256), 0, c->stream, (const double2*)c->d_so3_S,
-                       (const double2*)c->d_so3_tw, c->d_so3_P, c->L);
-    hipLaunchKernelGGL(k_so3_C, dim3((unsigned)nb, (unsigned)c->B), dim3(256), 0, c->stream, (const double2*)c->d_so3_P,
-                       (const double2*)c->d_so3_tw, c->d_so3_C, c->L);
-    MTIP_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    const int nb = 2 * c->so3_bw;
+    const int rc = so3_correlate(c, ref, sig, r_lo, r_hi);
+    if (rc != MTIP_OK) return rc;
     MTIP_HIP_CHECK(c, mtip_copy(c, C, c->d_so3_C, (size_t)c->B * nb * nb * nb * sizeof(double), hipMemcpyDeviceToHost));
+    return MTIP_OK;
+}
+
+/* the correlation and, per restart, its arg-max in the reference's reading order (see k_so3_argmax): arg (B) int64 =
+ * i_beta nb^2 + i_alpha nb + i_gamma of average.py:936-938's argmax, vmax (B) the maximum; C (B, nb, nb, nb) is copied out too
+ * unless null.  All buffers host or device memory. */
+int mtip_op_so3_find_rotation(mtip_ctx* c, const mtip_cdouble* ref, const mtip_cdouble* sig, int r_lo, int r_hi, int64_t* arg,
+                              double* vmax, double* C) {
+    if (!c) return MTIP_EINVAL;
+    if (c->so3_bw == 0) {
+        c->err = "mtip_set_so3_tables has not been called";
+        return MTIP_ESTATE;
+    }
+    if (!ref || !sig || !arg || !vmax || r_lo < 0 || r_hi > c->N || r_lo >= r_hi) {
+        c->err = "so3_find_rotation: null buffer or bad shell range";
+        return MTIP_EINVAL;
+    }
+    (void)hipSetDevice(c->device);
+    const int nb = 2 * c->so3_bw;
+    const int rc = so3_correlate(c, ref, sig, r_lo, r_hi);
+    if (rc != MTIP_OK) return rc;
+    // (d_so3_P is free again: the first words of it take the B results)
+    long long* d_arg = reinterpret_cast<long long*>(c->d_so3_P);
+    double* d_max = reinterpret_cast<double*>(c->d_so3_P) + c->B;
+    hipLaunchKernelGGL(k_so3_argmax, dim3((unsigned)c->B), dim3(1024), 0, c->stream, (const double*)c->d_so3_C, nb, d_arg, d_max);
+    MTIP_HIP_CHECK(c, mtip_copy(c, arg, d_arg, (size_t)c->B * sizeof(long long), hipMemcpyDeviceToHost));
+    MTIP_HIP_CHECK(c, mtip_copy(c, vmax, d_max, (size_t)c->B * sizeof(double), hipMemcpyDeviceToHost));
+    if (C) MTIP_HIP_CHECK(c, mtip_copy(c, C, c->d_so3_C, (size_t)c->B * nb * nb * nb * sizeof(double), hipMemcpyDeviceToHost));
+    return MTIP_OK;
+}
+
+/* rotate_coefficients for Euler angles whose beta is sample beta_index[b] of the SO(3) grid (what find_rotation hands out):
+ * D^l_mn = e^{-i m alpha} d^l_mn(beta) e^{-i n gamma} is built on the device from the Wigner table */
+int mtip_op_rotate_coefficients_grid(mtip_ctx* c, const mtip_cdouble* coeff, const int32_t* beta_index, const double* alpha,
+                                     const double* gamma, mtip_cdouble* out) {
+    if (!c) return MTIP_EINVAL;
+    if (c->so3_bw == 0) {
+        c->err = "mtip_set_so3_tables has not been called";
+        return MTIP_ESTATE;
+    }
+    if (!coeff || !beta_index || !alpha || !gamma || !out) {
+        c->err = "rotate_coefficients_grid: null buffer";
+        return MTIP_EINVAL;
+    }
+    for (int b = 0; b < c->B; ++b)
+        if (beta_index[b] < 0 || beta_index[b] >= 2 * c->so3_bw) {
+            c->err = "rotate_coefficients_grid: beta index outside the SO(3) grid";
+            return MTIP_EINVAL;
+        }
+    (void)hipSetDevice(c->device);
+    const int ntab = so3_ntab(c->L);
+    MTIP_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    MTIP_HIP_CHECK(c, mtip_copy(c, c->d_c[0], coeff, (size_t)c->B * c->C * sizeof(double2), hipMemcpyHostToDevice));
+    // (angles and indices are host arrays of B entries: staged in the head of d_so3_S)
+    double* d_al = reinterpret_cast<double*>(c->d_so3_S);
+    double* d_ga = d_al + c->B;
+    int* d_bi = reinterpret_cast<int*>(d_ga + c->B);
+    MTIP_HIP_CHECK(c, mtip_copy(c, d_al, alpha, (size_t)c->B * sizeof(double), hipMemcpyHostToDevice));
+    MTIP_HIP_CHECK(c, mtip_copy(c, d_ga, gamma, (size_t)c->B * sizeof(double), hipMemcpyHostToDevice));
+    MTIP_HIP_CHECK(c, mtip_copy(c, d_bi, beta_index, (size_t)c->B * sizeof(int), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_so3_build_D, dim3((unsigned)(c->L + 1), (unsigned)c->B), dim3(256), 0, c->stream, (const double*)c->d_so3_d,
+                       (const int*)d_bi, (const double*)d_al, (const double*)d_ga, c->d_so3_D, ntab);
+    hipLaunchKernelGGL(k_rotate_coeff, dim3((unsigned)c->N, (unsigned)c->B), dim3(256), 0, c->stream, (const double2*)c->d_c[0],
+                       (const double2*)c->d_so3_D, c->d_c[1], c->N, c->L, c->nlm, ntab);
+    MTIP_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    MTIP_HIP_CHECK(c, mtip_copy(c, out, c->d_c[1], (size_t)c->B * c->C * sizeof(double2), hipMemcpyDeviceToHost));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
-        c->err = std::string("mtip_op_so3_correlation: ") + hipGetErrorString(e);
+        c->err = std::string("mtip_op_rotate_coefficients_grid: ") + hipGetErrorString(e);
         return MTIP_EHIP;
     }
     return MTIP_OK;

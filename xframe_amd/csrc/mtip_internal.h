@@ -333,9 +333,15 @@ struct ProfScope {
 // engine no longer stalls the kernels of the other engines of the process (measured in the worker: -20 % loop time).  The price:
 // nothing orders a null-stream copy against the stream's kernels any more -- every blocking copy therefore first waits for the
 // stream (free when it is idle, as in all setters), and memsets / device-to-device copies are enqueued ON the stream.
+// The caller's side of a copy (`kind` names the direction the ABI documents) may itself be device memory -- the averaging keeps
+// its batch in HBM between operator calls -- so the direction is left to the runtime (unified addressing); a device-to-device
+// hipMemcpy is ordered on the null stream, which this context's stream does not wait for: wait for it here.
 static inline hipError_t mtip_copy(mtip_ctx* c, void* dst, const void* src, size_t n, hipMemcpyKind kind) {
-    const hipError_t e = hipStreamSynchronize(c->stream);
-    return e != hipSuccess ? e : hipMemcpy(dst, src, n, kind);
+    (void)kind;
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) return e;
+    e = hipMemcpy(dst, src, n, hipMemcpyDefault);
+    return e != hipSuccess ? e : hipStreamSynchronize(nullptr);
 }
 
 static inline int div_up(long long a, long long b) { return (int)((a + b - 1) / b); }

@@ -79,6 +79,8 @@ _SIGNATURES = {
     'mtip_set_so3_tables': (C.c_int, [c_void, C.c_int, c_void]),
     'mtip_op_so3_correlation': (C.c_int, [c_void, c_void, c_void, C.c_int, C.c_int, c_void]),
     'mtip_op_rotate_coefficients': (C.c_int, [c_void, c_void, c_void, c_void]),
+    'mtip_op_so3_find_rotation': (C.c_int, [c_void, c_void, c_void, C.c_int, C.c_int, c_void, c_void, c_void]),
+    'mtip_op_rotate_coefficients_grid': (C.c_int, [c_void, c_void, c_void, c_void, c_void, c_void]),
     'mtip_op_hermitian_eig': (C.c_int, [c_void, C.c_int, C.c_int, c_void, c_void, c_void]),
     'mtip_op_symmetric_eig': (C.c_int, [c_void, C.c_int, C.c_int, c_void, c_void, c_void]),
     'mtip_profile': (C.c_int, [c_void, C.c_int]),
@@ -102,6 +104,14 @@ def load(path=None):
     if not os.path.exists(path):
         raise MtipError(f'{path} not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
                         '(hipcc --offload-arch=gfx950). There is no CPU fallback.')
+    # One HIP runtime per process: the torch wheel bundles its own libamdhip64.so.7 (+ libhsa-runtime64) and /opt/rocm holds
+    # another with the same soname.  Whichever is loaded first serves both; with this library first, torch's later import mixes
+    # its bundled HSA runtime with /opt/rocm's HIP and finds "No HIP GPUs", and device memory of one runtime is unknown to the
+    # other.  The averaging hands torch device tensors to the operators, so torch goes first.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(path)
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError = ABI mismatch: fail loudly

@@ -2,13 +2,16 @@
 359-627, ``Alignment`` 729-1111): centre the reconstructions, normalise them, align every one (and its point inverse) to
 the reference by the SO(3) correlation of their harmonic coefficients, average the aligned ones and compute the PRTF.
 
-Where the reference forks one process per reconstruction and runs numpy / shtns / pysofft in each, here all transforms
-(FT, SHT), the SO(3) correlation and the rotation of the coefficients run on the device for a whole batch of
-reconstructions per call (``csrc/k_align.hip``); centre of mass, arg-max over the Euler grid, the error integrals and the
-final mean are host numpy on the downloaded grids, as cheap as the downloads themselves.  With several ranks
-(``torch.distributed``: one process per GPU) every rank aligns its own restarts against the reference, which its owner
-broadcasts, and the sums of the aligned densities are all-reduced (RCCL over xGMI) -- the only collective of the
-``reconstruct -> average`` pipeline that moves grid-sized data.
+Where the reference forks one process per reconstruction and runs numpy / shtns / pysofft in each, here the batch of
+reconstructions stays in HBM from the first upload to the last download: torch tensors own the memory, the transforms (FT, SHT),
+the SO(3) correlation with its arg-max and the rotation of the coefficients are the engine's HIP kernels working on those tensors
+in place (``csrc/k_align.hip``, ``Engine.t_*``), and the glue between them -- centre-of-mass and error integrals (weighted sums),
+phase ramps, scaling, the sums over the selected alignments, the PRTF shell statistics -- is elementwise / reduction arithmetic on
+the same device tensors.  What crosses PCIe: the inputs once (unless they are device tensors already), a few scalars per
+reconstruction (centres, maxima, arg-max indices, errors -- the decisions are host logic, as they depend on each other in the
+reference's order), and the results.  With several ranks (``torch.distributed``: one process per GPU) every rank aligns its own
+restarts against the reference, which its owner broadcasts, and the sums of the aligned densities are all-reduced from the
+device buffers (RCCL over xGMI) -- the only collective of the ``reconstruct -> average`` pipeline that moves grid-sized data.
 
 pysofft (the reference's SO(3) library) is not available: conventions of the correlation / rotation are those of
 ``oracle/alignment.py`` (see its parity note); only their composition enters the result.  The flow around those two calls is
@@ -58,172 +61,256 @@ def normalize_density(d, d_min=False):
 
 
 class Alignment:
-    """average.py:729-1111 on a transforms engine (``Engine(settings, None, n_batch=B, max_q=...)`` of the reconstruction grid)."""
+    """average.py:729-1111 on a transforms engine (``Engine(settings, None, n_batch=B, max_q=...)`` of the reconstruction grid).
+    Works on torch tensors of the engine's device: stacks (n, Nq, n_theta, n_phi) complex128."""
 
-    def __init__(self, engine, opt=None):
-        self.e = engine
+    def __init__(self, engine, opt=None, device=None):
+        import torch
+        self.torch = torch
+        self.e = e = engine
         self.opt = dict(DEFAULTS)
         self.opt.update(opt or {})
-        self.L = engine.L
+        self.L = e.L
+        self.dev = torch.device(device) if device is not None else e.torch_device()
         self.soft_grid = np.stack(np.meshgrid(*hs.euler_grid(self.L + 1), indexing='ij'), -1)     # make_SO3_grid; edited in place
         self.results = {}
+        # weights of the plain SphericalIntegrator (mathLibrary.py:1223-1232) and of the centre of mass (misk.py:295-312), the
+        # cartesian components of the reciprocal grid points for the shift phases (fxs_Projections.py:1436-1443): device constants
+        wr, wt = hs.integrator_weights(e.rs, e.n_theta)
+        st, ct = np.sin(e.theta)[None, :, None], np.cos(e.theta)[None, :, None]
+        cp, sp = np.cos(e.phi)[None, None, :], np.sin(e.phi)[None, None, :]
+        w0 = np.broadcast_to(wr[:, None, None] * wt[None, :, None], e.shape)
+        r = np.asarray(e.rs)[:, None, None]
+        self.W = torch.from_numpy(np.stack([w0, w0 * r * st * cp, w0 * r * st * sp, w0 * r * ct * np.ones_like(cp)])).to(self.dev)
+        q = np.asarray(e.qs)[:, None, None]
+        self.K = torch.from_numpy(np.stack([q * st * cp, q * st * sp, q * ct * np.ones_like(cp)])).to(self.dev)
+        self.volume = 4 / 3 * np.pi * np.max(e.rs) ** 3
 
-    # -- batched transforms: lists of grids -> lists, in chunks of the engine's batch size
-    def _batched(self, fn, arrays, out_shape=None):
-        B, out = self.e.B, []
-        for i in range(0, len(arrays), B):
-            chunk = list(arrays[i:i + B])
-            pad = B - len(chunk)
-            res = fn(np.stack(chunk + [chunk[-1]] * pad))
-            out.extend(res[:len(chunk)])
-        return out
+    # -- helpers
+    def to_device(self, x):
+        t = self.torch
+        if not t.is_tensor(x):
+            x = t.from_numpy(np.ascontiguousarray(x, dtype=np.complex128))
+        return x.to(self.dev, dtype=t.complex128)
 
-    def ft(self, grids):
-        return self._batched(lambda g: self.e.fourier_transform(g), grids)
+    def _batched(self, fn, X):
+        """X (n, ...) -> fn over chunks of the engine's batch size (the last chunk padded with its last item)"""
+        t, B, n = self.torch, self.e.B, X.shape[0]
+        out = []
+        for i in range(0, n, B):
+            chunk = X[i:i + B]
+            m = chunk.shape[0]
+            if m < B:
+                chunk = t.cat([chunk, chunk[-1:].expand(B - m, *chunk.shape[1:])])
+            out.append(fn(chunk.contiguous())[:m])
+        return t.cat(out) if len(out) > 1 else out[0]
 
-    def ift(self, grids):
-        return self._batched(lambda g: self.e.fourier_transform(g, True), grids)
+    def ft(self, X):
+        return self._batched(lambda g: self.e.t_fourier_transform(g), X)
 
-    def sht(self, grids):
-        return self._batched(lambda g: self.e.sht_forward(g), grids)
+    def ift(self, X):
+        return self._batched(lambda g: self.e.t_fourier_transform(g, True), X)
 
-    def isht(self, coeffs):
-        return self._batched(lambda c: self.e.sht_inverse(c), coeffs)
+    def sht(self, X):
+        return self._batched(lambda g: self.e.t_sht_forward(g), X)
 
-    def shift_to_center(self, densities, ft_densities):
-        """assemble_shift_to_center (1007-1020) for a list of reconstructions: (IFT(FT(rho) e^{i k c}), F e^{i k c}, c)"""
-        e = self.e
-        centers = [hs.calc_center(e.rs, e.theta, e.phi, d) for d in densities]
-        phases = [hs.shift_phases(e.qs, e.theta, e.phi, c, opposite_direction=True) for c in centers]
-        shifted = self.ift([f * p for f, p in zip(self.ft(densities), phases)])
-        return shifted, [f * p for f, p in zip(ft_densities, phases)], centers
+    def isht(self, Cf):
+        return self._batched(lambda c: self.e.t_sht_inverse(c), Cf)
 
-    def correlations(self, ref_coeff, sig_coeffs):
-        """mean_C of find_rotation (920-935) for a list of signals, in the layout the reference reads it in: [beta, alpha, gamma],
-        tabulated at the angles whose flip is the aligning rotation (oracle/alignment.py mean_C_layout)"""
-        r_lim = self.opt['find_rotation'].get('r_limit_ids', [0, self.e.N])
-        r_lim = [int(r_lim[0]), int(r_lim[1])]                      # the reference reads entries 0 and 1 (soft_plugin.py:92-94)
-        Cs = self._batched(lambda c: self.e.so3_correlation(ref_coeff, c, r_lim), sig_coeffs)
-        n = 2 * (self.L + 1)
-        flip = (-np.arange(n)) % n
-        return [C[flip][:, :, flip].transpose(1, 0, 2) for C in Cs]
+    def integrate_normed(self, V):
+        """SphericalIntegrator.integrate_normed (mathLibrary.py:1223-1237) of real stacks (n, ...): (n,) on the host"""
+        return ((V * self.W[0]).sum(dim=(1, 2, 3)) / self.volume).cpu().numpy()
 
-    def pick_rotation(self, mean_C):
-        """find_rotation (936-946), literally: arg-max in the reference's order, the grid entry is a VIEW and is flipped in place"""
-        am = np.unravel_index(np.argmax(mean_C), mean_C.shape)
+    def centers(self, R):
+        """generate_calc_center (misk.py:295-312): centres of mass of Re(rho), spherical coordinates, (n, 3) on the host"""
+        # (elementwise product + sum: einsum would hand this 4 x 10^6 contraction to a BLAS GEMM of a hopeless shape, 112 ms)
+        re = R.real
+        m = self.torch.stack([(re * self.W[k]).sum(dim=(1, 2, 3)) for k in range(4)], dim=1).cpu().numpy()
+        total = np.where(m[:, 0] == 0, 1.0, m[:, 0])
+        return np.stack([hs.cartesian_to_spherical(m[i, 1:] / total[i]) for i in range(len(m))])
+
+    def phases(self, vectors, opposite_direction=False):
+        """generate_shift_by_operator (fxs_Projections.py:1419-1444): exp(-i s k.c) for spherical vectors (n, 3)"""
+        t = self.torch
+        pre = -1.0 if opposite_direction else 1.0
+        c = t.from_numpy(np.stack([hs.spherical_to_cartesian(np.asarray(v, dtype=float)) for v in vectors])).to(self.dev)
+        kc = sum(self.K[k][None] * c[:, k, None, None, None] for k in range(3))
+        return t.polar(t.ones_like(kc), -pre * kc)
+
+    def shift_to_center(self, R, F):
+        """assemble_shift_to_center (1007-1020) for stacks: (IFT(FT(rho) e^{i k c}), F e^{i k c}, c)"""
+        c = self.centers(R)
+        ph = self.phases(c, opposite_direction=True)
+        return self.ift(self.ft(R) * ph), F * ph, c
+
+    def pick_rotation(self, am):
+        """find_rotation (936-946), literally: the grid entry at the arg-max (i_beta, i_alpha, i_gamma) is a VIEW and is flipped in place"""
         euler = self.soft_grid[am[1], am[0], am[2]]
         euler[0] = 2 * np.pi - euler[0]
         euler[2] = 2 * np.pi - euler[2]
         return euler
 
-    def rotate(self, coeffs, eulers):
-        B, out = self.e.B, []
-        for i in range(0, len(coeffs), B):
-            cc, ee = list(coeffs[i:i + B]), list(eulers[i:i + B])
-            pad = B - len(cc)
-            res = self.e.rotate_coefficients(np.stack(cc + [cc[-1]] * pad), np.stack(ee + [ee[-1]] * pad))
-            out.extend(res[:len(cc)])
-        return out
+    def metric_layout(self, C):
+        """a correlation of the device ([alpha, beta, gamma]) in the layout the reference stores it in (oracle mean_C_layout)"""
+        t = self.torch
+        n = C.shape[0]
+        flip = t.from_numpy((-np.arange(n)) % n).to(C.device)
+        return C.index_select(0, flip).index_select(2, flip).permute(1, 0, 2)
 
-    def apply_to(self, reference, signals):
-        """alignment_routine (1089-1109) for a list of signals: each signal and its point inverse are aligned (rotate_signal
-        sketch 970-975: the rotation found on the densities is applied to both halves), the one with the smaller difference to the
+    def apply_to(self, reference, S_rho, S_F):
+        """alignment_routine (1089-1109) for stacks of signals: each signal and its point inverse are aligned (rotate_signal sketch
+        970-975: the rotation found on the densities is applied to both halves), the one with the smaller difference to the
         reference is kept.  Transforms, correlations and rotations run batched over all signals and their inverses; the angles are
         picked in the reference's order (signal 0, its inverse, signal 1, ...) because picking edits the grid.  Returns a list of
-        dicts like the reference's."""
-        e = self.e
-        inv_d = self.ift([f.conj() for f in self.ft([s[0] for s in signals])])
-        both = [[s[0], s[1]] for s in signals] + [[d, s[1].conj()] for d, s in zip(inv_d, signals)]
-        n = len(signals)
-        norm = integrate_normed(e.rs, e.n_theta, reference.real ** 2)
+        dicts like the reference's (tensors on the device)."""
+        t, e = self.torch, self.e
+        n = S_rho.shape[0]
+        keep_metric = bool(self.opt.get('keep_rotation_metrics', True))
+        inv_d = self.ift(self.ft(S_rho).conj().resolve_conj())
+        both_rho = t.cat([S_rho, inv_d])
+        both_F = t.cat([S_F, S_F.conj().resolve_conj()])
+        norm = float(self.integrate_normed(reference.real[None] ** 2)[0])
         norm = norm if norm != 0 else 1
-        ref_c = self.e.sht_forward(np.stack([reference] * self.e.B))[0]
-        sig_c = self.sht([s[0] for s in both])
-        ft_c = self.sht([s[1] for s in both])
-        Cs = self.correlations(ref_c, sig_c)
-        eulers, at_pick = [None] * (2 * n), [None] * (2 * n)
+        ref_c = self.sht(reference[None])[0].contiguous()
+        sig_c = self.sht(both_rho)
+        ft_c = self.sht(both_F)
+        r_lim = self.opt['find_rotation'].get('r_limit_ids', [0, e.N])
+        r_lim = [int(r_lim[0]), int(r_lim[1])]                      # the reference reads entries 0 and 1 (soft_plugin.py:92-94)
+        args, metrics = [], []
+        B = e.B
+        for i in range(0, 2 * n, B):
+            chunk = sig_c[i:i + B]
+            m = chunk.shape[0]
+            if m < B:
+                chunk = t.cat([chunk, chunk[-1:].expand(B - m, *chunk.shape[1:])])
+            am, _, Cm = e.t_find_rotation(ref_c, chunk.contiguous(), r_lim, keep_metric)
+            args.extend(am[:m])
+            metrics.extend([Cm[j] for j in range(m)] if keep_metric else [None] * m)
+        eulers, at_pick, beta_ids = [None] * (2 * n), np.zeros((2 * n, 3)), np.zeros(2 * n, np.int32)
         for i in range(n):
             for j in (i, n + i):
-                eulers[j] = self.pick_rotation(Cs[j])           # the view the reference stores: a later pick of the same point edits it
-                at_pick[j] = np.array(eulers[j])                # what the reference rotates with (it rotates right after the pick)
-        dens = self.isht(self.rotate(sig_c, at_pick))
-        fts = self.isht(self.rotate(ft_c, at_pick))
-        errs = [integrate_normed(e.rs, e.n_theta, (reference.real - d.real) ** 2) / norm for d in dens]
+                eulers[j] = self.pick_rotation(args[j])          # the view the reference stores: a later pick of the same point edits it
+                at_pick[j] = eulers[j]                           # what the reference rotates with (it rotates right after the pick)
+                beta_ids[j] = args[j][0]
+
+        def rotate(Cf):
+            out = []
+            for i in range(0, 2 * n, B):
+                chunk, idx = Cf[i:i + B], np.arange(i, min(i + B, 2 * n))
+                m = chunk.shape[0]
+                if m < B:
+                    chunk = t.cat([chunk, chunk[-1:].expand(B - m, *chunk.shape[1:])])
+                    idx = np.concatenate([idx, np.full(B - m, idx[-1])])
+                out.append(e.t_rotate_grid(chunk.contiguous(), beta_ids[idx], at_pick[idx, 0], at_pick[idx, 2])[:m])
+            return t.cat(out) if len(out) > 1 else out[0]
+        dens = self.isht(rotate(sig_c))
+        fts = self.isht(rotate(ft_c))
+        errs = self.integrate_normed((reference.real[None] - dens.real) ** 2) / norm
         res = []
         for i in range(n):
             k = i if errs[i] < errs[n + i] else n + i
-            res.append({'densities': [dens[k], fts[k]], 'errors': [errs[k]], 'rotation_angles': [eulers[k]],
-                        'rotation_metrics': [Cs[k]], 'inverted': k >= n})
+            res.append({'densities': [dens[k], fts[k]], 'errors': [float(errs[k])], 'rotation_angles': [eulers[k]],
+                        'rotation_metrics': [metrics[k]], 'inverted': k >= n})
         return res
 
 
+def _prtf(t, a1, a2, b1, b2):
+    """resolution_metrics.py:62-78 on device tensors: per-shell mean and standard deviation, on the host"""
+    nd = t.ones_like(a1)
+    nz = (b1 != 0) & (b2 != 0)
+    den = t.where(nz, b1 * b2.conj(), t.ones_like(b1))
+    nd = t.where(nz, a1 * a2.conj() / den, nd)
+    nd = t.where(~nz & (a1 != 0) & (a2 != 0), t.zeros_like(nd), nd)
+    nd = t.sqrt(nd)
+    mean = nd.mean(dim=(1, 2))
+    std = t.sqrt(((nd - mean[:, None, None]).abs() ** 2).mean(dim=(1, 2)))
+    return mean.cpu().numpy(), std.cpu().numpy()
+
+
+def _normalize(t, d, d_min=False):
+    """average.py:721-727"""
+    if isinstance(d_min, bool):
+        d_min = float(d.real.min())
+    return (d - d_min) / (float(d.real.max()) - d_min)
+
+
 def average_reconstructions(engine, reconstructions, errors, opt=None, dist=None, device=None):
-    """run_3d (average.py:359-570).  reconstructions: list of (real_density, reciprocal_density) of THIS rank, errors: their
-    selection errors.  dist: torch.distributed module of an initialised multi-rank job (None: single process); then the
-    reference is the globally best reconstruction and the aligned sums are all-reduced.  Returns the result dict of the
-    reference (``average``, ``resolution_metrics``, ``centered_average``, ``aligned`` (local ones), ...)."""
+    """run_3d (average.py:359-570).  reconstructions: list of (real_density, reciprocal_density) of THIS rank -- numpy arrays, or
+    torch tensors already on the engine's device -- errors: their selection errors.  dist: torch.distributed module of an
+    initialised multi-rank job (None: single process); then the reference is the globally best reconstruction and the aligned
+    sums are all-reduced.  Returns the result dict of the reference (``average``, ``resolution_metrics``, ``centered_average``,
+    ``aligned`` (local ones), ...) as numpy arrays; with ``opt['keep_on_device']`` the grid-sized entries of ``aligned`` and
+    ``rotation_metric`` stay torch tensors on the device (the averages are always downloaded)."""
+    import torch as t
     o = dict(DEFAULTS)
     o.update(opt or {})
-    al = Alignment(engine, o)
-    e = engine
-    recs = [[np.array(r[0], dtype=complex), np.array(r[1], dtype=complex)] for r in reconstructions]
+    al = Alignment(engine, o, device)
+    e, dv = engine, al.dev
+    n_in = len(reconstructions)
     errors = np.asarray(errors, dtype=float)
-    if o['center_reconstructions'] and recs:
-        d, f, _ = al.shift_to_center([r[0] for r in recs], [r[1] for r in recs])
-        recs = [[a, b] for a, b in zip(d, f)]
-    scales = np.ones(len(recs))
-    if o['normalize_reconstructions']['use']:
-        for i, r in enumerate(recs):
-            if o['normalize_reconstructions']['mode'] == 'max':
-                if np.max(r[0]).real <= 0:
-                    continue
-                scale = np.max(r[0][r[0] > 0].real)
-            else:
-                scale = np.mean(r[0][r[0] > 0])               # (432-435: complex; only its real part reaches scaling_factors)
-            scales[i] = np.real(scale)
-            recs[i] = [r[0] / scale, r[1] / scale]
+    if n_in:
+        R = t.stack([al.to_device(r[0]) for r in reconstructions])
+        F = t.stack([al.to_device(r[1]) for r in reconstructions])
+    else:
+        R = F = t.zeros((0,) + e.shape, dtype=t.complex128, device=dv)
+    if o['center_reconstructions'] and n_in:
+        R, F, _ = al.shift_to_center(R, F)
+    scales = np.ones(n_in)
+    if o['normalize_reconstructions']['use'] and n_in:
+        fac = np.ones(n_in, complex)
+        if o['normalize_reconstructions']['mode'] == 'max':
+            # 424-429: skipped when np.max (lexicographic on complex) has a real part <= 0; else the largest real part
+            mx = R.real.amax(dim=(1, 2, 3)).cpu().numpy()
+            fac = np.where(mx > 0, mx, 1.0).astype(complex)
+        else:
+            # 432-435: the mean over the entries > 0 (numpy compares complex numbers lexicographically); complex, and only its
+            # real part reaches scaling_factors
+            pos = (R.real > 0) | ((R.real == 0) & (R.imag > 0))
+            fac = ((R * pos).sum(dim=(1, 2, 3)) / pos.sum(dim=(1, 2, 3))).cpu().numpy()
+        scales = np.real(fac).astype(float)
+        ft_ = t.from_numpy(np.ascontiguousarray(fac)).to(dv)[:, None, None, None]
+        R, F = R / ft_, F / ft_
     # ---- reference: the reconstruction with the lowest error (of all ranks)
     world = dist.get_world_size() if dist is not None else 1
     rank = dist.get_rank() if dist is not None else 0
     if world > 1:
-        import torch
         best_local = float(errors.min()) if len(errors) else np.inf
-        t = torch.tensor([best_local], dtype=torch.float64, device=device if device is not None else 'cpu')
-        allb = [torch.empty_like(t) for _ in range(world)]
-        dist.all_gather(allb, t)
+        tb = t.tensor([best_local], dtype=t.float64, device=dv)
+        allb = [t.empty_like(tb) for _ in range(world)]
+        dist.all_gather(allb, tb)
         owner = int(np.argmin([float(x.item()) for x in allb]))
     else:
         owner = 0
     ref_arg = int(np.argmin(errors)) if (rank == owner and len(errors)) else -1
-    if rank == owner:
-        reference = recs.pop(ref_arg)
+    keep = [i for i in range(n_in) if i != ref_arg]
     if world > 1:
-        import torch
-        buf = torch.empty((2,) + e.shape + (2,), dtype=torch.float64, device=device if device is not None else 'cpu')
+        buf = t.empty((2,) + e.shape + (2,), dtype=t.float64, device=dv)
         if rank == owner:
-            buf.copy_(torch.view_as_real(torch.from_numpy(np.stack(reference))))
+            buf.copy_(t.view_as_real(t.stack([R[ref_arg], F[ref_arg]])))
         dist.broadcast(buf, src=owner)
-        ref_arr = torch.view_as_complex(buf.cpu().contiguous()).numpy()
-        reference = [ref_arr[0].copy(), ref_arr[1].copy()]
+        ref_pair = t.view_as_complex(buf)
+        reference = [ref_pair[0].contiguous(), ref_pair[1].contiguous()]
+    else:
+        reference = [R[ref_arg].clone(), F[ref_arg].clone()]
+    S_rho, S_F = R[keep], F[keep]
     if o.get('pointinvert_reference', False):
-        ri = reference[1].conj()
-        reference = [al.ift([ri])[0], ri]
+        ri = reference[1].conj().resolve_conj()
+        reference = [al.ift(ri[None])[0], ri]
     # ---- align
-    outs = al.apply_to(reference[0].copy(), recs) if recs else []
+    outs = al.apply_to(reference[0], S_rho, S_F) if len(keep) else []
     limit = o['alignment_error_limit']
     loc_err = np.array([x['errors'][-1] for x in outs])
     # average.py:519-524, literally: the list of valid alignments starts with the reference but the list of their errors does
     # not, and the argsort of the errors indexes the former: the reference is always in, the last valid alignment (in
     # processing order: rank by rank, restart by restart) never is; then the list is cut to n_reconstructions
     if world > 1:
-        import torch
-        n_loc = torch.tensor([len(loc_err)], dtype=torch.int64, device=device if device is not None else 'cpu')
-        counts = [torch.empty_like(n_loc) for _ in range(world)]
+        n_loc = t.tensor([len(loc_err)], dtype=t.int64, device=dv)
+        counts = [t.empty_like(n_loc) for _ in range(world)]
         dist.all_gather(counts, n_loc)
         counts = [int(c.item()) for c in counts]
-        pad = torch.full((max(counts + [1]),), np.inf, dtype=torch.float64, device=device if device is not None else 'cpu')
-        pad[:len(loc_err)] = torch.from_numpy(loc_err)
-        alle = [torch.empty_like(pad) for _ in range(world)]
+        pad = t.full((max(counts + [1]),), np.inf, dtype=t.float64, device=dv)
+        pad[:len(loc_err)] = t.from_numpy(loc_err).to(dv)
+        alle = [t.empty_like(pad) for _ in range(world)]
         dist.all_gather(alle, pad)
         glob = [(rk, i, float(alle[rk][i].item())) for rk in range(world) for i in range(counts[rk])]
     else:
@@ -245,50 +332,52 @@ def average_reconstructions(engine, reconstructions, errors, opt=None, dist=None
                 aligned.append(reference)
         elif rk == rank:
             aligned.append(outs[i]['densities'])
-    # ---- sums over the selected alignments (all-reduced over the ranks), then the means
-    ftd = al.ft([a[0] for a in aligned]) if aligned else []
-    sums = np.zeros((4,) + e.shape, complex)
-    for a, fd in zip(aligned, ftd):
-        sums[0] += a[0]
-        sums[1] += a[1]
-        sums[2] += (a[1] * a[1].conj()).real
-        sums[3] += (fd * fd.conj()).real
+    # ---- sums over the selected alignments (all-reduced over the ranks from the device buffer), then the means
+    sums = t.zeros((4,) + e.shape, dtype=t.complex128, device=dv)
+    if aligned:
+        A_rho, A_F = t.stack([a[0] for a in aligned]), t.stack([a[1] for a in aligned])
+        ftd = al.ft(A_rho)
+        sums[0], sums[1] = A_rho.sum(0), A_F.sum(0)
+        sums[2] = (A_F.abs() ** 2).sum(0)
+        sums[3] = (ftd.abs() ** 2).sum(0)
     count = float(len(aligned))
     if world > 1:
-        import torch
-        t = torch.view_as_real(torch.from_numpy(sums)).contiguous()
-        n = torch.tensor([count], dtype=torch.float64)
-        if device is not None:
-            t, n = t.to(device), n.to(device)
-        dist.all_reduce(t)
-        dist.all_reduce(n)
-        sums = torch.view_as_complex(t.cpu().contiguous()).numpy()
-        count = float(n.cpu()[0])
+        tr = t.view_as_real(sums)
+        nn = t.tensor([count], dtype=t.float64, device=dv)
+        dist.all_reduce(tr)
+        dist.all_reduce(nn)
+        count = float(nn.cpu()[0])
     average = [sums[0] / count, sums[1] / count]
     I_ft, I_d = (sums[2] / count).real, (sums[3] / count).real
     # average.py:538: the averaged pair is centred BEFORE the metrics and the reference's shift operator multiplies its argument in
     # place (fxs_Projections.py:1442): the averaged reciprocal density that is saved and that enters 'PRTF' is the shifted one
-    cen = al.shift_to_center([average[0]], [average[1]])
+    cen = al.shift_to_center(average[0][None], average[1][None])
     average[1] = cen[1][0]
-    ft_avg = al.ft([average[0]])[0]
+    ft_avg = al.ft(average[0][None])[0]
     metrics = {}
     if o['resolution_metrics'].get('PRTF', False):
-        for name, args in (('PRTF', (ft_avg, average[1], np.sqrt(I_d), np.sqrt(I_ft))),
-                           ('PRTF_from_density', (ft_avg, ft_avg, np.sqrt(I_d), np.sqrt(I_d))),
-                           ('PRTF_from_ft_density', (average[1], average[1], np.sqrt(I_ft), np.sqrt(I_ft))),
-                           ('PRTF_ftI', (ft_avg, ft_avg, np.sqrt(I_ft), np.sqrt(I_ft)))):
-            p = PRTF(*args)
-            metrics[name], metrics[name + '_std'] = p
+        sd, sf = t.sqrt(I_d).to(t.complex128), t.sqrt(I_ft).to(t.complex128)
+        for name, args in (('PRTF', (ft_avg, average[1], sd, sf)), ('PRTF_from_density', (ft_avg, ft_avg, sd, sd)),
+                           ('PRTF_from_ft_density', (average[1], average[1], sf, sf)), ('PRTF_ftI', (ft_avg, ft_avg, sf, sf))):
+            metrics[name], metrics[name + '_std'] = _prtf(t, *args)
     dmin = o.get('average_normalization_min', False)
+    on_dev = bool(o.get('keep_on_device', False))
+
+    def out(x):
+        return x if on_dev else x.cpu().numpy()
+
+    def host(x):
+        return x.cpu().numpy()
     return {
-        'average': {'real_density': average[0], 'normalized_real_density': normalize_density(average[0], dmin),
-                    'reciprocal_density': average[1], 'intensity_from_densities': I_d, 'intensity_from_ft_densities': I_ft},
+        'average': {'real_density': host(average[0]), 'normalized_real_density': host(_normalize(t, average[0], dmin)),
+                    'reciprocal_density': host(average[1]), 'intensity_from_densities': host(I_d), 'intensity_from_ft_densities': host(I_ft)},
         'resolution_metrics': metrics,
-        'centered_average': {'real_density': cen[0][0], 'normalized_real_density': normalize_density(cen[0][0], dmin),
-                             'reciprocal_density': cen[1][0]},
-        'aligned': {str(i): {'real_density': a[0], 'reciprocal_density': a[1]} for i, a in enumerate(aligned)},
+        'centered_average': {'real_density': host(cen[0][0]), 'normalized_real_density': host(_normalize(t, cen[0][0], dmin)),
+                             'reciprocal_density': host(cen[1][0])},
+        'aligned': {str(i): {'real_density': out(a[0]), 'reciprocal_density': out(a[1])} for i, a in enumerate(aligned)},
         'n_averaged': int(count), 'alignment_errors': loc_err, 'reference_owner': owner, 'reference_arg': ref_arg,
         'rotation_angles': {str(i + 1): x['rotation_angles'] for i, x in enumerate(outs)},
+        'rotation_metric': {str(i + 1): [out(al.metric_layout(m)) for m in x['rotation_metrics'] if m is not None] for i, x in enumerate(outs)},
         'inverted': [x['inverted'] for x in outs],
         # average.py:479, 520: 0 for the reference, then the position (in this rank's list without the reference) of every valid one
         'average_ids': [0] + [i for i, x in enumerate(loc_err) if x < limit],

@@ -19,6 +19,8 @@ class Engine:
         """settings: resolved (or override) settings dict; data: invariants dict (may be None for a
         transforms-only engine, then ``max_q`` must be given)."""
         self.lib = _lib.load(lib_path)
+        self.device_index = int(device)
+        self.emulated = hasattr(self.lib, 'mtip_emulated')          # the CPU emulation of tests/emul: its device memory is host memory
         opt = resolve(settings)
         self.opt = opt
         g = opt['grid']
@@ -297,6 +299,66 @@ class Engine:
         D = np.ascontiguousarray(np.stack([hs.wigner_D_flat(self.L, e) for e in eulers]))
         out = np.empty_like(c)
         self._ck(self.lib.mtip_op_rotate_coefficients(self.ctx, _lib.ptr(c), _lib.ptr(D), _lib.ptr(out)))
+        return out
+
+    # ------------------------------------------------------------------ the same operators on device-resident batches
+    # torch tensors hold the memory (complex128, contiguous, leading dimension n_batch) on the context's device -- CPU tensors
+    # under the emulation; the operators read and write them in place in HBM, nothing crosses PCIe.
+    def torch_device(self):
+        import torch
+        return torch.device('cpu') if self.emulated else torch.device('cuda', self.device_index)
+
+    @staticmethod
+    def _tp(t):
+        assert t.is_contiguous()
+        return C.c_void_p(t.data_ptr())
+
+    def t_fourier_transform(self, g, inverse=False):
+        import torch
+        assert tuple(g.shape) == (self.B,) + self.shape and g.dtype == torch.complex128
+        out = torch.empty_like(g)
+        self._ck(self.lib.mtip_op_fourier_transform(self.ctx, self._tp(g), self._tp(out), int(inverse)))
+        return out
+
+    def t_sht_forward(self, g):
+        import torch
+        assert tuple(g.shape) == (self.B,) + self.shape and g.dtype == torch.complex128
+        out = torch.empty((self.B, self.N, self.nlm), dtype=torch.complex128, device=g.device)
+        self._ck(self.lib.mtip_op_sht_forward(self.ctx, self._tp(g), self._tp(out), 0))
+        return out
+
+    def t_sht_inverse(self, c):
+        import torch
+        assert tuple(c.shape) == (self.B, self.N, self.nlm) and c.dtype == torch.complex128
+        out = torch.empty((self.B,) + self.shape, dtype=torch.complex128, device=c.device)
+        self._ck(self.lib.mtip_op_sht_inverse(self.ctx, self._tp(c), self._tp(out)))
+        return out
+
+    def t_find_rotation(self, ref_coeff, sig_coeff, r_limit_ids=None, keep_metric=False):
+        """find_rotation (average.py:920-947) for a batch: (arg-max in the reference's reading order as (i_beta, i_alpha, i_gamma)
+        per restart, the maxima, the correlation (B, nb, nb, nb) [alpha, beta, gamma] on the device or None)"""
+        import torch
+        self._so3_setup()
+        assert tuple(ref_coeff.shape) == (self.N, self.nlm) and tuple(sig_coeff.shape) == (self.B, self.N, self.nlm)
+        lo, hi = (0, self.N) if r_limit_ids is None else (int(r_limit_ids[0]), int(r_limit_ids[1]))
+        nb = 2 * (self.L + 1)
+        arg = np.empty(self.B, np.int64)
+        vmax = np.empty(self.B)
+        Cm = torch.empty((self.B, nb, nb, nb), dtype=torch.float64, device=sig_coeff.device) if keep_metric else None
+        self._ck(self.lib.mtip_op_so3_find_rotation(self.ctx, self._tp(ref_coeff), self._tp(sig_coeff), lo, hi, _lib.ptr(arg),
+                                                    _lib.ptr(vmax), self._tp(Cm) if keep_metric else None))
+        return np.stack(np.unravel_index(arg, (nb, nb, nb)), axis=1), vmax, Cm
+
+    def t_rotate_grid(self, coeff, beta_index, alpha, gamma):
+        """rotate (average.py:948-960) by Euler angles (alpha[b], beta sample beta_index[b], gamma[b])"""
+        import torch
+        self._so3_setup()
+        assert tuple(coeff.shape) == (self.B, self.N, self.nlm) and coeff.dtype == torch.complex128
+        bi = np.ascontiguousarray(beta_index, dtype=np.int32)
+        al, ga = _lib.as_f64(alpha), _lib.as_f64(gamma)
+        assert bi.shape == (self.B,) and al.shape == (self.B,) and ga.shape == (self.B,)
+        out = torch.empty_like(coeff)
+        self._ck(self.lib.mtip_op_rotate_coefficients_grid(self.ctx, self._tp(coeff), _lib.ptr(bi), _lib.ptr(al), _lib.ptr(ga), self._tp(out)))
         return out
 
     # ------------------------------------------------------------------ state and loop
