@@ -86,6 +86,10 @@ int mtip_set_hankel_weights(mtip_ctx* ctx, const double* w_raw, double fwd_scale
 int mtip_set_projection_matrix(mtip_ctx* ctx, int l, const mtip_cdouble* V, int k_l,
                                const uint8_t* radial_mask, int used);
 int mtip_set_number_of_particles(mtip_ctx* ctx, double n_particles);   /* fxs_Projections.py:497,870 */
+/* projections.reciprocal.SO_freedom (fxs_Projections.py:493, 768-780): after every approximate_unknowns the element [4][2] of the
+ * unknowns of `order` loses its imaginary part before the unknowns are applied (the host ranks the orders,
+ * fxs_invariant_tools.py:1467-1486); order = -1 switches it off (default) */
+int mtip_set_so_freedom(mtip_ctx* ctx, int order);
 /* reference B_l = V_l V_l^+ masks for the deg2_invariant_l2_diff metric are derived internally
  * (fxs_IO_methods.py:408-447); enable = 1 evaluates it every step. */
 int mtip_set_deg2_metric(mtip_ctx* ctx, int enable);

@@ -155,6 +155,25 @@ def regrid_1d(values, old_points, new_points, interpolation='cubic'):
 
 
 # ----------------------------------------------------------------------------- reciprocal projection
+def rank_projection_matrices_3d(projection_matrices, orders, radial_points, radial_high_pass=0.15):
+    """fxs_invariant_tools.py:1467-1486 with RadialIntegrator(., 2) of mathLibrary.py:1270-1294: even non-zero orders ranked by
+    int int |B_l(q, q')|^2 q dq q' dq' over q, q' >= the high-pass radius, B_l = Re(V_l V_l^+) (1255); largest first."""
+    orders = np.asarray(orders)
+    hp = int((len(radial_points) - 1) * radial_high_pass)
+    r = np.asarray(radial_points)[hp:]
+    trapz = getattr(np, 'trapezoid', None) or np.trapz
+    mask = (orders % 2 == 0) & (orders != 0)
+    ids = np.nonzero(mask)[0]
+    metrics = []
+    for i in ids:
+        bl = (projection_matrices[i] @ projection_matrices[i].conj().T).real[hp:, hp:]
+        inner = trapz((bl * bl.conj()) * r[None, :], x=r, axis=-1)
+        metrics.append(trapz((inner * inner.conj()) * r, x=r, axis=-1))
+    metrics = np.array(metrics)
+    srt = np.argsort(metrics)[::-1]
+    return ids[srt], orders[ids[srt]], metrics[srt]
+
+
 class ReciprocalProjection:
     """fxs_Projections.py:443-930, dimensions == 3 only.
 
@@ -206,6 +225,12 @@ class ReciprocalProjection:
         # ---- approximate_unknowns precompute 753-754
         D2 = np.diag(self.radial_points) ** 2
         self.PDs = tuple(self.projection_matrices[i].T.conj() @ D2 for i in order_ids)
+        # SO_freedom 493, 768-780: the order with the largest radial L2 norm of its B_l gets one unknown made real
+        self.SO_order_id = None
+        if opt.get('SO_freedom', {}).get('use', False):
+            ids, _, _ = rank_projection_matrices_3d(self.projection_matrices, self.positive_orders, self.radial_points,
+                                                    opt['SO_freedom']['radial_high_pass'])
+            self.SO_order_id = int(ids[0])
         # calc_deg2_invariants 631-637
         self.deg2_invariants = harmonic_coeff_to_deg2_invariants_3d(self.projection_matrices)
         self.fixed_intensity = None
@@ -266,6 +291,15 @@ class ReciprocalProjection:
     # 752-767
     def approximate_unknowns(self, Ilm):
         unknowns = []
+        if self.SO_order_id is not None:
+            # 771-777, literally: the coefficient list is walked from order 0 next to the per-used-order lists (the same thing when
+            # all orders are used), then element [4, 2] of the chosen order's unknowns loses its imaginary part
+            for PD, I in zip(self.PDs, Ilm):
+                u, s, vh = np.linalg.svd(PD @ I, full_matrices=False)
+                unknowns.append(u @ vh)
+            u_SO = unknowns[self.SO_order_id]
+            u_SO[4, 2] = u_SO[4, 2].real
+            return tuple(unknowns)
         for PD, oid in zip(self.PDs, self.used_orders.values()):
             u, s, vh = np.linalg.svd(PD @ Ilm[oid], full_matrices=False)
             unknowns.append(u @ vh)

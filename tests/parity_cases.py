@@ -454,7 +454,7 @@ def check_projection_vs_oracle(N, L, lib_path=None, n_batch=2, seed=1):
     e.close()
 
 
-def check_projection_real_vs_oracle(N, L, lib_path=None, n_batch=2, seed=1, reciprocal_opt=None, imag_residue=None):
+def check_projection_real_vs_oracle(N, L, lib_path=None, n_batch=2, seed=1, reciprocal_opt=None, imag_residue=None, so_order=None):
     """The real-arithmetic form of the projection (k_projr.hip: real V_l, coefficients of a real intensity) against the
     oracle's complex numpy-SVD route (fxs_Projections.py:752-767, 832-871): projected coefficients, unknowns, and the
     general (complex) kernel on the same input; second call = warm start."""
@@ -479,6 +479,10 @@ def check_projection_real_vs_oracle(N, L, lib_path=None, n_batch=2, seed=1, reci
     finally:
         os.environ.pop('MTIP_PROJ_REAL_TOL', None)
     om = OM.MTIP(opt, data)
+    if so_order is not None:
+        # SO_freedom on a given order (the ranking of the synthetic particle picks l = 2, whose column 2 is m = 0: real anyway)
+        e._ck(e.lib.mtip_set_so_freedom(e.ctx, int(so_order)))
+        om.rp.SO_order_id = int(so_order)
     rng = np.random.default_rng(seed)
     for rep in range(3):                                   # later calls: warm start from the previous V_r
         grid = rng.uniform(0.0, 1.0, (n_batch, N, sht.n_theta, sht.n_phi)) * rng.uniform(0.5, 2.0, (n_batch, N, 1, 1))
@@ -505,6 +509,9 @@ def check_projection_real_vs_oracle(N, L, lib_path=None, n_batch=2, seed=1, reci
         junk[:, :, l * l:l * l + l] = 1.0 + 2.0j
     same = rel_l2(e.project_coefficients(junk, real_intensity=True), proj) < TOL_SHT
     assert same, 'the real-arithmetic projection was expected to run'
+    if so_order is not None:
+        U = e.unknowns(0)[so_order]
+        assert U[4, 2].imag == 0 and np.abs(U[4, 1].imag) > 1e-6       # the one element lost its imaginary part, its neighbours kept theirs
     if imag_residue:
         e2 = Engine(opt, data, n_batch=n_batch, lib_path=lib_path)      # without the opt-in: the general kernels
         assert rel_l2(e2.project_coefficients(junk, real_intensity=True), proj) > 1e-3
@@ -738,7 +745,7 @@ def variant_settings(N, L, name):
     return OM.deep_update(opt, mg.VARIANTS[name])
 
 
-VARIANT_NAMES = ('nonfxs', 'swcenter', 'main_recip_mean', 'main_recip_max', 'main_recip_min', 'main_recip_prod')
+VARIANT_NAMES = ('nonfxs', 'swcenter', 'main_recip_mean', 'main_recip_max', 'main_recip_min', 'main_recip_prod', 'so_freedom')
 
 
 def check_variant_golden(g, v, name, lib_path=None, use_oracle=False, n_restarts=2):

@@ -130,10 +130,16 @@ def test_extract_vs_numpy(emul_lib):
 
 
 @pytest.mark.parametrize('N,L,ropt', [(16, 4, None), (24, 10, None), (16, 4, {'odd_orders_to_0': False, 'use_averaged_intensity': False}),
-                                      (16, 4, {'used_order_ids': np.arange(3)})])
+                                      (16, 4, {'used_order_ids': np.arange(3)}),
+                                      (16, 4, {'SO_freedom': {'use': True, 'radial_high_pass': 0.2}})])
 def test_projection_real_vs_oracle(emul_lib, N, L, ropt):
     """the real-arithmetic projection kernel (k_projr.hip) on the emulator"""
     PC.check_projection_real_vs_oracle(N, L, emul_lib, n_batch=1, reciprocal_opt=ropt)
+
+
+def test_so_freedom_on_a_higher_order(emul_lib):
+    """SO_freedom (fxs_Projections.py:768-780) forced onto l = 4, where column 2 is m = -2 and the correction is not a no-op"""
+    PC.check_projection_real_vs_oracle(16, 6, emul_lib, n_batch=1, so_order=4)
 
 
 def test_projection_real_tolerance_opt_in(emul_lib):

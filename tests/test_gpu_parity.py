@@ -107,9 +107,17 @@ def test_projection_real_vs_oracle(N, L):
     PC.check_projection_real_vs_oracle(N, L)
 
 
-@pytest.mark.parametrize('ropt', [{'odd_orders_to_0': False}, {'use_averaged_intensity': False}, {'used_order_ids': np.arange(3)}])
+@pytest.mark.parametrize('ropt', [{'odd_orders_to_0': False}, {'use_averaged_intensity': False}, {'used_order_ids': np.arange(3)},
+                                  {'SO_freedom': {'use': True, 'radial_high_pass': 0.2}}])
 def test_projection_real_option_variants(ropt):
     PC.check_projection_real_vs_oracle(24, 10, reciprocal_opt=ropt)
+
+
+@pytest.mark.parametrize('N,L,so', [(16, 6, 4), (40, 18, 10)])
+def test_so_freedom_on_a_higher_order(N, L, so):
+    """SO_freedom (fxs_Projections.py:768-780) forced onto an order where column 2 is m = 2 - l != 0: the correction kernel after
+    the real-arithmetic projection and after the general kernels, against the oracle"""
+    PC.check_projection_real_vs_oracle(N, L, so_order=so)
 
 
 def test_projection_real_tolerance_opt_in():

@@ -1108,7 +1108,39 @@ static int kmax_used(const mtip_ctx* c) {
     return k;
 }
 
+// SO_freedom (fxs_Projections.py:768-780): `u_SO[4, 2] = u_SO[4, 2].real` on the unknowns of the chosen order after the polar
+// factors, before they are applied -- here as a correction after the fact, the same for the real and the complex kernels: with
+// y = Im U[4][2], U[4][2] -= i y and I'_l(q)[2] -= V_l[q][4] i y on the masked shells (column 2 of the order is m = 2 - l).
+__global__ void __launch_bounds__(256) k_so_freedom(double2* __restrict__ U, double2* __restrict__ coef, const double2* __restrict__ V,
+                                                    const uint8_t* __restrict__ rmask, int l, int kmax, int N, int nlm, int xtot,
+                                                    int xoff_l, int voff_l) {
+    const int b = blockIdx.x, n = 2 * l + 1;
+    double2* u = U + (size_t)b * xtot + xoff_l + 4 * n + 2;
+    const double y = u->y;
+    __syncthreads();
+    if (threadIdx.x == 0) u->y = 0.0;
+    for (int q = threadIdx.x; q < N; q += blockDim.x) {
+        if (!rmask[(size_t)l * N + q]) continue;
+        const double2 v = V[(size_t)voff_l + (size_t)q * kmax + 4];
+        double2* cq = coef + ((size_t)b * N + q) * nlm + l * l + 2;
+        cq->x += v.y * y;                                         // - (v.x + i v.y) (i y)
+        cq->y -= v.x * y;
+    }
+}
+
+static int launch_project_coefficients_impl(mtip_ctx* c, const double2* Ilm, double2* out, bool real_intensity);
+
 int launch_project_coefficients(mtip_ctx* c, const double2* Ilm, double2* out, bool real_intensity) {
+    const int rc = launch_project_coefficients_impl(c, Ilm, out, real_intensity);
+    if (rc == MTIP_OK && c->so_order >= 0 && c->active[c->so_order] && c->kl[c->so_order] >= 5) {
+        const int l = c->so_order;
+        hipLaunchKernelGGL(k_so_freedom, dim3((unsigned)c->B), dim3(256), 0, c->stream, c->d_U, out, (const double2*)c->d_V,
+                           (const uint8_t*)c->d_rmask, l, std::min(2 * l + 1, c->N), c->N, c->nlm, c->xtot, c->xoff[l], c->voff[l]);
+    }
+    return rc;
+}
+
+static int launch_project_coefficients_impl(mtip_ctx* c, const double2* Ilm, double2* out, bool real_intensity) {
     ProfScope ps(c, "proj");
     if (real_intensity && rproj_supported(c)) {
         // real V_l and coefficients of a real intensity: the whole projection is one kernel in real arithmetic (k_projr.hip)

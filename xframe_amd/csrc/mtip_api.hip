@@ -353,6 +353,14 @@ int mtip_set_number_of_particles(mtip_ctx* c, double n) {
     return MTIP_OK;
 }
 
+int mtip_set_so_freedom(mtip_ctx* c, int order) {
+    CTX_CHECK(c);
+    if (order > c->L || (order >= 0 && (order < 2 || std::min(2 * order + 1, c->N) < 5)))
+        FAIL(c, MTIP_EINVAL, "SO_freedom: order must be -1 (off) or an order >= 2 with at least 5 unknown rows");
+    c->so_order = order < 0 ? -1 : order;
+    return MTIP_OK;
+}
+
 // reference B_l = V_l V_l^+ masked (fxs_Projections.py:631-637, fxs_IO_methods.py:408-425), host side one-off
 static int build_bref(mtip_ctx* c) {
     const int N = c->N, L = c->L;

@@ -42,6 +42,7 @@ _SIGNATURES = {
     'mtip_set_hankel_weights': (C.c_int, [c_void, c_void, C.c_double, C.c_double]),
     'mtip_set_projection_matrix': (C.c_int, [c_void, C.c_int, c_void, C.c_int, c_void, C.c_int]),
     'mtip_set_number_of_particles': (C.c_int, [c_void, C.c_double]),
+    'mtip_set_so_freedom': (C.c_int, [c_void, C.c_int]),
     'mtip_set_deg2_metric': (C.c_int, [c_void, C.c_int]),
     'mtip_set_main_error': (C.c_int, [c_void, C.c_int, C.c_int]),
     'mtip_set_real_constraints': (C.c_int, [c_void, C.c_uint32, C.c_double, C.c_double, C.c_double, C.c_uint32]),

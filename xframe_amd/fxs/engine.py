@@ -81,6 +81,7 @@ class Engine:
             else:
                 self._ck(self.lib.mtip_set_projection_matrix(self.ctx, l, None, 1, None, 0))
         self._ck(self.lib.mtip_set_number_of_particles(self.ctx, rs_.number_of_particles))
+        self._ck(self.lib.mtip_set_so_freedom(self.ctx, int(rs_.so_order)))
         popt = opt['projections']['real']['projections']
         considered = opt['projections']['real']['HIO'].get('considered_projections', ['all'])
         flags, lo, hi, thr, hio = hs.real_constraint_flags(popt, considered)

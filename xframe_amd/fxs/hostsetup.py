@@ -164,8 +164,6 @@ class ReciprocalSetup:
 
     def __init__(self, qs, data, max_order, opt):
         # variants of the reference that are not on the accelerated path must not be ignored silently
-        if opt.get('SO_freedom', {}).get('use', False):
-            raise NotImplementedError('projections.reciprocal.SO_freedom.use = True (fxs_Projections.py:493, 768-780)')
         if opt.get('number_of_particles', {}).get('estimate', False):
             raise NotImplementedError('projections.reciprocal.number_of_particles.estimate = True (marked "NOT WORKING" upstream, '
                                       'default_0.01.yaml:135-137)')
@@ -200,6 +198,16 @@ class ReciprocalSetup:
         for oid in proj:
             proj[oid] = proj[oid] * 2
         self.projection_matrices = proj                     # keyed by order id
+        # SO_freedom (fxs_Projections.py:493, 768-780): element [4, 2] of the unknowns of the best ranked even order is made real
+        self.so_order = -1
+        if opt.get('SO_freedom', {}).get('use', False):
+            if sorted(self.used_orders.values()) != list(range(max_order + 1)):
+                # upstream walks the coefficient list from order 0 next to the per-used-order lists (771): only defined for all orders
+                raise NotImplementedError('SO_freedom with a subset of the orders (fxs_Projections.py:771 pairs the lists by position)')
+            ids = rank_projection_matrices_3d([proj[i] for i in range(max_order + 1)], orders, self.qs, opt['SO_freedom']['radial_high_pass'])
+            self.so_order = int(ids[0])
+            if proj[self.so_order].shape[1] < 5:
+                raise ValueError('SO_freedom: the chosen order has fewer than 5 unknown rows (upstream indexes row 4)')
         # radial mask, 578-629
         data_mask = (self.qs >= q_d.min()) & (self.qs <= q_d.max())
         mask = np.ones((max_order + 1, n), dtype=bool)
@@ -236,6 +244,26 @@ class ReciprocalSetup:
                 raise NotImplementedError(f'q_mask type {mtype!r}')
         self.radial_mask = mask & data_mask[None, :]
         self.max_order = max_order
+
+
+def rank_projection_matrices_3d(projection_matrices, orders, radial_points, radial_high_pass=0.15):
+    """fxs_invariant_tools.py:1467-1486 (RadialIntegrator(., 2), mathLibrary.py:1270-1294): ids of the even non-zero orders, ranked by
+    the radial L2 norm of B_l = Re(V_l V_l^+) beyond the high-pass radius, largest first"""
+    orders = np.asarray(orders)
+    hp = int((len(radial_points) - 1) * radial_high_pass)
+    r = np.asarray(radial_points, dtype=float)[hp:]
+    ids = np.nonzero((orders % 2 == 0) & (orders != 0))[0]
+    w = np.zeros(len(r))                                    # trapezoid weights times the radial weight r^(2-1)
+    w[:-1] += np.diff(r) / 2
+    w[1:] += np.diff(r) / 2
+    w = w * r
+    metrics = []
+    for i in ids:
+        pm = np.asarray(projection_matrices[i])
+        bl = (pm @ pm.conj().T).real[hp:, hp:]
+        inner = (bl * bl) @ w
+        metrics.append(float((inner * inner) @ w))
+    return ids[np.argsort(np.array(metrics))[::-1]]
 
 
 def initial_support(rs, shape, opt, particle_radius, auto_correlation=None):
