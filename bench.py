@@ -266,6 +266,7 @@ def main():
     best_err = np.concatenate([e.best_error()[0] for e in engines])
     n_done = e0.best_error()[1]
     sweeps = e0.jacobi_sweeps()
+    closing = e0.jacobi_closing_step()
     bl_sum = np.zeros((L + 1, N, N), complex)
     n_bl = 0
     for e in engines[:2]:                                       # bounded sample: the download is PCIe bound
@@ -392,6 +393,7 @@ def main():
             'best_error_rank0': [float(x) for x in best_err], 'steps_done_per_restart': int(n_done),
             'mean_B0_trace': float(np.trace(bl_mean[0]).real),
             'jacobi_sweeps_last_step_restart0': [int(x) for x in sweeps[0]],
+            'jacobi_closing_step_last_step_restart0': [int(x) for x in closing[0]],   # 0 confirming sweep, 1 / 2 first / second order polar step
         }
         print(json.dumps(line))
     for e in engines:

@@ -28,12 +28,30 @@
 #include "k_jacobi.h"
 
 #define RP_MAX_THREADS 1024
+// The last sweep of the classic loop only confirms convergence: its rotations are below JL_EARLY and it takes the columns from
+// ~1e-6 of non-orthogonality to ~1e-12.  With the padded layout the loop stops one level earlier -- after a sweep whose largest
+// |gamma| / sqrt(alpha beta) stayed below RP_EARLY_CORR, which by quadratic convergence leaves E ~ RP_EARLY_CORR^2 -- and the rest is
+// done by ONE first-order step on the matrix pipe: with G = W^T W = D (1 + E) D (D = diag sigma), the polar factor of W is
+// W G^-1/2 and G^1/2 = D + Delta + O(E^2), Delta_ij = G_ij / (sigma_i + sigma_j) (the Sylvester equation D Delta + Delta D = G - D^2
+// is diagonal in this basis; no division by sigma_i - sigma_j: clustered spectra are harmless), so
+//   W G^-1/2 = W D^-1 (1 - Delta D^-1) + O(E^2),   (D^-1 (1 - Delta D^-1))_ij = delta_ij / sigma_i - G_ij / (sigma_i sigma_j (sigma_i + sigma_j)),
+// a symmetric k x k matrix: one Gram product and one k x k x n' product (about a third of a sweep at k = 65) leave E^2 <= 1e-11.
+// The Gram matrix is also the check: if its largest |E_ij| is above RP_CORR_MAX the sweeps go on with the classic criterion.
+// Second order (taken when the Gram matrix shows RP_CORR_MAX < max |E_ij| <= RP_CORR2_MAX), with A = D^-1 Delta D^-1 and A~ = A D:
+//   G^-1/2 = D^-1 - A + (A~ A~^T) o S + A~ A + O(E^3),   S_ij = 1 / (sigma_i + sigma_j)
+// (the second Newton correction of the square root, Delta2 = -(Delta^2) o S, and the second term of the Neumann series of the
+// inverse): two more k x k x k products, measured error 0.3 E^3 -- so the sweeps may stop after one with rotations up to
+// RP_EARLY_CORR = 1e-2, which leaves E ~ 1e-6 .. 1e-4.
+#define RP_EARLY_CORR 1e-2
+#define RP_CORR_MAX 3e-6
+#define RP_CORR2_MAX 1.5e-4
 #define RP_SLACK 128            // doubles behind the matrices: predicated-off lanes of the last row slot still form addresses
 #define RP_ACC_MAX 5            // 16 x 16 output tiles a wave works on at a time (and holds across a barrier: in-place products)
 
 struct RpShared {
     double gmax[RP_MAX_THREADS / 16];
     double isig[128];
+    double sig[128];
     int perm[128];
     int cont, keff;
     double red[RP_MAX_THREADS / 64];
@@ -222,7 +240,7 @@ __device__ __forceinline__ double rp_sum1(double v) {
 
 template <int NC, int TG, bool TIMED = false>
 __device__ __forceinline__ void rp_sweep_pad(double* xt /* X~ + lane of the group */, const int2* tab, int n_rounds, int ngroups,
-                                             int group, double tabs2, double S, bool& big, long long* tacc = nullptr) {
+                                             int group, double tabs2, double S, double early2, bool& big, bool& mid, long long* tacc = nullptr) {
     constexpr int NR = rp_pad_nrt(NC, TG);
     constexpr int VOFF = rp_pad_voff(NC, TG);
     long long tq = 0;
@@ -275,7 +293,8 @@ __device__ __forceinline__ void rp_sweep_pad(double* xt /* X~ + lane of the grou
         // rotation [a b] <- [a b] [[c, w], [-w, c]] (see rp_params), the identity for a pair that is orthogonal already
         const double g2 = g * g, ab = alpha * beta;
         const bool rot = g2 > (JAC_TOL * JAC_TOL) * ab && g2 > tabs2 * fmax(alpha, beta) * S && g2 > 0.0;
-        big = big || (rot && g2 > (JL_EARLY * JL_EARLY) * ab);
+        big = big || (rot && g2 > early2 * ab);
+        mid = mid || (rot && g2 > (JL_EARLY * JL_EARLY) * ab);
         const double d = 0.5 * (beta - alpha);
         const double h2 = fma(d, d, g2);
         const double ih = fast_rsqrt(rot ? h2 : 1.0);
@@ -327,7 +346,7 @@ struct RProjArgs {
     int slot_len;
     const int *sched, *sched_off, *sched_rounds;
     int sched_ps, tab_ints;       // tab_ints: ints reserved in LDS for the raw pairing table (even)
-    int N, L, nlm, utot, xtot, warm;
+    int N, L, nlm, utot, xtot, warm, corr;
     double tabs2, inv_sqrt_np;
     int* sweeps_out;
     long long* dbg;               // mtip_debug_polar_timing: 32 slots per (restart, order): cycles of the phases A, W, J, U, E of wave 0,
@@ -541,6 +560,11 @@ __device__ __forceinline__ void rp_solve(const RProjArgs& A, int b, int l, RpSha
     const int group = tid / TG, t = tid % TG;
     const bool xl_ok = t + (nr - 1) * TG < n2, vl_ok = t + (nr - 1) * TG < k;
     double S = 0.0;
+    const bool corr = pad && A.corr != 0;
+    double early2 = corr ? RP_EARLY_CORR * RP_EARLY_CORR : JL_EARLY * JL_EARLY;
+    bool use_corr = false, corr2 = false;
+    double* Pm = reinterpret_cast<double*>(s_tab);       // k x kp: Gram matrix, then D^-1 (1 - Delta D^-1) (the tables are done with by then)
+    const int kp = k | 1;
     if (k > 1) {
         int tab_ke = -1;
         for (int sweep = 0; sweep < JAC_MAX_SWEEPS; ++sweep) {
@@ -582,7 +606,7 @@ __device__ __forceinline__ void rp_solve(const RProjArgs& A, int b, int l, RpSha
             }
             __syncthreads();
             const int ke = sh.keff;
-            bool big = false;
+            bool big = false, mid = false;
             if (ke >= 2) {
                 const int* gtab = A.sched + A.sched_off[ke];
                 const int nrd = A.sched_rounds[ke];
@@ -615,7 +639,7 @@ __device__ __forceinline__ void rp_solve(const RProjArgs& A, int b, int l, RpSha
                     double* xt = Xs + t;
                     if (dbg != nullptr && nc == 5) {             // diagnostic instance with segment timers
                         long long tacc[7] = {0, 0, 0, 0, 0, 0, 0};
-                        rp_sweep_pad<5, TG, true>(xt, s_tab2, nrd, ngroups, group, A.tabs2, S, big, tacc);
+                        rp_sweep_pad<5, TG, true>(xt, s_tab2, nrd, ngroups, group, A.tabs2, S, early2, big, mid, tacc);
                         if ((tid & 63) == 0 && (tid >> 6) < 8) {   // per wave: busy, LDS drain + barrier; wave 0 and 5 also the segments
                             dbg[10 + (tid >> 6)] += tacc[0] + tacc[1] + tacc[2] + tacc[3] + tacc[4];
                             dbg[18 + (tid >> 6)] += tacc[5] + tacc[6];
@@ -624,11 +648,11 @@ __device__ __forceinline__ void rp_solve(const RProjArgs& A, int b, int l, RpSha
                         }
                     } else {
                         switch (nc) {
-                        case 1: rp_sweep_pad<1, TG>(xt, s_tab2, nrd, ngroups, group, A.tabs2, S, big); break;
-                        case 2: rp_sweep_pad<2, TG>(xt, s_tab2, nrd, ngroups, group, A.tabs2, S, big); break;
-                        case 3: rp_sweep_pad<3, TG>(xt, s_tab2, nrd, ngroups, group, A.tabs2, S, big); break;
-                        case 4: rp_sweep_pad<4, TG>(xt, s_tab2, nrd, ngroups, group, A.tabs2, S, big); break;
-                        default: rp_sweep_pad<5, TG>(xt, s_tab2, nrd, ngroups, group, A.tabs2, S, big); break;
+                        case 1: rp_sweep_pad<1, TG>(xt, s_tab2, nrd, ngroups, group, A.tabs2, S, early2, big, mid); break;
+                        case 2: rp_sweep_pad<2, TG>(xt, s_tab2, nrd, ngroups, group, A.tabs2, S, early2, big, mid); break;
+                        case 3: rp_sweep_pad<3, TG>(xt, s_tab2, nrd, ngroups, group, A.tabs2, S, early2, big, mid); break;
+                        case 4: rp_sweep_pad<4, TG>(xt, s_tab2, nrd, ngroups, group, A.tabs2, S, early2, big, mid); break;
+                        default: rp_sweep_pad<5, TG>(xt, s_tab2, nrd, ngroups, group, A.tabs2, S, early2, big, mid); break;
                         }
                     }
                 } else if (BIG) {
@@ -638,44 +662,206 @@ __device__ __forceinline__ void rp_solve(const RProjArgs& A, int b, int l, RpSha
                 }
                 n_rounds_done += nrd;
             }
-            if (t == 0) sh.gmax[group] = big ? 1.0 : 0.0;
+            if (t == 0) sh.gmax[group] = big ? 2.0 : (mid ? 1.0 : 0.0);
             __syncthreads();
             if (tid == 0) {
                 double m = 0.0;
                 for (int gq = 0; gq < ngroups; ++gq) m = fmax(m, sh.gmax[gq]);
-                sh.cont = (m > 0.0) ? 1 : 0;                   // quadratic convergence: see JL_EARLY
+                sh.cont = (int)m;                              // 2: sweep on; 1: below `early2` but above JL_EARLY; 0: below JL_EARLY (quadratic convergence)
                 A.sweeps_out[b * (A.L + 1) + l] = (sweep + 1) | (ke << 8);
             }
             __syncthreads();
             const int cont = sh.cont;
             __syncthreads();
-            if (!cont) break;
+            if (cont == 2) continue;
+            // below JL_EARLY: the sweep just done was the confirming one (it leaves ~1e-12), classic finish without the first-order step
+            if (cont == 0 || !corr || early2 == JL_EARLY * JL_EARLY) break;
+            // ---- Gram matrix G = W^T W on the matrix pipe, its diagonal (sigma^2) and the largest |E_ij| ----
+            for (int base = 0; base < ntm_k * ntm_k; base += nwaves * RP_ACC) {
+                v4f64 acc[RP_ACC];
+                const double *pa[RP_ACC], *pb[RP_ACC];
+                int nu = 0;
+#pragma unroll
+                for (int u = 0; u < RP_ACC; ++u) {
+                    const int tile = base + wave + u * nwaves;
+                    const bool ok = tile < ntm_k * ntm_k;
+                    const int tq = ok ? tile : 0;
+                    const int tm = tq / ntm_k, tn = tq - tm * ntm_k;
+                    const int i = tm * 16 + li, j = tn * 16 + li;
+                    pa[u] = Xs + (size_t)(i < k ? i : k - 1) * ns;
+                    pb[u] = Xs + (size_t)(j < k ? j : k - 1) * ns;
+                    if (ok) nu = u + 1;
+                }
+                rp_tiles<RP_ACC, UNR>(acc, pa, 1, pb, 1, n2, lk, nu);
+#pragma unroll
+                for (int u = 0; u < RP_ACC; ++u) {
+                    const int tile = base + wave + u * nwaves;
+                    if (tile < ntm_k * ntm_k) {
+                        const int tm = tile / ntm_k, tn = tile - tm * ntm_k;
+                        const int j = tn * 16 + li;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int i = tm * 16 + lk + 4 * r;
+                            if (i < k && j < k) Pm[(size_t)i * kp + j] = acc[u][r];
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            if (tid < k) {
+                const double g = Pm[(size_t)tid * kp + tid];
+                sh.sig[tid] = sqrt(fmax(g, 0.0));
+                sh.isig[tid] = g > 1e-300 ? 1.0 / sqrt(g) : 0.0;
+            }
+            __syncthreads();
+            double em = 0.0;
+            for (int e = tid; e < k * k; e += nthreads) {
+                const int i = e / k, j = e - i * k;
+                const double g = Pm[(size_t)i * kp + j], gi = Pm[(size_t)i * kp + i], gj = Pm[(size_t)j * kp + j];
+                // (pairs the sweeps leave alone -- below the absolute tolerance, rp_params -- are left alone here too)
+                const bool live = i != j && g * g > A.tabs2 * fmax(gi, gj) * S && g * g > (JAC_TOL * JAC_TOL) * gi * gj;
+                if (live) em = fmax(em, fabs(g) * sh.isig[i] * sh.isig[j]);
+            }
+            for (int o = 32; o > 0; o >>= 1) em = fmax(em, __shfl_xor(em, o, 64));
+            if ((tid & 63) == 0) sh.red[tid >> 6] = em;
+            __syncthreads();
+            em = 0.0;
+            for (int wv = 0; wv < nwaves; ++wv) em = fmax(em, sh.red[wv]);
+            __syncthreads();
+            if (em <= RP_CORR2_MAX) {
+                use_corr = true;
+                corr2 = em > RP_CORR_MAX;
+                // (bits 24, 25 of the sweep record: closed by the first / second order step)
+                if (tid == 0) A.sweeps_out[b * (A.L + 1) + l] |= corr2 ? (2 << 24) : (1 << 24);
+                break;
+            }
+            early2 = JL_EARLY * JL_EARLY;                        // not there yet: sweep on, classic criterion (the Gram matrix
+            tab_ke = -1;                                         // overwrote the pairing table: staged again)
         }
     } else if (tid == 0) {
         A.sweeps_out[b * (A.L + 1) + l] = 0 | (k << 8);
     }
     RP_STAMP(2)
     // ---- sigma_c; V_r for the next call -----------------------------------------------------------------------------------
-    for (int cc0 = 0; cc0 < k; cc0 += ngroups) {               // uniform trip count: DPP sums need the whole group
-        const int cc = cc0 + group;
-        double s2 = 0.0;
-        if (cc < k)
-            for (int u = 0; u < nr; ++u)
-                if (t + u * TG < n2) {
-                    const double x = Xs[(size_t)cc * ns + t + u * TG];
-                    s2 = fma(x, x, s2);
-                }
-        s2 = rp_sum1<TG>(s2);
-        if (cc < k && t == 0) sh.isig[cc] = s2 > 1e-300 ? 1.0 / sqrt(s2) : 0.0;
+    if (!use_corr) {
+        for (int cc0 = 0; cc0 < k; cc0 += ngroups) {           // uniform trip count: DPP sums need the whole group
+            const int cc = cc0 + group;
+            double s2 = 0.0;
+            if (cc < k)
+                for (int u = 0; u < nr; ++u)
+                    if (t + u * TG < n2) {
+                        const double x = Xs[(size_t)cc * ns + t + u * TG];
+                        s2 = fma(x, x, s2);
+                    }
+            s2 = rp_sum1<TG>(s2);
+            if (cc < k && t == 0) sh.isig[cc] = s2 > 1e-300 ? 1.0 / sqrt(s2) : 0.0;
+        }
     }
     for (int e = tid; e < k * k; e += nthreads) {
         const int cc = e / k, i = e - cc * k;
         Vr[e] = Vs[(size_t)cc * ks + i];
     }
     __syncthreads();
-    // columns of X~ <- left singular vectors W / sigma (numerical-zero columns: 0)
-    for (int e = tid; e < k * ns; e += nthreads) Xs[e] *= sh.isig[e / ns];
-    __syncthreads();
+    if (!use_corr) {
+        // columns of X~ <- left singular vectors W / sigma (numerical-zero columns: 0)
+        for (int e = tid; e < k * ns; e += nthreads) Xs[e] *= sh.isig[e / ns];
+        __syncthreads();
+    } else {
+        // columns of X~ <- W G^-1/2 to first or second order in E: the symmetric factor P in place of the Gram matrix, then one
+        // product held in registers across the barrier (it overwrites its own operand).  V_r is in global memory by now: its LDS
+        // block serves as scratch for A~ and is read back before the U product.
+        double* Ab = Vs;
+        for (int e = tid; e < k * k; e += nthreads) {
+            const int i = e / k, j = e - i * k;
+            const double g = Pm[(size_t)i * kp + j], gi = sh.sig[i] * sh.sig[i], gj = sh.sig[j] * sh.sig[j];
+            const bool live = i != j && g * g > A.tabs2 * fmax(gi, gj) * S && g * g > (JAC_TOL * JAC_TOL) * gi * gj;
+            const double ss = sh.sig[i] + sh.sig[j];
+            const double a = live && ss > 0.0 ? g * sh.isig[i] * sh.isig[j] / ss : 0.0;      // A_ij
+            if (corr2) {
+                Pm[(size_t)i * kp + j] = a;
+                Ab[(size_t)i * kp + j] = a * sh.sig[j];
+            } else {
+                Pm[(size_t)i * kp + j] = i == j ? sh.isig[i] : -a;
+            }
+        }
+        __syncthreads();
+        if (corr2) {
+            // T1 = A~ A~^T, T2 = A~ A (A symmetric): all tiles in registers, then P = D^-1 - A + T1 o S + T2 in place of A
+            v4f64 t1[RP_ACC], t2[RP_ACC];
+            const double *pa[RP_ACC], *pb[RP_ACC], *pc[RP_ACC];
+            int nu = 0;
+#pragma unroll
+            for (int u = 0; u < RP_ACC; ++u) {
+                const int tile = wave + u * nwaves;
+                const bool ok = tile < ntm_k * ntm_k;
+                const int tq = ok ? tile : 0;
+                const int tm = tq / ntm_k, tn = tq - tm * ntm_k;
+                const int i = tm * 16 + li, j = tn * 16 + li;
+                pa[u] = Ab + (size_t)(i < k ? i : k - 1) * kp;
+                pb[u] = Ab + (size_t)(j < k ? j : k - 1) * kp;
+                pc[u] = Pm + (size_t)(j < k ? j : k - 1) * kp;
+                if (ok) nu = u + 1;
+            }
+            rp_tiles<RP_ACC, UNR>(t1, pa, 1, pb, 1, k, lk, nu);
+            rp_tiles<RP_ACC, UNR>(t2, pa, 1, pc, 1, k, lk, nu);
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < RP_ACC; ++u) {
+                const int tile = wave + u * nwaves;
+                if (tile < ntm_k * ntm_k) {
+                    const int tm = tile / ntm_k, tn = tile - tm * ntm_k;
+                    const int j = tn * 16 + li;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int i = tm * 16 + lk + 4 * r;
+                        if (i < k && j < k) {
+                            const double ss = sh.sig[i] + sh.sig[j];
+                            Pm[(size_t)i * kp + j] = (i == j ? sh.isig[i] : 0.0) - Pm[(size_t)i * kp + j] + (ss > 0.0 ? t1[u][r] / ss : 0.0) + t2[u][r];
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        v4f64 acc[RP_ACC];
+        {
+            const double *pa[RP_ACC], *pb[RP_ACC];
+            int nu = 0;
+#pragma unroll
+            for (int u = 0; u < RP_ACC; ++u) {
+                const int tile = wave + u * nwaves;
+                const bool ok = tile < ntm_k * ntn;
+                const int tq = ok ? tile : 0;
+                const int tm = tq / ntn, tn = tq - tm * ntn;
+                const int j = tm * 16 + li, rho = tn * 16 + li;
+                pa[u] = Pm + (size_t)(j < k ? j : k - 1) * kp;
+                pb[u] = Xs + (rho < n2 ? rho : n2 - 1);
+                if (ok) nu = u + 1;
+            }
+            rp_tiles<RP_ACC, UNR>(acc, pa, 1, pb, ns, k, lk, nu);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < RP_ACC; ++u) {
+            const int tile = wave + u * nwaves;
+            if (tile < ntm_k * ntn) {
+                const int tm = tile / ntn, tn = tile - tm * ntn;
+                const int rho = tn * 16 + li;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int j = tm * 16 + lk + 4 * r;
+                    if (j < k && rho < n2) Xs[(size_t)j * ns + rho] = acc[u][r];
+                }
+            }
+        }
+        if (corr2) {                                           // V_r back into its LDS block (its zero padding was never an operand)
+            for (int e = tid; e < k * k; e += nthreads) {
+                const int cc = e / k, i = e - cc * k;
+                Vs[(size_t)cc * ks + i] = Vr[e];
+            }
+        }
+        __syncthreads();
+    }
     // ---- U: U~^T[rho'][i] = sum_c (X~[rho'][c] / sigma_c) V_r[i][c]:  D[i][rho'] -> Xs[i * ns + rho'], complex U_l -> A.U ----
     {
         double2* Uo = A.U + (size_t)b * A.xtot + A.xoff[l];
@@ -859,6 +1045,8 @@ static RpGeom rp_launch_geometry(const mtip_ctx* c) {
         const int nc = (kpad + 1 + 15) / 16;
         g.lds = (2 * (size_t)rp_pad_voff(nc, g.tg) + RP_SLACK) * sizeof(double) + (size_t)g.tab_ints * sizeof(int) +
                 (size_t)nrd * (g.threads / g.tg) * sizeof(int2);
+        // the Gram matrix of the closing first-order step takes the place of the tables
+        g.lds = std::max(g.lds, (2 * (size_t)rp_pad_voff(nc, g.tg) + RP_SLACK + (size_t)kpad * (kpad | 1)) * sizeof(double));
     }
     if (kbig >= 2)
         g.lds = std::max(g.lds, ((size_t)kbig * ((kbig + 1) | 1) + (size_t)kbig * (kbig | 1) + RP_SLACK) * sizeof(double));
@@ -1006,6 +1194,7 @@ int launch_rproj(mtip_ctx* c, double2* coef) {
     // cold start every 64 calls bounds the accumulated rounding drift of the carried V_r
     a.warm = (c->vr_kind == 2 && (c->proj_calls % 64) != 0) ? 1 : 0;
     a.tabs2 = c->polar_abs_tol * c->polar_abs_tol;
+    a.corr = c->rp_corr ? 1 : 0;
     a.inv_sqrt_np = 1.0 / std::sqrt(c->n_particles);
     a.sweeps_out = c->d_sweeps;
     a.dbg = c->d_polar_dbg;

@@ -155,6 +155,7 @@ mtip_ctx* mtip_create(const mtip_cfg* cfg, int device) {
     c->v_real.assign(L + 1, 1);
     if (const char* e = std::getenv("MTIP_PROJ_REAL")) c->proj_real = std::atoi(e) != 0;
     if (const char* e = std::getenv("MTIP_RP_TG")) c->rp_tg = std::atoi(e);
+    if (const char* e = std::getenv("MTIP_RP_CORR")) c->rp_corr = std::atoi(e) != 0;
     for (int l = 0; l <= L; ++l) {
         const int n = 2 * l + 1, k = std::min(n, N);
         c->kl[l] = k;                               // default; mtip_set_projection_matrix may give a smaller k_l

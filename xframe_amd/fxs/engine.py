@@ -480,7 +480,14 @@ class Engine:
         """columns of X_l the last polar-factor call still rotated in its final sweep (numerical rank estimate)"""
         out = np.zeros((self.B, self.L + 1), np.int32)
         self._ck(self.lib.mtip_debug_jacobi_sweeps(self.ctx, _lib.ptr(out)))
-        return out >> 8
+        return (out >> 8) & 0xffff
+
+    def jacobi_closing_step(self):
+        """how the real-arithmetic projection closed its sweeps in the last call, per (restart, order): 0 = classic confirming sweep,
+        1 = first-order, 2 = second-order polar step on the Gram matrix (k_projr.hip)"""
+        out = np.zeros((self.B, self.L + 1), np.int32)
+        self._ck(self.lib.mtip_debug_jacobi_sweeps(self.ctx, _lib.ptr(out)))
+        return (out >> 24) & 3
 
     # ------------------------------------------------------------------ helpers shared with synthetic.py
     @property
