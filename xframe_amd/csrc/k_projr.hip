@@ -1079,8 +1079,11 @@ bool rproj_supported(mtip_ctx* c) {
     return true;
 }
 
-// cost model of one order inside a slot: rounds ~ k, a round ~ constant + rows
-static double rp_cost(int k) { return (double)k * (40.0 + k); }
+// cost model of one order inside a slot, in cycles, from the in-kernel timers at 128 x L32 (profiles/r03_rproj_round_timers.txt):
+// the four products and the bookkeeping around them 38 k + 1.55 k per column, a sweep 1.08 k rounds of 2000 + 8 k cycles, three
+// sweeps per call.  (Round 3 first packed with k (40 + k): the fixed part was missing, and the slots of three or four small
+// orders -- {20, 12, 8, 4}: 413 k cycles against 315 k for l = 32 alone -- set the duration of the launch.)
+static double rp_cost(int k) { return 38e3 + 1550.0 * k + 3.0 * (1.08 * k) * (2000.0 + 8.0 * k); }
 
 static int build_rproj_tables(mtip_ctx* c) {
     if (c->d_rp_slots != nullptr) return MTIP_OK;
