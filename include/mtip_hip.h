@@ -228,6 +228,32 @@ int mtip_op_hermitian_eig(mtip_ctx* ctx, int n, int n_mat, const mtip_cdouble* A
  * fxs_invariant_tools.py:1114-1131 stay on the host): LDS-resident solver, eigenvalues accurate to eps |A|_F as LAPACK's */
 int mtip_op_symmetric_eig(mtip_ctx* ctx, int n, int n_mat, const double* A, double* eigvals, double* eigvecs);
 
+/* ---- the 2-D (polar) variant, operator level --------------------------------------
+ * Grids (n_batch, Nq, n_phi) complex128 with n_phi = 2 M + 1 (harmonic_transforms.py:44-47); harmonic coefficients in numpy's
+ * FFT order (orders 0..M, -M..-1); coefficients of the real transform (n_batch, Nq, M + 1).  Buffers: host or device memory. */
+typedef struct mtip2d_ctx mtip2d_ctx;
+mtip2d_ctx* mtip2d_create(int n_radial, int n_phi, int n_batch, int device);
+void mtip2d_destroy(mtip2d_ctx* ctx);
+const char* mtip2d_last_error(const mtip2d_ctx* ctx);
+/* forward / inverse weights (Nq summed, Nq new, n_phi orders) as assemble_weights_mid returns them (hankel_transforms.py:300-362),
+ * unused_orders (n_phi): 1 = zeroed by the transform pair (generate_polar_ht, 613-628) */
+int mtip2d_set_hankel_weights(mtip2d_ctx* ctx, const mtip_cdouble* forward, const mtip_cdouble* inverse, const uint8_t* unused_orders);
+/* the 2-D reciprocal projection (fxs_Projections.py:723-745, 803-826, 855-863): order_ids (n_used, ascending, 0 included),
+ * projection vectors (n_used, Nq), their radial masks (n_used, Nq), reciprocal radial points (Nq), number of particles */
+int mtip2d_set_projection(mtip2d_ctx* ctx, int n_used, const int32_t* order_ids, const mtip_cdouble* projection_vectors,
+                          const uint8_t* radial_mask, const double* radial_points, double n_particles);
+/* circularHarmonicTransform_complex_forward / _inverse (mathLibrary.py:469-483) */
+int mtip2d_op_harmonic(mtip2d_ctx* ctx, const mtip_cdouble* in, mtip_cdouble* out, int inverse);
+/* circularHarmonicTransform_real_forward (485-491: of the real part of a complex grid) / _real_inverse (493-496: real grid out) */
+int mtip2d_op_real_harmonic_forward(mtip2d_ctx* ctx, const mtip_cdouble* grid, mtip_cdouble* coeff);
+int mtip2d_op_real_harmonic_inverse(mtip2d_ctx* ctx, const mtip_cdouble* coeff, double* grid);
+/* generate_polar_ht (hankel_transforms.py:629-640) and generate_ft for dimensions = 2 (fourier_transforms.py:57-88) */
+int mtip2d_op_hankel(mtip2d_ctx* ctx, const mtip_cdouble* in, mtip_cdouble* out, int inverse);
+int mtip2d_op_fourier_transform(mtip2d_ctx* ctx, const mtip_cdouble* in, mtip_cdouble* out, int inverse);
+/* approximate_unknowns + mtip_projection + the number-of-particles rule on coefficients of the real transform; unknowns
+ * (n_batch, n_used) or NULL */
+int mtip2d_op_project(mtip2d_ctx* ctx, const mtip_cdouble* I, mtip_cdouble* I_projected, mtip_cdouble* unknowns);
+
 /* ---- timing ----------------------------------------------------------------------------------- */
 /* average duration (ms) and launch count of kernel family `name` ("sht_fwd", "sht_inv", "hankel",
  * "proj", "real_update", ...) measured with hipEvents on the ctx stream since the last reset;

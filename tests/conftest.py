@@ -36,6 +36,11 @@ def golden_flow():
 
 
 @pytest.fixture(scope='session')
+def golden_polar2d():
+    return np.load(os.path.join(GOLDEN, 'polar2d_ops.npz'))
+
+
+@pytest.fixture(scope='session')
 def golden_cfg1():
     return np.load(os.path.join(GOLDEN, 'mtip_cfg1_N32_L8.npz'))
 

@@ -906,6 +906,85 @@ def check_average_flow_golden_hip(golden_flow, lib_path=None):
         e.close()
 
 
+def check_polar2d_golden_oracle(g):
+    """oracle/polar2d.py against the reference's own 2-D functions (fixture G18)"""
+    from oracle import polar2d as P2
+    N, M, kappa, max_q = int(g['G18_N']), int(g['G18_M']), float(g['G18_kappa']), float(g['G18_max_q'])
+    x = g['G18_x']
+    assert rel_l2(P2.harmonic_forward(x), g['G18_cht_fwd']) < 1e-14 and rel_l2(P2.harmonic_inverse(x), g['G18_cht_inv']) < 1e-14
+    assert rel_l2(P2.real_harmonic_forward(x), g['G18_rht_fwd']) < 1e-14
+    assert rel_l2(P2.real_harmonic_inverse(g['G18_xr'], 2 * M + 1), g['G18_rht_inv']) < 1e-14
+    fp = P2.PolarFourierPair(N, M, max_q, kappa)
+    assert fp.n_phi == int(g['G18_ht_n_phi'])
+    assert np.allclose(fp.rs, g['G18_rs'], rtol=1e-14) and np.allclose(fp.qs, g['G18_qs'], rtol=1e-14) and np.allclose(fp.phis, g['G18_phis'], atol=1e-15)
+    assert rel_l2(fp.raw_weights, g['G18_weights_raw']) < 1e-14
+    assert rel_l2(fp.weights['forward'], g['G18_weights_forward']) < 1e-14 and rel_l2(fp.weights['inverse'], g['G18_weights_inverse']) < 1e-14
+    assert rel_l2(fp.zht(x), g['G18_hankel_fwd_all']) < 1e-14 and rel_l2(fp.izht(x), g['G18_hankel_inv_all']) < 1e-14
+    assert rel_l2(fp.ft(x), g['G18_ft_all']) < 1e-13 and rel_l2(fp.ift(x), g['G18_ift_all']) < 1e-13
+    used = g['G18_used_sub']
+    rp = P2.ReciprocalProjection2D(g['G18_proj_pm'], {int(o): int(o) for o in used}, g['G18_proj_mask'], g['G18_qs'], M + 1,
+                                   float(g['G18_proj_n_particles']))
+    u = rp.approximate_unknowns(g['G18_proj_I'])
+    assert rel_l2(u, g['G18_proj_unknowns']) < 1e-14
+    assert rel_l2(rp.mtip_projection(g['G18_proj_I'], u), g['G18_proj_out']) < 1e-14
+
+
+def check_polar2d_golden_hip(g, lib_path=None):
+    """the mtip2d_* operators (k_polar2d.hip) against the same fixture, two grids per call"""
+    from xframe_amd.fxs.polar2d import Engine2D
+    N, M, kappa, max_q = int(g['G18_N']), int(g['G18_M']), float(g['G18_kappa']), float(g['G18_max_q'])
+    e = Engine2D(N, M, max_q, kappa, n_batch=2, lib_path=lib_path)
+    assert np.allclose(e.rs, g['G18_rs'], rtol=1e-14) and np.allclose(e.qs, g['G18_qs'], rtol=1e-14)
+    x = g['G18_x']
+    xb = np.stack([x, 2.0 * x[::-1]])
+    for got, ref in ((e.harmonic(xb), g['G18_cht_fwd']), (e.harmonic(xb, True), g['G18_cht_inv']), (e.hankel(xb), g['G18_hankel_fwd_all']),
+                     (e.hankel(xb, True), g['G18_hankel_inv_all']), (e.fourier_transform(xb), g['G18_ft_all']),
+                     (e.fourier_transform(xb, True), g['G18_ift_all'])):
+        assert rel_l2(got[0], ref) < 1e-12
+    assert rel_l2(e.real_harmonic_forward(xb)[0], g['G18_rht_fwd']) < 1e-12
+    xr = g['G18_xr']
+    assert rel_l2(e.real_harmonic_inverse(np.stack([xr, xr]))[1], g['G18_rht_inv']) < 1e-12
+    used = g['G18_used_sub']
+    e.set_projection(g['G18_proj_pm'], {int(o): int(o) for o in used}, g['G18_proj_mask'], float(g['G18_proj_n_particles']))
+    out, unk = e.project(np.stack([g['G18_proj_I'], g['G18_proj_I']]))
+    assert rel_l2(unk[0], g['G18_proj_unknowns']) < 1e-12 and rel_l2(out[1], g['G18_proj_out']) < 1e-12
+    e.close()
+
+
+def check_polar2d_vs_oracle(N, M, lib_path=None, seed=0):
+    """the 2-D Fourier pair and projection at other sizes against the oracle; round trip ift(ft(x)) as the size-independent property"""
+    from oracle import polar2d as P2
+    from xframe_amd.fxs.polar2d import Engine2D
+    rng = np.random.default_rng(seed)
+    max_q = 0.7
+    fp = P2.PolarFourierPair(N, M, max_q, 2.0)
+    e = Engine2D(N, M, max_q, 2.0, n_batch=2, lib_path=lib_path)
+    x = cplx(rng, (2, N, 2 * M + 1))
+    F = e.fourier_transform(x)
+    for b in range(2):
+        assert rel_l2(F[b], fp.ft(x[b])) < 1e-11
+        assert rel_l2(e.fourier_transform(x, True)[b], fp.ift(x[b])) < 1e-11
+    # size-independent property: the pair is linear (the midpoint pair is NOT an exact inverse pair upstream either: a smooth function
+    # comes back from ift(ft(.)) with 8 % error at 128 x M64 and kappa = 2, oracle and device alike)
+    y = cplx(rng, (2, N, 2 * M + 1))
+    assert rel_l2(e.fourier_transform(2.0 * x - 0.5j * y), 2.0 * F - 0.5j * e.fourier_transform(y)) < 1e-12
+    r, phi = fp.rs[:, None], fp.phis[None, :]
+    smooth = (np.exp(-(r / (0.25 * fp.r_max)) ** 2) * (1.0 + 0.5 * np.cos(2 * phi) + 0.2 * np.sin(3 * phi))).astype(complex)
+    back = e.fourier_transform(e.fourier_transform(np.stack([smooth, smooth])), True)[0]
+    assert rel_l2(back, fp.ift(fp.ft(smooth))) < 1e-11
+    used = {int(o): int(o) for o in range(0, M + 1) if o != 3}
+    pm = cplx(rng, (len(used), N))
+    mask = rng.random((M + 1, N)) > 0.2
+    rp = P2.ReciprocalProjection2D(pm, used, mask, fp.qs, M + 1, 2.5)
+    e.set_projection(pm, used, mask, 2.5)
+    I = cplx(rng, (2, N, M + 1))
+    out, unk = e.project(I)
+    for b in range(2):
+        u = rp.approximate_unknowns(I[b])
+        assert rel_l2(unk[b], u) < 1e-12 and rel_l2(out[b], rp.mtip_projection(I[b], u)) < 1e-12
+    e.close()
+
+
 def check_symmetric_eig(lib_path=None, n=130, K=3, seed=0):
     """mtip_op_symmetric_eig against LAPACK on what `extract` feeds it (fxs_invariant_tools.py:1114-1131): a rank-deficient
     semi-definite matrix (B_l of 2l+1 coefficients), an indefinite one, the zero matrix; n > 128 takes the solver that cuts the

@@ -22,7 +22,7 @@ def lib():
 def header_symbols():
     txt = open(HEADER).read()
     txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
-    return sorted(set(re.findall(r'\b(mtip_[a-z0-9_]+)\s*\(', txt)))
+    return sorted(set(re.findall(r'\b(mtip(?:2d)?_[a-z0-9_]+)\s*\(', txt)))
 
 
 def test_every_declared_symbol_is_exported(lib):

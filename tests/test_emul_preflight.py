@@ -120,6 +120,15 @@ def test_average_flow_golden(emul_lib, golden_flow):
     PC.check_average_flow_golden_hip(golden_flow, emul_lib)
 
 
+def test_polar2d_golden(emul_lib, golden_polar2d):
+    """the 2-D operators against the reference's own functions (fixture G18)"""
+    PC.check_polar2d_golden_hip(golden_polar2d, emul_lib)
+
+
+def test_polar2d_vs_oracle(emul_lib):
+    PC.check_polar2d_vs_oracle(10, 6, emul_lib)
+
+
 def test_symmetric_eig_blocked(emul_lib):
     """n > 128: column blocks over workgroups (k_sym_eig_block), 5 blocks -> an empty sixth pads the tournament"""
     PC.check_symmetric_eig(emul_lib, n=130, K=3)

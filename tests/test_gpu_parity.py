@@ -163,6 +163,17 @@ def test_average_flow_golden(golden_flow):
     PC.check_average_flow_golden_hip(golden_flow)
 
 
+def test_polar2d_golden(golden_polar2d):
+    """the 2-D (polar) operators -- circular harmonic transforms, polar Hankel pair, Fourier pair, reciprocal projection -- against
+    the reference's own functions (fixture G18, tests/golden/polar2d_ops.npz)"""
+    PC.check_polar2d_golden_hip(golden_polar2d)
+
+
+@pytest.mark.parametrize('N,M', [(10, 6), (64, 30), (128, 64)])
+def test_polar2d_vs_oracle(N, M):
+    PC.check_polar2d_vs_oracle(N, M)
+
+
 @pytest.mark.parametrize('n,K', [(100, 6), (128, 33), (130, 5), (200, 7), (256, 49), (288, 4)])
 def test_symmetric_eig(n, K):
     """the eigensolvers of `extract` against LAPACK: LDS-resident up to 128, column blocks over workgroups up to 288

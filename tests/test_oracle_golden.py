@@ -271,3 +271,9 @@ def test_g17_average_flow_oracle(golden_flow):
     """oracle/alignment.py reproduces the reference's own averaging flow (run_3d + Alignment of the imported average.py)"""
     import parity_cases as PC
     PC.check_average_flow_golden_oracle(golden_flow)
+
+
+def test_g18_polar2d_oracle(golden_polar2d):
+    """oracle/polar2d.py reproduces the reference's own 2-D transforms, weights, Fourier pair and projection closures"""
+    import parity_cases as PC
+    PC.check_polar2d_golden_oracle(golden_polar2d)

@@ -80,6 +80,17 @@ _SIGNATURES = {
     'mtip_set_so3_tables': (C.c_int, [c_void, C.c_int, c_void]),
     'mtip_op_so3_correlation': (C.c_int, [c_void, c_void, c_void, C.c_int, C.c_int, c_void]),
     'mtip_op_rotate_coefficients': (C.c_int, [c_void, c_void, c_void, c_void]),
+    'mtip2d_create': (c_void, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    'mtip2d_destroy': (None, [c_void]),
+    'mtip2d_last_error': (C.c_char_p, [c_void]),
+    'mtip2d_set_hankel_weights': (C.c_int, [c_void, c_void, c_void, c_void]),
+    'mtip2d_set_projection': (C.c_int, [c_void, C.c_int, c_void, c_void, c_void, c_void, C.c_double]),
+    'mtip2d_op_harmonic': (C.c_int, [c_void, c_void, c_void, C.c_int]),
+    'mtip2d_op_real_harmonic_forward': (C.c_int, [c_void, c_void, c_void]),
+    'mtip2d_op_real_harmonic_inverse': (C.c_int, [c_void, c_void, c_void]),
+    'mtip2d_op_hankel': (C.c_int, [c_void, c_void, c_void, C.c_int]),
+    'mtip2d_op_fourier_transform': (C.c_int, [c_void, c_void, c_void, C.c_int]),
+    'mtip2d_op_project': (C.c_int, [c_void, c_void, c_void, c_void]),
     'mtip_op_so3_find_rotation': (C.c_int, [c_void, c_void, c_void, C.c_int, C.c_int, c_void, c_void, c_void]),
     'mtip_op_rotate_coefficients_grid': (C.c_int, [c_void, c_void, c_void, c_void, c_void, c_void]),
     'mtip_op_hermitian_eig': (C.c_int, [c_void, C.c_int, C.c_int, c_void, c_void, c_void]),

@@ -1,0 +1,132 @@
+"""The 2-D (polar) variant of the hot path on the MI355X, operator level: the circular harmonic transforms
+(``xframe/library/mathLibrary.py:469-496``), the polar Hankel pair with midpoint weights (``hankel_transforms.py:411-424, 300-362,
+602-640``), the Fourier pair ``generate_ft`` builds from them (``fourier_transforms.py:49-88``) on the polar midpoint grid pair
+(``ft_grid_pairs.py:282-291, 325-336``) and the 2-D reciprocal projection (``fxs_Projections.py:723-745, 803-826, 855-863``),
+through the ``mtip2d_*`` entry points of ``include/mtip_hip.h`` (``csrc/k_polar2d.hip``).  The 2-D phasing LOOP is not wired
+(DESIGN section 6); no CPU fallback."""
+import ctypes as C
+
+import numpy as np
+from scipy.special import jv
+
+from . import _lib
+
+
+def polar_mid_weights(orders, n_radial_points, reciprocity_coefficient):
+    """calc_polar_mid_weights (hankel_transforms.py:411-424)"""
+    N = n_radial_points
+    ps = np.arange(N) + 0.5
+    ks = np.arange(N) + 0.5
+    ms = np.asarray(orders, dtype=float)
+    return ps[None, :, None] * jv(ms[:, None, None], ks[None, None, :] * ps[None, :, None] * reciprocity_coefficient / N)
+
+
+def assemble_weights_mid(weights, orders, r_max, reciprocity_coefficient):
+    """assemble_weights_mid, 2-D branch (hankel_transforms.py:300-362)"""
+    orders = np.asarray(orders)
+    N = weights.shape[-1]
+    q_max = reciprocity_coefficient * N / r_max
+    all_orders = np.concatenate((orders, -orders[:0:-1]))
+    w = np.concatenate((weights, (-1.0) ** orders[:0:-1, None, None] * weights[:0:-1]), axis=0)
+    w = np.moveaxis(w, 0, 2)
+    return (w * ((-1.j) ** all_orders[None, None, :] * (r_max / N) ** 2), w * ((1.j) ** all_orders[None, None, :] * (q_max / N) ** 2))
+
+
+class Engine2D:
+    """transforms (and, after ``set_projection``, the reciprocal projection) of the 2-D variant for batches of ``n_batch`` grids"""
+
+    def __init__(self, n_radial_points, max_order, max_q, reciprocity_coefficient=2.0, n_batch=1, device=0, lib_path=None, used_orders=None):
+        self.lib = _lib.load(lib_path)
+        self.N, self.M, self.B = int(n_radial_points), int(max_order), int(n_batch)
+        self.n_phi = 2 * self.M + 1                              # harmonic_transforms.py:44-47
+        self.kappa = float(reciprocity_coefficient)
+        self.q_max = float(max_q)
+        self.r_max = self.kappa * self.N / self.q_max            # mathLibrary.py:1169-1176
+        dr, dq = self.r_max / self.N, self.q_max / self.N
+        self.rs = np.linspace(dr / 2, self.r_max - dr / 2, num=self.N, endpoint=True)
+        self.qs = np.linspace(dq / 2, self.q_max - dq / 2, num=self.N, endpoint=True)
+        self.phis = np.arange(self.n_phi) / self.n_phi * 2 * np.pi
+        self.shape = (self.N, self.n_phi)
+        if self.lib.mtip_device_count() <= 0:
+            raise _lib.MtipError('no HIP device visible: the 2-D operators need an MI355X (no CPU fallback)')
+        self.ctx = self.lib.mtip2d_create(self.N, self.n_phi, self.B, int(device))
+        if not self.ctx:
+            raise _lib.MtipError('mtip2d_create failed (sizes: n_phi odd, 3..2047; a visible device)')
+        orders = np.arange(self.M + 1)
+        fw, iw = assemble_weights_mid(polar_mid_weights(orders, self.N, self.kappa), orders, self.r_max, self.kappa)
+        all_abs = np.concatenate((orders, orders[:0:-1]))
+        unused = ~np.isin(all_abs, orders if used_orders is None else np.asarray(used_orders))     # hankel_transforms.py:611-613
+        self._ck(self.lib.mtip2d_set_hankel_weights(self.ctx, _lib.ptr(_lib.as_c128(fw)), _lib.ptr(_lib.as_c128(iw)), _lib.ptr(_lib.as_u8(unused))))
+        self.n_used = 0
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise _lib.MtipError(f'libmtip_hip (2-D) error {rc}: ' + self.lib.mtip2d_last_error(self.ctx).decode())
+
+    def close(self):
+        if getattr(self, 'ctx', None):
+            self.lib.mtip2d_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _grid(self, a, last=None):
+        a = _lib.as_c128(a)
+        shape = (self.N, self.n_phi if last is None else last)
+        if a.shape == shape:
+            a = np.broadcast_to(a, (self.B,) + shape)
+        assert a.shape == (self.B,) + shape, (a.shape, shape)
+        return np.ascontiguousarray(a)
+
+    def harmonic(self, grid, inverse=False):
+        g = self._grid(grid)
+        out = np.empty_like(g)
+        self._ck(self.lib.mtip2d_op_harmonic(self.ctx, _lib.ptr(g), _lib.ptr(out), int(inverse)))
+        return out
+
+    def real_harmonic_forward(self, grid):
+        g = self._grid(grid)
+        out = np.empty((self.B, self.N, self.M + 1), complex)
+        self._ck(self.lib.mtip2d_op_real_harmonic_forward(self.ctx, _lib.ptr(g), _lib.ptr(out)))
+        return out
+
+    def real_harmonic_inverse(self, coeff):
+        c = self._grid(coeff, self.M + 1)
+        out = np.empty((self.B, self.N, self.n_phi))
+        self._ck(self.lib.mtip2d_op_real_harmonic_inverse(self.ctx, _lib.ptr(c), _lib.ptr(out)))
+        return out
+
+    def hankel(self, coeff, inverse=False):
+        c = self._grid(coeff)
+        out = np.empty_like(c)
+        self._ck(self.lib.mtip2d_op_hankel(self.ctx, _lib.ptr(c), _lib.ptr(out), int(inverse)))
+        return out
+
+    def fourier_transform(self, grid, inverse=False):
+        g = self._grid(grid)
+        out = np.empty_like(g)
+        self._ck(self.lib.mtip2d_op_fourier_transform(self.ctx, _lib.ptr(g), _lib.ptr(out), int(inverse)))
+        return out
+
+    def set_projection(self, projection_vectors, used_orders, radial_mask, number_of_particles=1.0):
+        """projection_vectors (n_used, Nq): one per used order; used_orders {order: id} (ascending ids, order 0 included);
+        radial_mask (n_orders, Nq) indexed by id as upstream"""
+        ids = np.ascontiguousarray(list(used_orders.values()), dtype=np.int32)
+        pm = _lib.as_c128(projection_vectors)
+        assert pm.shape == (len(ids), self.N)
+        rm = _lib.as_u8(np.asarray(radial_mask, dtype=bool)[ids])
+        self._ck(self.lib.mtip2d_set_projection(self.ctx, len(ids), _lib.ptr(ids), _lib.ptr(pm), _lib.ptr(rm), _lib.ptr(_lib.as_f64(self.qs)),
+                                                float(number_of_particles)))
+        self.n_used = len(ids)
+
+    def project(self, I):
+        """approximate_unknowns + mtip_projection + number-of-particles rule: (projected coefficients, unknowns)"""
+        c = self._grid(I, self.M + 1)
+        out = np.empty_like(c)
+        unk = np.empty((self.B, self.n_used), complex)
+        self._ck(self.lib.mtip2d_op_project(self.ctx, _lib.ptr(c), _lib.ptr(out), _lib.ptr(unk)))
+        return out, unk
