@@ -213,8 +213,7 @@ def test_config5_properties_full_size():
 
 # ---- every MTIP_* switch that selects another kernel of the shipping library gets a forced parity case ------------------
 _TRAJ_SWITCHES = [('MTIP_SHT_MODE', '0'), ('MTIP_SHT_MODE', '1'), ('MTIP_SHT_WIDE', '0'), ('MTIP_FUSE_REAL', '0'),
-                  ('MTIP_DEG2_SIMPLE', '1'), ('MTIP_HANKEL_SIMPLE', '1'), ('MTIP_HANKEL_WAVE_TILES', '1'),
-                  ('MTIP_HANKEL_FLAT_ORDER', '1'), ('MTIP_SHT_FWD_PAIR', '0'),
+                  ('MTIP_DEG2_SIMPLE', '1'), ('MTIP_SHT_FWD_PAIR', '0'),
                   ('MTIP_PROJ_FUSE', '0'), ('MTIP_PROJ_REAL', '0')]
 
 

@@ -140,8 +140,6 @@ struct mtip_ctx {
     double2* d_twN = nullptr;                         // exp(-2 pi i j / n_phi), j < n_phi
     double2* d_tw = nullptr;
     double* d_W = nullptr;
-    void* d_htiles = nullptr;                         // HankelTile list of the MFMA kernel
-    int n_htiles = 0;
     int n_cu = 256;                                   // compute units of the device (persistent-grid sizing)
     bool fuse_real_update = true;                     // env MTIP_FUSE_REAL=0: separate coefficient-difference / real-space kernels
     bool sht_wide = true;                             // env MTIP_SHT_WIDE=0: pass-wise inverse Legendre synthesis
@@ -159,11 +157,8 @@ struct mtip_ctx {
     long long* d_polar_dbg = nullptr;                 // (B, L+1, 32) phase / round timers of k_rproj, allocated by mtip_debug_polar_timing
     int jac_tg = 16;                                  // env MTIP_JAC_TG=8|16: lanes per Jacobi column pair
     bool sht_fwd_pair = true;                         // env MTIP_SHT_FWD_PAIR=0: k_sht_fwd_reg (table loads inside the accumulation loop)
-    bool hankel_flat_order = false;                   // env MTIP_HANKEL_FLAT_ORDER=1: tiles in order-major sequence (not XCD-aware)
-    bool hankel_wave_tiles = false;                   // env MTIP_HANKEL_WAVE_TILES=1: per-wave tiles straight from L2 (k_hankel_mfma)
     void* d_htiles32 = nullptr;                       // workgroup tiles (order, first column) of k_hankel_tile
     int n_htiles32 = 0, htile_ct = 5;                 // 16-column MFMA tiles per workgroup
-    bool hankel_simple = false;                       // env MTIP_HANKEL_SIMPLE=1: one-thread-per-output kernel
     double fwd_scale = 0, inv_scale = 0;
     bool have_angular = false, have_radial = false, have_weights = false, have_support = false, have_errw = false;
     // projection data
