@@ -41,8 +41,9 @@
 //   G^-1/2 = D^-1 - A + (A~ A~^T) o S + A~ A + O(E^3),   S_ij = 1 / (sigma_i + sigma_j)
 // (the second Newton correction of the square root, Delta2 = -(Delta^2) o S, and the second term of the Neumann series of the
 // inverse): two more k x k x k products, measured error 0.3 E^3 -- so the sweeps may stop after one with rotations up to
-// RP_EARLY_CORR = 1e-2, which leaves E ~ 1e-6 .. 1e-4.
-#define RP_EARLY_CORR 1e-2
+// RP_EARLY_CORR = 3e-2, which leaves E ~ 1e-6 .. 1e-4 (when the Gram matrix says more, one more sweep runs and the check repeats;
+// measured 1e-2 / 3e-2 / 1e-1: 365 / 352 / 348 us per projection in the HIO blocks).
+#define RP_EARLY_CORR 3e-2
 #define RP_CORR_MAX 3e-6
 #define RP_CORR2_MAX 1.5e-4
 #define RP_SLACK 128            // doubles behind the matrices: predicated-off lanes of the last row slot still form addresses
@@ -347,6 +348,7 @@ struct RProjArgs {
     const int *sched, *sched_off, *sched_rounds;
     int sched_ps, tab_ints;       // tab_ints: ints reserved in LDS for the raw pairing table (even)
     int N, L, nlm, utot, xtot, warm, corr;
+    double rp_early, rp_corr2_max;   // closing step: stop sweeping below this rotation size / accept the second-order step below this |E|
     double tabs2, inv_sqrt_np;
     int* sweeps_out;
     long long* dbg;               // mtip_debug_polar_timing: 32 slots per (restart, order): cycles of the phases A, W, J, U, E of wave 0,
@@ -561,7 +563,7 @@ __device__ __forceinline__ void rp_solve(const RProjArgs& A, int b, int l, RpSha
     const bool xl_ok = t + (nr - 1) * TG < n2, vl_ok = t + (nr - 1) * TG < k;
     double S = 0.0;
     const bool corr = pad && A.corr != 0;
-    double early2 = corr ? RP_EARLY_CORR * RP_EARLY_CORR : JL_EARLY * JL_EARLY;
+    double early2 = corr ? A.rp_early * A.rp_early : JL_EARLY * JL_EARLY;
     bool use_corr = false, corr2 = false;
     double* Pm = reinterpret_cast<double*>(s_tab);       // k x kp: Gram matrix, then D^-1 (1 - Delta D^-1) (the tables are done with by then)
     const int kp = k | 1;
@@ -675,7 +677,7 @@ __device__ __forceinline__ void rp_solve(const RProjArgs& A, int b, int l, RpSha
             __syncthreads();
             if (cont == 2) continue;
             // below JL_EARLY: the sweep just done was the confirming one (it leaves ~1e-12), classic finish without the first-order step
-            if (cont == 0 || !corr || early2 == JL_EARLY * JL_EARLY) break;
+            if (cont == 0 || !corr) break;
             // ---- Gram matrix G = W^T W on the matrix pipe, its diagonal (sigma^2) and the largest |E_ij| ----
             for (int base = 0; base < ntm_k * ntm_k; base += nwaves * RP_ACC) {
                 v4f64 acc[RP_ACC];
@@ -728,15 +730,15 @@ __device__ __forceinline__ void rp_solve(const RProjArgs& A, int b, int l, RpSha
             em = 0.0;
             for (int wv = 0; wv < nwaves; ++wv) em = fmax(em, sh.red[wv]);
             __syncthreads();
-            if (em <= RP_CORR2_MAX) {
+            if (em <= A.rp_corr2_max) {
                 use_corr = true;
                 corr2 = em > RP_CORR_MAX;
                 // (bits 24, 25 of the sweep record: closed by the first / second order step)
                 if (tid == 0) A.sweeps_out[b * (A.L + 1) + l] |= corr2 ? (2 << 24) : (1 << 24);
                 break;
             }
-            early2 = JL_EARLY * JL_EARLY;                        // not there yet: sweep on, classic criterion (the Gram matrix
-            tab_ke = -1;                                         // overwrote the pairing table: staged again)
+            tab_ke = -1;                                         // not there yet: one more sweep (the Gram matrix overwrote the
+                                                                 // pairing table: staged again), then the check again
         }
     } else if (tid == 0) {
         A.sweeps_out[b * (A.L + 1) + l] = 0 | (k << 8);
@@ -1198,6 +1200,8 @@ int launch_rproj(mtip_ctx* c, double2* coef) {
     a.warm = (c->vr_kind == 2 && (c->proj_calls % 64) != 0) ? 1 : 0;
     a.tabs2 = c->polar_abs_tol * c->polar_abs_tol;
     a.corr = c->rp_corr ? 1 : 0;
+    a.rp_early = c->rp_early;
+    a.rp_corr2_max = c->rp_corr2_max;
     a.inv_sqrt_np = 1.0 / std::sqrt(c->n_particles);
     a.sweeps_out = c->d_sweeps;
     a.dbg = c->d_polar_dbg;

@@ -153,6 +153,8 @@ mtip_ctx* mtip_create(const mtip_cfg* cfg, int device) {
     if (const char* e = std::getenv("MTIP_PROJ_REAL")) c->proj_real = std::atoi(e) != 0;
     if (const char* e = std::getenv("MTIP_RP_TG")) c->rp_tg = std::atoi(e);
     if (const char* e = std::getenv("MTIP_RP_CORR")) c->rp_corr = std::atoi(e) != 0;
+    if (const char* e = std::getenv("MTIP_RP_EARLY")) c->rp_early = std::atof(e);
+    if (const char* e = std::getenv("MTIP_RP_CORR2_MAX")) c->rp_corr2_max = std::atof(e);
     for (int l = 0; l <= L; ++l) {
         const int n = 2 * l + 1, k = std::min(n, N);
         c->kl[l] = k;                               // default; mtip_set_projection_matrix may give a smaller k_l

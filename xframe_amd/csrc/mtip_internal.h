@@ -147,6 +147,7 @@ struct mtip_ctx {
     int *d_jsched = nullptr, *d_jsched_off = nullptr, *d_jsched_rounds = nullptr;   // resident-column pairing schedule
     int jsched_kmax = 0, jsched_ps = 0;
     std::vector<int> jsched_nrd;                      // rounds of a sweep for every column count (host copy of d_jsched_rounds)
+    double rp_early = 3e-2, rp_corr2_max = 1.5e-4;     // thresholds of the closing step (k_projr.hip RP_EARLY_CORR, RP_CORR2_MAX; env MTIP_RP_EARLY, MTIP_RP_CORR2_MAX)
     bool rp_corr = true;                              // k_rproj: close the Jacobi sweeps with the first-order polar step (MTIP_RP_CORR=0: classic)
     int so_order = -1;                                // SO_freedom: order whose unknown [4][2] is made real after every projection (-1: off)
     std::vector<int> jsched_off_h;                    // offsets of the per-column-count tables in d_jsched (host copy of d_jsched_off)
