@@ -321,6 +321,12 @@ def main():
                 tops['proj_gemms'] = {'total_ms': fam_ms['proj']['total_ms'] - fam_ms['polar']['total_ms']}
             top = max(tops, key=lambda k: tops[k]['total_ms'])
             if top == 'polar':
+                polar_traffic = None
+                try:
+                    if pmc.get('restarts_per_launch') == Bp and pmc.get('config') == a.config:
+                        polar_traffic = pmc['hbm_bytes_per_launch'].get('polar')
+                except (NameError, KeyError, AttributeError):
+                    polar_traffic = None
                 swp = np.asarray(e0.jacobi_sweeps(), dtype=float)                  # (Bp, L+1): sweeps of the last call
                 ns = 2 * np.arange(L + 1) + 1
                 active = swp.mean(0) > 0
@@ -346,7 +352,7 @@ def main():
                 ach = flops / (fam_ms['polar']['avg_ms'] * 1e-3) / 1e12
                 crit = float(swp[:, -1].max() * per_sweep[-1] + prod[-1])
                 roofline = {'bound': 'fp64_valu', 'kernel': kname,
-                            'achieved': ach, 'peak': e0_cus * peak_cu, 'unit': 'TFLOP/s', 'frac': ach / (e0_cus * peak_cu), 'traffic': None,
+                            'achieved': ach, 'peak': e0_cus * peak_cu, 'unit': 'TFLOP/s', 'frac': ach / (e0_cus * peak_cu), 'traffic': polar_traffic,
                             'cus_used': cus, 'cus_total': e0_cus, 'frac_of_cus_used': ach / (cus * peak_cu),
                             'avg_launch_ms': fam_ms['polar']['avg_ms'],
                             'algorithmic_flops_per_launch': flops, 'restarts_per_launch': Bp,

@@ -2,14 +2,15 @@
 TCC slots require).  Units: both counters are in KiB; on gfx950 FETCH_SIZE tallies 128-byte read requests at 64 bytes,
 so wide coalesced reads are doubled (MI355X_MICROARCH.md, HBM section) -- printed raw and corrected.
 usage: pmc_summary.py <fetch_dir> <write_dir> [out.json restarts_per_launch config]"""
-import csv, glob, sys
+import csv
+import os, glob, sys
 from collections import defaultdict
 
 
 def per_kernel(d, counter):
     """mean counter value per kernel over its launches with the LARGEST grid (with several engines per GPU the launches of
     the engine that holds fewer restarts are smaller; the bench line quotes engine 0, which holds the most)"""
-    f = glob.glob(d + "/*/*counter_collection.csv")[0]
+    f = max(glob.glob(d + "/*/*counter_collection.csv"), key=os.path.getmtime)       # (the newest run when several were merged into d)
     rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter]
     gmax = defaultdict(int)
     for r in rows:
@@ -39,7 +40,7 @@ for tot, k, n, fk, wk in rows[:24]:
 if len(sys.argv) > 3:
     import json
     fam_of = [("k_sht_fwd_pair", "sht_fwd"), ("k_sht_fwd_reg", "sht_fwd"), ("k_sht_inv_wide<0", "sht_inv"), ("k_sht_inv_wide<1", "sht_inv_modulus"),
-              ("k_sht_inv_wide<4", "sht_inv_real"), ("k_hankel", "hankel"), ("k_real_update", "real_update")]
+              ("k_sht_inv_wide<4", "sht_inv_real"), ("k_hankel", "hankel"), ("k_real_update", "real_update"), ("k_rproj", "polar")]
     fam = defaultdict(lambda: [0.0, 0])
     for k in fetch:
         for pat, name in fam_of:
