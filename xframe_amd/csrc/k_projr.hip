@@ -45,6 +45,7 @@
 // measured 1e-2 / 3e-2 / 1e-1: 365 / 352 / 348 us per projection in the HIO blocks).
 #define RP_EARLY_CORR 3e-2
 #define RP_CORR_MAX 3e-6
+#define RP_CORR_SKIP 1e-12    // below this the plain finish (error ~ |E|) is as good as the step: no step needed
 #define RP_CORR2_MAX 1.5e-4
 #define RP_SLACK 128            // doubles behind the matrices: predicated-off lanes of the last row slot still form addresses
 #define RP_ACC_MAX 5            // 16 x 16 output tiles a wave works on at a time (and holds across a barrier: in-place products)
@@ -241,7 +242,7 @@ __device__ __forceinline__ double rp_sum1(double v) {
 
 template <int NC, int TG, bool TIMED = false>
 __device__ __forceinline__ void rp_sweep_pad(double* xt /* X~ + lane of the group */, const int2* tab, int n_rounds, int ngroups,
-                                             int group, double tabs2, double S, double early2, bool& big, bool& mid, long long* tacc = nullptr) {
+                                             int group, double tabs2, double S, double early2, bool& big, long long* tacc = nullptr) {
     constexpr int NR = rp_pad_nrt(NC, TG);
     constexpr int VOFF = rp_pad_voff(NC, TG);
     long long tq = 0;
@@ -295,7 +296,6 @@ __device__ __forceinline__ void rp_sweep_pad(double* xt /* X~ + lane of the grou
         const double g2 = g * g, ab = alpha * beta;
         const bool rot = g2 > (JAC_TOL * JAC_TOL) * ab && g2 > tabs2 * fmax(alpha, beta) * S && g2 > 0.0;
         big = big || (rot && g2 > early2 * ab);
-        mid = mid || (rot && g2 > (JL_EARLY * JL_EARLY) * ab);
         const double d = 0.5 * (beta - alpha);
         const double h2 = fma(d, d, g2);
         const double ih = fast_rsqrt(rot ? h2 : 1.0);
@@ -608,7 +608,7 @@ __device__ __forceinline__ void rp_solve(const RProjArgs& A, int b, int l, RpSha
             }
             __syncthreads();
             const int ke = sh.keff;
-            bool big = false, mid = false;
+            bool big = false;
             if (ke >= 2) {
                 const int* gtab = A.sched + A.sched_off[ke];
                 const int nrd = A.sched_rounds[ke];
@@ -641,7 +641,7 @@ __device__ __forceinline__ void rp_solve(const RProjArgs& A, int b, int l, RpSha
                     double* xt = Xs + t;
                     if (dbg != nullptr && nc == 5) {             // diagnostic instance with segment timers
                         long long tacc[7] = {0, 0, 0, 0, 0, 0, 0};
-                        rp_sweep_pad<5, TG, true>(xt, s_tab2, nrd, ngroups, group, A.tabs2, S, early2, big, mid, tacc);
+                        rp_sweep_pad<5, TG, true>(xt, s_tab2, nrd, ngroups, group, A.tabs2, S, early2, big, tacc);
                         if ((tid & 63) == 0 && (tid >> 6) < 8) {   // per wave: busy, LDS drain + barrier; wave 0 and 5 also the segments
                             dbg[10 + (tid >> 6)] += tacc[0] + tacc[1] + tacc[2] + tacc[3] + tacc[4];
                             dbg[18 + (tid >> 6)] += tacc[5] + tacc[6];
@@ -650,11 +650,11 @@ __device__ __forceinline__ void rp_solve(const RProjArgs& A, int b, int l, RpSha
                         }
                     } else {
                         switch (nc) {
-                        case 1: rp_sweep_pad<1, TG>(xt, s_tab2, nrd, ngroups, group, A.tabs2, S, early2, big, mid); break;
-                        case 2: rp_sweep_pad<2, TG>(xt, s_tab2, nrd, ngroups, group, A.tabs2, S, early2, big, mid); break;
-                        case 3: rp_sweep_pad<3, TG>(xt, s_tab2, nrd, ngroups, group, A.tabs2, S, early2, big, mid); break;
-                        case 4: rp_sweep_pad<4, TG>(xt, s_tab2, nrd, ngroups, group, A.tabs2, S, early2, big, mid); break;
-                        default: rp_sweep_pad<5, TG>(xt, s_tab2, nrd, ngroups, group, A.tabs2, S, early2, big, mid); break;
+                        case 1: rp_sweep_pad<1, TG>(xt, s_tab2, nrd, ngroups, group, A.tabs2, S, early2, big); break;
+                        case 2: rp_sweep_pad<2, TG>(xt, s_tab2, nrd, ngroups, group, A.tabs2, S, early2, big); break;
+                        case 3: rp_sweep_pad<3, TG>(xt, s_tab2, nrd, ngroups, group, A.tabs2, S, early2, big); break;
+                        case 4: rp_sweep_pad<4, TG>(xt, s_tab2, nrd, ngroups, group, A.tabs2, S, early2, big); break;
+                        default: rp_sweep_pad<5, TG>(xt, s_tab2, nrd, ngroups, group, A.tabs2, S, early2, big); break;
                         }
                     }
                 } else if (BIG) {
@@ -664,20 +664,19 @@ __device__ __forceinline__ void rp_solve(const RProjArgs& A, int b, int l, RpSha
                 }
                 n_rounds_done += nrd;
             }
-            if (t == 0) sh.gmax[group] = big ? 2.0 : (mid ? 1.0 : 0.0);
+            if (t == 0) sh.gmax[group] = big ? 1.0 : 0.0;
             __syncthreads();
             if (tid == 0) {
                 double m = 0.0;
                 for (int gq = 0; gq < ngroups; ++gq) m = fmax(m, sh.gmax[gq]);
-                sh.cont = (int)m;                              // 2: sweep on; 1: below `early2` but above JL_EARLY; 0: below JL_EARLY (quadratic convergence)
+                sh.cont = (m > 0.0) ? 1 : 0;                   // 1: some rotation was above `early2`: sweep on (quadratic convergence)
                 A.sweeps_out[b * (A.L + 1) + l] = (sweep + 1) | (ke << 8);
             }
             __syncthreads();
             const int cont = sh.cont;
             __syncthreads();
-            if (cont == 2) continue;
-            // below JL_EARLY: the sweep just done was the confirming one (it leaves ~1e-12), classic finish without the first-order step
-            if (cont == 0 || !corr) break;
+            if (cont) continue;
+            if (!corr) break;                                    // classic exit: the sweep just done was the confirming one
             // ---- Gram matrix G = W^T W on the matrix pipe, its diagonal (sigma^2) and the largest |E_ij| ----
             for (int base = 0; base < ntm_k * ntm_k; base += nwaves * RP_ACC) {
                 v4f64 acc[RP_ACC];
@@ -730,6 +729,7 @@ __device__ __forceinline__ void rp_solve(const RProjArgs& A, int b, int l, RpSha
             em = 0.0;
             for (int wv = 0; wv < nwaves; ++wv) em = fmax(em, sh.red[wv]);
             __syncthreads();
+            if (em <= RP_CORR_SKIP) break;                       // already orthogonal to rounding: the plain finish
             if (em <= A.rp_corr2_max) {
                 use_corr = true;
                 corr2 = em > RP_CORR_MAX;
