@@ -120,6 +120,20 @@ def test_average_flow_golden(emul_lib, golden_flow):
     PC.check_average_flow_golden_hip(golden_flow, emul_lib)
 
 
+@pytest.mark.parametrize('cat,name', [('reciprocal', 'II_error'), ('reciprocal', 'fqc_error'), ('reciprocal', 'ccd_diff'), ('real', 'support_size')])
+def test_unknown_error_metrics_are_rejected(emul_lib, golden_mtip16, cat, name):
+    """metrics the reference knows but this build does not (fxs_IO_methods.py:690-703) raise instead of being dropped silently"""
+    from helpers import data_from_golden, golden_settings
+    from xframe_amd.fxs.engine import Engine
+    g = golden_mtip16
+    N, L = int(g['N']), int(g['L'])
+    opt = golden_settings(N, L)
+    calc = opt['main_loop']['error']['methods'][cat]
+    calc['calculate'] = list(calc.get('calculate', [])) + [name]
+    with pytest.raises(NotImplementedError):
+        Engine(opt, data_from_golden(g, L), n_batch=1, lib_path=emul_lib)
+
+
 def test_polar2d_golden(emul_lib, golden_polar2d):
     """the 2-D operators against the reference's own functions (fixture G18)"""
     PC.check_polar2d_golden_hip(golden_polar2d, emul_lib)

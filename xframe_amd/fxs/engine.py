@@ -98,6 +98,12 @@ class Engine:
         wr, wt, use_mask = hs.error_weights(self.rs, self.n_theta, self.shape, inside, gen.get('cache_aware', True),
                                             gen.get('L2_cache', 512))
         self._ck(self.lib.mtip_set_error_weights(self.ctx, _lib.ptr(_lib.as_f64(wr)), _lib.ptr(_lib.as_f64(wt)), int(use_mask)))
+        # metrics that are not on the accelerated path must not be dropped silently (fxs_IO_methods.py:690-703 lists them)
+        for cat, known in (('real', ('l2_projection_diff',)), ('reciprocal', ('deg2_invariant_l2_diff',))):
+            for name in em.get(cat, {}).get('calculate', []) or []:
+                if name not in known:
+                    raise NotImplementedError('main_loop.error.methods.%s.calculate: %r is not built (DESIGN section 6); built: %s'
+                                              % (cat, name, ', '.join(known)))
         self.deg2_enabled = 'deg2_invariant_l2_diff' in em['reciprocal']['calculate']
         self._ck(self.lib.mtip_set_deg2_metric(self.ctx, int(self.deg2_enabled)))
         # generate_main_error_routine, fxs_IO_methods.py:746-765
