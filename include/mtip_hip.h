@@ -98,6 +98,19 @@ int mtip_set_deg2_metric(mtip_ctx* ctx, int enable);
  * scalar: every type returns it); 1: the per-order values of deg2_invariant_l2_diff (one entry per used order, -1 where
  * the reference invariant vanishes).  Mixing both makes the reference itself raise (np.array of a scalar and a vector). */
 int mtip_set_main_error(mtip_ctx* ctx, int use_reciprocal_deg2, int type);
+/* the non-default reciprocal metrics II_error / ccd_diff / fqc_error (fxs_IO_methods.py:587-627, 651-683, 507-550), evaluated in
+ * every FXS step from B_l of the current intensity coefficients.  which: 1 | 2 | 4 (0 switches them off); zero_mask (L+1, Nq, Nq):
+ * 1 = entry of B_l outside the invariant mask (zeroed); II: masked reference sum_{l>=1} B_l^ref (Nq, Nq), qq = (q q')^2;
+ * ccd: P^C_l(q) P^C_l(q') / (2l+1) per order with the rows of order 0 and of orders < C_order zero (L+1, Nq, Nq), reference C (Nq, Nq),
+ * its squared norm; fqc: P (L+1, Nq, Nq, L+1) = P^m_l(q) P^m_l(q') / (2l+1) indexed [l][q][q'][m], reference average (Nq, Nq),
+ * reference weights (L+1, Nq, Nq).  The host prepares the tables (xframe_amd/fxs/hostsetup.py). */
+int mtip_set_invariant_metrics(mtip_ctx* ctx, uint32_t which, const uint8_t* zero_mask, const mtip_cdouble* II_reference, const double* qq,
+                               const double* ccd_weights, const mtip_cdouble* ccd_reference, double ccd_norm, const double* fqc_P,
+                               const double* fqc_reference_average, const double* fqc_reference_weights);
+/* their values for the steps [first, first + n_steps): II (n, n_batch), ccd (n, n_batch), fqc (n, n_batch, Nq); NULL skips one */
+int mtip_fetch_invariant_metrics(mtip_ctx* ctx, int64_t first_step, int64_t n_steps, double* II, double* ccd, double* fqc);
+/* the same metrics of given intensity coefficients (n_batch, Nq, (L+1)^2): II (n_batch), ccd (n_batch), fqc (n_batch, Nq) */
+int mtip_op_invariant_metrics(mtip_ctx* ctx, const mtip_cdouble* Ilm, double* II, double* ccd, double* fqc);
 /* real-space constraints (fxs_Projections.py:72-130, pythonLibrary.py:1289-1320):
  * flags bit0 support, bit1 value lower bound, bit2 value upper bound, bit3 limit_imag;
  * hio_mask_flags: which of those feed the HIO mask gamma ('considered_projections',

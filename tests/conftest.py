@@ -36,6 +36,11 @@ def golden_flow():
 
 
 @pytest.fixture(scope='session')
+def golden_metrics():
+    return np.load(os.path.join(GOLDEN, 'metrics_ops.npz'))
+
+
+@pytest.fixture(scope='session')
 def golden_polar2d():
     return np.load(os.path.join(GOLDEN, 'polar2d_ops.npz'))
 

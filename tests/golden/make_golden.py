@@ -1181,6 +1181,86 @@ def main_polar2d():
     print('polar 2-D fixture:', len(out), 'arrays')
 
 
+# ---- (f-4) the non-default reciprocal metrics ------------------------------------------------------------------------------------
+def main_metrics():
+    """tests/golden/metrics_ops.npz (G19): the reference's `_generate_fqc_3d`, `_generate_II_3d`, `_generate_ccd_diff_3d`
+    (fxs_IO_methods.py:507-550, 587-627, 651-683) on seeded invariants, masks and intensity coefficients.  pygsl is absent: the slot
+    `mathLibrary.gsl` gets a double that serves `legendre_sphPlm_array(_single_m)` from oracle/metrics.py (the published definition of
+    gsl_sf_legendre_sphPlm through scipy), so the metric formulas are the reference's, the Legendre values are not pinned."""
+    mods = bootstrap()
+    ml = mods['xframe.library.mathLibrary']
+    ml.shtns = ShAdapter
+    import types as _t
+    from oracle import metrics as OMx
+
+    class GslDouble:
+        @staticmethod
+        def legendre_sphPlm_array(l_max, m_max, xs, return_orders=False, sorted_by_l=False):
+            assert not sorted_by_l
+            v, ls, ms = OMx.legendre_sphPlm_array(l_max, m_max, xs)
+            return (np.squeeze(v), ls, ms) if return_orders else np.squeeze(v)
+
+        @staticmethod
+        def legendre_sphPlm_array_single_m(l_max, m, xs, return_orders=False):
+            v, ls, ms = OMx.legendre_sphPlm_array_single_m(l_max, m, xs)
+            return (np.squeeze(v), ls, ms) if return_orders else np.squeeze(v)
+    ml.gsl = GslDouble
+
+    class _Any:
+        def __init__(s, *a, **k):
+            pass
+
+        def __getattr__(s, n):
+            return _Any()
+
+        def __call__(s, *a, **k):
+            return _Any()
+
+    class AnyModule(_t.ModuleType):
+        def __getattr__(s, n):
+            if n.startswith('__'):
+                raise AttributeError(n)
+            return _Any()
+    for name in ('xframe.presenters', 'xframe.presenters.matplotlibPresenter', 'xframe.presenters.openCVPresenter'):
+        sys.modules[name] = AnyModule(name)
+    pl = mods['xframe.library.pythonLibrary']
+    st = mods['xframe.settings']
+    from oracle import mtip as OM
+    from xframe_amd.fxs import synthetic as S
+    st.project = pl.DictNamespace.dict_to_dictnamespace(OM.deep_update(OM.default_settings(), S.config_overrides(1)))
+    io = importlib.import_module('xframe.projects.fxs.projectLibrary.fxs_IO_methods')
+    rng = np.random.default_rng(1919)
+    N, L = 10, 5
+    qs = (np.arange(N) + 0.5) * 0.012
+    wavelength = 1.23984
+    Iref = [cplx(rng, (N, 2 * l + 1)) for l in range(L + 1)]
+    ref = np.array([a @ a.T.conj() for a in Iref])
+    used = {l: l for l in range(L + 1)}
+    rm = rng.random((L + 1, N)) > 0.2
+    inv_mask = rm[:, :, None] * rm[:, None, :]
+    n_particles = np.array([2.0])
+    Ims = [a + 0.3 * cplx(rng, a.shape) for a in Iref]
+    out = {'G19_N': np.array(N), 'G19_L': np.array(L), 'G19_qs': qs, 'G19_wavelength': np.array(wavelength), 'G19_ref': ref,
+           'G19_radial_mask': rm, 'G19_n_particles': n_particles, 'G19_C_order': np.array(2)}
+    for l in range(L + 1):
+        out[f'G19_I{l}'] = Ims[l]
+    fqc = io._generate_fqc_3d(qs, ref.copy(), used, n_particles, inv_mask, wavelength)
+    II = io._generate_II_3d(qs, ref.copy(), used, n_particles, inv_mask, wavelength)
+    ccd = io._generate_ccd_diff_3d(qs, ref.copy(), used, n_particles, inv_mask, 2, wavelength)
+    out['G19_fqc'] = np.asarray(fqc(None, None, [a.copy() for a in Ims]))
+    out['G19_II'] = np.asarray(II(None, None, [a.copy() for a in Ims]))
+    out['G19_ccd'] = np.asarray(ccd(None, None, [a.copy() for a in Ims]))
+    # a second evaluation on other coefficients (the routines keep state in preallocated arrays)
+    Ims2 = [a + 1.0 * cplx(rng, a.shape) for a in Iref]
+    for l in range(L + 1):
+        out[f'G19_J{l}'] = Ims2[l]
+    out['G19_fqc2'] = np.asarray(fqc(None, None, [a.copy() for a in Ims2]))
+    out['G19_II2'] = np.asarray(II(None, None, [a.copy() for a in Ims2]))
+    out['G19_ccd2'] = np.asarray(ccd(None, None, [a.copy() for a in Ims2]))
+    np.savez_compressed(os.path.join(HERE, 'metrics_ops.npz'), **out)
+    print('metrics fixture:', len(out), 'arrays; fqc', out['G19_fqc'][:3], 'II', out['G19_II'], 'ccd', out['G19_ccd'])
+
+
 if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'io':
         main_io()
@@ -1192,6 +1272,8 @@ if __name__ == '__main__':
         main_average_flow()
     elif len(sys.argv) > 1 and sys.argv[1] == 'polar2d':
         main_polar2d()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'metrics':
+        main_metrics()
     elif len(sys.argv) > 1 and sys.argv[1] == 'variants':
         main_variants()
     else:

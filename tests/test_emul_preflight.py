@@ -120,7 +120,17 @@ def test_average_flow_golden(emul_lib, golden_flow):
     PC.check_average_flow_golden_hip(golden_flow, emul_lib)
 
 
-@pytest.mark.parametrize('cat,name', [('reciprocal', 'II_error'), ('reciprocal', 'fqc_error'), ('reciprocal', 'ccd_diff'), ('real', 'support_size')])
+def test_invariant_metrics_golden(emul_lib, golden_metrics):
+    PC.check_invariant_metrics_golden_hip(golden_metrics, emul_lib)
+
+
+@pytest.mark.parametrize('fused', [True, False])
+def test_invariant_metrics_vs_oracle(emul_lib, golden_mtip16, fused):
+    """II_error / ccd_diff / fqc_error recorded by the loop against the oracle's routines on the oracle's trajectory"""
+    PC.check_invariant_metrics_vs_oracle(golden_mtip16, emul_lib, fused)
+
+
+@pytest.mark.parametrize('cat,name', [('reciprocal', 'l2_projection_diff'), ('reciprocal', 'deg2_ranked_invariant_l2_diff'), ('real', 'support_size')])
 def test_unknown_error_metrics_are_rejected(emul_lib, golden_mtip16, cat, name):
     """metrics the reference knows but this build does not (fxs_IO_methods.py:690-703) raise instead of being dropped silently"""
     from helpers import data_from_golden, golden_settings

@@ -163,6 +163,18 @@ def test_average_flow_golden(golden_flow):
     PC.check_average_flow_golden_hip(golden_flow)
 
 
+def test_invariant_metrics_golden(golden_metrics):
+    """II_error / ccd_diff / fqc_error on the device against the reference's own routines (fixture G19, operator level)"""
+    PC.check_invariant_metrics_golden_hip(golden_metrics)
+
+
+@pytest.mark.parametrize('fused', [True, False])
+def test_invariant_metrics_vs_oracle(golden_mtip16, fused):
+    """the non-default reciprocal metrics II_error / ccd_diff / fqc_error (fxs_IO_methods.py:587-627, 651-683, 507-550) as the loop
+    records them per step (k_metrics.hip) against the oracle's routines evaluated on the oracle's trajectory"""
+    PC.check_invariant_metrics_vs_oracle(golden_mtip16, None, fused)
+
+
 def test_polar2d_golden(golden_polar2d):
     """the 2-D (polar) operators -- circular harmonic transforms, polar Hankel pair, Fourier pair, reciprocal projection -- against
     the reference's own functions (fixture G18, tests/golden/polar2d_ops.npz)"""

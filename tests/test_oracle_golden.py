@@ -277,3 +277,9 @@ def test_g18_polar2d_oracle(golden_polar2d):
     """oracle/polar2d.py reproduces the reference's own 2-D transforms, weights, Fourier pair and projection closures"""
     import parity_cases as PC
     PC.check_polar2d_golden_oracle(golden_polar2d)
+
+
+def test_g19_metrics_oracle(golden_metrics):
+    """oracle/metrics.py reproduces the reference's fqc_error / II_error / ccd_diff routines (gsl doubled, see the module header)"""
+    import parity_cases as PC
+    PC.check_metrics_golden_oracle(golden_metrics)

@@ -1,0 +1,236 @@
+// The reference's non-default reciprocal error metrics, per step on the device from B_l = I_l I_l^+ of the
+// current intensity coefficients:
+//   II_error   xframe/projects/fxs/projectLibrary/fxs_IO_methods.py:587-627
+//   ccd_diff   fxs_IO_methods.py:651-683
+//   fqc_error  fxs_IO_methods.py:507-550
+// All three are contractions of the masked B_l (L+1, Nq, Nq) with constant tensors the host prepares once (the normalised
+// associated Legendre products of fxs_invariant_tools.py:23-33, 48-58, the masked reference invariants): a few MB per restart and
+// step, diagnostics that are off by default -- plain kernels, one workgroup per restart (II, ccd) or per (restart, shell) (fqc).
+#include "mtip_internal.h"
+
+__device__ __forceinline__ double2 c_sqrt(double2 z) {           // principal branch, as numpy's
+    const double r = sqrt(sqrt(z.x * z.x + z.y * z.y));
+    const double t = 0.5 * atan2(z.y, z.x);
+    double s, c;
+    sincos(t, &s, &c);
+    return make_double2(r * c, r * s);
+}
+
+__device__ __forceinline__ double2 c_div(double2 a, double2 b) {
+    const double d = b.x * b.x + b.y * b.y;
+    return make_double2((a.x * b.x + a.y * b.y) / d, (a.y * b.x - a.x * b.y) / d);
+}
+
+__device__ __forceinline__ double2 block_sum2(double2 v, double2* red) {
+    for (int o = 32; o > 0; o >>= 1) {
+        v.x += __shfl_xor(v.x, o, 64);
+        v.y += __shfl_xor(v.y, o, 64);
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double2 s = make_double2(0.0, 0.0);
+    for (int wv = 0; wv < (int)(blockDim.x >> 6); ++wv) s = cadd(s, red[wv]);
+    return s;
+}
+
+// II_error = 1 - sum(cur ref qq) / sqrt(sum(cur^2 qq) sum(ref^2 qq)), cur = sum_{l >= 1} masked B_l (complex, not conjugated: 624)
+__global__ void __launch_bounds__(256) k_metric_II(const double2* __restrict__ Bl, const uint8_t* __restrict__ zmask,
+                                                   const double2* __restrict__ ref, const double* __restrict__ qq, double* __restrict__ out,
+                                                   int N, int L) {
+    __shared__ double2 red[4];
+    const int b = blockIdx.x;
+    const size_t NN = (size_t)N * N;
+    double2 sa = make_double2(0.0, 0.0), sb = sa, sc = sa;
+    for (size_t e = threadIdx.x; e < NN; e += blockDim.x) {
+        double2 cur = make_double2(0.0, 0.0);
+        for (int l = 1; l <= L; ++l)
+            if (!zmask[(size_t)l * NN + e]) cur = cadd(cur, Bl[((size_t)b * (L + 1) + l) * NN + e]);
+        const double w = qq[e];
+        const double2 r = ref[e];
+        sa = cadd(sa, cscale(cmul(cur, r), w));
+        sb = cadd(sb, cscale(cmul(cur, cur), w));
+        sc = cadd(sc, cscale(cmul(r, r), w));
+    }
+    sa = block_sum2(sa, red);
+    sb = block_sum2(sb, red);
+    sc = block_sum2(sc, red);
+    if (threadIdx.x == 0) out[b] = 1.0 - c_div(sa, c_sqrt(cmul(sb, sc))).x;
+}
+
+// ccd_diff = sum |sum_l masked B_l T_l - ref|^2 / norm  (T_l = 0 for order 0 and the orders below C_order)
+__global__ void __launch_bounds__(256) k_metric_ccd(const double2* __restrict__ Bl, const uint8_t* __restrict__ zmask,
+                                                    const double* __restrict__ T, const double2* __restrict__ ref, double inv_norm,
+                                                    double* __restrict__ out, int N, int L) {
+    __shared__ double2 red[4];
+    const int b = blockIdx.x;
+    const size_t NN = (size_t)N * N;
+    double2 acc = make_double2(0.0, 0.0);
+    for (size_t e = threadIdx.x; e < NN; e += blockDim.x) {
+        double2 d = make_double2(-ref[e].x, -ref[e].y);
+        for (int l = 0; l <= L; ++l)
+            if (!zmask[(size_t)l * NN + e]) d = cadd(d, cscale(Bl[((size_t)b * (L + 1) + l) * NN + e], T[(size_t)l * NN + e]));
+        acc.x += d.x * d.x + d.y * d.y;
+    }
+    acc = block_sum2(acc, red);
+    if (threadIdx.x == 0) out[b] = acc.x * inv_norm;
+}
+
+// fqc_error[q] = 1 - mean_{q' <= q} fqc[q, q'];  workgroup = (shell q, restart), threads over q'
+__global__ void __launch_bounds__(256) k_metric_fqc(const double2* __restrict__ Bl, const uint8_t* __restrict__ zmask,
+                                                    const double* __restrict__ P, const double* __restrict__ ref_avg,
+                                                    const double* __restrict__ ref_w, double* __restrict__ out, int N, int L) {
+    HIP_DYNAMIC_SHARED(double, fq)                   // N
+    const int q = blockIdx.x, b = blockIdx.y;
+    const size_t NN = (size_t)N * N;
+    const int M1 = L + 1;
+    for (int qp = threadIdx.x; qp < N; qp += blockDim.x) {
+        const size_t e = (size_t)q * N + qp;
+        double avg = 0.0;
+        double2 ctrl = make_double2(0.0, 0.0);
+        for (int j = 0; j < M1; ++j) {
+            double2 cj = make_double2(0.0, 0.0);
+            for (int l = 1; l <= L; ++l)
+                if (!zmask[(size_t)l * NN + e]) cj = cadd(cj, cscale(Bl[((size_t)b * M1 + l) * NN + e], P[((size_t)l * NN + e) * M1 + j]));
+            avg += j == 0 ? (cj.x * cj.x - cj.y * cj.y) : 2.0 * (cj.x * cj.x + cj.y * cj.y);       // Re(c_0 c_0) + 2 sum |c_j|^2 (521-522)
+        }
+        for (int l = 1; l <= L; ++l)
+            if (!zmask[(size_t)l * NN + e]) ctrl = cadd(ctrl, cscale(Bl[((size_t)b * M1 + l) * NN + e], ref_w[(size_t)l * NN + e]));
+        const double prod = avg * ref_avg[e];
+        // norm = sqrt(prod); `norm >= 0` is false for NaN (negative prod): fqc = 1 there (536-543); a zero norm divides as numpy does
+        fq[qp] = prod >= 0.0 ? ctrl.x / sqrt(prod) : 1.0;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = 0.0;
+        for (int qp = 0; qp <= q; ++qp) s += fq[qp];
+        out[(size_t)b * N + q] = 1.0 - s / (double)(q + 1);
+    }
+}
+
+void free_invariant_metrics(mtip_ctx* c) {
+    for (void* p : {(void*)c->d_im_zmask, (void*)c->d_im_IIref, (void*)c->d_im_qq, (void*)c->d_im_ccdT, (void*)c->d_im_ccdref, (void*)c->d_im_P,
+                    (void*)c->d_im_refavg, (void*)c->d_im_refw, (void*)c->d_im_hist})
+        if (p) (void)hipFree(p);
+    c->d_im_zmask = nullptr; c->d_im_IIref = nullptr; c->d_im_qq = nullptr; c->d_im_ccdT = nullptr; c->d_im_ccdref = nullptr;
+    c->d_im_P = nullptr; c->d_im_refavg = nullptr; c->d_im_refw = nullptr; c->d_im_hist = nullptr;
+    c->im_which = 0;
+}
+
+// per step: B_l of the current coefficients, then the enabled metrics into the step's row of the history
+// (row layout: II (B) | ccd (B) | fqc (B, Nq))
+static int launch_invariant_metrics_row(mtip_ctx* c, const double2* Ilm, double* row);
+
+int launch_invariant_metrics(mtip_ctx* c, const double2* Ilm, long long step) {
+    if (!c->im_which) return MTIP_OK;
+    return launch_invariant_metrics_row(c, Ilm, c->d_im_hist + (size_t)step * c->B * (2 + c->N));
+}
+
+static int launch_invariant_metrics_row(mtip_ctx* c, const double2* Ilm, double* row) {
+    const size_t per = (size_t)(c->L + 1) * c->N * c->N;
+    if (!c->d_Bl && hipMalloc((void**)&c->d_Bl, (size_t)c->B * per * sizeof(double2)) != hipSuccess) {
+        c->err = "invariant metrics: out of device memory for B_l";
+        return MTIP_ENOMEM;
+    }
+    launch_deg2(c, Ilm, c->d_Bl);
+    if (c->im_which & 1)
+        hipLaunchKernelGGL(k_metric_II, dim3((unsigned)c->B), dim3(256), 0, c->stream, (const double2*)c->d_Bl, (const uint8_t*)c->d_im_zmask,
+                           (const double2*)c->d_im_IIref, (const double*)c->d_im_qq, row, c->N, c->L);
+    if (c->im_which & 2)
+        hipLaunchKernelGGL(k_metric_ccd, dim3((unsigned)c->B), dim3(256), 0, c->stream, (const double2*)c->d_Bl, (const uint8_t*)c->d_im_zmask,
+                           (const double*)c->d_im_ccdT, (const double2*)c->d_im_ccdref, c->im_ccd_inv_norm, row + c->B, c->N, c->L);
+    if (c->im_which & 4)
+        hipLaunchKernelGGL(k_metric_fqc, dim3((unsigned)c->N, (unsigned)c->B), dim3(256), (size_t)c->N * sizeof(double), c->stream,
+                           (const double2*)c->d_Bl, (const uint8_t*)c->d_im_zmask, (const double*)c->d_im_P, (const double*)c->d_im_refavg,
+                           (const double*)c->d_im_refw, row + 2 * (size_t)c->B, c->N, c->L);
+    return MTIP_OK;
+}
+
+extern "C" {
+
+int mtip_set_invariant_metrics(mtip_ctx* c, uint32_t which, const uint8_t* zero_mask, const mtip_cdouble* II_reference, const double* qq,
+                               const double* ccd_weights, const mtip_cdouble* ccd_reference, double ccd_norm, const double* fqc_P,
+                               const double* fqc_reference_average, const double* fqc_reference_weights) {
+    if (!c) return MTIP_EINVAL;
+    (void)hipSetDevice(c->device);
+    MTIP_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    free_invariant_metrics(c);
+    if (which == 0) return MTIP_OK;
+    if (which > 7 || !zero_mask || ((which & 1) && (!II_reference || !qq)) || ((which & 2) && (!ccd_weights || !ccd_reference || !(ccd_norm != 0.0))) ||
+        ((which & 4) && (!fqc_P || !fqc_reference_average || !fqc_reference_weights))) {
+        c->err = "invariant metrics: flags 1 (II_error) | 2 (ccd_diff) | 4 (fqc_error) with their tables, zero_mask not null";
+        return MTIP_EINVAL;
+    }
+    const size_t NN = (size_t)c->N * c->N, LNN = (size_t)(c->L + 1) * NN;
+#define IM_UP(dst, src, bytes)                                                        \
+    do {                                                                              \
+        MTIP_HIP_CHECK(c, hipMalloc((void**)&(dst), (bytes)));                        \
+        MTIP_HIP_CHECK(c, mtip_copy(c, (dst), (src), (bytes), hipMemcpyHostToDevice)); \
+    } while (0)
+    IM_UP(c->d_im_zmask, zero_mask, LNN);
+    if (which & 1) {
+        IM_UP(c->d_im_IIref, II_reference, NN * sizeof(double2));
+        IM_UP(c->d_im_qq, qq, NN * sizeof(double));
+    }
+    if (which & 2) {
+        IM_UP(c->d_im_ccdT, ccd_weights, LNN * sizeof(double));
+        IM_UP(c->d_im_ccdref, ccd_reference, NN * sizeof(double2));
+        c->im_ccd_inv_norm = 1.0 / ccd_norm;
+    }
+    if (which & 4) {
+        IM_UP(c->d_im_P, fqc_P, LNN * (c->L + 1) * sizeof(double));
+        IM_UP(c->d_im_refavg, fqc_reference_average, NN * sizeof(double));
+        IM_UP(c->d_im_refw, fqc_reference_weights, LNN * sizeof(double));
+    }
+#undef IM_UP
+    MTIP_HIP_CHECK(c, hipMalloc((void**)&c->d_im_hist, (size_t)c->err_cap * c->B * (2 + c->N) * sizeof(double)));
+    MTIP_HIP_CHECK(c, hipMemsetAsync(c->d_im_hist, 0, (size_t)c->err_cap * c->B * (2 + c->N) * sizeof(double), c->stream));
+    c->im_which = which;
+    return MTIP_OK;
+}
+
+/* per step of steps [first, first + n): II (n, B), ccd (n, B), fqc (n, B, Nq); a null pointer skips that metric */
+int mtip_fetch_invariant_metrics(mtip_ctx* c, int64_t first, int64_t n, double* II, double* ccd, double* fqc) {
+    if (!c) return MTIP_EINVAL;
+    if (!c->im_which || first < 0 || n < 0 || first + n > c->n_steps_done) {
+        c->err = "fetch_invariant_metrics: metrics not enabled or steps out of range";
+        return MTIP_EINVAL;
+    }
+    (void)hipSetDevice(c->device);
+    const size_t rowlen = (size_t)c->B * (2 + c->N);
+    std::vector<double> rows((size_t)n * rowlen);
+    if (n) MTIP_HIP_CHECK(c, mtip_copy(c, rows.data(), c->d_im_hist + (size_t)first * rowlen, rows.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (int64_t s = 0; s < n; ++s) {
+        const double* r = rows.data() + (size_t)s * rowlen;
+        if (II) std::copy(r, r + c->B, II + (size_t)s * c->B);
+        if (ccd) std::copy(r + c->B, r + 2 * c->B, ccd + (size_t)s * c->B);
+        if (fqc) std::copy(r + 2 * c->B, r + rowlen, fqc + (size_t)s * c->B * c->N);
+    }
+    return MTIP_OK;
+}
+
+/* the enabled metrics of given intensity coefficients (n_batch, Nq, (L+1)^2): II (n_batch), ccd (n_batch), fqc (n_batch, Nq); NULL skips */
+int mtip_op_invariant_metrics(mtip_ctx* c, const mtip_cdouble* Ilm, double* II, double* ccd, double* fqc) {
+    if (!c) return MTIP_EINVAL;
+    if (!c->im_which || !Ilm) {
+        c->err = "op_invariant_metrics: metrics not enabled (mtip_set_invariant_metrics) or null coefficients";
+        return MTIP_EINVAL;
+    }
+    (void)hipSetDevice(c->device);
+    const size_t rowlen = (size_t)c->B * (2 + c->N);
+    double* d_row = nullptr;
+    MTIP_HIP_CHECK(c, hipMalloc((void**)&d_row, rowlen * sizeof(double)));
+    MTIP_HIP_CHECK(c, hipMemsetAsync(d_row, 0, rowlen * sizeof(double), c->stream));
+    MTIP_HIP_CHECK(c, mtip_copy(c, c->d_c[2], Ilm, (size_t)c->B * c->C * sizeof(double2), hipMemcpyHostToDevice));
+    int rc = launch_invariant_metrics_row(c, c->d_c[2], d_row);
+    std::vector<double> row(rowlen);
+    if (rc == MTIP_OK && mtip_copy(c, row.data(), d_row, rowlen * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) rc = MTIP_EHIP;
+    (void)hipFree(d_row);
+    if (rc != MTIP_OK) return rc;
+    if (II) std::copy(row.begin(), row.begin() + c->B, II);
+    if (ccd) std::copy(row.begin() + c->B, row.begin() + 2 * c->B, ccd);
+    if (fqc) std::copy(row.begin() + 2 * c->B, row.end(), fqc);
+    return MTIP_OK;
+}
+
+}  // extern "C"

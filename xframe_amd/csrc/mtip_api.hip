@@ -53,6 +53,7 @@ void mtip_destroy(mtip_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    free_invariant_metrics(c);
     void* ptrs[] = {c->d_cost, c->d_gw, c->d_P, c->d_r, c->d_q, c->d_poff, c->d_PT, c->d_AB, c->d_lmtab, c->d_twN, c->d_tw, c->d_W, c->d_htiles32, c->d_kl, c->d_used, c->d_active, c->d_sweeps, c->d_jsched, c->d_jsched_off, c->d_jsched_rounds, c->d_jorder, c->d_pg_tiles[0], c->d_pg_tiles[1], c->d_pg_tiles[2], c->d_pg_tiles[3], c->d_pg_tiles[4], c->d_pg_tiles[5], c->d_voff,
                     c->d_xoff, c->d_uoff, c->d_V, c->d_rmask, c->d_Bref, c->d_Bnorm, c->d_deg2_part, c->d_S0, c->d_sup, c->d_err_wr,
                     c->d_err_wt, c->d_rho, c->d_Fp, c->d_slot, c->d_best_err, c->d_last_err, c->d_op_err, c->d_gq, c->d_polar_dbg, c->d_so3_d, c->d_so3_tw, c->d_so3_T, c->d_so3_S, c->d_so3_P, c->d_so3_D, c->d_so3_C, c->d_err_hist, c->d_main_hist,
@@ -496,6 +497,16 @@ static int ensure_hist(mtip_ctx* c, long long need) {
     (void)hipFree(c->d_deg2_hist);
     c->d_err_hist = nh;
     c->d_deg2_hist = nd;
+    if (c->d_im_hist) {
+        double* ni = nullptr;
+        const size_t rowlen = (size_t)c->B * (2 + c->N);
+        r = dev_alloc(c, &ni, (size_t)cap * rowlen);
+        if (r) return r;
+        MTIP_HIP_CHECK(c, hipMemcpyAsync(ni, c->d_im_hist, (size_t)c->n_steps_done * rowlen * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        MTIP_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+        (void)hipFree(c->d_im_hist);
+        c->d_im_hist = ni;
+    }
     c->err_cap = cap;
     return MTIP_OK;
 }
@@ -513,6 +524,10 @@ static int enqueue_step(mtip_ctx* c, int method, int ft_stab, double beta) {
         // 2-3 I_lm = SHT(|F|^2);  4-5 projection;  6-7 I' = iSHT, F' = F sqrt(I'/I) -> Fp[out]
         launch_sht_forward(c, c->d_F, cc[2], MTIP_PRE_SQUARE);
         if (c->deg2_enable) launch_deg2_metric(c, cc[2], c->d_deg2_hist + (size_t)c->n_steps_done * c->B * (c->L + 1));
+        if (c->im_which) {
+            const int rm = launch_invariant_metrics(c, cc[2], c->n_steps_done);
+            if (rm != MTIP_OK) return rm;
+        }
         const int rp = launch_project_coefficients(c, cc[2], cc[2], true);    // in place: I_lm is not needed afterwards; SHT of the real |F|^2
         if (rp != MTIP_OK) return rp;
         InvEpilogue mod;

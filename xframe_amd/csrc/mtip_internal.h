@@ -149,6 +149,12 @@ struct mtip_ctx {
     std::vector<int> jsched_nrd;                      // rounds of a sweep for every column count (host copy of d_jsched_rounds)
     double rp_early = 3e-2, rp_corr2_max = 1.5e-4;     // thresholds of the closing step (k_projr.hip RP_EARLY_CORR, RP_CORR2_MAX; env MTIP_RP_EARLY, MTIP_RP_CORR2_MAX)
     bool rp_corr = true;                              // k_rproj: close the Jacobi sweeps with the first-order polar step (MTIP_RP_CORR=0: classic)
+    // non-default reciprocal metrics (k_metrics.hip): flags 1 II_error | 2 ccd_diff | 4 fqc_error, their constant tables, history rows
+    uint32_t im_which = 0;
+    uint8_t* d_im_zmask = nullptr;
+    double2 *d_im_IIref = nullptr, *d_im_ccdref = nullptr;
+    double *d_im_qq = nullptr, *d_im_ccdT = nullptr, *d_im_P = nullptr, *d_im_refavg = nullptr, *d_im_refw = nullptr, *d_im_hist = nullptr;
+    double im_ccd_inv_norm = 0.0;
     int so_order = -1;                                // SO_freedom: order whose unknown [4][2] is made real after every projection (-1: off)
     std::vector<int> jsched_off_h;                    // offsets of the per-column-count tables in d_jsched (host copy of d_jsched_off)
     int* d_jorder = nullptr;                          // active orders, heaviest first (grid of the polar-factor kernel)
@@ -265,6 +271,9 @@ void launch_hankel_mfma_sub(mtip_ctx* c, const double2* in, const double2* in_su
 int build_jacobi_schedule(mtip_ctx* c, int kmax);    // k_proj.hip: resident-column pairing schedule, verified on the host
 int jacobi_groups(int k);                            // pair-groups a round of that schedule keeps busy for k columns (<= jsched_ps: the table's row length)
 int build_hankel_tiles(mtip_ctx* c);
+int launch_invariant_metrics(mtip_ctx* c, const double2* Ilm, long long step);
+void free_invariant_metrics(mtip_ctx* c);
+void launch_deg2(mtip_ctx* c, const double2* Ilm, double2* Bl);
 void launch_coeff_diff(mtip_ctx* c, const double2* a, const double2* b, double2* out);
 // reciprocal projection
 // real_intensity: the caller guarantees I_{l,-m} = (-1)^m conj(I_{l,m}) (coefficients of a real grid, as in the phasing

@@ -69,6 +69,7 @@ class Engine:
 
     def _setup_projections(self, data):
         opt = self.opt
+        self.xray_wavelength = data.get('xray_wavelength', None)
         ropt = opt['projections']['reciprocal']
         rs_ = hs.reciprocal_setup(self.qs, data, self.L, ropt)      # (shared by the engines of one worker: read only)
         self.rsetup = rs_
@@ -99,13 +100,33 @@ class Engine:
                                             gen.get('L2_cache', 512))
         self._ck(self.lib.mtip_set_error_weights(self.ctx, _lib.ptr(_lib.as_f64(wr)), _lib.ptr(_lib.as_f64(wt)), int(use_mask)))
         # metrics that are not on the accelerated path must not be dropped silently (fxs_IO_methods.py:690-703 lists them)
-        for cat, known in (('real', ('l2_projection_diff',)), ('reciprocal', ('deg2_invariant_l2_diff',))):
+        for cat, known in (('real', ('l2_projection_diff',)), ('reciprocal', ('deg2_invariant_l2_diff', 'II_error', 'ccd_diff', 'fqc_error'))):
             for name in em.get(cat, {}).get('calculate', []) or []:
                 if name not in known:
                     raise NotImplementedError('main_loop.error.methods.%s.calculate: %r is not built (DESIGN section 6); built: %s'
                                               % (cat, name, ', '.join(known)))
         self.deg2_enabled = 'deg2_invariant_l2_diff' in em['reciprocal']['calculate']
         self._ck(self.lib.mtip_set_deg2_metric(self.ctx, int(self.deg2_enabled)))
+        # II_error / ccd_diff / fqc_error (fxs_IO_methods.py:587-627, 651-683, 507-550): per step on the device from B_l
+        self.invariant_metrics = [n for n in ('II_error', 'ccd_diff', 'fqc_error') if n in em['reciprocal']['calculate']]
+        if self.invariant_metrics:
+            if sorted(self.rsetup.used_orders.values()) != list(range(self.L + 1)):
+                raise NotImplementedError('II_error / ccd_diff / fqc_error with a subset of the orders (upstream masks B_l of ALL orders with '
+                                          'arrays shaped by the used ones, fxs_IO_methods.py:594-597, 610)')
+            if self.xray_wavelength is None:
+                raise KeyError("II_error / ccd_diff / fqc_error need data['xray_wavelength'] (fxs_IO_methods.py:511, 590, 657)")
+            t = hs.invariant_metric_tables(self.invariant_metrics, self.qs, [self.rsetup.projection_matrices[l] for l in range(self.L + 1)],
+                                           self.rsetup.radial_mask, float(self.xray_wavelength),
+                                           em['reciprocal'].get('ccd_diff', {}).get('C_order', None))
+            flags = sum(f for f, n in ((1, 'II_error'), (2, 'ccd_diff'), (4, 'fqc_error')) if n in self.invariant_metrics)
+
+            def pp(key, conv):
+                return _lib.ptr(conv(t[key])) if key in t else None
+            self._im_keep = t                                         # (the arrays must outlive the call)
+            self._ck(self.lib.mtip_set_invariant_metrics(
+                self.ctx, flags, _lib.ptr(_lib.as_u8(t['zero_mask'])), pp('II_reference', _lib.as_c128), pp('qq', _lib.as_f64),
+                pp('ccd_weights', _lib.as_f64), pp('ccd_reference', _lib.as_c128), float(t.get('ccd_norm', 0.0)), pp('fqc_P', _lib.as_f64),
+                pp('fqc_reference_average', _lib.as_f64), pp('fqc_reference_weights', _lib.as_f64)))
         # generate_main_error_routine, fxs_IO_methods.py:746-765
         main = em.get('main', {'metrics': {'real': ['l2_projection_diff'], 'reciprocal': []}, 'type': 'mean'})
         real_m, rec_m = list(main['metrics'].get('real', [])), list(main['metrics'].get('reciprocal', []))
@@ -436,6 +457,27 @@ class Engine:
         deg2 = np.empty((n, self.B, self.L + 1)) if self.deg2_enabled else None
         self._ck(self.lib.mtip_fetch_errors(self.ctx, first, n, _lib.ptr(err), _lib.ptr(deg2)))
         return err, deg2
+
+    def fetch_invariant_metrics(self, first, n):
+        """{'II_error': (n, B), 'ccd_diff': (n, B), 'fqc_error': (n, B, Nq)} for the enabled ones"""
+        out = {}
+        if not self.invariant_metrics:
+            return out
+        II = np.empty((n, self.B)) if 'II_error' in self.invariant_metrics else None
+        ccd = np.empty((n, self.B)) if 'ccd_diff' in self.invariant_metrics else None
+        fqc = np.empty((n, self.B, self.N)) if 'fqc_error' in self.invariant_metrics else None
+        self._ck(self.lib.mtip_fetch_invariant_metrics(self.ctx, first, n, _lib.ptr(II), _lib.ptr(ccd), _lib.ptr(fqc)))
+        for k, v in (('II_error', II), ('ccd_diff', ccd), ('fqc_error', fqc)):
+            if v is not None:
+                out[k] = v
+        return out
+
+    def invariant_metrics_of(self, Ilm):
+        """the enabled metrics of given intensity coefficients: {'II_error': (B,), 'ccd_diff': (B,), 'fqc_error': (B, Nq)}"""
+        c = self._bcoef(Ilm)
+        II, ccd, fqc = np.empty(self.B), np.empty(self.B), np.empty((self.B, self.N))
+        self._ck(self.lib.mtip_op_invariant_metrics(self.ctx, _lib.ptr(c), _lib.ptr(II), _lib.ptr(ccd), _lib.ptr(fqc)))
+        return {k: v for k, v in (('II_error', II), ('ccd_diff', ccd), ('fqc_error', fqc)) if k in self.invariant_metrics}
 
     def fetch_main_errors(self, first, n):
         err = np.empty((n, self.B))

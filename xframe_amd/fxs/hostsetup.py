@@ -246,6 +246,57 @@ class ReciprocalSetup:
         self.max_order = max_order
 
 
+def sph_plm(l, m, x):
+    """gsl_sf_legendre_sphPlm(l, m, x) = sqrt((2l+1)/(4 pi) (l-m)!/(l+m)!) P_l^m(x) = Y_l^m(arccos x, 0) (the reference gets it from
+    pygsl, gsl_plugin.py:8-69; restated from the published definition)"""
+    from scipy.special import sph_harm_y
+    return sph_harm_y(np.asarray(l), np.asarray(m), np.arccos(np.clip(x, -1.0, 1.0)), 0.0).real
+
+
+def invariant_metric_tables(which, qs, projection_matrices, radial_mask, xray_wavelength, C_order=None):
+    """Constant tables of the non-default reciprocal metrics for mtip_set_invariant_metrics (fxs_IO_methods.py:507-550 fqc_error,
+    587-627 II_error, 651-683 ccd_diff; Legendre products fxs_invariant_tools.py:23-33, 48-58).  projection_matrices: list over all
+    orders 0..L of the modified V_l (the reference's rp.projection_matrices; its reference invariants are V_l V_l^+, 631-637)."""
+    qs = np.asarray(qs, dtype=float)
+    N, L = len(qs), len(projection_matrices) - 1
+    ref = np.array([np.asarray(p) @ np.asarray(p).conj().T for p in projection_matrices])
+    rm = np.asarray(radial_mask, dtype=bool)
+    zero = ~(rm[:, :, None] & rm[:, None, :])                     # entries of B_l outside the invariant mask
+    ref[zero] = 0
+    out = {'zero_mask': zero.astype(np.uint8)}
+    orders = np.arange(L + 1)
+    x = qs * xray_wavelength / (4 * np.pi)                        # cos(theta) of ewald_sphere_theta_pi (physicsLibrary.py:94-95)
+    if 'II_error' in which:
+        out['II_reference'] = np.sum(ref[1:], axis=0)
+        out['qq'] = (qs[:, None] * qs[None, :]) ** 2
+    if 'ccd_diff' in which:
+        if C_order is None:
+            raise KeyError("main_loop.error.methods.reciprocal.ccd_diff.C_order is required (fxs_IO_methods.py:637)")
+        pl = sph_plm(orders[None, :], np.full((1, L + 1), int(C_order)), x[:, None])                  # (q, l); 0 for l < C_order
+        pl = np.where(orders[None, :] >= int(C_order), pl, 0.0)
+        T = np.moveaxis(pl[None, :, :] * pl[:, None, :] / (2 * orders + 1)[None, None, :], -1, 0).copy()    # (l, q, q')
+        T[0] = 0
+        T[orders < int(C_order)] = 0
+        T[np.isnan(T)] = 0
+        refC = np.sum(ref * T, axis=0)
+        norm = np.sum(refC * refC.conj())
+        if norm == 0:
+            raise ValueError('ccd_diff: the reference C_m vanishes (fxs_IO_methods.py:669)')
+        out['ccd_weights'], out['ccd_reference'], out['ccd_norm'] = T, refC, float(np.real(norm))
+    if 'fqc_error' in which:
+        qm = np.zeros((N, L + 1, L + 1))                          # (q, m, l)
+        for m in range(L + 1):
+            ls = np.arange(m, L + 1)
+            qm[:, m, ls] = sph_plm(ls[None, :], np.full((1, len(ls)), m), x[:, None])
+        P = np.moveaxis(qm[None, :] * qm[:, None] / (2 * orders + 1)[None, None, None, :], -1, 0)     # (l, q, q', m)
+        ccn = np.sum(ref[1:, ..., None] * P[1:], axis=0)
+        out['fqc_reference_average'] = (ccn[..., 0] * ccn[..., 0]).real + 2 * np.sum(ccn[..., 1:] * ccn[..., 1:].conj(), axis=-1).real
+        rw = np.zeros((L + 1, N, N))
+        rw[1:] = (P[1:, ..., 0] * ccn[None, ..., 0]).real + 2 * np.sum(P[1:, ..., 1:] * ccn[None, ..., 1:].conj(), axis=-1).real
+        out['fqc_P'], out['fqc_reference_weights'] = np.ascontiguousarray(P), rw
+    return out
+
+
 def rank_projection_matrices_3d(projection_matrices, orders, radial_points, radial_high_pass=0.15):
     """fxs_invariant_tools.py:1467-1486 (RadialIntegrator(., 2), mathLibrary.py:1270-1294): ids of the even non-zero orders, ranked by
     the radial L2 norm of B_l = Re(V_l V_l^+) beyond the high-pass radius, largest first"""

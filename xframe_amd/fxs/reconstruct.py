@@ -264,6 +264,7 @@ class MTIP:
     def _generate_output(self, iterations, initial_density, initial_mask, n_steps):
         e = self.engine
         real_err, deg2 = e.fetch_errors(0, n_steps)
+        inv_metrics = e.fetch_invariant_metrics(0, n_steps)         # II_error / ccd_diff / fqc_error, when enabled
         main_err = e.fetch_main_errors(0, n_steps)
         best_err, _ = e.best_error()
         masked_pm = []
@@ -298,6 +299,8 @@ class MTIP:
             err = {'main': main_err[:, b].copy(),
                    'real': {'l2_projection_diff': real_err[:, b].copy()},
                    'reciprocal': ({'deg2_invariant_l2_diff': deg2[:, b][:, order_array].copy()} if deg2 is not None else {})}
+            for name, hist in inv_metrics.items():
+                err['reciprocal'][name] = hist[:, b].copy()
             out[b] = {
                 'real_density': real[True][b], 'last_real_density': real[False][b],
                 'reciprocal_density': recip[True][b], 'last_reciprocal_density': recip[False][b],
