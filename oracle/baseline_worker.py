@@ -34,6 +34,10 @@ def run(args):
 
             def forward_l(s, x):
                 return s.fp.sht.forward_l(x)
+
+            def hermitian_eig(s, mats):                      # numpy eigensolver in Engine.hermitian_eig's layout (descending, columns)
+                w, v = np.linalg.eigh(np.asarray(mats))
+                return w[:, ::-1].copy(), np.ascontiguousarray(v[:, :, ::-1])
         N, L = S._SIZES[cfg]
         data, _ = S.make_invariants(_T(FourierPair(SHT(L), N, S.data_cutoff(N), 2.0)), N, L)
     opt = OM.deep_update(OM.default_settings(), S.config_overrides(cfg))

@@ -179,6 +179,10 @@ def main():
         def forward_l(s, x):
             return s.fp.sht.forward_l(x)
 
+        def hermitian_eig(s, mats):                          # numpy eigensolver in Engine.hermitian_eig's layout (descending, columns)
+            w, v = np.linalg.eigh(np.asarray(mats))
+            return w[:, ::-1].copy(), np.ascontiguousarray(v[:, :, ::-1])
+
     def make_settings(N, L, extra=None):
         o = OM.deep_update(OM.default_settings(), S.config_overrides(1))
         o = OM.deep_update(o, {'grid': {'n_radial_points': N, 'max_order': L},
@@ -366,6 +370,10 @@ def run_mtip_golden(mods, N, L, name, n_hio, n_er, with_steps, extra=None, save=
 
         def forward_l(s, x):
             return s.fp.sht.forward_l(x)
+
+        def hermitian_eig(s, mats):                          # numpy eigensolver in Engine.hermitian_eig's layout (descending, columns)
+            w, v = np.linalg.eigh(np.asarray(mats))
+            return w[:, ::-1].copy(), np.ascontiguousarray(v[:, :, ::-1])
     if data_npz is None:
         data, rho_true = S.make_invariants(T(FourierPair(SHT(L), N, Qd, kappa)), N, L)
     else:

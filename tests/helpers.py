@@ -22,6 +22,12 @@ class OracleTransforms:
     def forward_l(self, x):
         return self.fp.sht.forward_l(x)
 
+    def hermitian_eig(self, mats):
+        """numpy eigensolver in Engine.hermitian_eig's layout (descending eigenvalues, eigenvectors in columns): lets the synthetic
+        front half build inputs for the CPU oracle without a device (test infrastructure only)"""
+        w, v = np.linalg.eigh(np.asarray(mats))
+        return w[:, ::-1].copy(), np.ascontiguousarray(v[:, :, ::-1])
+
 
 def data_from_golden(g, L, prefix='data_'):
     pms = np.empty(L + 1, dtype=object)

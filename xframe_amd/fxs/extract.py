@@ -14,8 +14,9 @@ import numpy as np
 
 def _batched_eigh(engine, mats):
     """eigenvalues ASCENDING (K, n) and eigenvectors (K, n, n) in columns, like numpy.linalg.eigh, from the device solver"""
-    if engine is None:                                           # host reference of the same rules (synthetic inputs without a device)
-        return np.linalg.eigh(np.asarray(mats))
+    if engine is None or not hasattr(engine, 'hermitian_eig'):
+        raise TypeError('the extract rules need an eigensolver object with `hermitian_eig` (an Engine: the device solvers); there is no '
+                        'CPU fallback in the product')
     vals, vecs = engine.hermitian_eig(np.asarray(mats))          # descending
     vecs = vecs[:, :, ::-1]
     if not np.iscomplexobj(np.asarray(mats)):

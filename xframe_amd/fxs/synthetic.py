@@ -49,8 +49,9 @@ def invariants_from_intensity_coefficients(Ilm, data_radial_points, max_order, e
     """I_lm (list over l of (N,2l+1)) -> the dict ``load_invariants`` would hand to the worker
     (``xframe/projects/fxs/_database_.py:566-609``).  Stored in the reference's on-disk convention:
     V_l halved (``fxs_Projections.py:710-713`` multiplies by 2), average_intensity from B_0.
-    ``eigh``: an object with ``hermitian_eig`` (an Engine: the ``extract`` step on the device, reference rules in
-    ``xframe_amd.fxs.extract``); default: the same rules with numpy's eigh (fxs_invariant_tools.py:1114-1207, sort_mode 0)."""
+    ``eigh``: an object with ``hermitian_eig`` (an Engine: the ``extract`` step on the device with the reference's rules of
+    ``xframe_amd.fxs.extract``, fxs_invariant_tools.py:1114-1207, sort_mode 0).  Required: the product has no CPU eigensolver (the
+    test infrastructure hands in a numpy adapter when it builds inputs for the CPU oracle)."""
     N = len(data_radial_points)
     bls = []
     for l in range(max_order + 1):
@@ -80,7 +81,8 @@ def make_invariants(transforms, n_radial_points, max_order, seed=20241020, eigh=
     I = F * F.conj()
     Ilm = transforms.forward_l(I)
     q_d = midpoint_points(data_cutoff(n_radial_points), n_radial_points)
-    return invariants_from_intensity_coefficients(Ilm, q_d, max_order, eigh), rho
+    # the eigensolver: given explicitly, else the transforms object itself when it is an Engine (it has `hermitian_eig`)
+    return invariants_from_intensity_coefficients(Ilm, q_d, max_order, eigh if eigh is not None else transforms), rho
 
 
 # ---- BASELINE.json configs (SURVEY section 8 d) ---------------------------------------------
