@@ -248,14 +248,19 @@ def test_G14_average_metrics():
     from oracle import alignment as OA
     from xframe_amd.fxs import average as AV
     g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'average_ops.npz'))
+    import torch
     a1, a2, b1, b2 = g['G14_a1'], g['G14_a2'], np.sqrt(g['G14_I1']), np.sqrt(g['G14_I2'])
-    for fn in (OA.PRTF, AV.PRTF):
+
+    def product_prtf(*arrs):                                  # the product's version works on (device) tensors
+        return AV._prtf(torch, *[torch.from_numpy(np.ascontiguousarray(x, dtype=complex)) for x in arrs])
+    for fn in (OA.PRTF, product_prtf):
         p, sd = fn(a1, a2, b1, b2)
         assert np.allclose(p, g['G14_prtf'], rtol=1e-13) and np.allclose(sd, g['G14_prtf_std'], rtol=1e-13)
         p, sd = fn(a1, a1, b1, b1)
         assert np.allclose(p, g['G14_prtf_single'], rtol=1e-13) and np.allclose(sd, g['G14_prtf_single_std'], rtol=1e-13)
     rs, vals = g['G14_int_rs'], g['G14_int_values']
-    assert np.isclose(AV.integrate_normed(rs, vals.shape[1], vals), float(g['G14_int_normed']), rtol=1e-13)
+    w = AV.integrate_normed_weights(rs, vals.shape[1])
+    assert np.isclose(np.sum(w[:, :, None] * vals), float(g['G14_int_normed']), rtol=1e-13)
     assert np.isclose(SphericalIntegrator(rs, vals.shape[1]).integrate_normed(vals), float(g['G14_int_normed']), rtol=1e-13)
 
 

@@ -33,33 +33,6 @@ DEFAULTS = {
 }
 
 
-def integrate_normed(rs, n_theta, values):
-    """SphericalIntegrator.integrate_normed (mathLibrary.py:1223-1237)"""
-    from scipy.special import roots_legendre
-    w = roots_legendre(n_theta)[1]
-    s2 = np.pi / n_theta * np.sum(w[None, :] * np.sum(values, axis=2), axis=1)
-    f = s2 * rs ** 2
-    return np.sum(np.diff(rs) * (f[1:] + f[:-1]) / 2.0) / (4 / 3 * np.pi * np.max(rs) ** 3)
-
-
-def PRTF(a1, a2, b1, b2):
-    """resolution_metrics.py:62-78"""
-    axes = tuple(range(1, a1.ndim))
-    nd = np.ones(a1.shape, dtype=complex)
-    nz = (b1 != 0) & (b2 != 0)
-    nd[nz] = (a1[nz] * a2[nz].conj()) / (b1[nz] * b2[nz].conj())
-    nd[~nz & (a1 != 0) & (a2 != 0)] = 0
-    nd = np.sqrt(nd)
-    return np.average(nd, axis=axes), np.std(nd, axis=axes)
-
-
-def normalize_density(d, d_min=False):
-    """average.py:721-727"""
-    if isinstance(d_min, bool):
-        d_min = d.real.min()
-    return (d - d_min) / (np.max(d.real) - d_min)
-
-
 class Alignment:
     """average.py:729-1111 on a transforms engine (``Engine(settings, None, n_batch=B, max_q=...)`` of the reconstruction grid).
     Works on torch tensors of the engine's device: stacks (n, Nq, n_theta, n_phi) complex128."""
@@ -76,7 +49,7 @@ class Alignment:
         self.results = {}
         # weights of the plain SphericalIntegrator (mathLibrary.py:1223-1232) and of the centre of mass (misk.py:295-312), the
         # cartesian components of the reciprocal grid points for the shift phases (fxs_Projections.py:1436-1443): device constants
-        wr, wt = hs.integrator_weights(e.rs, e.n_theta)
+        wr, wt = hs.integrator_weights(e.rs, e.n_theta)       # (the same weights integrate_normed_weights() below is tested with, G14)
         st, ct = np.sin(e.theta)[None, :, None], np.cos(e.theta)[None, :, None]
         cp, sp = np.cos(e.phi)[None, None, :], np.sin(e.phi)[None, None, :]
         w0 = np.broadcast_to(wr[:, None, None] * wt[None, :, None], e.shape)
@@ -212,6 +185,13 @@ class Alignment:
             res.append({'densities': [dens[k], fts[k]], 'errors': [float(errs[k])], 'rotation_angles': [eulers[k]],
                         'rotation_metrics': [metrics[k]], 'inverted': k >= n})
         return res
+
+
+def integrate_normed_weights(rs, n_theta):
+    """weights w[q, t] with integrate_normed(f) = sum_qtp w[q, t] f[q, t, p] (SphericalIntegrator.integrate_normed,
+    mathLibrary.py:1223-1237: Gauss weights in theta, plain sum in phi, trapezoid in r with r^2, over the ball's volume)"""
+    wr, wt = hs.integrator_weights(rs, n_theta)
+    return wr[:, None] * wt[None, :] / (4 / 3 * np.pi * np.max(rs) ** 3)
 
 
 def _prtf(t, a1, a2, b1, b2):
