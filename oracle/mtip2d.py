@@ -1,0 +1,183 @@
+"""CPU restatement (TEST INFRASTRUCTURE) of the 2-D (polar) phasing loop, SURVEY section 8 f-4: the `dimensions == 2` branches of
+``xframe/projects/fxs/reconstruct.py`` (263-266, 347-350, 421-423, 1126-1129) and ``projectLibrary/fxs_Projections.py`` (473-476,
+506-511, 631-637, 679-714, 723-745, 803-826, 855-863, 189-203) on top of the 3-D restatement ``oracle/mtip.py`` (the loop, the
+sketches, the real-space projections, the shrink-wrap and the ramps are the same code upstream) and the operators of
+``oracle/polar2d.py``.
+
+**Parity status**: pinned by fixture G20 (tests/golden/mtip2d_N12_M6.npz, `make_golden.py mtip2d`): single steps, the shrink-wrap
+mask and a trajectory of the reference's own ``reconstruct.MTIP`` with ``dimensions: 2`` (its data grid differs from the internal one
+by one ulp, so the regridding of fxs_Projections.py:651-662 runs -- per order vector, cubic, zero outside the data range -- and
+the end points fall outside)."""
+import numpy as np
+
+from . import mtip as OM
+from . import polar2d as P2
+from . import projections as P
+
+
+class PolarIntegrator:
+    """mathLibrary.py:1242-1267: trapezoid in phi (over the samples, without closing the circle) and in r with weight r"""
+
+    def __init__(self, rs, phis):
+        self.rs, self.phis = np.asarray(rs), np.asarray(phis)
+        self.max_r = np.max(self.rs)
+        self.norm = np.pi * self.max_r ** 2
+
+    def integrate(self, values):
+        dp = np.diff(self.phis)
+        s_int = np.sum(dp[None, :] * (values[:, 1:] + values[:, :-1]) / 2.0, axis=1)
+        f = s_int * self.rs
+        return np.sum(np.diff(self.rs) * (f[1:] + f[:-1]) / 2.0)
+
+    def integrate_normed(self, values):
+        return self.integrate(values) / self.norm
+
+
+class _RealHarmonic:
+    """the `harmonic_transform` pair of the 2-D loop (reconstruct.py:347-350: HarmonicTransform('real', ...)) under the names the
+    3-D loop uses"""
+
+    def __init__(self, n_phi):
+        self.n_phi = n_phi
+
+    def forward_l(self, grid):
+        return P2.real_harmonic_forward(grid)
+
+    def inverse_l(self, coeff):
+        return P2.real_harmonic_inverse(coeff, self.n_phi)
+
+
+class ReciprocalSetup2D(P2.ReciprocalProjection2D):
+    """ReciprocalProjection.__init__ for dimensions == 2 (fxs_Projections.py:471-537)"""
+
+    def __init__(self, radial_points, data, max_order, opt):
+        q_d = np.asarray(data['data_radial_points'], dtype=float)
+        aint = np.asarray(getattr(data['average_intensity'], 'data', data['average_intensity']), dtype=float)
+        qs = np.asarray(radial_points, dtype=float)
+        needs_regridding = q_d.shape != qs.shape or not (q_d == qs).all()                                   # 642-648
+        interp = opt['regrid']['interpolation']
+        self.opt = opt
+        self.data_radial_points = q_d
+        self.data_min_q, self.data_max_q = np.min(q_d), np.max(q_d)
+        self.integrated_intensity = (q_d[1] - q_d[0]) * np.sum(aint * q_d, axis=0) * 2 * np.sqrt(np.pi)      # 473-474
+        self.positive_orders = np.arange(max_order + 1)
+        self.used_order_ids = np.asarray(opt['used_order_ids'])
+        used_orders = {int(o): int(i) for o, i in zip(self.positive_orders, self.used_order_ids)}
+        pm = np.array(np.asarray(data['data_projection_matrices'])[list(used_orders.values())], dtype=complex)
+        if needs_regridding:                                                                                # 655-662: one vector at a time
+            aint = P.regrid_1d(aint, q_d, qs, interp)
+            pm = np.array([P.regrid_1d(v, q_d, qs, interp) for v in pm])
+        self.average_intensity = aint
+        self.full_projection_matrices = np.zeros((max_order + 1, len(qs)), dtype=complex)                   # 508-511
+        for oid, p in zip(self.used_order_ids, pm):
+            self.full_projection_matrices[oid] = p
+        # modify_projection_matrices 679-714, 2-D branches: no factor 2, the zero order is the average intensity itself
+        proj = pm.copy()
+        keys = np.array(tuple(used_orders))
+        if opt.get('odd_orders_to_0', False):
+            proj[keys % 2 == 1, :] = 0
+        if opt.get('use_averaged_intensity', False):
+            proj[used_orders[0]] = aint.astype(complex)
+        self.radial_points = qs
+        self.used_orders = used_orders
+        self.data_q_id_limits = False
+        radial_mask = P.ReciprocalProjection._radial_mask(self, opt.get('q_mask', None))
+        self.number_of_particles_list = [opt['number_of_particles']['initial']]
+        super().__init__(proj, used_orders, radial_mask, qs, max_order + 1, self.number_of_particles_list[0])
+        self.projection_matrices = proj
+        self.number_of_particles = self.number_of_particles_list
+        self.deg2_invariants = np.array([v[:, None] * v[None, :].conj() for v in proj])                     # 631-633, fxs_invariant_tools.py:906-914
+        self.fixed_intensity = None
+        self.SO_order_id = None
+        if opt.get('SO_freedom', {}).get('use', False):
+            raise NotImplementedError('2-D SO_freedom')
+
+    def mtip_projection(self, I, unknowns):
+        self.n_particles = float(self.number_of_particles_list[0])
+        self.number_of_particles = float(self.number_of_particles_list[0])
+        out = super().mtip_projection(I, unknowns)
+        self.number_of_particles = self.number_of_particles_list
+        return out
+
+    project_to_modified_intensity = P.ReciprocalProjection.project_to_modified_intensity
+    project_to_fixed_intensity = P.ReciprocalProjection.project_to_fixed_intensity
+
+
+class ShrinkWrap2D(P.ShrinkWrap):
+    def __init__(self, qs, shape, threshold=0.06):
+        self.qgrid = np.broadcast_to(np.asarray(qs)[:, None], shape)
+        self.default_sigma = np.pi / np.max(qs)                                  # fxs_Projections.py:189-190
+        self._threshold = threshold
+        self._sigma = self.default_sigma
+        self.gaussian_values = P.gaussian_fourier_transformed_spherical(self.qgrid, self._sigma)
+
+
+class MTIP2D(OM.MTIP):
+    def __init__(self, opt, data):
+        self.opt = opt
+        self.data = data
+        g = opt['grid']
+        M = int(g['max_order'])
+        N = int(g['n_radial_points'])
+        self.kappa = OM.reciprocity_coefficient(opt['fourier_transform'])
+        max_q = g['max_q']
+        if not isinstance(max_q, float):
+            max_q = float(np.max(data['data_radial_points']))
+        self.max_q = max_q
+        assert opt['fourier_transform']['type'] == 'midpoint'
+        dr = self.kappa * N / max_q / N
+        self.fp = P2.PolarFourierPair(N, M, max_q, self.kappa, weights_r_max=self.kappa * N / max_q - dr / 2)    # r_max = max(r_p), reconstruct.py:329
+        self.sht = _RealHarmonic(self.fp.n_phi)
+        self.shape = (N, self.fp.n_phi)
+        self.rp = ReciprocalSetup2D(self.fp.qs, data, M, opt['projections']['reciprocal'])
+        r_opt = opt['projections']['real']
+        self.real_r = np.broadcast_to(self.fp.rs[:, None], self.shape)
+        auto = None
+        if r_opt['projections']['support']['initial_support']['type'] == 'auto_correlation':
+            auto = self.autocorrelation_guess()
+        self.real_pr = P.RealProjection(r_opt['projections'], self.real_r, opt['particle_radius'], auto)
+        self.sw = ShrinkWrap2D(self.fp.qs, self.shape)
+        self.integrator = PolarIntegrator(self.fp.rs, self.fp.phis)
+        self.hio_considered = r_opt['HIO'].get('considered_projections', ['all']) or ['all']
+        self.beta = r_opt['HIO']['beta'][0][0]
+        em = opt['main_loop']['error']['methods']
+        self.real_metrics = list(em['real']['calculate'])
+        self.reciprocal_metrics = list(em['reciprocal']['calculate'])
+        if self.reciprocal_metrics:
+            raise NotImplementedError('2-D reciprocal metrics')
+        self.inside_initial = em['real'].get('l2_projection_diff', {}).get('inside_initial_support', False)
+        self.initial_mask = self.real_pr.initial_support
+        gen = opt.get('general', {})
+        self.real_error_mask = P.select_real_error_mask(self.shape, self.inside_initial, self.initial_mask, gen.get('cache_aware', True),
+                                                        gen.get('L2_cache', 512))
+        self.deg2_diff = None
+        self.results = {}
+        self._init_sw_ramps()
+
+    def autocorrelation_guess(self):
+        """reconstruct.py:421-423: ift(icht(pr.T)).real with the complex inverse transform of the (Nq, M + 1) vectors zero padded?  The
+        reference hands the (Nq, M + 1) array to the COMPLEX inverse transform of n_phi points: only defined when M + 1 == n_phi"""
+        raise NotImplementedError('2-D auto-correlation support')
+
+    def output_modifier(self, pair):
+        if self.opt.get('output_density_modifiers', {}).get('shift_to_center', False):
+            raise NotImplementedError('2-D shift_to_center')
+        return pair
+
+    def phasing_loop(self, rho0=None, rng=None, step_hook=None):
+        if rho0 is None:
+            rho0 = self.density_guess(rng if rng is not None else np.random.default_rng())
+        state = self.create_initial_state(np.array(rho0, dtype=complex))
+        initial_densities = tuple(d.copy() for d in state['best_density_pair'])
+        initial_mask = state['mask'].copy()
+        iterations = []
+        for lid, name in enumerate(self.opt['main_loop']['sub_loops']['order']):
+            state, it = self.run_sub_loop(name, lid, state, step_hook)
+            iterations.append(it)
+        best = self.output_modifier(state['best_density_pair'])
+        last = self.output_modifier(state['density_pair_history'][-1])
+        err = {'main': np.array(self.errors['main']), 'real': {k: np.array(v) for k, v in self.errors['real'].items()}, 'reciprocal': {}}
+        return {'real_density': best[1], 'last_real_density': last[1], 'reciprocal_density': best[0], 'last_reciprocal_density': last[0],
+                'final_error': state['best_error'], 'initial_density': initial_densities[1], 'initial_support': initial_mask,
+                'error_dict': err, 'support_mask': state['best_mask'], 'last_support_mask': state['mask'],
+                'loop_iterations': np.sum(iterations) + 1, 'fxs_unknowns': self.results.get('fxs_unknowns')}

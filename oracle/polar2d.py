@@ -87,7 +87,7 @@ def polar_ht(w, used_orders):
 class PolarFourierPair:
     """generate_ft for dimensions = 2 (fourier_transforms.py:49-88) on the midpoint grid pair (ft_grid_pairs.py:282-291, 325-336)"""
 
-    def __init__(self, n_radial_points, max_order, max_q, reciprocity_coefficient=2.0, used_orders=None):
+    def __init__(self, n_radial_points, max_order, max_q, reciprocity_coefficient=2.0, used_orders=None, weights_r_max=None):
         self.N, self.M, self.kappa = n_radial_points, max_order, reciprocity_coefficient
         self.n_phi = 2 * max_order + 1                          # harmonic_transforms.py:44-47
         self.q_max = float(max_q)
@@ -98,7 +98,9 @@ class PolarFourierPair:
         self.phis = np.arange(self.n_phi) / self.n_phi * 2 * np.pi
         self.orders = np.arange(max_order + 1)
         self.raw_weights = polar_mid_weights(self.orders, self.N, reciprocity_coefficient)
-        self.weights = assemble_weights_mid(self.raw_weights, self.orders, self.r_max, reciprocity_coefficient)
+        # the phasing loop hands generate_ft max(r_p), not the cutoff (reconstruct.py:329): `weights_r_max`
+        self.weights = assemble_weights_mid(self.raw_weights, self.orders, self.r_max if weights_r_max is None else weights_r_max,
+                                            reciprocity_coefficient)
         self.zht, self.izht, self.unused = polar_ht(self.weights, self.orders if used_orders is None else np.asarray(used_orders))
 
     def ft(self, data):

@@ -36,6 +36,11 @@ def golden_flow():
 
 
 @pytest.fixture(scope='session')
+def golden_mtip2d():
+    return np.load(os.path.join(GOLDEN, 'mtip2d_N12_M6.npz'))
+
+
+@pytest.fixture(scope='session')
 def golden_metrics():
     return np.load(os.path.join(GOLDEN, 'metrics_ops.npz'))
 

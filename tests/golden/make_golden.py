@@ -1269,6 +1269,143 @@ def main_metrics():
     print('metrics fixture:', len(out), 'arrays; fqc', out['G19_fqc'][:3], 'II', out['G19_II'], 'ccd', out['G19_ccd'])
 
 
+# ---- (f-4) the 2-D phasing loop through the reference's own MTIP class --------------------------------------------------------
+def main_mtip2d():
+    """tests/golden/mtip2d_N12_M6.npz (G20): the reference's real `reconstruct.MTIP(...).generate_phasing_loop() / phasing_loop()` with
+    `dimensions: 2` on seeded 2-D invariants (projection vectors (n_orders, Nq), average intensity) and a stored initial density:
+    single HIO / ER (+ft_stab) steps and the shrink-wrap mask from a stored state, and a short trajectory (errors, densities,
+    supports).  Nothing third party is on the 2-D path."""
+    mods = bootstrap()
+    settings = mods['xframe.settings']
+    pl = mods['xframe.library.pythonLibrary']
+    gl = mods['xframe.library.gridLibrary']
+    ml = mods['xframe.library.mathLibrary']
+    ml.shtns = ShAdapter
+    import types as _t
+
+    class _Any:
+        def __init__(s, *a, **k):
+            pass
+
+        def __getattr__(s, n):
+            return _Any()
+
+        def __call__(s, *a, **k):
+            return _Any()
+
+    class AnyModule(_t.ModuleType):
+        def __getattr__(s, n):
+            if n.startswith('__'):
+                raise AttributeError(n)
+            return _Any()
+    for name in ('xframe.presenters', 'xframe.presenters.matplotlibPresenter', 'xframe.presenters.openCVPresenter'):
+        sys.modules[name] = AnyModule(name)
+    from oracle import mtip as OM
+    from xframe_amd.fxs import synthetic as S
+    N, M, kappa, max_q = 12, 6, 2.0, 0.9
+    n_phi = 2 * M + 1
+    rng = np.random.default_rng(2020)
+    q = (np.arange(N) + 0.5) * max_q / N
+    # 2-D invariants of a seeded smooth intensity: v_m(q) = I_m(q) (any complex vectors would do: the loop is what is pinned)
+    phi = np.arange(n_phi) / n_phi * 2 * np.pi
+    inten = (1.0 + 0.5 * np.cos(2 * phi)[None, :] * np.exp(-q[:, None] * 3) + 0.3 * np.sin(4 * phi)[None, :] * q[:, None]) * np.exp(-(q[:, None] * 2.5) ** 2) * 50
+    Im = np.fft.rfft(inten) / n_phi
+    pm = Im.T.astype(complex) + 0.05 * cplx(rng, (M + 1, N))
+    aint = np.abs(Im[:, 0]) + 0.1
+    data = {'dimensions': 2, 'xray_wavelength': 1.23984,
+            'average_intensity': gl.SampledFunction(gl.NestedArray(q[:, None], 1), aint, coord_sys='cartesian'),
+            'data_radial_points': q, 'data_angular_points': np.zeros(1), 'max_order': M, 'data_projection_matrices': pm}
+    o = OM.deep_update(OM.default_settings(), S.config_overrides(1))
+    o = OM.deep_update(o, {'dimensions': 2, 'grid': {'n_radial_points': N, 'max_order': M, 'max_q': max_q},
+                           'projections': {'reciprocal': {'used_order_ids': np.arange(M + 1)}},
+                           'GPU': {'use': False}, 'multi_process': {'use': False}, 'output_density_modifiers': {'fix_orientation': False}})
+    main = o['main_loop']['sub_loops']['main']
+    main['methods']['HIO']['iterations'] = 4
+    main['methods']['ER']['iterations'] = 3
+    main['iterations'] = 2
+    settings.project = pl.DictNamespace.dict_to_dictnamespace(o)
+    for k in list(sys.modules):
+        if k.endswith('fxs.reconstruct'):
+            del sys.modules[k]
+    cwd = os.getcwd()
+    rc = importlib.import_module('xframe.projects.fxs.reconstruct')
+    os.chdir(cwd)
+    gp = importlib.import_module('xframe.projects.fxs.projectLibrary.ft_grid_pairs')
+    ht = importlib.import_module('xframe.projects.fxs.projectLibrary.hankel_transforms')
+    MT = rc.MTIP
+    MT.dimensions = 2
+    MT.mtip_data = data
+    MT.data_q_limits = [q.min(), q.max()]
+    MT.data_number_of_radial_points = N
+    MT.max_q = max_q
+    mock = gp.get_grid({**o['fourier_transform'], 'dimensions': 2, **o['grid'], 'phis': np.array([1.0, 2.0]), 'max_q': max_q,
+                        'n_radial_points_from_data': N})
+    MT.reciprocal_radial_points = mock.reciprocalGrid[:, 0, 0]
+    MT.real_radial_points = mock.realGrid[:, 0, 0]
+    MT.fourier_transform_weights = {'weights': ht.calc_polar_mid_weights(np.arange(M + 1), N, kappa), 'posHarmOrders': np.arange(M + 1),
+                                    'mode': 'midpoint'}
+    MT.preinit_was_called = True
+    rc.xprint = lambda *a, **k: None
+    mp = mods['xframe.Multiprocessing']
+    if not hasattr(mp, 'comm_module'):
+        mp.comm_module = None
+    m = MT(pl.RecipeFactory({}))
+    m.generate_phasing_loop()
+    ops = m.process_factory.operatorDict
+    rs = np.asarray(MT.real_radial_points)
+    rho0 = ((1.0 + 0.3 * rng.random((N, n_phi))) * np.exp(-(rs[:, None] / (0.35 * rs.max())) ** 2)).astype(complex)
+    out = {'N': np.array(N), 'M': np.array(M), 'kappa': np.array(kappa), 'max_q': np.array(max_q), 'data_pm': pm, 'data_aint': aint, 'data_q': q,
+           'rho0': rho0, 'n_hio': np.array(4), 'n_er': np.array(3), 'loop_iterations_main': np.array(2)}
+    # prepared fields of the reference's objects (what the product's host setup has to reproduce)
+    rp = m.projection_objects['reciprocal']
+    out['rp_projection_matrices'] = np.asarray(rp.projection_matrices)
+    out['rp_radial_mask'] = np.asarray(rp.radial_mask)
+    out['rp_integrated_intensity'] = np.asarray(rp.integrated_intensity)
+    out['rp_radial_points'] = np.asarray(rp.radial_points)
+    real_pr = m.projection_objects['real']
+    out['initial_support'] = np.asarray(real_pr.initial_support)
+    # single steps from a stored state
+    F0 = ops['fourier_transform'](rho0)
+    rho_s = ops['inverse_fourier_transform'](F0)
+    out['step_rho_in'] = np.array(rho_s)
+    out['step_F0'] = np.array(F0)
+    hio = m.projection_objects['hio']
+    sup = np.random.default_rng(5).random(rho_s.shape) > 0.3
+    for enforce in (True, False):
+        real_pr.enforce_initial_support = enforce
+        real_pr.support = sup
+        for meth in ('HIO', 'ER', 'HIO_ft_stab', 'ER_ft_stab'):
+            hio.beta = 0.45
+            m.results.setdefault('errors', {'real': {'l2_projection_diff': []}, 'reciprocal': {}, 'main': []})
+            m.init_error_dict()
+            Fn, rn = m.routines[meth].run(np.array(F0), np.array(rho_s))
+            tag = f'step_{meth}_enf{int(enforce)}'
+            out[tag + '_F'], out[tag + '_rho'] = np.array(Fn), np.array(rn)
+            out[tag + '_err'] = np.array(m.results['errors']['real']['l2_projection_diff'][-1])
+    out['step_support'] = sup
+    sw = m.projection_objects['sw']
+    sw.gaussian_sigma = 20.0
+    sw.threshold = 0.09
+    out['step_SW_mask'] = np.array(m.routines['SW'].run(np.array(rho_s)))
+    real_pr.enforce_initial_support = True
+    real_pr.support = real_pr.initial_support
+    # full trajectory with the stored rho0
+    m2 = MT(pl.RecipeFactory({}))
+    m2.generate_density_guess_method = lambda *a, **k: (lambda: np.array(rho0))
+    m2.generate_phasing_loop()
+    res = m2.phasing_loop()
+    out['traj_main'] = res['error_dict']['main']
+    out['traj_real_err'] = res['error_dict']['real']['l2_projection_diff']
+    for k in ('last_real_density', 'real_density', 'last_reciprocal_density', 'reciprocal_density', 'support_mask', 'last_support_mask',
+              'initial_density'):
+        out['traj_' + k] = np.asarray(res[k])
+    out['traj_final_error'] = np.array(res['final_error'])
+    out['traj_loop_iterations'] = np.array(res['loop_iterations'])
+    out['traj_unknowns'] = np.asarray(res['fxs_unknowns'])
+    np.savez_compressed(os.path.join(HERE, 'mtip2d_N12_M6.npz'), **out)
+    print('2-D loop fixture:', len(out), 'arrays; final error', res['final_error'], 'steps', len(res['error_dict']['main']))
+
+
 if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'io':
         main_io()
@@ -1282,6 +1419,8 @@ if __name__ == '__main__':
         main_polar2d()
     elif len(sys.argv) > 1 and sys.argv[1] == 'metrics':
         main_metrics()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'mtip2d':
+        main_mtip2d()
     elif len(sys.argv) > 1 and sys.argv[1] == 'variants':
         main_variants()
     else:

@@ -999,6 +999,58 @@ def check_invariant_metrics_golden_hip(g, lib_path=None):
     e.close()
 
 
+def mtip2d_problem(g):
+    """data dict and settings of the 2-D loop fixture G20"""
+    N, M = int(g['N']), int(g['M'])
+    data = {'dimensions': 2, 'xray_wavelength': 1.23984, 'average_intensity': g['data_aint'], 'data_radial_points': g['data_q'], 'max_order': M,
+            'data_projection_matrices': g['data_pm']}
+    o = OM.deep_update(OM.default_settings(), S.config_overrides(1))
+    o = OM.deep_update(o, {'dimensions': 2, 'grid': {'n_radial_points': N, 'max_order': M, 'max_q': float(g['max_q'])},
+                           'projections': {'reciprocal': {'used_order_ids': np.arange(M + 1)}}})
+    main = o['main_loop']['sub_loops']['main']
+    main['methods']['HIO']['iterations'] = int(g['n_hio'])
+    main['methods']['ER']['iterations'] = int(g['n_er'])
+    main['iterations'] = int(g['loop_iterations_main'])
+    return data, o
+
+
+def _compare_mtip2d_trajectory(res, g, tol_e, tol_d):
+    assert len(res['error_dict']['main']) == len(g['traj_main'])
+    assert np.allclose(res['error_dict']['main'], g['traj_main'], rtol=tol_e, atol=1e-300)
+    assert np.allclose(res['error_dict']['real']['l2_projection_diff'], g['traj_real_err'], rtol=tol_e)
+    for k in ('last_real_density', 'real_density', 'last_reciprocal_density', 'reciprocal_density'):
+        assert rel_l2(res[k], g['traj_' + k]) < tol_d, k
+    assert (res['support_mask'] != g['traj_support_mask']).sum() == 0 and (res['last_support_mask'] != g['traj_last_support_mask']).sum() == 0
+    assert np.isclose(res['final_error'], float(g['traj_final_error']), rtol=tol_e)
+    assert int(res['loop_iterations']) == int(g['traj_loop_iterations'])
+    assert rel_l2(res['fxs_unknowns'], g['traj_unknowns']) < tol_d
+
+
+def check_mtip2d_golden_oracle(g):
+    """oracle/mtip2d.py against the reference's own 2-D MTIP run (fixture G20): prepared fields, single steps, shrink-wrap, trajectory"""
+    from oracle import mtip2d as O2
+    data, o = mtip2d_problem(g)
+    m = O2.MTIP2D(o, data)
+    assert rel_l2(m.rp.projection_matrices, g['rp_projection_matrices']) < 1e-14 and (m.rp.radial_mask != g['rp_radial_mask']).sum() == 0
+    assert np.isclose(m.rp.integrated_intensity, float(g['rp_integrated_intensity']), rtol=1e-14)
+    assert (m.real_pr.initial_support != g['initial_support']).sum() == 0
+    assert rel_l2(m.fp.ft(g['rho0']), g['step_F0']) < 1e-13 and rel_l2(m.fp.ift(g['step_F0']), g['step_rho_in']) < 1e-13
+    for enf in (1, 0):
+        for meth in ('HIO', 'ER', 'HIO_ft_stab', 'ER_ft_stab'):
+            m.real_pr.enforce_initial_support = bool(enf)
+            m.real_pr.support = g['step_support']
+            m.beta = 0.45
+            m.errors = {'real': {'l2_projection_diff': []}, 'reciprocal': {}, 'main': []}
+            Fn, rn = m.step(meth.replace('_ft_stab', ''), np.array(g['step_rho_in']), meth.endswith('ft_stab'))
+            tag = f'step_{meth}_enf{enf}'
+            assert rel_l2(Fn, g[tag + '_F']) < 1e-12 and rel_l2(rn, g[tag + '_rho']) < 1e-12, tag
+            assert np.isclose(m.errors['real']['l2_projection_diff'][-1], float(g[tag + '_err']), rtol=1e-10), tag
+    m.sw.gaussian_sigma, m.sw.threshold = 20.0, 0.09
+    assert (m.sw_step(np.array(g['step_rho_in'])) != g['step_SW_mask']).sum() == 0
+    m = O2.MTIP2D(o, data)
+    _compare_mtip2d_trajectory(m.phasing_loop(rho0=g['rho0']), g, 1e-10, 1e-10)
+
+
 def check_polar2d_golden_oracle(g):
     """oracle/polar2d.py against the reference's own 2-D functions (fixture G18)"""
     from oracle import polar2d as P2

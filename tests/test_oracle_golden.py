@@ -288,3 +288,9 @@ def test_g19_metrics_oracle(golden_metrics):
     """oracle/metrics.py reproduces the reference's fqc_error / II_error / ccd_diff routines (gsl doubled, see the module header)"""
     import parity_cases as PC
     PC.check_metrics_golden_oracle(golden_metrics)
+
+
+def test_g20_mtip2d_oracle(golden_mtip2d):
+    """oracle/mtip2d.py reproduces the reference's own 2-D phasing loop (reconstruct.MTIP with dimensions: 2)"""
+    import parity_cases as PC
+    PC.check_mtip2d_golden_oracle(golden_mtip2d)
