@@ -266,6 +266,16 @@ int mtip2d_op_fourier_transform(mtip2d_ctx* ctx, const mtip_cdouble* in, mtip_cd
 /* approximate_unknowns + mtip_projection + the number-of-particles rule on coefficients of the real transform; unknowns
  * (n_batch, n_used) or NULL */
 int mtip2d_op_project(mtip2d_ctx* ctx, const mtip_cdouble* I, mtip_cdouble* I_projected, mtip_cdouble* unknowns);
+/* ---- the operators of the 2-D phasing loop (the schedule, ramps, support bookkeeping and best tracking are host logic) ---- */
+int mtip2d_set_real_constraints(mtip2d_ctx* ctx, uint32_t flags, double value_lo, double value_hi, double imag_threshold, uint32_t hio_flags);
+/* (Nq, n_phi) weights of l2_projection_diff: PolarIntegrator weights (mathLibrary.py:1242-1265) times the metric's mask */
+int mtip2d_set_error_weights(mtip2d_ctx* ctx, const double* weights);
+/* one HIO (0) / ER (1) step, optionally with the ft_stab add-back (sketches reconstruct.py:518-528, 576-593): rho, support
+ * (n_batch, Nq, n_phi) in; F' and the new density, the error per restart and the unknowns (n_batch, n_used; or NULL) out */
+int mtip2d_op_step(mtip2d_ctx* ctx, int method, int ft_stab, double beta, const mtip_cdouble* rho, const uint8_t* support,
+                   mtip_cdouble* F_new, mtip_cdouble* rho_new, double* err, mtip_cdouble* unknowns);
+/* the SW sketch (reconstruct.py:598-605, fxs_Projections.py:245-258, 294-298): support mask (n_batch, Nq, n_phi) from rho */
+int mtip2d_op_shrinkwrap(mtip2d_ctx* ctx, const mtip_cdouble* rho, double sigma, double threshold, uint8_t* mask);
 
 /* ---- timing ----------------------------------------------------------------------------------- */
 /* average duration (ms) and launch count of kernel family `name` ("sht_fwd", "sht_inv", "hankel",

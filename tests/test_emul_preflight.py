@@ -153,6 +153,11 @@ def test_polar2d_vs_oracle(emul_lib):
     PC.check_polar2d_vs_oracle(10, 6, emul_lib)
 
 
+def test_mtip2d_loop_golden(emul_lib, golden_mtip2d):
+    """the 2-D phasing loop on the device operators against the reference's own 2-D run (fixture G20)"""
+    PC.check_mtip2d_golden_hip(golden_mtip2d, emul_lib)
+
+
 def test_symmetric_eig_blocked(emul_lib):
     """n > 128: column blocks over workgroups (k_sym_eig_block), 5 blocks -> an empty sixth pads the tournament"""
     PC.check_symmetric_eig(emul_lib, n=130, K=3)

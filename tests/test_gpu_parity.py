@@ -186,6 +186,12 @@ def test_polar2d_vs_oracle(N, M):
     PC.check_polar2d_vs_oracle(N, M)
 
 
+def test_mtip2d_loop_golden(golden_mtip2d):
+    """the 2-D phasing loop (reconstruct2d.MTIP2D on mtip2d_op_step / mtip2d_op_shrinkwrap): single HIO / ER steps with and without
+    ft_stab, the shrink-wrap mask and the 14-step trajectory of the reference's own `dimensions: 2` run (fixture G20)"""
+    PC.check_mtip2d_golden_hip(golden_mtip2d)
+
+
 @pytest.mark.parametrize('n,K', [(100, 6), (128, 33), (130, 5), (200, 7), (256, 49), (288, 4)])
 def test_symmetric_eig(n, K):
     """the eigensolvers of `extract` against LAPACK: LDS-resident up to 128, column blocks over workgroups up to 288

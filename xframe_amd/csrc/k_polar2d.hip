@@ -28,6 +28,13 @@ struct mtip2d_ctx {
     double2* d_unk = nullptr;                      // (B, n_used)
     double n_particles = 1.0;
     bool have_weights = false;
+    // loop operators (step, shrink-wrap)
+    RealParams rp{};
+    double* d_errw = nullptr;                      // (N, n_phi) weights of the real error metric (integrator weights x metric mask)
+    double2 *d_c = nullptr, *d_d = nullptr, *d_e = nullptr;   // more (B, N, n_phi) work grids
+    uint8_t* d_sup = nullptr;                      // (B, N, n_phi)
+    double* d_red = nullptr;                       // (B, 4) reductions
+    bool have_errw = false;
     std::string err;
 };
 
@@ -58,7 +65,7 @@ __global__ void __launch_bounds__(256) k2d_dft(const double2* __restrict__ in, d
     for (int e = threadIdx.x; e < n; e += blockDim.x) {
         tw[e] = tw_g[e];
         const double2 v = in[row * n + e];
-        x[e] = real_in ? make_double2(v.x, 0.0) : v;
+        x[e] = real_in == 2 ? make_double2(v.x * v.x + v.y * v.y, 0.0) : (real_in ? make_double2(v.x, 0.0) : v);
     }
     __syncthreads();
     for (int m = threadIdx.x; m < n_out; m += blockDim.x) {
@@ -142,9 +149,109 @@ __global__ void __launch_bounds__(256) k2d_project(const double2* __restrict__ I
         for (int qq = threadIdx.x; qq < N; qq += blockDim.x) ob[(size_t)qq * n_coef + zero_id] = cscale(ob[(size_t)qq * n_coef + zero_id], inv_sqrt_np);
 }
 
+// F' = F sqrt(I' / |F|^2) where |F|^2 >= 0 and I' >= 0, else 0 (project_to_modified_intensity, fxs_Projections.py:899-909);
+// I' real grid (B, N, n)
+__global__ void __launch_bounds__(256) k2d_modulus(const double2* __restrict__ F, const double* __restrict__ Inew, double2* __restrict__ out,
+                                                   long long total) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const double2 f = F[e];
+    const double I = f.x * f.x + f.y * f.y, In = Inew[e];
+    const bool ok = (I >= 0.0) && (In >= 0.0);
+    out[e] = cscale(f, ok ? sqrt(In / I) : 0.0);
+}
+
+// the real-space stage of a step (one workgroup per restart): w = rho' (+ (rho_in - IFT(F)) above shell 0 with ft_stab:
+// add_above_zero_index, misk.py:326-329), P = real projection, HIO / ER, and the l2_projection_diff sums with the metric weights
+__global__ void __launch_bounds__(256) k2d_real_update(const double2* __restrict__ rho_p, const double2* __restrict__ rho_in,
+                                                       const double2* __restrict__ rho_rt, const uint8_t* __restrict__ sup,
+                                                       const double* __restrict__ errw, double2* __restrict__ out, double* __restrict__ red,
+                                                       RealParams rp, int method, double beta, int ft_stab, int N, int n) {
+    __shared__ double s_n[4], s_d[4];
+    const int b = blockIdx.x;
+    const size_t G = (size_t)N * n;
+    double num = 0.0, den = 0.0;
+    for (size_t e = threadIdx.x; e < G; e += blockDim.x) {
+        const size_t i = (size_t)b * G + e;
+        double2 w = rho_p[i];
+        const double2 pv = rho_in[i];
+        if (ft_stab && e >= (size_t)n) w = cadd(w, csub(pv, rho_rt[i]));
+        double2 P;
+        out[i] = real_update_point(rp, method, beta, w, pv, sup[i] != 0, P);
+        const double wg = errw[e];
+        const double dx = w.x - P.x, dy = w.y - P.y;
+        num = fma(wg, dx * dx + dy * dy, num);
+        den = fma(wg, w.x * w.x + w.y * w.y, den);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        num += __shfl_xor(num, o, 64);
+        den += __shfl_xor(den, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        s_n[threadIdx.x >> 6] = num;
+        s_d[threadIdx.x >> 6] = den;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0.0, d = 0.0;
+        for (int wv = 0; wv < (int)(blockDim.x >> 6); ++wv) {
+            a += s_n[wv];
+            d += s_d[wv];
+        }
+        red[2 * b] = a;
+        red[2 * b + 1] = d;
+    }
+}
+
+// shrink-wrap (fxs_Projections.py:245-258, 294-298): |rho| -> FT -> x Gaussian(q, sigma) -> IFT is done by the caller's launches;
+// these two kernels are the elementwise ends: abs, the Gaussian factor, and the threshold between min and max of the clamped result
+__global__ void __launch_bounds__(256) k2d_abs(const double2* __restrict__ in, double2* __restrict__ out, long long total) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < total) out[e] = make_double2(sqrt(in[e].x * in[e].x + in[e].y * in[e].y), 0.0);
+}
+
+__global__ void __launch_bounds__(256) k2d_gauss(double2* __restrict__ F, const double* __restrict__ q, double sigma, int N, int n, long long total) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const int qi = (int)((e / n) % N);
+    const double a = 1.0 / (2.0 * sigma * sigma), pi = 3.14159265358979323846;
+    const double q2 = q[qi] * q[qi];
+    F[e] = cscale(F[e], sqrt(pi / a) * exp(-pi * pi * q2 * q2 / a));                  // gaussian_fourier_transformed_spherical: q^4 (mathLibrary.py:616-624)
+}
+
+__global__ void __launch_bounds__(256) k2d_sw_mask(const double2* __restrict__ conv, uint8_t* __restrict__ mask, double threshold, int N, int n) {
+    __shared__ double s_lo[4], s_hi[4];
+    const int b = blockIdx.x;
+    const size_t G = (size_t)N * n;
+    double lo = HUGE_VAL, hi = -HUGE_VAL;
+    for (size_t e = threadIdx.x; e < G; e += blockDim.x) {
+        const double c = fmax(conv[(size_t)b * G + e].x, 0.0);
+        lo = fmin(lo, c);
+        hi = fmax(hi, c);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        lo = fmin(lo, __shfl_xor(lo, o, 64));
+        hi = fmax(hi, __shfl_xor(hi, o, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        s_lo[threadIdx.x >> 6] = lo;
+        s_hi[threadIdx.x >> 6] = hi;
+    }
+    __syncthreads();
+    lo = s_lo[0];
+    hi = s_hi[0];
+    for (int wv = 1; wv < (int)(blockDim.x >> 6); ++wv) {
+        lo = fmin(lo, s_lo[wv]);
+        hi = fmax(hi, s_hi[wv]);
+    }
+    const double cut = lo + threshold * (hi - lo);
+    for (size_t e = threadIdx.x; e < G; e += blockDim.x) mask[(size_t)b * G + e] = fmax(conv[(size_t)b * G + e].x, 0.0) >= cut ? 1 : 0;
+}
+
 static void c2_free(mtip2d_ctx* c) {
     for (void* p : {(void*)c->d_tw, (void*)c->d_wf, (void*)c->d_wi, (void*)c->d_unused, (void*)c->d_a, (void*)c->d_b, (void*)c->d_order_ids,
-                    (void*)c->d_pm, (void*)c->d_rmask, (void*)c->d_q, (void*)c->d_unk})
+                    (void*)c->d_pm, (void*)c->d_rmask, (void*)c->d_q, (void*)c->d_unk, (void*)c->d_errw, (void*)c->d_c, (void*)c->d_d,
+                    (void*)c->d_e, (void*)c->d_sup, (void*)c->d_red})
         if (p) (void)hipFree(p);
     if (c->stream) (void)hipStreamDestroy(c->stream);
 }
@@ -363,6 +470,121 @@ int mtip2d_op_project(mtip2d_ctx* c, const mtip_cdouble* I, mtip_cdouble* out, m
                        n_coef, c->n_used, c->zero_pos, c->zero_id, 1.0 / std::sqrt(c->n_particles));
     C2_CHECK(c, c2_copy(c, out, c->d_b, n));
     if (unknowns) C2_CHECK(c, c2_copy(c, unknowns, c->d_unk, (size_t)c->B * c->n_used * sizeof(double2)));
+    C2_CHECK(c, hipGetLastError());
+    return MTIP_OK;
+}
+
+int mtip2d_set_real_constraints(mtip2d_ctx* c, uint32_t flags, double lo, double hi, double imag_thr, uint32_t hio_flags) {
+    if (!c) return MTIP_EINVAL;
+    c->rp.flags = flags; c->rp.hio_flags = hio_flags; c->rp.lo = lo; c->rp.hi = hi; c->rp.imag_thr = imag_thr;
+    return MTIP_OK;
+}
+
+/* weights (Nq, n_phi) of the real error metric: integrator weights times the metric's mask (fxs_IO_methods.py:97-128 with
+ * PolarIntegrator, mathLibrary.py:1242-1265) */
+int mtip2d_set_error_weights(mtip2d_ctx* c, const double* weights) {
+    if (!c || !weights) return MTIP_EINVAL;
+    (void)hipSetDevice(c->device);
+    const size_t G = (size_t)c->N * c->n_phi, BG = (size_t)c->B * G;
+    if (!c->d_errw) {
+        C2_CHECK(c, hipMalloc((void**)&c->d_errw, G * sizeof(double)));
+        C2_CHECK(c, hipMalloc((void**)&c->d_c, BG * sizeof(double2)));
+        C2_CHECK(c, hipMalloc((void**)&c->d_d, BG * sizeof(double2)));
+        C2_CHECK(c, hipMalloc((void**)&c->d_e, BG * sizeof(double2)));
+        C2_CHECK(c, hipMalloc((void**)&c->d_sup, BG));
+        C2_CHECK(c, hipMalloc((void**)&c->d_red, (size_t)c->B * 4 * sizeof(double)));
+    }
+    C2_CHECK(c, c2_copy(c, c->d_errw, weights, G * sizeof(double)));
+    c->have_errw = true;
+    return MTIP_OK;
+}
+
+/* one HIO (method 0) / ER (method 1) step of the 2-D loop (sketches reconstruct.py:518-528, 576-593 with the 2-D operators):
+ * F = FT(rho); I_m = real harmonic transform of |F|^2; unknowns + projection; I' back on the grid; F' = F sqrt(I' / |F|^2);
+ * rho' = IFT(F') (+ rho - IFT(F) above shell 0 with ft_stab); real-space projection with `support` (n_batch, Nq, n_phi; the
+ * effective one) + HIO / ER; error = l2_projection_diff.  F_new, rho_new (n_batch, Nq, n_phi), err (n_batch), unknowns
+ * (n_batch, n_used) or NULL. */
+int mtip2d_op_step(mtip2d_ctx* c, int method, int ft_stab, double beta, const mtip_cdouble* rho, const uint8_t* support,
+                   mtip_cdouble* F_new, mtip_cdouble* rho_new, double* err, mtip_cdouble* unknowns) {
+    if (!c) return MTIP_EINVAL;
+    if (!c->have_weights || c->n_used == 0 || !c->have_errw) {
+        c->err = "step: hankel weights, projection and error weights must be set first";
+        return MTIP_ESTATE;
+    }
+    if ((method != MTIP_HIO && method != MTIP_ER) || !rho || !support || !F_new || !rho_new || !err) {
+        c->err = "step: method 0 (HIO) or 1 (ER), buffers not null";
+        return MTIP_EINVAL;
+    }
+    (void)hipSetDevice(c->device);
+    const int N = c->N, n = c->n_phi, M1 = c->M + 1, B = c->B;
+    const size_t BG = (size_t)B * N * n;
+    const long long total = (long long)BG;
+    const size_t lds = (size_t)2 * n * sizeof(double2);
+    const unsigned rows = (unsigned)(B * N);
+    C2_CHECK(c, c2_copy(c, c->d_e, rho, BG * sizeof(double2)));                      // rho_in
+    C2_CHECK(c, c2_copy(c, c->d_sup, support, BG));
+    // F = FT(rho) -> d_c
+    c2_dft(c, c->d_e, c->d_a, 0);
+    c2_hankel(c, c->d_a, c->d_b, 0);
+    c2_dft(c, c->d_b, c->d_c, 1);
+    // I_m of |F|^2 -> d_a (B, N, M + 1); projection -> d_b; I' (real grid) -> d_a (as doubles)
+    hipLaunchKernelGGL(k2d_dft, dim3(rows), dim3(256), lds, c->stream, (const double2*)c->d_c, c->d_a, (const double2*)c->d_tw, n, M1, -1, 1.0 / n, 2);
+    hipLaunchKernelGGL(k2d_project, dim3((unsigned)B), dim3(256), (size_t)c->n_used * sizeof(double2), c->stream, (const double2*)c->d_a, c->d_b,
+                       c->d_unk, (const double2*)c->d_pm, (const uint8_t*)c->d_rmask, (const int*)c->d_order_ids, (const double*)c->d_q, N, M1,
+                       c->n_used, c->zero_pos, c->zero_id, 1.0 / std::sqrt(c->n_particles));
+    hipLaunchKernelGGL(k2d_irdft, dim3(rows), dim3(256), lds, c->stream, (const double2*)c->d_b, reinterpret_cast<double*>(c->d_a),
+                       (const double2*)c->d_tw, n, c->M);
+    // F' -> d_d
+    hipLaunchKernelGGL(k2d_modulus, dim3((unsigned)div_up(total, 256)), dim3(256), 0, c->stream, (const double2*)c->d_c,
+                       (const double*)reinterpret_cast<double*>(c->d_a), c->d_d, total);
+    // rho' = IFT(F') -> d_a
+    c2_dft(c, c->d_d, c->d_a, 0);
+    c2_hankel(c, c->d_a, c->d_b, 1);
+    c2_dft(c, c->d_b, c->d_a, 1);
+    C2_CHECK(c, c2_copy(c, F_new, c->d_d, BG * sizeof(double2)));                   // F' delivered: d_d is free for the outputs below
+    if (ft_stab) {                                                                  // IFT(F) -> d_b (through d_d)
+        c2_dft(c, c->d_c, c->d_b, 0);
+        c2_hankel(c, c->d_b, c->d_d, 1);
+        c2_dft(c, c->d_d, c->d_b, 1);
+    }
+    hipLaunchKernelGGL(k2d_real_update, dim3((unsigned)B), dim3(256), 0, c->stream, (const double2*)c->d_a, (const double2*)c->d_e,
+                       (const double2*)c->d_b, (const uint8_t*)c->d_sup, (const double*)c->d_errw, c->d_d, c->d_red, c->rp, method, beta,
+                       ft_stab ? 1 : 0, N, n);
+    C2_CHECK(c, c2_copy(c, rho_new, c->d_d, BG * sizeof(double2)));
+    std::vector<double> red((size_t)B * 2);
+    C2_CHECK(c, c2_copy(c, red.data(), c->d_red, red.size() * sizeof(double)));
+    for (int b = 0; b < B; ++b) err[b] = red[2 * b + 1] != 0.0 ? red[2 * b] / red[2 * b + 1] : HUGE_VAL;   // fxs_IO_methods.py:121-126
+    if (unknowns) C2_CHECK(c, c2_copy(c, unknowns, c->d_unk, (size_t)B * c->n_used * sizeof(double2)));
+    C2_CHECK(c, hipGetLastError());
+    return MTIP_OK;
+}
+
+/* the SW sketch (reconstruct.py:598-605; fxs_Projections.py:245-258, 294-298): mask = c >= min + threshold (max - min) of
+ * c = max(Re IFT(FT(|rho|) gaussian(q, sigma)), 0); mask (n_batch, Nq, n_phi) */
+int mtip2d_op_shrinkwrap(mtip2d_ctx* c, const mtip_cdouble* rho, double sigma, double threshold, uint8_t* mask) {
+    if (!c) return MTIP_EINVAL;
+    if (!c->have_weights || !c->have_errw || c->d_q == nullptr) {
+        c->err = "shrinkwrap: hankel weights, projection (radial points) and error weights must be set first";
+        return MTIP_ESTATE;
+    }
+    if (!rho || !mask || !(sigma > 0.0)) {
+        c->err = "shrinkwrap: null buffer or sigma <= 0";
+        return MTIP_EINVAL;
+    }
+    (void)hipSetDevice(c->device);
+    const size_t BG = (size_t)c->B * c->N * c->n_phi;
+    const long long total = (long long)BG;
+    C2_CHECK(c, c2_copy(c, c->d_e, rho, BG * sizeof(double2)));
+    hipLaunchKernelGGL(k2d_abs, dim3((unsigned)div_up(total, 256)), dim3(256), 0, c->stream, (const double2*)c->d_e, c->d_c, total);
+    c2_dft(c, c->d_c, c->d_a, 0);
+    c2_hankel(c, c->d_a, c->d_b, 0);
+    c2_dft(c, c->d_b, c->d_c, 1);
+    hipLaunchKernelGGL(k2d_gauss, dim3((unsigned)div_up(total, 256)), dim3(256), 0, c->stream, c->d_c, (const double*)c->d_q, sigma, c->N, c->n_phi, total);
+    c2_dft(c, c->d_c, c->d_a, 0);
+    c2_hankel(c, c->d_a, c->d_b, 1);
+    c2_dft(c, c->d_b, c->d_c, 1);
+    hipLaunchKernelGGL(k2d_sw_mask, dim3((unsigned)c->B), dim3(256), 0, c->stream, (const double2*)c->d_c, c->d_sup, threshold, c->N, c->n_phi);
+    C2_CHECK(c, c2_copy(c, mask, c->d_sup, BG));
     C2_CHECK(c, hipGetLastError());
     return MTIP_OK;
 }

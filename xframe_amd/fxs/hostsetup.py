@@ -159,6 +159,47 @@ def _regrid(values, old, new, interpolation):
     return out.reshape((len(new),) + np.shape(values)[1:])
 
 
+def reciprocal_radial_mask(qs, q_d, max_order, mopt, data):
+    """generate_radial_mask (fxs_Projections.py:578-629): (n_orders, Nq) bool, data range AND the q_mask option"""
+    qs = np.asarray(qs, dtype=float)
+    n = len(qs)
+    data_mask = (qs >= q_d.min()) & (qs <= q_d.max())
+    mask = np.ones((max_order + 1, n), dtype=bool)
+    
+    if isinstance(mopt, dict):
+        mtype = mopt['type']
+        if mtype == 'manual' and mopt['manual']['type'] == 'region':
+            lo, hi = mopt['manual']['region']
+            lo_set = not (isinstance(lo, bool) and lo is False)
+            hi_set = not (isinstance(hi, bool) and hi is False)
+            if not lo_set and hi_set:
+                mask[:] = (qs < hi)[None, :]
+            elif lo_set and not hi_set:
+                mask[:] = (qs >= lo)[None, :]
+            elif lo_set and hi_set:
+                mask[:] = ((qs >= lo) & (qs < hi))[None, :]
+        elif mtype == 'manual' and mopt['manual']['type'] == 'order_dependent_line':
+            # fxs_Projections.py:619-624, mathLibrary.py:1131-1137: side of the line through two (order, q) points
+            p1, p2 = np.asarray(mopt['manual']['order_dependent_line'], dtype=float)
+            rot = np.array([p2[1] - p1[1], -(p2[0] - p1[0])])
+            oq = np.stack(np.meshgrid(np.arange(max_order + 1, dtype=float), qs, indexing='ij'), axis=-1)
+            mask = (-1 * np.sum((oq - p1) * rot[None, None, :], axis=-1)) >= 0
+        elif mtype == 'from_projection_matrices':
+            # 592-597: per order the open q interval covered by the data matrices
+            lims = data.get('data_projection_matrices_q_id_limits', False)
+            if isinstance(lims, dict):
+                lims = lims['I1I1']
+            if isinstance(lims, bool):
+                raise ValueError("q_mask 'from_projection_matrices' needs data_projection_matrices_q_id_limits")
+            mask = np.zeros((max_order + 1, n), dtype=bool)
+            for row, lim in zip(mask, lims):
+                row[:] = (qs > q_d[int(lim[0])]) & (qs < q_d[int(lim[1]) - 1])
+        elif mtype != 'none':
+            raise NotImplementedError(f'q_mask type {mtype!r}')
+
+    return mask & data_mask[None, :]
+
+
 class ReciprocalSetup:
     """Everything ``ReciprocalProjection.__init__`` prepares on the host (fxs_Projections.py:471-537)."""
 
@@ -208,41 +249,7 @@ class ReciprocalSetup:
             self.so_order = int(ids[0])
             if proj[self.so_order].shape[1] < 5:
                 raise ValueError('SO_freedom: the chosen order has fewer than 5 unknown rows (upstream indexes row 4)')
-        # radial mask, 578-629
-        data_mask = (self.qs >= q_d.min()) & (self.qs <= q_d.max())
-        mask = np.ones((max_order + 1, n), dtype=bool)
-        mopt = opt.get('q_mask', None)
-        if isinstance(mopt, dict):
-            mtype = mopt['type']
-            if mtype == 'manual' and mopt['manual']['type'] == 'region':
-                lo, hi = mopt['manual']['region']
-                lo_set = not (isinstance(lo, bool) and lo is False)
-                hi_set = not (isinstance(hi, bool) and hi is False)
-                if not lo_set and hi_set:
-                    mask[:] = (self.qs < hi)[None, :]
-                elif lo_set and not hi_set:
-                    mask[:] = (self.qs >= lo)[None, :]
-                elif lo_set and hi_set:
-                    mask[:] = ((self.qs >= lo) & (self.qs < hi))[None, :]
-            elif mtype == 'manual' and mopt['manual']['type'] == 'order_dependent_line':
-                # fxs_Projections.py:619-624, mathLibrary.py:1131-1137: side of the line through two (order, q) points
-                p1, p2 = np.asarray(mopt['manual']['order_dependent_line'], dtype=float)
-                rot = np.array([p2[1] - p1[1], -(p2[0] - p1[0])])
-                oq = np.stack(np.meshgrid(np.arange(max_order + 1, dtype=float), self.qs, indexing='ij'), axis=-1)
-                mask = (-1 * np.sum((oq - p1) * rot[None, None, :], axis=-1)) >= 0
-            elif mtype == 'from_projection_matrices':
-                # 592-597: per order the open q interval covered by the data matrices
-                lims = data.get('data_projection_matrices_q_id_limits', False)
-                if isinstance(lims, dict):
-                    lims = lims['I1I1']
-                if isinstance(lims, bool):
-                    raise ValueError("q_mask 'from_projection_matrices' needs data_projection_matrices_q_id_limits")
-                mask = np.zeros((max_order + 1, n), dtype=bool)
-                for row, lim in zip(mask, lims):
-                    row[:] = (self.qs > q_d[int(lim[0])]) & (self.qs < q_d[int(lim[1]) - 1])
-            elif mtype != 'none':
-                raise NotImplementedError(f'q_mask type {mtype!r}')
-        self.radial_mask = mask & data_mask[None, :]
+        self.radial_mask = reciprocal_radial_mask(self.qs, q_d, max_order, opt.get('q_mask', None), data)
         self.max_order = max_order
 
 

@@ -35,7 +35,8 @@ def assemble_weights_mid(weights, orders, r_max, reciprocity_coefficient):
 class Engine2D:
     """transforms (and, after ``set_projection``, the reciprocal projection) of the 2-D variant for batches of ``n_batch`` grids"""
 
-    def __init__(self, n_radial_points, max_order, max_q, reciprocity_coefficient=2.0, n_batch=1, device=0, lib_path=None, used_orders=None):
+    def __init__(self, n_radial_points, max_order, max_q, reciprocity_coefficient=2.0, n_batch=1, device=0, lib_path=None, used_orders=None,
+                 weights_r_max=None):
         self.lib = _lib.load(lib_path)
         self.N, self.M, self.B = int(n_radial_points), int(max_order), int(n_batch)
         self.n_phi = 2 * self.M + 1                              # harmonic_transforms.py:44-47
@@ -53,7 +54,9 @@ class Engine2D:
         if not self.ctx:
             raise _lib.MtipError('mtip2d_create failed (sizes: n_phi odd, 3..2047; a visible device)')
         orders = np.arange(self.M + 1)
-        fw, iw = assemble_weights_mid(polar_mid_weights(orders, self.N, self.kappa), orders, self.r_max, self.kappa)
+        # (the phasing loop hands generate_ft max(r_p) instead of the cutoff, reconstruct.py:329: `weights_r_max`)
+        fw, iw = assemble_weights_mid(polar_mid_weights(orders, self.N, self.kappa), orders,
+                                      self.r_max if weights_r_max is None else float(weights_r_max), self.kappa)
         all_abs = np.concatenate((orders, orders[:0:-1]))
         unused = ~np.isin(all_abs, orders if used_orders is None else np.asarray(used_orders))     # hankel_transforms.py:611-613
         self._ck(self.lib.mtip2d_set_hankel_weights(self.ctx, _lib.ptr(_lib.as_c128(fw)), _lib.ptr(_lib.as_c128(iw)), _lib.ptr(_lib.as_u8(unused))))
@@ -130,3 +133,29 @@ class Engine2D:
         unk = np.empty((self.B, self.n_used), complex)
         self._ck(self.lib.mtip2d_op_project(self.ctx, _lib.ptr(c), _lib.ptr(out), _lib.ptr(unk)))
         return out, unk
+
+    # ---- operators of the phasing loop
+    def set_real_constraints(self, flags, lo, hi, imag_thr, hio_flags):
+        self._ck(self.lib.mtip2d_set_real_constraints(self.ctx, int(flags), float(lo), float(hi), float(imag_thr), int(hio_flags)))
+
+    def set_error_weights(self, weights):
+        w = _lib.as_f64(weights)
+        assert w.shape == (self.N, self.n_phi)
+        self._ck(self.lib.mtip2d_set_error_weights(self.ctx, _lib.ptr(w)))
+
+    def step(self, method, ft_stab, beta, rho, support):
+        """one HIO / ER step for the batch: (F_new, rho_new, errors (B,), unknowns (B, n_used))"""
+        r = self._grid(rho)
+        sup = np.ascontiguousarray(np.broadcast_to(np.asarray(support, dtype=np.uint8), (self.B,) + self.shape))
+        F_new, rho_new = np.empty_like(r), np.empty_like(r)
+        err = np.empty(self.B)
+        unk = np.empty((self.B, self.n_used), complex)
+        self._ck(self.lib.mtip2d_op_step(self.ctx, {'HIO': 0, 'ER': 1}[method], int(bool(ft_stab)), float(beta), _lib.ptr(r), _lib.ptr(sup),
+                                         _lib.ptr(F_new), _lib.ptr(rho_new), _lib.ptr(err), _lib.ptr(unk)))
+        return F_new, rho_new, err, unk
+
+    def shrinkwrap(self, rho, sigma, threshold):
+        r = self._grid(rho)
+        mask = np.empty((self.B,) + self.shape, np.uint8)
+        self._ck(self.lib.mtip2d_op_shrinkwrap(self.ctx, _lib.ptr(r), float(sigma), float(threshold), _lib.ptr(mask)))
+        return mask.astype(bool)

@@ -1,0 +1,258 @@
+"""The 2-D (polar) phasing loop of ``fxs reconstruct`` (``dimensions: 2``) on the MI355X -- host mirror of the `dimensions == 2`
+branches of ``xframe/projects/fxs/reconstruct.py`` (263-266, 347-350, 421-423, 1126-1129) and
+``projectLibrary/fxs_Projections.py`` (473-476, 506-511, 631-637, 651-662, 679-714, 189-203) around the loop of 814-952.
+
+A 2-D restart is 260 KB at 128 x 129, so unlike the 3-D engine the loop is orchestrated from the host, as the reference's is:
+every phasing step (Fourier pair, real harmonic transform of |F|^2, unknowns + projection, modulus replacement, inverse transform
+with the ft_stab add-back, real-space projection + HIO / ER, error sums) is ONE call into the device operators for the whole
+batch of restarts (`mtip2d_op_step`, csrc/k_polar2d.hip), the shrink-wrap another (`mtip2d_op_shrinkwrap`); schedule, beta and
+shrink-wrap ramps, support bookkeeping, history and best tracking are the host logic of the reference.  Pinned by fixture G20 (the
+reference's own 2-D `MTIP` run).  Not built for 2-D: `SW_center`, the `*_non_FXS` variants, reciprocal metrics, `SO_freedom`,
+the auto-correlation support / guess, `shift_to_center` -- they raise."""
+import numpy as np
+
+from . import hostsetup as hs
+from .polar2d import Engine2D
+from .settings import reciprocity_coefficient, resolve
+
+
+def polar_integrator_weights(rs, phis):
+    """PolarIntegrator.integrate (mathLibrary.py:1254-1262) as weights: trapezoid over the phi samples (the circle is not closed) and
+    over r with the weight r"""
+    def trapz_w(x):
+        w = np.zeros(len(x))
+        d = np.diff(x)
+        w[:-1] += d / 2
+        w[1:] += d / 2
+        return w
+    return (trapz_w(np.asarray(rs)) * np.asarray(rs))[:, None] * trapz_w(np.asarray(phis))[None, :]
+
+
+class ReciprocalSetup2D:
+    """ReciprocalProjection.__init__ for dimensions == 2 (fxs_Projections.py:471-537) on the host"""
+
+    def __init__(self, qs, data, max_order, opt):
+        for key in ('SO_freedom',):
+            if opt.get(key, {}).get('use', False):
+                raise NotImplementedError('2-D %s' % key)
+        q_d = np.asarray(data['data_radial_points'], dtype=float)
+        aint = np.asarray(getattr(data['average_intensity'], 'data', data['average_intensity']), dtype=float)
+        self.qs = np.asarray(qs, dtype=float)
+        self.integrated_intensity = (q_d[1] - q_d[0]) * np.sum(aint * q_d) * 2 * np.sqrt(np.pi)              # 473-474
+        orders = np.arange(max_order + 1)
+        used_ids = np.asarray(opt.get('used_orders', opt['used_order_ids']))
+        self.used_orders = {int(o): int(i) for o, i in zip(orders, used_ids)}
+        self.number_of_particles = float(opt['number_of_particles']['initial'])
+        pm = np.array(np.asarray(data['data_projection_matrices'])[list(self.used_orders.values())], dtype=complex)
+        if q_d.shape != self.qs.shape or not (q_d == self.qs).all():                                        # 642-662: one vector at a time
+            interp = opt['regrid']['interpolation']
+            aint = hs._regrid(aint, q_d, self.qs, interp)
+            pm = np.array([hs._regrid(v, q_d, self.qs, interp) for v in pm])
+        self.average_intensity = aint
+        proj = pm.copy()                                                                                    # 679-714, 2-D branches
+        keys = np.array(tuple(self.used_orders))
+        if opt.get('odd_orders_to_0', False):
+            proj[keys % 2 == 1, :] = 0
+        if opt.get('use_averaged_intensity', False) and 0 in self.used_orders:
+            proj[self.used_orders[0]] = aint.astype(complex)
+        self.projection_matrices = proj
+        self.radial_mask = hs.reciprocal_radial_mask(self.qs, q_d, max_order, opt.get('q_mask', None), data)
+
+
+class MTIP2D:
+    """the 2-D loop for a batch of restarts; settings as for the 3-D worker (`dimensions: 2`), data = the 2-D invariants
+    (`data_projection_matrices` (n_orders, Nq), `average_intensity`, `data_radial_points`)"""
+
+    def __init__(self, settings, data, n_restarts=1, initial_densities=None, seeds=None, device=0, lib_path=None):
+        opt = self.opt = resolve(settings)
+        if opt.get('dimensions', 3) != 2:
+            raise ValueError('MTIP2D is the dimensions == 2 loop')
+        g = opt['grid']
+        self.N, self.M = int(g['n_radial_points']), int(g['max_order'])
+        if opt['fourier_transform']['type'] != 'midpoint':
+            raise NotImplementedError("2-D fourier_transform.type %r: 'midpoint' is built" % (opt['fourier_transform']['type'],))
+        kappa = reciprocity_coefficient(opt['fourier_transform'])
+        max_q = g['max_q']
+        if not isinstance(max_q, float):
+            max_q = float(np.max(data['data_radial_points']))
+        self.B = int(n_restarts)
+        dr = kappa / max_q
+        self.engine = e = Engine2D(self.N, self.M, max_q, kappa, n_batch=self.B, device=device, lib_path=lib_path,
+                                   weights_r_max=kappa * self.N / max_q - dr / 2)                           # r_max = max(r_p), reconstruct.py:329
+        self.shape = e.shape
+        self.rsetup = rs_ = ReciprocalSetup2D(e.qs, data, self.M, opt['projections']['reciprocal'])
+        e.set_projection(rs_.projection_matrices, rs_.used_orders, rs_.radial_mask, rs_.number_of_particles)
+        popt = opt['projections']['real']['projections']
+        considered = opt['projections']['real']['HIO'].get('considered_projections', ['all'])
+        e.set_real_constraints(*hs.real_constraint_flags(popt, considered))
+        sup = popt['support']['initial_support']
+        if sup['type'] != 'max_radius':
+            raise NotImplementedError('2-D initial support %r' % (sup['type'],))
+        self.initial_support = np.ascontiguousarray(np.broadcast_to(e.rs[:, None] < sup['max_radius'], self.shape))
+        em = opt['main_loop']['error']['methods']
+        if list(em['reciprocal'].get('calculate', [])) or list(em['real'].get('calculate', [])) != ['l2_projection_diff']:
+            raise NotImplementedError('2-D error metrics other than the real l2_projection_diff')
+        main = em.get('main', {'metrics': {'real': ['l2_projection_diff'], 'reciprocal': []}, 'type': 'mean'})
+        if list(main['metrics'].get('real', [])) != ['l2_projection_diff'] or list(main['metrics'].get('reciprocal', [])):
+            raise NotImplementedError('2-D main error over other metrics than l2_projection_diff')
+        # l2_projection_diff (fxs_IO_methods.py:97-128) with the PolarIntegrator; which mask the reference really uses: hostsetup.error_weights
+        inside = em['real'].get('l2_projection_diff', {}).get('inside_initial_support', False)
+        gen = opt.get('general', {})
+        units = (gen.get('L2_cache', 512) / 2) * 1024 / 16
+        use_mask = bool(inside) and not (gen.get('cache_aware', True) and not (np.prod(self.shape) > units))
+        W = polar_integrator_weights(e.rs, e.phis)
+        if use_mask:
+            W = W * self.initial_support
+        else:
+            W[self.N - 2, :] = 0.0                                    # `square[~True] = 0`: shell N - 2 (fxs_IO_methods.py:113-116)
+        e.set_error_weights(W)
+        self.default_sigma = np.pi / np.max(e.qs)                     # fxs_Projections.py:189-190
+        self.initial_densities = initial_densities
+        self.seeds = seeds
+
+    # -- density guess (reconstruct.py:1115-1174 with the PolarIntegrator, 1126-1127)
+    def _initial_density(self, i):
+        if self.initial_densities is not None:
+            return np.asarray(self.initial_densities[i], dtype=complex)
+        dg = self.opt['density_guess']
+        rng = np.random.default_rng(None if self.seeds is None else self.seeds[i])
+        e = self.engine
+        radius = dg['radius']
+        if isinstance(radius, bool):
+            radius = self.opt['particle_radius']
+        if radius < 0:
+            radius = np.max(e.rs)
+        r = np.broadcast_to(e.rs[:, None], self.shape)
+        if dg['type'] == 'ball':
+            density = np.zeros(self.shape)
+            inside = r < radius
+            density[inside] = 1 + 1 / dg['random']['SNR'] * rng.random(int(inside.sum()))
+        elif dg['type'] == 'bump':
+            amp = 1 + 1 / dg['random']['SNR'] * rng.random(self.shape)
+            inside = (r > -radius) & (r < radius)
+            env = np.zeros(self.shape)
+            env[inside] = np.exp(-dg['bump']['slope'] * radius ** 2 / (radius ** 2 - r[inside] ** 2))
+            density = amp * env
+        else:
+            raise NotImplementedError('2-D density guess %r' % (dg['type'],))
+        total_sq = np.sum(polar_integrator_weights(e.rs, e.phis) * density * density)
+        return (density * np.sqrt(self.rsetup.integrated_intensity / total_sq)).astype(complex)
+
+    def _sw_ramps(self):
+        sw_opt = self.opt['projections']['real']['shrink_wrap']
+        order = self.opt['main_loop']['sub_loops']['order']
+        sig, thr = [], []
+        for lid in range(len(order)):
+            s = sw_opt['sigmas'][lid] if len(sw_opt['sigmas']) - 1 >= lid else False
+            sig.append(hs.LinearRamp(*(s if isinstance(s, (list, tuple)) else [s]), default_start=self.default_sigma, default_stop=self.default_sigma))
+            t = sw_opt['thresholds'][lid] if len(sw_opt['thresholds']) - 1 >= lid else 0.1
+            thr.append(hs.LinearRamp(*(t if isinstance(t, (list, tuple)) else [t])))
+        return sig, thr
+
+    def _update_shrink_wrap(self, iteration, loop_number):
+        r = self._sig_ramps[loop_number]
+        if not r.undefined:
+            v = r(iteration)
+            ok = np.issubdtype(np.array(v).dtype, np.number) and not isinstance(v, bool) and v > 0
+            self.sw_sigma = v if ok else self.default_sigma             # fxs_Projections.py:233-243
+        t = self._thr_ramps[loop_number]
+        if not t.undefined:
+            v = t(iteration)
+            self.sw_threshold = 0 if v < 0 else (1 if v >= 1 else v)    # 218-227
+
+    @staticmethod
+    def _change_to_ft_stab(popt, name, eis_list):
+        """reconstruct.py:836-850 (one decision per batch, as in the 3-D worker)"""
+        if name[-8:] == '_ft_stab' or 'ft_stab' not in popt:
+            return False
+        v = popt['ft_stab']
+        if isinstance(v, bool):
+            return v
+        if v == 'link_to_enforce_initial_support':
+            delay = max(int(popt['link_to_enforce_initial_support']['delay']), 1)
+            if len(eis_list) >= delay:
+                flags = ~(np.array(eis_list[-delay:]) == True).any(axis=0)          # noqa: E712
+                if flags.all() != flags.any():
+                    raise NotImplementedError('restarts of one batch disagree on ft_stab linking')
+                return bool(flags.all())
+        return False
+
+    def phasing_loop(self):
+        """create_initial_state + the sub-loops + generate_output (reconstruct.py:957-1035) for the batch: list of result dicts"""
+        e, B, opt = self.engine, self.B, self.opt
+        rho0 = np.stack([self._initial_density(b) for b in range(B)])
+        F0 = e.fourier_transform(rho0)
+        rho0 = e.fourier_transform(F0, True)                          # 962-963: the state starts from IFT(FT(guess))
+        hl = opt['main_loop'].get('history_length', 3)
+        hist = [(F0.copy(), rho0.copy())] * hl                        # per entry: (F (B, ...), rho (B, ...))
+        init_sup = np.broadcast_to(self.initial_support, (B,) + self.shape).copy()
+        support = init_sup.copy()                                     # effective support (what RealProjection's mask holds)
+        best = {'pair': (F0.copy(), rho0.copy()), 'err': np.full(B, np.inf), 'iter': np.zeros(B, int), 'mask': init_sup.copy()}
+        err_real, err_main, unknowns = [], [], None
+        self._sig_ramps, self._thr_ramps = self._sw_ramps()
+        self.sw_sigma, self.sw_threshold = self.default_sigma, 0.06
+        hio_opt = opt['projections']['real']['HIO']
+        eis_opt = opt['projections']['real']['projections']['support']['enforce_initial_support']
+        limit = eis_opt['if_error_bigger_than'] if eis_opt['apply'] else np.inf
+        loops = opt['main_loop']['sub_loops']
+        eis_list, iterations = [], []
+        for loop_number, loop_name in enumerate(loops['order']):
+            lo = loops[loop_name]
+            methods = {}
+            for key in lo['order']:
+                mo = lo['methods'][key]
+                methods[key] = ({'iterations': mo.get('iterations', 0), 'options': mo} if isinstance(mo, dict) else {'iterations': mo, 'options': {}})
+                if key not in ('HIO', 'ER', 'SW'):
+                    raise NotImplementedError('2-D loop method %r' % (key,))
+            beta_cfg = hio_opt['beta'][loop_number] if len(hio_opt['beta']) - 1 >= loop_number else [0.5, 0.5, -1 / 700, 1600]
+            ramp = hs.ExponentialRamp(*beta_cfg)
+            if 'SW' in methods:
+                self._update_shrink_wrap(0, loop_number)
+            step = sw_step = iteration = 0
+            for iteration in range(1, lo['iterations'] + 1):
+                for key in lo['order']:
+                    if key == 'SW':                                   # 877-885
+                        new_sup = e.shrinkwrap(hist[-1][1], self.sw_sigma, self.sw_threshold)
+                        last = np.asarray(err_main[-1]) if err_main else np.full(B, np.nan)
+                        enforce = last > limit if err_main else np.zeros(B, bool)      # (`error_dict['main'][-1:] > limit` of an empty list is empty: falsy)
+                        eis_list.append(enforce)
+                        support = np.where(enforce[:, None, None], new_sup & init_sup, new_sup)    # support setter, fxs_Projections.py:53-58
+                        sw_step += 1
+                        self._update_shrink_wrap(sw_step, loop_number)
+                        continue
+                    ft_stab = self._change_to_ft_stab(methods[key]['options'], key, eis_list)
+                    for _ in range(methods[key]['iterations']):
+                        F_new, rho_new, err, unknowns = e.step(key, ft_stab, ramp.eval(step), hist[-1][1], support)
+                        hist = hist[1:] + [(F_new, rho_new)]
+                        err_real.append(err)
+                        err_main.append(err)                          # main = mean over [l2_projection_diff]
+                        better = best['err'] > err
+                        if better.any():
+                            sel = better[:, None, None]
+                            best['pair'] = (np.where(sel, F_new, best['pair'][0]), np.where(sel, rho_new, best['pair'][1]))
+                            best['mask'] = np.where(sel, support, best['mask'])
+                            best['err'] = np.where(better, err, best['err'])
+                            best['iter'] = np.where(better, iteration, best['iter'])
+                        step += 1
+            n_first = lo.get('best_density_not_in_first_n_iterations', np.inf)
+            res = best['iter'] > n_first                              # 945-949
+            if np.any(res):
+                sel = res[:, None, None]
+                hist = hist[1:] + [(np.where(sel, best['pair'][0], hist[-1][0]), np.where(sel, best['pair'][1], hist[-1][1]))]
+                support = np.where(sel, best['mask'], support)
+            iterations.append(iteration)
+        if opt.get('output_density_modifiers', {}).get('shift_to_center', False):
+            raise NotImplementedError('2-D shift_to_center')
+        err_real, err_main = np.array(err_real), np.array(err_main)
+        out = []
+        for b in range(B):
+            out.append({'real_density': best['pair'][1][b], 'last_real_density': hist[-1][1][b], 'reciprocal_density': best['pair'][0][b],
+                        'last_reciprocal_density': hist[-1][0][b], 'final_error': float(best['err'][b]), 'initial_density': rho0[b],
+                        'initial_support': self.initial_support.copy(),
+                        'error_dict': {'main': err_main[:, b].copy(), 'real': {'l2_projection_diff': err_real[:, b].copy()}, 'reciprocal': {}},
+                        'support_mask': best['mask'][b], 'last_support_mask': support[b], 'loop_iterations': int(np.sum(iterations) + 1),
+                        'fxs_unknowns': None if unknowns is None else unknowns[b]})
+        return out
+
+    def close(self):
+        self.engine.close()
