@@ -176,8 +176,17 @@ class MTIP2D(OM.MTIP):
             iterations.append(it)
         best = self.output_modifier(state['best_density_pair'])
         last = self.output_modifier(state['density_pair_history'][-1])
+        I_last = P2.real_harmonic_forward(np.abs(self.fp.ft(np.array(last[1]))) ** 2)                      # calc_deg2_invariant, 757-765, 993
+        last_deg2 = np.array([v[:, None] * v[None, :].conj() for v in I_last.T])
+        masked = np.array(self.rp.projection_matrices)
+        masked[~self.rp.radial_mask] = 0                                                                     # 997-1001
+        n_steps = len(self.errors['main'])
+        grids = {'real_grid': np.stack(np.meshgrid(self.fp.rs, self.fp.phis, indexing='ij'), -1),
+                 'reciprocal_grid': np.stack(np.meshgrid(self.fp.qs, self.fp.phis, indexing='ij'), -1)}
         err = {'main': np.array(self.errors['main']), 'real': {k: np.array(v) for k, v in self.errors['real'].items()}, 'reciprocal': {}}
         return {'real_density': best[1], 'last_real_density': last[1], 'reciprocal_density': best[0], 'last_reciprocal_density': last[0],
                 'final_error': state['best_error'], 'initial_density': initial_densities[1], 'initial_support': initial_mask,
                 'error_dict': err, 'support_mask': state['best_mask'], 'last_support_mask': state['mask'],
-                'loop_iterations': np.sum(iterations) + 1, 'fxs_unknowns': self.results.get('fxs_unknowns')}
+                'loop_iterations': np.sum(iterations) + 1, 'fxs_unknowns': self.results.get('fxs_unknowns'),
+                'n_particles': np.full((n_steps, 1), self.rp.number_of_particles_list[0]), 'n_particles_gradients': np.array([]),
+                'n_particles_fraction': np.array([]), 'grid_pair': grids, 'projection_matrices': masked, 'last_deg2_invariant': last_deg2}

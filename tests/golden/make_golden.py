@@ -1402,6 +1402,11 @@ def main_mtip2d():
     out['traj_final_error'] = np.array(res['final_error'])
     out['traj_loop_iterations'] = np.array(res['loop_iterations'])
     out['traj_unknowns'] = np.asarray(res['fxs_unknowns'])
+    out['traj_last_deg2_invariant'] = np.asarray(res['last_deg2_invariant'])
+    out['traj_projection_matrices'] = np.asarray(res['projection_matrices'])
+    out['traj_n_particles'] = np.asarray(res['n_particles'])
+    out['traj_real_grid'] = np.array(res['grid_pair']['real_grid'][:], dtype=float)
+    out['traj_reciprocal_grid'] = np.array(res['grid_pair']['reciprocal_grid'][:], dtype=float)
     np.savez_compressed(os.path.join(HERE, 'mtip2d_N12_M6.npz'), **out)
     print('2-D loop fixture:', len(out), 'arrays; final error', res['final_error'], 'steps', len(res['error_dict']['main']))
 

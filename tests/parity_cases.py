@@ -1024,6 +1024,11 @@ def _compare_mtip2d_trajectory(res, g, tol_e, tol_d):
     assert np.isclose(res['final_error'], float(g['traj_final_error']), rtol=tol_e)
     assert int(res['loop_iterations']) == int(g['traj_loop_iterations'])
     assert rel_l2(res['fxs_unknowns'], g['traj_unknowns']) < tol_d
+    assert rel_l2(res['last_deg2_invariant'], g['traj_last_deg2_invariant']) < tol_d
+    assert rel_l2(res['projection_matrices'], g['traj_projection_matrices']) < 1e-14
+    assert np.array_equal(np.asarray(res['n_particles'], dtype=float), np.asarray(g['traj_n_particles'], dtype=float))
+    assert np.allclose(res['grid_pair']['real_grid'], g['traj_real_grid'], rtol=1e-14, atol=1e-15)
+    assert np.allclose(res['grid_pair']['reciprocal_grid'], g['traj_reciprocal_grid'], rtol=1e-14, atol=1e-15)
 
 
 def check_mtip2d_golden_oracle(g):
@@ -1075,6 +1080,37 @@ def check_mtip2d_golden_hip(g, lib_path=None):
     for r in res:
         _compare_mtip2d_trajectory(r, g, 1e-8, 1e-8)
     m.close()
+
+
+def check_mtip2d_worker_vs_oracle(g, lib_path=None, N=None, M=None, n_restarts=3):
+    """`fxs reconstruct` with `dimensions: 2` through ProjectWorker: seeded density guesses (bump), each restart against the oracle's
+    loop run from the same generator; sizes of the fixture unless N, M are given (then data interpolated from the fixture's)"""
+    from oracle import mtip2d as O2
+    data, o = mtip2d_problem(g)
+    if N is not None:
+        qd = np.linspace(data['data_radial_points'][0], data['data_radial_points'][-1], N)
+        m0 = int(g['M'])
+        pm = np.zeros((M + 1, N), complex)
+        for i in range(M + 1):
+            src = data['data_projection_matrices'][min(i, m0)]
+            pm[i] = (np.interp(qd, data['data_radial_points'], src.real) + 1j * np.interp(qd, data['data_radial_points'], src.imag)) / (1 + max(i - m0, 0))
+        data = dict(data, data_radial_points=qd, data_projection_matrices=pm, max_order=M,
+                    average_intensity=np.interp(qd, data['data_radial_points'], np.asarray(data['average_intensity'], dtype=float)))
+        o = OM.deep_update(o, {'grid': {'n_radial_points': N, 'max_order': M}, 'projections': {'reciprocal': {'used_order_ids': np.arange(M + 1)}}})
+    o = OM.deep_update(o, {'multi_process': {'use': True, 'n_parallel_reconstructions': n_restarts}, 'GPU': {'use': True, 'n_gpu_workers': 1}})
+    seeds = [77 + i for i in range(n_restarts)]
+    w = R.ProjectWorker(o, data, seeds=seeds, lib_path=lib_path)
+    res, _ = w.run()
+    assert len(res) == n_restarts and set(w.results['reconstruction_results']) == {str(i) for i in range(n_restarts)}
+    for b in range(n_restarts):
+        ref = O2.MTIP2D(o, data).phasing_loop(rng=np.random.default_rng(seeds[b]))
+        assert rel_l2(res[b]['initial_density'], ref['initial_density']) < 1e-12
+        assert np.allclose(res[b]['error_dict']['main'], ref['error_dict']['main'], rtol=1e-7)
+        for k in ('real_density', 'last_real_density', 'reciprocal_density', 'last_reciprocal_density', 'last_deg2_invariant', 'fxs_unknowns'):
+            assert rel_l2(res[b][k], ref[k]) < 1e-7, k
+        assert (res[b]['support_mask'] != ref['support_mask']).sum() == 0 and (res[b]['last_support_mask'] != ref['last_support_mask']).sum() == 0
+    for m in w.mtip_instances:
+        m.engine.close()
 
 
 def check_polar2d_golden_oracle(g):

@@ -192,6 +192,12 @@ def test_mtip2d_loop_golden(golden_mtip2d):
     PC.check_mtip2d_golden_hip(golden_mtip2d)
 
 
+@pytest.mark.parametrize('N,M', [(None, None), (64, 30)])
+def test_mtip2d_worker_vs_oracle(golden_mtip2d, N, M):
+    """`dimensions: 2` through ProjectWorker with seeded guesses, every restart against the oracle's loop"""
+    PC.check_mtip2d_worker_vs_oracle(golden_mtip2d, None, N, M)
+
+
 @pytest.mark.parametrize('n,K', [(100, 6), (128, 33), (130, 5), (200, 7), (256, 49), (288, 4)])
 def test_symmetric_eig(n, K):
     """the eigensolvers of `extract` against LAPACK: LDS-resident up to 128, column blocks over workgroups up to 288

@@ -36,8 +36,8 @@ class MTIP:
         cls.settings = resolve(settings)
         cls.mtip_data = mtip_data
         cls.dimensions = cls.settings['dimensions']
-        if cls.dimensions != 3:
-            raise NotImplementedError('only dimensions == 3 is on the accelerated path')
+        if cls.dimensions not in (2, 3):
+            raise NotImplementedError('dimensions must be 2 or 3')
         q = np.asarray(mtip_data['data_radial_points'])
         cls.data_q_limits = [q.min(), q.max()]
         cls.data_number_of_radial_points = len(q)
@@ -74,6 +74,24 @@ class MTIP:
     # ------------------------------------------------------------------ assembly (reference 1269-1278)
     def generate_phasing_loop(self):
         t_engine = time.perf_counter()
+        if MTIP.dimensions == 2:
+            # the polar loop: host-orchestrated on the batched device operators (reconstruct2d.py)
+            from .reconstruct2d import MTIP2D
+            self.loop2d = MTIP2D(self.opt, MTIP.mtip_data, n_restarts=self.n_restarts, initial_densities=self.initial_densities,
+                                 seeds=self.seeds, device=self.device, lib_path=self.lib_path)
+            self.engine = self.loop2d.engine
+            self._engine_seconds = time.perf_counter() - t_engine
+            self.rprojection = self.loop2d.rsetup
+
+            def loop2d(*args, **kwargs):
+                t0 = time.perf_counter()
+                res = self.loop2d.phasing_loop()
+                self.timing = {'engine_seconds': self._engine_seconds, 'loop_seconds': time.perf_counter() - t0}
+                out = np.empty(len(res), dtype=object)
+                out[:] = res
+                return out
+            self.phasing_loop = loop2d
+            return
         self.engine = Engine(self.opt, MTIP.mtip_data, n_batch=self.n_restarts, device=self.device, fused=self.fused,
                              lib_path=self.lib_path)
         self._engine_seconds = time.perf_counter() - t_engine

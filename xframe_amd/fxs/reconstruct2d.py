@@ -244,6 +244,14 @@ class MTIP2D:
         if opt.get('output_density_modifiers', {}).get('shift_to_center', False):
             raise NotImplementedError('2-D shift_to_center')
         err_real, err_main = np.array(err_real), np.array(err_main)
+        # calc_deg2_invariant of the last density (reconstruct.py:757-765, 993): B_m = I_m (x) I_m^* (fxs_invariant_tools.py:906-914)
+        F_last = e.fourier_transform(hist[-1][1])
+        I_last = e.real_harmonic_forward((F_last * F_last.conj()).real)
+        masked = np.array(self.rsetup.projection_matrices)           # 997-1001 (one vector per used order in 2-D)
+        masked[~self.rsetup.radial_mask[list(self.rsetup.used_orders.values())]] = 0
+        grids = {'real_grid': np.stack(np.meshgrid(e.rs, e.phis, indexing='ij'), -1),
+                 'reciprocal_grid': np.stack(np.meshgrid(e.qs, e.phis, indexing='ij'), -1)}
+        n_steps = len(err_main)
         out = []
         for b in range(B):
             out.append({'real_density': best['pair'][1][b], 'last_real_density': hist[-1][1][b], 'reciprocal_density': best['pair'][0][b],
@@ -251,7 +259,10 @@ class MTIP2D:
                         'initial_support': self.initial_support.copy(),
                         'error_dict': {'main': err_main[:, b].copy(), 'real': {'l2_projection_diff': err_real[:, b].copy()}, 'reciprocal': {}},
                         'support_mask': best['mask'][b], 'last_support_mask': support[b], 'loop_iterations': int(np.sum(iterations) + 1),
-                        'fxs_unknowns': None if unknowns is None else unknowns[b]})
+                        'fxs_unknowns': None if unknowns is None else unknowns[b],
+                        'n_particles': np.full((n_steps, 1), self.rsetup.number_of_particles), 'n_particles_gradients': np.array([]),
+                        'n_particles_fraction': np.array([]), 'grid_pair': grids, 'projection_matrices': masked,
+                        'last_deg2_invariant': np.einsum('qm,pm->mqp', I_last[b], I_last[b].conj())})
         return out
 
     def close(self):
