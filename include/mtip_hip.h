@@ -111,6 +111,11 @@ int mtip_set_invariant_metrics(mtip_ctx* ctx, uint32_t which, const uint8_t* zer
 int mtip_fetch_invariant_metrics(mtip_ctx* ctx, int64_t first_step, int64_t n_steps, double* II, double* ccd, double* fqc);
 /* the same metrics of given intensity coefficients (n_batch, Nq, (L+1)^2): II (n_batch), ccd (n_batch), fqc (n_batch, Nq) */
 int mtip_op_invariant_metrics(mtip_ctx* ctx, const mtip_cdouble* Ilm, double* II, double* ccd, double* fqc);
+/* the reciprocal metric l2_projection_diff (fxs_IO_methods.py:301-310, 96-127, 131-205): per FXS step int |F - F'|^2 / int |F|^2 with the
+ * integrator weights radial_w (Nq), theta_w (n_theta) -- shell Nq - 2 zeroed by the caller, the reference's `square[~True] = 0`; NULL
+ * weights switch the metric off.  fetch: the steps [first, first + n_steps) as (n, n_batch). */
+int mtip_set_reciprocal_l2_metric(mtip_ctx* ctx, const double* radial_w, const double* theta_w);
+int mtip_fetch_reciprocal_l2_metric(mtip_ctx* ctx, int64_t first_step, int64_t n_steps, double* out);
 /* real-space constraints (fxs_Projections.py:72-130, pythonLibrary.py:1289-1320):
  * flags bit0 support, bit1 value lower bound, bit2 value upper bound, bit3 limit_imag;
  * hio_mask_flags: which of those feed the HIO mask gamma ('considered_projections',

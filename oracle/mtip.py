@@ -132,7 +132,8 @@ class MTIP:
         self.real_error_mask = P.select_real_error_mask(self.shape, self.inside_initial, self.initial_mask,
                                                         gen.get('cache_aware', True), gen.get('L2_cache', 512))
         self.deg2_diff = None
-        if 'deg2_invariant_l2_diff' in self.reciprocal_metrics:
+        self._ranked_id = None
+        if 'deg2_invariant_l2_diff' in self.reciprocal_metrics or 'deg2_ranked_invariant_l2_diff' in self.reciprocal_metrics:
             inv_mask = self.rp.radial_mask[:, :, None] * self.rp.radial_mask[:, None, :]
             self.deg2_diff = P.Deg2InvariantDiff(self.rp.deg2_invariants, self.rp.used_orders,
                                                  self.rp.number_of_particles, inv_mask)
@@ -202,6 +203,20 @@ class MTIP:
         for name in self.reciprocal_metrics:
             if name == 'deg2_invariant_l2_diff':
                 val = self.deg2_diff(Ilm)
+            elif name == 'deg2_ranked_invariant_l2_diff':
+                # fxs_IO_methods.py:330-366: the entry of the per-order metric at the best ranked even order, or at the order the option names
+                if self._ranked_id is None:
+                    order = self.opt['main_loop']['error']['methods']['reciprocal'].get(name, {}).get('order', False)
+                    if isinstance(order, (int, np.integer)) and not isinstance(order, (bool, np.bool_)):
+                        self._ranked_id = self.rp.used_orders[int(order)]
+                    else:
+                        orders = np.array(list(self.rp.used_orders.keys())).astype(int)
+                        self._ranked_id = P.rank_projection_matrices_3d(self.rp.projection_matrices, orders, self.rp.radial_points)[0][0]
+                val = self.deg2_diff(Ilm)[self._ranked_id]
+            elif name == 'l2_projection_diff':
+                # 301-310: the cache-aware branch asks for type 'reziprocal' -> the REAL grid's integrator (131-140); the plain branch takes
+                # the reciprocal grid's, whose radial points are proportional -- the same ratio; mask True in both (shell N - 2 drops out)
+                val = P.l2_rel_diff_error(self.integrator, np.array(F), np.array(F_new), True)
             else:
                 raise NotImplementedError(name)
             self.errors['reciprocal'][name].append(val)

@@ -360,6 +360,8 @@ def run_mtip_golden(mods, N, L, name, n_hio, n_er, with_steps, extra=None, save=
     from xframe_amd.fxs import synthetic as S
     kappa = 2.0
     Qd = S.data_cutoff(N)
+    # the error routines read the GLOBAL general settings (fxs_IO_methods.py:289, 303), not the project's
+    settings.general.cache_aware = bool((extra or {}).get('general', {}).get('cache_aware', True))
 
     class T:
         def __init__(s, fp):
@@ -485,6 +487,10 @@ def run_mtip_golden(mods, N, L, name, n_hio, n_er, with_steps, extra=None, save=
             small['traj_' + k] = np.asarray(res[k])
         small['traj_final_error'] = np.array(res['final_error'])
         small['traj_loop_iterations'] = np.array(res['loop_iterations'])
+        for cat in ('real', 'reciprocal'):                   # every recorded metric, by name
+            for mname, vals in res['error_dict'][cat].items():
+                if (cat, mname) not in (('real', 'l2_projection_diff'), ('reciprocal', 'deg2_invariant_l2_diff')):
+                    small[f'traj_metric_{cat}_{mname}'] = np.asarray(vals)
         print(name, 'final error', res['final_error'], 'steps', len(res['error_dict']['main']))
         return small
     out['traj_last_real_density'] = res['last_real_density']
@@ -536,6 +542,14 @@ VARIANTS = {
     # projections.reciprocal.SO_freedom (fxs_Projections.py:493, 768-780): the best ranked even order (fxs_invariant_tools.py:1467-1486)
     # gets element [4, 2] of its unknowns made real in every step
     'so_freedom': {'projections': {'reciprocal': {'SO_freedom': {'use': True, 'radial_high_pass': 0.2}}}},
+    # the remaining metrics of fxs_IO_methods.py:690-701: reciprocal l2_projection_diff (301-310: the cache-aware branch asks for
+    # type 'reziprocal' and so integrates over the REAL grid) and deg2_ranked_invariant_l2_diff (330-366).  (The real metric
+    # support_size, 685-688, is handed the projection's output LIST and raises AttributeError upstream: nothing to pin.)
+    'extra_metrics': {'main_loop': {'error': {'methods': {
+        'reciprocal': {'calculate': ['deg2_invariant_l2_diff', 'l2_projection_diff', 'deg2_ranked_invariant_l2_diff']}}}}},
+    'extra_metrics_plain': {'general': {'cache_aware': False}, 'main_loop': {'error': {'methods': {
+        'reciprocal': {'calculate': ['l2_projection_diff', 'deg2_ranked_invariant_l2_diff'],
+                       'deg2_ranked_invariant_l2_diff': {'order': 4}}}}}},
 }
 
 

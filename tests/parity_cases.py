@@ -745,7 +745,8 @@ def variant_settings(N, L, name):
     return OM.deep_update(opt, mg.VARIANTS[name])
 
 
-VARIANT_NAMES = ('nonfxs', 'swcenter', 'main_recip_mean', 'main_recip_max', 'main_recip_min', 'main_recip_prod', 'so_freedom')
+VARIANT_NAMES = ('nonfxs', 'swcenter', 'main_recip_mean', 'main_recip_max', 'main_recip_min', 'main_recip_prod', 'so_freedom', 'extra_metrics',
+                 'extra_metrics_plain')
 
 
 def check_variant_golden(g, v, name, lib_path=None, use_oracle=False, n_restarts=2):
@@ -776,6 +777,9 @@ def check_variant_golden(g, v, name, lib_path=None, use_oracle=False, n_restarts
         assert (r['last_support_mask'] != v[name + '/traj_last_support_mask']).sum() == 0
         assert np.isclose(r['final_error'], float(v[name + '/traj_final_error']), rtol=tol_e)
         assert int(r['loop_iterations']) == int(v[name + '/traj_loop_iterations'])
+        for key in [k for k in v.files if k.startswith(name + '/traj_metric_')]:                 # every other metric the reference recorded
+            cat, mname = key.split('traj_metric_')[1].split('_', 1)
+            assert np.allclose(r['error_dict'][cat][mname], v[key], rtol=10 * tol_e), key
 
 
 # ---- alignment + averaging of reconstructions ----------------------------------------------------

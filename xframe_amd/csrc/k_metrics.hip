@@ -108,7 +108,66 @@ __global__ void __launch_bounds__(256) k_metric_fqc(const double2* __restrict__ 
     }
 }
 
+// reciprocal l2_projection_diff (fxs_IO_methods.py:301-310 -> 131-205 / 96-127): E = int |F - F'|^2 / int |F|^2 over the grid, F the
+// amplitude before and F' after the modulus projection.  The cache-aware branch asks for the type 'reziprocal' (303) and so takes the
+// REAL grid's integrator, the plain branch the reciprocal grid's: the two radial grids are proportional, the ratio is the same; the
+// mask is `True` in both, i.e. shell N - 2 drops out (`square[~True] = 0`) -- the weights the host hands over carry both facts.
+// One workgroup per (shell, restart): polar-weighted sums of the shell; a second launch folds the shells with the radial weights.
+__global__ void __launch_bounds__(256) k_metric_rl2_shell(const double2* __restrict__ F, const double2* __restrict__ Fp, const int* __restrict__ slot,
+                                                          const double* __restrict__ wt, double* __restrict__ part, int B, int N, int nt, int np) {
+    const int q = blockIdx.x, b = blockIdx.y;
+    const size_t G = (size_t)N * nt * np, sh = (size_t)q * nt * np;
+    const double2* f = F + (size_t)b * G + sh;
+    const double2* fp = Fp + ((size_t)slot[b * SL_N + SL_OUT] * B + b) * G + sh;
+    double sd = 0.0, sv = 0.0;
+    for (int i = threadIdx.x; i < nt * np; i += 256) {
+        const double w = wt[i / np];
+        const double2 a = f[i], p = fp[i];
+        const double dx = a.x - p.x, dy = a.y - p.y;
+        sd += w * (dx * dx + dy * dy);
+        sv += w * (a.x * a.x + a.y * a.y);
+    }
+    __shared__ double r0[256], r1[256];
+    r0[threadIdx.x] = sd;
+    r1[threadIdx.x] = sv;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            r0[threadIdx.x] += r0[threadIdx.x + s];
+            r1[threadIdx.x] += r1[threadIdx.x + s];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        part[((size_t)b * N + q) * 2] = r0[0];
+        part[((size_t)b * N + q) * 2 + 1] = r1[0];
+    }
+}
+
+__global__ void k_metric_rl2_finish(const double* __restrict__ part, const double* __restrict__ wr, double* __restrict__ out, int B, int N) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    double d = 0.0, v = 0.0;
+    for (int q = 0; q < N; ++q) {
+        d += wr[q] * part[((size_t)b * N + q) * 2];
+        v += wr[q] * part[((size_t)b * N + q) * 2 + 1];
+    }
+    out[b] = v != 0.0 ? d / v : INFINITY;
+}
+
+int launch_reciprocal_l2_metric(mtip_ctx* c, const double2* F, const double2* Fp, long long step) {
+    if (!c->d_rl2_hist) return MTIP_OK;
+    hipLaunchKernelGGL(k_metric_rl2_shell, dim3((unsigned)c->N, (unsigned)c->B), dim3(256), 0, c->stream, F, Fp, (const int*)c->d_slot,
+                       (const double*)c->d_rl2_wt, c->d_rl2_part, c->B, c->N, c->nt, c->np);
+    hipLaunchKernelGGL(k_metric_rl2_finish, dim3((unsigned)((c->B + 63) / 64)), dim3(64), 0, c->stream, (const double*)c->d_rl2_part,
+                       (const double*)c->d_rl2_wr, c->d_rl2_hist + (size_t)step * c->B, c->B, c->N);
+    return MTIP_OK;
+}
+
 void free_invariant_metrics(mtip_ctx* c) {
+    for (void* p : {(void*)c->d_rl2_wr, (void*)c->d_rl2_wt, (void*)c->d_rl2_part, (void*)c->d_rl2_hist})
+        if (p) (void)hipFree(p);
+    c->d_rl2_wr = nullptr; c->d_rl2_wt = nullptr; c->d_rl2_part = nullptr; c->d_rl2_hist = nullptr;
     for (void* p : {(void*)c->d_im_zmask, (void*)c->d_im_IIref, (void*)c->d_im_qq, (void*)c->d_im_ccdT, (void*)c->d_im_ccdref, (void*)c->d_im_P,
                     (void*)c->d_im_refavg, (void*)c->d_im_refw, (void*)c->d_im_hist})
         if (p) (void)hipFree(p);
@@ -206,6 +265,37 @@ int mtip_fetch_invariant_metrics(mtip_ctx* c, int64_t first, int64_t n, double* 
         if (ccd) std::copy(r + c->B, r + 2 * c->B, ccd + (size_t)s * c->B);
         if (fqc) std::copy(r + 2 * c->B, r + rowlen, fqc + (size_t)s * c->B * c->N);
     }
+    return MTIP_OK;
+}
+
+/* the reciprocal metric l2_projection_diff per FXS step: radial_w (Nq), theta_w (n_theta) of the integrator (shell N - 2 zeroed by the
+   caller, see k_metric_rl2_shell); NULL weights switch it off */
+int mtip_set_reciprocal_l2_metric(mtip_ctx* c, const double* radial_w, const double* theta_w) {
+    if (!c) return MTIP_EINVAL;
+    (void)hipSetDevice(c->device);
+    for (void* p : {(void*)c->d_rl2_wr, (void*)c->d_rl2_wt, (void*)c->d_rl2_part, (void*)c->d_rl2_hist})
+        if (p) (void)hipFree(p);
+    c->d_rl2_wr = nullptr; c->d_rl2_wt = nullptr; c->d_rl2_part = nullptr; c->d_rl2_hist = nullptr;
+    if (!radial_w || !theta_w) return MTIP_OK;
+    MTIP_HIP_CHECK(c, hipMalloc((void**)&c->d_rl2_wr, c->N * sizeof(double)));
+    MTIP_HIP_CHECK(c, hipMalloc((void**)&c->d_rl2_wt, c->nt * sizeof(double)));
+    MTIP_HIP_CHECK(c, hipMalloc((void**)&c->d_rl2_part, (size_t)c->B * c->N * 2 * sizeof(double)));
+    MTIP_HIP_CHECK(c, mtip_copy(c, c->d_rl2_wr, radial_w, c->N * sizeof(double), hipMemcpyHostToDevice));
+    MTIP_HIP_CHECK(c, mtip_copy(c, c->d_rl2_wt, theta_w, c->nt * sizeof(double), hipMemcpyHostToDevice));
+    MTIP_HIP_CHECK(c, hipMalloc((void**)&c->d_rl2_hist, (size_t)c->err_cap * c->B * sizeof(double)));
+    MTIP_HIP_CHECK(c, hipMemsetAsync(c->d_rl2_hist, 0, (size_t)c->err_cap * c->B * sizeof(double), c->stream));
+    return MTIP_OK;
+}
+
+/* steps [first, first + n): out (n, B) */
+int mtip_fetch_reciprocal_l2_metric(mtip_ctx* c, int64_t first, int64_t n, double* out) {
+    if (!c) return MTIP_EINVAL;
+    if (!c->d_rl2_hist || !out || first < 0 || n < 0 || first + n > c->n_steps_done) {
+        c->err = "fetch_reciprocal_l2_metric: metric not enabled or steps out of range";
+        return MTIP_EINVAL;
+    }
+    (void)hipSetDevice(c->device);
+    if (n) MTIP_HIP_CHECK(c, mtip_copy(c, out, c->d_rl2_hist + (size_t)first * c->B, (size_t)n * c->B * sizeof(double), hipMemcpyDeviceToHost));
     return MTIP_OK;
 }
 

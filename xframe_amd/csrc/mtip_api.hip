@@ -497,6 +497,15 @@ static int ensure_hist(mtip_ctx* c, long long need) {
     (void)hipFree(c->d_deg2_hist);
     c->d_err_hist = nh;
     c->d_deg2_hist = nd;
+    if (c->d_rl2_hist) {
+        double* ni = nullptr;
+        r = dev_alloc(c, &ni, (size_t)cap * c->B);
+        if (r) return r;
+        MTIP_HIP_CHECK(c, hipMemcpyAsync(ni, c->d_rl2_hist, (size_t)c->n_steps_done * c->B * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        MTIP_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+        (void)hipFree(c->d_rl2_hist);
+        c->d_rl2_hist = ni;
+    }
     if (c->d_im_hist) {
         double* ni = nullptr;
         const size_t rowlen = (size_t)c->B * (2 + c->N);
@@ -535,6 +544,7 @@ static int enqueue_step(mtip_ctx* c, int method, int ft_stab, double beta) {
         mod.F = c->d_F;
         mod.out_slot = SL_OUT;
         launch_sht_inverse(c, cc[2], c->d_Fp, mod);
+        launch_reciprocal_l2_metric(c, c->d_F, c->d_Fp, c->n_steps_done);     // (non-default metric; no launch unless enabled)
     } else {
         launch_modulus_fixed_slots(c, c->d_F);
     }

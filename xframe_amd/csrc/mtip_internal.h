@@ -153,6 +153,7 @@ struct mtip_ctx {
     uint32_t im_which = 0;
     uint8_t* d_im_zmask = nullptr;
     double2 *d_im_IIref = nullptr, *d_im_ccdref = nullptr;
+    double *d_rl2_wr = nullptr, *d_rl2_wt = nullptr, *d_rl2_part = nullptr, *d_rl2_hist = nullptr;   // reciprocal l2_projection_diff (k_metrics.hip)
     double *d_im_qq = nullptr, *d_im_ccdT = nullptr, *d_im_P = nullptr, *d_im_refavg = nullptr, *d_im_refw = nullptr, *d_im_hist = nullptr;
     double im_ccd_inv_norm = 0.0;
     int so_order = -1;                                // SO_freedom: order whose unknown [4][2] is made real after every projection (-1: off)
@@ -273,6 +274,7 @@ int jacobi_groups(int k);                            // pair-groups a round of t
 int build_hankel_tiles(mtip_ctx* c);
 int launch_invariant_metrics(mtip_ctx* c, const double2* Ilm, long long step);
 void free_invariant_metrics(mtip_ctx* c);
+int launch_reciprocal_l2_metric(mtip_ctx* c, const double2* F, const double2* Fp, long long step);
 void launch_deg2(mtip_ctx* c, const double2* Ilm, double2* Bl);
 void launch_coeff_diff(mtip_ctx* c, const double2* a, const double2* b, double2* out);
 // reciprocal projection

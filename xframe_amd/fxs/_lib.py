@@ -45,6 +45,8 @@ _SIGNATURES = {
     'mtip_set_so_freedom': (C.c_int, [c_void, C.c_int]),
     'mtip_set_invariant_metrics': (C.c_int, [c_void, C.c_uint32, c_void, c_void, c_void, c_void, c_void, C.c_double, c_void, c_void, c_void]),
     'mtip_fetch_invariant_metrics': (C.c_int, [c_void, C.c_int64, C.c_int64, c_void, c_void, c_void]),
+    'mtip_set_reciprocal_l2_metric': (C.c_int, [c_void, c_void, c_void]),
+    'mtip_fetch_reciprocal_l2_metric': (C.c_int, [c_void, C.c_int64, C.c_int64, c_void]),
     'mtip_op_invariant_metrics': (C.c_int, [c_void, c_void, c_void, c_void, c_void]),
     'mtip_set_deg2_metric': (C.c_int, [c_void, C.c_int]),
     'mtip_set_main_error': (C.c_int, [c_void, C.c_int, C.c_int]),

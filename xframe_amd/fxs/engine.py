@@ -100,13 +100,35 @@ class Engine:
                                             gen.get('L2_cache', 512))
         self._ck(self.lib.mtip_set_error_weights(self.ctx, _lib.ptr(_lib.as_f64(wr)), _lib.ptr(_lib.as_f64(wt)), int(use_mask)))
         # metrics that are not on the accelerated path must not be dropped silently (fxs_IO_methods.py:690-703 lists them)
-        for cat, known in (('real', ('l2_projection_diff',)), ('reciprocal', ('deg2_invariant_l2_diff', 'II_error', 'ccd_diff', 'fqc_error'))):
+        for cat, known in (('real', ('l2_projection_diff',)), ('reciprocal', ('deg2_invariant_l2_diff', 'II_error', 'ccd_diff', 'fqc_error', 'l2_projection_diff',
+                                                                                      'deg2_ranked_invariant_l2_diff'))):
             for name in em.get(cat, {}).get('calculate', []) or []:
                 if name not in known:
+                    if (cat, name) == ('real', 'support_size'):
+                        raise NotImplementedError("real metric 'support_size' raises upstream as well (fxs_IO_methods.py:687 is handed the "
+                                                  "projection's output list: AttributeError on .real)")
                     raise NotImplementedError('main_loop.error.methods.%s.calculate: %r is not built (DESIGN section 6); built: %s'
                                               % (cat, name, ', '.join(known)))
-        self.deg2_enabled = 'deg2_invariant_l2_diff' in em['reciprocal']['calculate']
+        rec_calc = list(em['reciprocal']['calculate'])
+        # deg2_ranked_invariant_l2_diff (fxs_IO_methods.py:330-366): the entry of deg2_invariant_l2_diff of the best ranked even order
+        # (fxs_invariant_tools.py:1467-1486) or of the order the option names -- a column of the same per-step history
+        self.deg2_ranked_id = None
+        if 'deg2_ranked_invariant_l2_diff' in rec_calc:
+            order = em['reciprocal'].get('deg2_ranked_invariant_l2_diff', {}).get('order', False)
+            if isinstance(order, (int, np.integer)) and not isinstance(order, (bool, np.bool_)):
+                self.deg2_ranked_id = int(self.rsetup.used_orders[int(order)])
+            else:
+                orders = np.array(list(self.rsetup.used_orders.keys())).astype(int)
+                self.deg2_ranked_id = int(hs.rank_projection_matrices_3d(self.rsetup.projection_matrices, orders, self.qs)[0])
+        self.deg2_listed = 'deg2_invariant_l2_diff' in rec_calc
+        self.deg2_enabled = self.deg2_listed or self.deg2_ranked_id is not None
         self._ck(self.lib.mtip_set_deg2_metric(self.ctx, int(self.deg2_enabled)))
+        # reciprocal l2_projection_diff (fxs_IO_methods.py:301-310): the real metric's integrator without a support mask, i.e. with shell
+        # N - 2 zeroed (the cache-aware branch integrates over the real grid, the plain one over the proportional reciprocal grid)
+        self.reciprocal_l2 = 'l2_projection_diff' in rec_calc
+        if self.reciprocal_l2:
+            wr2, wt2, _ = hs.error_weights(self.rs, self.n_theta, self.shape, False)
+            self._ck(self.lib.mtip_set_reciprocal_l2_metric(self.ctx, _lib.ptr(_lib.as_f64(wr2)), _lib.ptr(_lib.as_f64(wt2))))
         # II_error / ccd_diff / fqc_error (fxs_IO_methods.py:587-627, 651-683, 507-550): per step on the device from B_l
         self.invariant_metrics = [n for n in ('II_error', 'ccd_diff', 'fqc_error') if n in em['reciprocal']['calculate']]
         if self.invariant_metrics:
@@ -136,7 +158,7 @@ class Engine:
         if real_m == ['l2_projection_diff'] and not rec_m:
             self.main_is_reciprocal = False
         elif not real_m and rec_m == ['deg2_invariant_l2_diff']:
-            if not self.deg2_enabled:
+            if not self.deg2_listed:
                 raise KeyError("main error uses 'deg2_invariant_l2_diff' but main_loop.error.methods.reciprocal.calculate does not list it")
             self.main_is_reciprocal = True
         elif real_m == ['l2_projection_diff'] and rec_m == ['deg2_invariant_l2_diff']:
@@ -457,6 +479,14 @@ class Engine:
         deg2 = np.empty((n, self.B, self.L + 1)) if self.deg2_enabled else None
         self._ck(self.lib.mtip_fetch_errors(self.ctx, first, n, _lib.ptr(err), _lib.ptr(deg2)))
         return err, deg2
+
+    def fetch_reciprocal_l2(self, first, n):
+        """reciprocal l2_projection_diff of the steps [first, first + n): (n, B), or None when the metric is off"""
+        if not self.reciprocal_l2:
+            return None
+        out = np.empty((n, self.B))
+        self._ck(self.lib.mtip_fetch_reciprocal_l2_metric(self.ctx, first, n, _lib.ptr(out)))
+        return out
 
     def fetch_invariant_metrics(self, first, n):
         """{'II_error': (n, B), 'ccd_diff': (n, B), 'fqc_error': (n, B, Nq)} for the enabled ones"""

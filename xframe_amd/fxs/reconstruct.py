@@ -282,6 +282,7 @@ class MTIP:
     def _generate_output(self, iterations, initial_density, initial_mask, n_steps):
         e = self.engine
         real_err, deg2 = e.fetch_errors(0, n_steps)
+        rec_l2 = e.fetch_reciprocal_l2(0, n_steps)
         inv_metrics = e.fetch_invariant_metrics(0, n_steps)         # II_error / ccd_diff / fqc_error, when enabled
         main_err = e.fetch_main_errors(0, n_steps)
         best_err, _ = e.best_error()
@@ -316,7 +317,14 @@ class MTIP:
         for b in range(self.n_restarts):
             err = {'main': main_err[:, b].copy(),
                    'real': {'l2_projection_diff': real_err[:, b].copy()},
-                   'reciprocal': ({'deg2_invariant_l2_diff': deg2[:, b][:, order_array].copy()} if deg2 is not None else {})}
+                   'reciprocal': {}}
+            for name in self.opt['main_loop']['error']['methods']['reciprocal']['calculate']:      # in the order they are listed, as upstream
+                if name == 'deg2_invariant_l2_diff':
+                    err['reciprocal'][name] = deg2[:, b][:, order_array].copy()
+                elif name == 'deg2_ranked_invariant_l2_diff':
+                    err['reciprocal'][name] = deg2[:, b][:, order_array][:, e.deg2_ranked_id].copy()
+                elif name == 'l2_projection_diff':
+                    err['reciprocal'][name] = rec_l2[:, b].copy()
             for name, hist in inv_metrics.items():
                 err['reciprocal'][name] = hist[:, b].copy()
             out[b] = {
