@@ -1090,17 +1090,7 @@ def check_mtip2d_worker_vs_oracle(g, lib_path=None, N=None, M=None, n_restarts=3
     """`fxs reconstruct` with `dimensions: 2` through ProjectWorker: seeded density guesses (bump), each restart against the oracle's
     loop run from the same generator; sizes of the fixture unless N, M are given (then data interpolated from the fixture's)"""
     from oracle import mtip2d as O2
-    data, o = mtip2d_problem(g)
-    if N is not None:
-        qd = np.linspace(data['data_radial_points'][0], data['data_radial_points'][-1], N)
-        m0 = int(g['M'])
-        pm = np.zeros((M + 1, N), complex)
-        for i in range(M + 1):
-            src = data['data_projection_matrices'][min(i, m0)]
-            pm[i] = (np.interp(qd, data['data_radial_points'], src.real) + 1j * np.interp(qd, data['data_radial_points'], src.imag)) / (1 + max(i - m0, 0))
-        data = dict(data, data_radial_points=qd, data_projection_matrices=pm, max_order=M,
-                    average_intensity=np.interp(qd, data['data_radial_points'], np.asarray(data['average_intensity'], dtype=float)))
-        o = OM.deep_update(o, {'grid': {'n_radial_points': N, 'max_order': M}, 'projections': {'reciprocal': {'used_order_ids': np.arange(M + 1)}}})
+    data, o = mtip2d_scaled_problem(g, N, M)
     o = OM.deep_update(o, {'multi_process': {'use': True, 'n_parallel_reconstructions': n_restarts}, 'GPU': {'use': True, 'n_gpu_workers': 1}})
     seeds = [77 + i for i in range(n_restarts)]
     w = R.ProjectWorker(o, data, seeds=seeds, lib_path=lib_path)
@@ -1115,6 +1105,23 @@ def check_mtip2d_worker_vs_oracle(g, lib_path=None, N=None, M=None, n_restarts=3
         assert (res[b]['support_mask'] != ref['support_mask']).sum() == 0 and (res[b]['last_support_mask'] != ref['last_support_mask']).sum() == 0
     for m in w.mtip_instances:
         m.engine.close()
+
+
+def mtip2d_scaled_problem(g, N=None, M=None):
+    """the 2-D problem of fixture G20, or a larger one of the same kind: its invariants interpolated to N shells, the orders beyond the
+    fixture's repeated with falling weight"""
+    data, o = mtip2d_problem(g)
+    if N is not None:
+        qd = np.linspace(data['data_radial_points'][0], data['data_radial_points'][-1], N)
+        m0 = int(g['M'])
+        pm = np.zeros((M + 1, N), complex)
+        for i in range(M + 1):
+            src = data['data_projection_matrices'][min(i, m0)]
+            pm[i] = (np.interp(qd, data['data_radial_points'], src.real) + 1j * np.interp(qd, data['data_radial_points'], src.imag)) / (1 + max(i - m0, 0))
+        data = dict(data, data_radial_points=qd, data_projection_matrices=pm, max_order=M,
+                    average_intensity=np.interp(qd, data['data_radial_points'], np.asarray(data['average_intensity'], dtype=float)))
+        o = OM.deep_update(o, {'grid': {'n_radial_points': N, 'max_order': M}, 'projections': {'reciprocal': {'used_order_ids': np.arange(M + 1)}}})
+    return data, o
 
 
 def check_polar2d_golden_oracle(g):
