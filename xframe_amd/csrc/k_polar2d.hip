@@ -486,14 +486,13 @@ int mtip2d_set_error_weights(mtip2d_ctx* c, const double* weights) {
     if (!c || !weights) return MTIP_EINVAL;
     (void)hipSetDevice(c->device);
     const size_t G = (size_t)c->N * c->n_phi, BG = (size_t)c->B * G;
-    if (!c->d_errw) {
-        C2_CHECK(c, hipMalloc((void**)&c->d_errw, G * sizeof(double)));
-        C2_CHECK(c, hipMalloc((void**)&c->d_c, BG * sizeof(double2)));
-        C2_CHECK(c, hipMalloc((void**)&c->d_d, BG * sizeof(double2)));
-        C2_CHECK(c, hipMalloc((void**)&c->d_e, BG * sizeof(double2)));
-        C2_CHECK(c, hipMalloc((void**)&c->d_sup, BG));
-        C2_CHECK(c, hipMalloc((void**)&c->d_red, (size_t)c->B * 4 * sizeof(double)));
-    }
+    // (each buffer on its own: a call that failed half way is completed by the next one)
+    if (!c->d_errw) C2_CHECK(c, hipMalloc((void**)&c->d_errw, G * sizeof(double)));
+    if (!c->d_c) C2_CHECK(c, hipMalloc((void**)&c->d_c, BG * sizeof(double2)));
+    if (!c->d_d) C2_CHECK(c, hipMalloc((void**)&c->d_d, BG * sizeof(double2)));
+    if (!c->d_e) C2_CHECK(c, hipMalloc((void**)&c->d_e, BG * sizeof(double2)));
+    if (!c->d_sup) C2_CHECK(c, hipMalloc((void**)&c->d_sup, BG));
+    if (!c->d_red) C2_CHECK(c, hipMalloc((void**)&c->d_red, (size_t)c->B * 4 * sizeof(double)));
     C2_CHECK(c, c2_copy(c, c->d_errw, weights, G * sizeof(double)));
     c->have_errw = true;
     return MTIP_OK;
