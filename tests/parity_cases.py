@@ -1107,6 +1107,46 @@ def check_mtip2d_worker_vs_oracle(g, lib_path=None, N=None, M=None, n_restarts=3
         m.engine.close()
 
 
+SETTINGS_VARIANTS_2D = dict(
+    {k: SETTINGS_VARIANTS[k] for k in ('limit_imag', 'value_lo_hi', 'value_hi_only', 'support_only', 'no_enforce', 'hio_considers_support_only',
+                                       'pi_in_q', 'history5')},
+    n_particles={'projections': {'reciprocal': {'number_of_particles': {'initial': 7}}}},
+    odd_orders_to_0={'projections': {'reciprocal': {'odd_orders_to_0': True}}},
+    q_mask_region={'projections': {'reciprocal': {'q_mask': {'type': 'manual', 'manual': {'type': 'region', 'region': [0.02, 0.09]}}}}},
+    error_inside_support={'general': {'cache_aware': False},
+                          'main_loop': {'error': {'methods': {'real': {'l2_projection_diff': {'inside_initial_support': True}}}}}},
+    ft_stab_linked={'main_loop': {'sub_loops': {'main': {'methods': {
+        'HIO': {'iterations': 3, 'ft_stab': 'link_to_enforce_initial_support', 'link_to_enforce_initial_support': {'delay': 1}},
+        'ER': {'iterations': 2, 'ft_stab': False}}}}}},
+    er_only={'main_loop': {'sub_loops': {'main': {'order': ['ER'], 'methods': {'ER': {'iterations': 4, 'ft_stab': True}}}}}},
+    best_reselected={'main_loop': {'sub_loops': {'main': {'best_density_not_in_first_n_iterations': 0}}}})
+
+
+def check_mtip2d_settings_vs_oracle(g, lib_path, name):
+    """settings switches of the 2-D loop -- the real-space projections and HIO's considered ones, the reciprocity coefficient, history
+    length, number of particles, odd orders, q mask, the masked error metric, the ft_stab link, an ER-only loop, the end-of-loop
+    reselection of the best density -- product against oracle/mtip2d.py (itself at 0.0 from the reference's run, G20), two restarts"""
+    from oracle import mtip2d as O2
+    from xframe_amd.fxs.reconstruct2d import MTIP2D
+    data, o = mtip2d_problem(g)
+    main = o['main_loop']['sub_loops']['main']
+    main['methods']['HIO']['iterations'] = 3
+    main['methods']['ER']['iterations'] = 2
+    main['iterations'] = 2
+    o = OM.deep_update(o, SETTINGS_VARIANTS_2D[name])
+    rho0 = np.asarray(g['rho0'])
+    ref = O2.MTIP2D(o, data).phasing_loop(rho0=rho0)
+    m = MTIP2D(o, data, n_restarts=2, initial_densities=[rho0, 1.5 * rho0], lib_path=lib_path)
+    r = m.phasing_loop()[0]
+    m.close()
+    assert len(r['error_dict']['main']) == len(ref['error_dict']['main'])
+    assert np.allclose(r['error_dict']['main'], ref['error_dict']['main'], rtol=1e-8), name
+    for k in ('real_density', 'last_real_density', 'reciprocal_density', 'last_reciprocal_density', 'fxs_unknowns', 'last_deg2_invariant'):
+        assert rel_l2(r[k], ref[k]) < 1e-8, (name, k)
+    assert (r['support_mask'] != ref['support_mask']).sum() == 0 and (r['last_support_mask'] != ref['last_support_mask']).sum() == 0
+    assert np.isclose(r['final_error'], ref['final_error'], rtol=1e-8)
+
+
 def mtip2d_scaled_problem(g, N=None, M=None):
     """the 2-D problem of fixture G20, or a larger one of the same kind: its invariants interpolated to N shells, the orders beyond the
     fixture's repeated with falling weight"""

@@ -163,6 +163,11 @@ def test_mtip2d_worker_vs_oracle(emul_lib, golden_mtip2d):
     PC.check_mtip2d_worker_vs_oracle(golden_mtip2d, emul_lib)
 
 
+@pytest.mark.parametrize('name', sorted(PC.SETTINGS_VARIANTS_2D))
+def test_mtip2d_settings_vs_oracle(emul_lib, golden_mtip2d, name):
+    PC.check_mtip2d_settings_vs_oracle(golden_mtip2d, emul_lib, name)
+
+
 def test_symmetric_eig_blocked(emul_lib):
     """n > 128: column blocks over workgroups (k_sym_eig_block), 5 blocks -> an empty sixth pads the tournament"""
     PC.check_symmetric_eig(emul_lib, n=130, K=3)

@@ -198,6 +198,13 @@ def test_mtip2d_worker_vs_oracle(golden_mtip2d, N, M):
     PC.check_mtip2d_worker_vs_oracle(golden_mtip2d, None, N, M)
 
 
+@pytest.mark.parametrize('name', ['limit_imag', 'value_lo_hi', 'no_enforce', 'n_particles', 'q_mask_region', 'error_inside_support', 'ft_stab_linked',
+                                  'best_reselected'])
+def test_mtip2d_settings_vs_oracle(golden_mtip2d, name):
+    """settings switches of the 2-D loop against the oracle (pinned at 0.0 by the reference's own 2-D run, G20)"""
+    PC.check_mtip2d_settings_vs_oracle(golden_mtip2d, None, name)
+
+
 @pytest.mark.parametrize('n,K', [(100, 6), (128, 33), (130, 5), (200, 7), (256, 49), (288, 4)])
 def test_symmetric_eig(n, K):
     """the eigensolvers of `extract` against LAPACK: LDS-resident up to 128, column blocks over workgroups up to 288

@@ -108,3 +108,53 @@ def test_two_ranks_two_engines_best_only(emul_lib, tmp_path):
         else:
             assert kind == 'light' and r0['dens_norm'][i] == -1.0
     assert np.isclose(r0['bl_trace'], r1['bl_trace'], rtol=1e-12)
+
+
+WORKER_2D = r'''
+import os, sys, json
+import numpy as np
+sys.path.insert(0, {root!r}); sys.path.insert(0, {here!r})
+np.seterr(all='ignore')
+import torch.distributed as dist
+import parity_cases as PC
+from oracle import mtip as OM
+from xframe_amd.fxs import reconstruct as R
+rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+dist.init_process_group('gloo', rank=rank, world_size=world)
+g = np.load(os.path.join({here!r}, 'golden', 'mtip2d_N12_M6.npz'))
+data, o = PC.mtip2d_problem(g)
+o = OM.deep_update(o, {{'multi_process': {{'use': True, 'n_parallel_reconstructions': 3}}, 'GPU': {{'use': True, 'n_gpu_workers': 1}}}})
+w = R.ProjectWorker(o, data, seeds=[5, 6, 7], lib_path=os.path.join({emul!r}, 'libmtip_emul.so'))
+result, _ = w.run()
+out = {{'rank': rank, 'n_results': int(len(result)), 'errs': [float(r['final_error']) for r in result],
+       'kinds': [r.get('gathered', 'own') for r in result], 'shapes': [list(np.shape(r.get('real_density', []))) for r in result]}}
+print('RESULT ' + json.dumps(out), flush=True)
+dist.destroy_process_group()
+'''
+
+
+def test_two_rank_gloo_worker_2d(emul_lib, tmp_path):
+    """`dimensions: 2` through the same sharding and gather: three restarts over two ranks, rank 0 ends with all of them, equal to a
+    single-process run of the same seeds"""
+    import json
+    import parity_cases as PC
+    from oracle import mtip as OM
+    from xframe_amd.fxs import reconstruct as R
+    script = tmp_path / 'worker2d.py'
+    script.write_text(WORKER_2D.format(root=ROOT, here=HERE, emul=EMUL_DIR))
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29577', WORLD_SIZE='2', MTIP_EMUL_THREADS='2')
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for r in range(2)]
+    outs = []
+    for p in procs:
+        o, e = p.communicate(timeout=600)
+        assert p.returncode == 0, e[-3000:]
+        outs.append(json.loads([l for l in o.splitlines() if l.startswith('RESULT ')][0][7:]))
+    r0 = [o for o in outs if o['rank'] == 0][0]
+    assert r0['n_results'] == 3 and r0['kinds'] == ['own', 'full', 'own'] and r0['shapes'] == [[12, 13]] * 3
+    g = np.load(os.path.join(HERE, 'golden', 'mtip2d_N12_M6.npz'))
+    data, o = PC.mtip2d_problem(g)
+    o = OM.deep_update(o, {'multi_process': {'use': True, 'n_parallel_reconstructions': 3}, 'GPU': {'use': True, 'n_gpu_workers': 1}})
+    w = R.ProjectWorker(o, data, seeds=[5, 6, 7], rank=0, world_size=1, lib_path=os.path.join(EMUL_DIR, 'libmtip_emul.so'))
+    single, _ = w.run()
+    assert np.allclose(r0['errs'], [float(r['final_error']) for r in single], rtol=1e-12)
