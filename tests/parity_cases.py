@@ -749,7 +749,7 @@ VARIANT_NAMES = ('nonfxs', 'swcenter', 'main_recip_mean', 'main_recip_max', 'mai
                  'extra_metrics_plain')
 
 
-def check_variant_golden(g, v, name, lib_path=None, use_oracle=False, n_restarts=2):
+def check_variant_golden(g, v, name, lib_path=None, use_oracle=False, n_restarts=2, fused=True):
     """`name` in VARIANT_NAMES: the *_non_FXS / SW_center schedules (incl. the reference's stale `hist` and swapped
     SW_center outputs, reconstruct.py:859-913, 606-613) and the main error over the reciprocal deg2 metric
     (fxs_IO_methods.py:746-765), against trajectories recorded from the reference's own loop."""
@@ -761,7 +761,7 @@ def check_variant_golden(g, v, name, lib_path=None, use_oracle=False, n_restarts
         tol_e, tol_d = 1e-12, 1e-12
     else:
         R.MTIP.preinit(opt, data)
-        m = R.MTIP(n_restarts=n_restarts, initial_densities=[g['rho0']] * n_restarts, lib_path=lib_path)
+        m = R.MTIP(n_restarts=n_restarts, initial_densities=[g['rho0']] * n_restarts, lib_path=lib_path, fused=fused)
         m.generate_phasing_loop()
         res = m.phasing_loop()
         m.engine.close()

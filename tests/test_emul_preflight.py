@@ -109,6 +109,12 @@ def test_loop_variants_golden(emul_lib, golden_mtip16, golden_variants, name):
     PC.check_variant_golden(golden_mtip16, golden_variants, name, emul_lib, n_restarts=1)
 
 
+@pytest.mark.parametrize('name', ['extra_metrics', 'so_freedom', 'swcenter'])
+def test_loop_variants_golden_unfused(emul_lib, golden_mtip16, golden_variants, name):
+    """the same trajectories of the reference with the step assembled from the separate operators (fused = False)"""
+    PC.check_variant_golden(golden_mtip16, golden_variants, name, emul_lib, n_restarts=1, fused=False)
+
+
 def test_average_vs_oracle(emul_lib):
     """alignment + averaging of reconstructions (average.py run_3d): device SO(3) correlation / coefficient rotation / transforms
     against the oracle restatement"""
