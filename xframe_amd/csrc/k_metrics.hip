@@ -34,15 +34,18 @@ __device__ __forceinline__ double2 block_sum2(double2 v, double2* red) {
     return s;
 }
 
-// II_error = 1 - sum(cur ref qq) / sqrt(sum(cur^2 qq) sum(ref^2 qq)), cur = sum_{l >= 1} masked B_l (complex, not conjugated: 624)
+#define IM_BLOCKS 64            // workgroups per restart of the II / ccd sums (partials folded by k_metric_fold)
+
+// II_error = 1 - sum(cur ref qq) / sqrt(sum(cur^2 qq) sum(ref^2 qq)), cur = sum_{l >= 1} masked B_l (complex, not conjugated: 624).
+// Workgroup (chunk, restart): partial sums of its (q, q') elements -> part[(b * IM_BLOCKS + chunk) * 4 + 0..2]
 __global__ void __launch_bounds__(256) k_metric_II(const double2* __restrict__ Bl, const uint8_t* __restrict__ zmask,
-                                                   const double2* __restrict__ ref, const double* __restrict__ qq, double* __restrict__ out,
+                                                   const double2* __restrict__ ref, const double* __restrict__ qq, double2* __restrict__ part,
                                                    int N, int L) {
     __shared__ double2 red[4];
-    const int b = blockIdx.x;
+    const int b = blockIdx.y;
     const size_t NN = (size_t)N * N;
     double2 sa = make_double2(0.0, 0.0), sb = sa, sc = sa;
-    for (size_t e = threadIdx.x; e < NN; e += blockDim.x) {
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < NN; e += (size_t)gridDim.x * blockDim.x) {
         double2 cur = make_double2(0.0, 0.0);
         for (int l = 1; l <= L; ++l)
             if (!zmask[(size_t)l * NN + e]) cur = cadd(cur, Bl[((size_t)b * (L + 1) + l) * NN + e]);
@@ -55,57 +58,124 @@ __global__ void __launch_bounds__(256) k_metric_II(const double2* __restrict__ B
     sa = block_sum2(sa, red);
     sb = block_sum2(sb, red);
     sc = block_sum2(sc, red);
-    if (threadIdx.x == 0) out[b] = 1.0 - c_div(sa, c_sqrt(cmul(sb, sc))).x;
+    if (threadIdx.x == 0) {
+        double2* o = part + ((size_t)b * gridDim.x + blockIdx.x) * 4;
+        o[0] = sa; o[1] = sb; o[2] = sc;
+    }
 }
 
-// ccd_diff = sum |sum_l masked B_l T_l - ref|^2 / norm  (T_l = 0 for order 0 and the orders below C_order)
+// ccd_diff = sum |sum_l masked B_l T_l - ref|^2 / norm  (T_l = 0 for order 0 and the orders below C_order): partial sums -> part[.. * 4 + 3]
 __global__ void __launch_bounds__(256) k_metric_ccd(const double2* __restrict__ Bl, const uint8_t* __restrict__ zmask,
-                                                    const double* __restrict__ T, const double2* __restrict__ ref, double inv_norm,
-                                                    double* __restrict__ out, int N, int L) {
+                                                    const double* __restrict__ T, const double2* __restrict__ ref, double2* __restrict__ part,
+                                                    int N, int L) {
     __shared__ double2 red[4];
-    const int b = blockIdx.x;
+    const int b = blockIdx.y;
     const size_t NN = (size_t)N * N;
     double2 acc = make_double2(0.0, 0.0);
-    for (size_t e = threadIdx.x; e < NN; e += blockDim.x) {
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < NN; e += (size_t)gridDim.x * blockDim.x) {
         double2 d = make_double2(-ref[e].x, -ref[e].y);
         for (int l = 0; l <= L; ++l)
             if (!zmask[(size_t)l * NN + e]) d = cadd(d, cscale(Bl[((size_t)b * (L + 1) + l) * NN + e], T[(size_t)l * NN + e]));
         acc.x += d.x * d.x + d.y * d.y;
     }
     acc = block_sum2(acc, red);
-    if (threadIdx.x == 0) out[b] = acc.x * inv_norm;
+    if (threadIdx.x == 0) part[((size_t)b * gridDim.x + blockIdx.x) * 4 + 3] = acc;
 }
 
-// fqc_error[q] = 1 - mean_{q' <= q} fqc[q, q'];  workgroup = (shell q, restart), threads over q'
+// the partials of a restart in a fixed order -> II_error (which & 1) and ccd_diff (which & 2); one thread per restart
+__global__ void k_metric_fold(const double2* __restrict__ part, int nblk, int which, double ccd_inv_norm, double* __restrict__ out_II,
+                              double* __restrict__ out_ccd, int B) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    double2 sa = make_double2(0.0, 0.0), sb = sa, sc = sa;
+    double acc = 0.0;
+    for (int k = 0; k < nblk; ++k) {
+        const double2* o = part + ((size_t)b * nblk + k) * 4;
+        if (which & 1) { sa = cadd(sa, o[0]); sb = cadd(sb, o[1]); sc = cadd(sc, o[2]); }
+        if (which & 2) acc += o[3].x;
+    }
+    if (which & 1) out_II[b] = 1.0 - c_div(sa, c_sqrt(cmul(sb, sc))).x;
+    if (which & 2) out_ccd[b] = acc * ccd_inv_norm;
+}
+
+// fqc_error[q] = 1 - mean_{q' <= q} fqc[q, q'];  workgroup = shell q, for up to FQC_B restarts at a time (the table P -- 143 MB at
+// 128 x L32 -- is read once per chunk of restarts, not once per restart).  A wave half (32 lanes) per q': the lanes run over the index j of
+// P[l][q][q'][j] (contiguous: coalesced runs of 8 (L + 1) bytes), two j per lane and pass (j, j + 32: L + 1 = 33 columns are one pass),
+// B_l(q, q') is a broadcast load, masked orders enter with weight 0 (independent loads in the l loop), the j-sum is a 32-lane butterfly.
+#define FQC_B 4
+#define FQC_QP 16               // q' per workgroup: grid (Nq, ceil(Nq / FQC_QP)); fq (B, Nq, Nq) in global memory, folded by k_metric_fqc_fold
 __global__ void __launch_bounds__(256) k_metric_fqc(const double2* __restrict__ Bl, const uint8_t* __restrict__ zmask,
                                                     const double* __restrict__ P, const double* __restrict__ ref_avg,
-                                                    const double* __restrict__ ref_w, double* __restrict__ out, int N, int L) {
-    HIP_DYNAMIC_SHARED(double, fq)                   // N
-    const int q = blockIdx.x, b = blockIdx.y;
+                                                    const double* __restrict__ ref_w, double* __restrict__ fq, int N, int L, int B) {
+    const int q = blockIdx.x;
     const size_t NN = (size_t)N * N;
     const int M1 = L + 1;
-    for (int qp = threadIdx.x; qp < N; qp += blockDim.x) {
-        const size_t e = (size_t)q * N + qp;
-        double avg = 0.0;
-        double2 ctrl = make_double2(0.0, 0.0);
-        for (int j = 0; j < M1; ++j) {
-            double2 cj = make_double2(0.0, 0.0);
-            for (int l = 1; l <= L; ++l)
-                if (!zmask[(size_t)l * NN + e]) cj = cadd(cj, cscale(Bl[((size_t)b * M1 + l) * NN + e], P[((size_t)l * NN + e) * M1 + j]));
-            avg += j == 0 ? (cj.x * cj.x - cj.y * cj.y) : 2.0 * (cj.x * cj.x + cj.y * cj.y);       // Re(c_0 c_0) + 2 sum |c_j|^2 (521-522)
+    const int jl = threadIdx.x & 31, sub = threadIdx.x >> 5;
+    for (int b0 = 0; b0 < B; b0 += FQC_B) {
+        const int nb = min(FQC_B, B - b0);
+        for (int qp0 = blockIdx.y * FQC_QP; qp0 < min((int)(blockIdx.y + 1) * FQC_QP, N); qp0 += 8) {
+            const int qp = qp0 + sub;
+            const bool live = qp < N;
+            const size_t e = (size_t)q * N + (live ? qp : 0);
+            double avg[FQC_B];
+            double2 ctrl[FQC_B];
+#pragma unroll
+            for (int bb = 0; bb < FQC_B; ++bb) {
+                avg[bb] = 0.0;
+                ctrl[bb] = make_double2(0.0, 0.0);
+            }
+            for (int j0 = 0; j0 < M1; j0 += 64) {
+                const int ja = j0 + jl, jb = ja + 32;
+                const bool va = ja < M1, vb = jb < M1;
+                double2 ca[FQC_B], cb[FQC_B];
+#pragma unroll
+                for (int bb = 0; bb < FQC_B; ++bb) ca[bb] = cb[bb] = make_double2(0.0, 0.0);
+#pragma unroll 2
+                for (int l = 1; l <= L; ++l) {
+                    const double m = zmask[(size_t)l * NN + e] ? 0.0 : 1.0;
+                    const double* pr = P + ((size_t)l * NN + e) * M1;
+                    const double pa = va ? m * pr[ja] : 0.0, pb = vb ? m * pr[jb] : 0.0;
+                    const double rw = m * ref_w[(size_t)l * NN + e];
+#pragma unroll
+                    for (int bb = 0; bb < FQC_B; ++bb) {
+                        if (bb < nb) {
+                            const double2 bv = Bl[((size_t)(b0 + bb) * M1 + l) * NN + e];
+                            ca[bb] = cadd(ca[bb], cscale(bv, pa));
+                            cb[bb] = cadd(cb[bb], cscale(bv, pb));
+                            if (j0 == 0) ctrl[bb] = cadd(ctrl[bb], cscale(bv, rw));
+                        }
+                    }
+                }
+#pragma unroll
+                for (int bb = 0; bb < FQC_B; ++bb) {
+                    // Re(c_0 c_0) + 2 sum |c_j|^2 (521-522)
+                    if (va) avg[bb] += ja == 0 ? (ca[bb].x * ca[bb].x - ca[bb].y * ca[bb].y) : 2.0 * (ca[bb].x * ca[bb].x + ca[bb].y * ca[bb].y);
+                    if (vb) avg[bb] += 2.0 * (cb[bb].x * cb[bb].x + cb[bb].y * cb[bb].y);
+                }
+            }
+#pragma unroll
+            for (int bb = 0; bb < FQC_B; ++bb) {
+                double a = avg[bb];
+                for (int o = 16; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+                if (live && jl == 0 && bb < nb) {
+                    const double prod = a * ref_avg[e];
+                    // norm = sqrt(prod); `norm >= 0` is false for NaN (negative prod): fqc = 1 there (536-543); a zero norm divides as numpy does
+                    fq[(size_t)(b0 + bb) * NN + e] = prod >= 0.0 ? ctrl[bb].x / sqrt(prod) : 1.0;
+                }
+            }
         }
-        for (int l = 1; l <= L; ++l)
-            if (!zmask[(size_t)l * NN + e]) ctrl = cadd(ctrl, cscale(Bl[((size_t)b * M1 + l) * NN + e], ref_w[(size_t)l * NN + e]));
-        const double prod = avg * ref_avg[e];
-        // norm = sqrt(prod); `norm >= 0` is false for NaN (negative prod): fqc = 1 there (536-543); a zero norm divides as numpy does
-        fq[qp] = prod >= 0.0 ? ctrl.x / sqrt(prod) : 1.0;
     }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double s = 0.0;
-        for (int qp = 0; qp <= q; ++qp) s += fq[qp];
-        out[(size_t)b * N + q] = 1.0 - s / (double)(q + 1);
-    }
+}
+
+// out[b][q] = 1 - mean_{q' <= q} fq[b][q][q'] (in the order of q', as the reference's cumulative mean)
+__global__ void k_metric_fqc_fold(const double* __restrict__ fq, double* __restrict__ out, int N, int B) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * N) return;
+    const int q = i % N;
+    const double* row = fq + (size_t)i * N;
+    double s = 0.0;
+    for (int qp = 0; qp <= q; ++qp) s += row[qp];
+    out[i] = 1.0 - s / (double)(q + 1);
 }
 
 // reciprocal l2_projection_diff (fxs_IO_methods.py:301-310 -> 131-205 / 96-127): E = int |F - F'|^2 / int |F|^2 over the grid, F the
@@ -168,6 +238,10 @@ void free_invariant_metrics(mtip_ctx* c) {
     for (void* p : {(void*)c->d_rl2_wr, (void*)c->d_rl2_wt, (void*)c->d_rl2_part, (void*)c->d_rl2_hist})
         if (p) (void)hipFree(p);
     c->d_rl2_wr = nullptr; c->d_rl2_wt = nullptr; c->d_rl2_part = nullptr; c->d_rl2_hist = nullptr;
+    if (c->d_im_part) (void)hipFree(c->d_im_part);
+    if (c->d_im_fq) (void)hipFree(c->d_im_fq);
+    c->d_im_part = nullptr;
+    c->d_im_fq = nullptr;
     for (void* p : {(void*)c->d_im_zmask, (void*)c->d_im_IIref, (void*)c->d_im_qq, (void*)c->d_im_ccdT, (void*)c->d_im_ccdref, (void*)c->d_im_P,
                     (void*)c->d_im_refavg, (void*)c->d_im_refw, (void*)c->d_im_hist})
         if (p) (void)hipFree(p);
@@ -192,16 +266,31 @@ static int launch_invariant_metrics_row(mtip_ctx* c, const double2* Ilm, double*
         return MTIP_ENOMEM;
     }
     launch_deg2(c, Ilm, c->d_Bl);
+    if ((c->im_which & 3) && !c->d_im_part && hipMalloc((void**)&c->d_im_part, (size_t)c->B * IM_BLOCKS * 4 * sizeof(double2)) != hipSuccess) {
+        c->err = "invariant metrics: out of device memory for the partial sums";
+        return MTIP_ENOMEM;
+    }
     if (c->im_which & 1)
-        hipLaunchKernelGGL(k_metric_II, dim3((unsigned)c->B), dim3(256), 0, c->stream, (const double2*)c->d_Bl, (const uint8_t*)c->d_im_zmask,
-                           (const double2*)c->d_im_IIref, (const double*)c->d_im_qq, row, c->N, c->L);
+        hipLaunchKernelGGL(k_metric_II, dim3(IM_BLOCKS, (unsigned)c->B), dim3(256), 0, c->stream, (const double2*)c->d_Bl,
+                           (const uint8_t*)c->d_im_zmask, (const double2*)c->d_im_IIref, (const double*)c->d_im_qq, c->d_im_part, c->N, c->L);
     if (c->im_which & 2)
-        hipLaunchKernelGGL(k_metric_ccd, dim3((unsigned)c->B), dim3(256), 0, c->stream, (const double2*)c->d_Bl, (const uint8_t*)c->d_im_zmask,
-                           (const double*)c->d_im_ccdT, (const double2*)c->d_im_ccdref, c->im_ccd_inv_norm, row + c->B, c->N, c->L);
+        hipLaunchKernelGGL(k_metric_ccd, dim3(IM_BLOCKS, (unsigned)c->B), dim3(256), 0, c->stream, (const double2*)c->d_Bl,
+                           (const uint8_t*)c->d_im_zmask, (const double*)c->d_im_ccdT, (const double2*)c->d_im_ccdref, c->d_im_part, c->N, c->L);
+    if (c->im_which & 3)
+        hipLaunchKernelGGL(k_metric_fold, dim3((unsigned)((c->B + 63) / 64)), dim3(64), 0, c->stream, (const double2*)c->d_im_part, IM_BLOCKS,
+                           (int)(c->im_which & 3), c->im_ccd_inv_norm, row, row + c->B, c->B);
     if (c->im_which & 4)
-        hipLaunchKernelGGL(k_metric_fqc, dim3((unsigned)c->N, (unsigned)c->B), dim3(256), (size_t)c->N * sizeof(double), c->stream,
+    {
+        if (!c->d_im_fq && hipMalloc((void**)&c->d_im_fq, (size_t)c->B * c->N * c->N * sizeof(double)) != hipSuccess) {
+            c->err = "invariant metrics: out of device memory for the fqc matrix";
+            return MTIP_ENOMEM;
+        }
+        hipLaunchKernelGGL(k_metric_fqc, dim3((unsigned)c->N, (unsigned)((c->N + FQC_QP - 1) / FQC_QP)), dim3(256), 0, c->stream,
                            (const double2*)c->d_Bl, (const uint8_t*)c->d_im_zmask, (const double*)c->d_im_P, (const double*)c->d_im_refavg,
-                           (const double*)c->d_im_refw, row + 2 * (size_t)c->B, c->N, c->L);
+                           (const double*)c->d_im_refw, c->d_im_fq, c->N, c->L, c->B);
+        hipLaunchKernelGGL(k_metric_fqc_fold, dim3((unsigned)((c->B * c->N + 63) / 64)), dim3(64), 0, c->stream, (const double*)c->d_im_fq,
+                           row + 2 * (size_t)c->B, c->N, c->B);
+    }
     return MTIP_OK;
 }
 

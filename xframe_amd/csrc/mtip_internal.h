@@ -154,6 +154,8 @@ struct mtip_ctx {
     uint8_t* d_im_zmask = nullptr;
     double2 *d_im_IIref = nullptr, *d_im_ccdref = nullptr;
     double *d_rl2_wr = nullptr, *d_rl2_wt = nullptr, *d_rl2_part = nullptr, *d_rl2_hist = nullptr;   // reciprocal l2_projection_diff (k_metrics.hip)
+    double* d_im_fq = nullptr;                         // (B, Nq, Nq) fqc values of a step (k_metric_fqc -> k_metric_fqc_fold)
+    double2* d_im_part = nullptr;                      // (B, IM_BLOCKS, 4) partial sums of II_error / ccd_diff
     double *d_im_qq = nullptr, *d_im_ccdT = nullptr, *d_im_P = nullptr, *d_im_refavg = nullptr, *d_im_refw = nullptr, *d_im_hist = nullptr;
     double im_ccd_inv_norm = 0.0;
     int so_order = -1;                                // SO_freedom: order whose unknown [4][2] is made real after every projection (-1: off)
