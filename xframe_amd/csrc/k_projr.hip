@@ -61,12 +61,12 @@ struct RpShared {
 };
 
 // rotation [a b] <- [a b] [[c, w], [-w, c]] that annihilates gamma = a.b (smaller angle); false: already orthogonal
-__device__ __forceinline__ bool rp_params(double alpha, double beta, double g, bool valid, double tabs2, double S, bool& big,
+__device__ __forceinline__ bool rp_params(double alpha, double beta, double g, bool valid, double tabs2, double S, double early2, bool& big,
                                           double& cs, double& w) {
     const double g2 = g * g;
     const double ab = alpha * beta;
     if (!(valid && g2 > (JAC_TOL * JAC_TOL) * ab && g2 > tabs2 * fmax(alpha, beta) * S && g2 > 0.0)) return false;
-    big = big || (g2 > (JL_EARLY * JL_EARLY) * ab);
+    big = big || (g2 > early2 * ab);
     // d = (beta - alpha)/2, h = sqrt(d^2 + g^2):  c^2 = (1 + |d|/h)/2,  w = sign(d) g / (2 h c)
     const double d = 0.5 * (beta - alpha);
     const double ih = fast_rsqrt(fma(d, d, g2));
@@ -83,7 +83,7 @@ __device__ __forceinline__ bool rp_params(double alpha, double beta, double g, b
 // (operands arrived | Gram sums + lane sums | rotation parameters | rotations + stores | barrier)
 template <int NR, bool TIMED = false>
 __device__ __forceinline__ void rp_sweep(double* Xs, double* Vs, int ns, int ks, int t, int group, const int* tab, int n_rounds,
-                                         int ps, const int* s_perm, bool xl_ok, bool vl_ok, double tabs2, double S, bool& big,
+                                         int ps, const int* s_perm, bool xl_ok, bool vl_ok, double tabs2, double S, double early2, bool& big,
                                          long long* tacc = nullptr) {
     long long tq = 0;
 #define RP_SEG(I)                            \
@@ -155,7 +155,7 @@ __device__ __forceinline__ void rp_sweep(double* Xs, double* Vs, int ns, int ks,
         if (TIMED) asm volatile("" ::"v"(alpha), "v"(beta), "v"(g));
         RP_SEG(1)
         double cs = 1.0, w = 0.0;
-        const bool rot = rp_params(alpha, beta, g, act, tabs2, S, big, cs, w);
+        const bool rot = rp_params(alpha, beta, g, act, tabs2, S, early2, big, cs, w);
         if (TIMED) asm volatile("" ::"v"(cs), "v"(w));
         RP_SEG(2)
         if (rot) {
@@ -562,11 +562,15 @@ __device__ __forceinline__ void rp_solve(const RProjArgs& A, int b, int l, RpSha
     const int group = tid / TG, t = tid % TG;
     const bool xl_ok = t + (nr - 1) * TG < n2, vl_ok = t + (nr - 1) * TG < k;
     double S = 0.0;
-    const bool corr = pad && A.corr != 0;
+    const bool corr = (pad || BIG) && A.corr != 0;
     double early2 = corr ? A.rp_early * A.rp_early : JL_EARLY * JL_EARLY;
     bool use_corr = false, corr2 = false;
-    double* Pm = reinterpret_cast<double*>(s_tab);       // k x kp: Gram matrix, then D^-1 (1 - Delta D^-1) (the tables are done with by then)
+    // k x kp: Gram matrix, then D^-1 (1 - Delta D^-1).  Padded layout: in place of the pairing tables (done with by then).  Tight layout
+    // (config 5: the matrices fill the CU): in place of V_r, which goes to global memory first -- where the next call wants it anyway --
+    // and is read back for one more sweep or for the U product (`v_saved`)
+    double* Pm = pad ? reinterpret_cast<double*>(s_tab) : Vs;
     const int kp = k | 1;
+    bool v_saved = false;
     if (k > 1) {
         int tab_ke = -1;
         for (int sweep = 0; sweep < JAC_MAX_SWEEPS; ++sweep) {
@@ -659,8 +663,8 @@ __device__ __forceinline__ void rp_solve(const RProjArgs& A, int b, int l, RpSha
                     }
                 } else if (BIG) {
                     // 6 or 7 row slots: the table is read from L2 one round ahead
-                    if (nr == 6) rp_sweep<6>(Xs, Vs, ns, ks, t, group, gtab, nrd, A.sched_ps, sh.perm, xl_ok, vl_ok, A.tabs2, S, big);
-                    else rp_sweep<7>(Xs, Vs, ns, ks, t, group, gtab, nrd, A.sched_ps, sh.perm, xl_ok, vl_ok, A.tabs2, S, big);
+                    if (nr == 6) rp_sweep<6>(Xs, Vs, ns, ks, t, group, gtab, nrd, A.sched_ps, sh.perm, xl_ok, vl_ok, A.tabs2, S, early2, big);
+                    else rp_sweep<7>(Xs, Vs, ns, ks, t, group, gtab, nrd, A.sched_ps, sh.perm, xl_ok, vl_ok, A.tabs2, S, early2, big);
                 }
                 n_rounds_done += nrd;
             }
@@ -677,6 +681,14 @@ __device__ __forceinline__ void rp_solve(const RProjArgs& A, int b, int l, RpSha
             __syncthreads();
             if (cont) continue;
             if (!corr) break;                                    // classic exit: the sweep just done was the confirming one
+            if (!pad) {
+                for (int e = tid; e < k * k; e += nthreads) {
+                    const int cc = e / k, i = e - cc * k;
+                    Vr[e] = Vs[(size_t)cc * ks + i];
+                }
+                v_saved = true;
+                __syncthreads();
+            }
             // ---- Gram matrix G = W^T W on the matrix pipe, its diagonal (sigma^2) and the largest |E_ij| ----
             for (int base = 0; base < ntm_k * ntm_k; base += nwaves * RP_ACC) {
                 v4f64 acc[RP_ACC];
@@ -739,6 +751,14 @@ __device__ __forceinline__ void rp_solve(const RProjArgs& A, int b, int l, RpSha
             }
             tab_ke = -1;                                         // not there yet: one more sweep (the Gram matrix overwrote the
                                                                  // pairing table: staged again), then the check again
+            if (!pad) {                                          // ... or V_r: read back
+                for (int e = tid; e < k * k; e += nthreads) {
+                    const int cc = e / k, i = e - cc * k;
+                    Vs[(size_t)cc * ks + i] = *reinterpret_cast<const volatile double*>(Vr + e);   // (written by this kernel: not through a stale L1 line)
+                }
+                v_saved = false;
+                __syncthreads();
+            }
         }
     } else if (tid == 0) {
         A.sweeps_out[b * (A.L + 1) + l] = 0 | (k << 8);
@@ -759,20 +779,27 @@ __device__ __forceinline__ void rp_solve(const RProjArgs& A, int b, int l, RpSha
             if (cc < k && t == 0) sh.isig[cc] = s2 > 1e-300 ? 1.0 / sqrt(s2) : 0.0;
         }
     }
-    for (int e = tid; e < k * k; e += nthreads) {
-        const int cc = e / k, i = e - cc * k;
-        Vr[e] = Vs[(size_t)cc * ks + i];
-    }
+    if (!v_saved)
+        for (int e = tid; e < k * k; e += nthreads) {
+            const int cc = e / k, i = e - cc * k;
+            Vr[e] = Vs[(size_t)cc * ks + i];
+        }
     __syncthreads();
     if (!use_corr) {
         // columns of X~ <- left singular vectors W / sigma (numerical-zero columns: 0)
         for (int e = tid; e < k * ns; e += nthreads) Xs[e] *= sh.isig[e / ns];
+        if (v_saved)                                           // (tight layout, Gram matrix orthogonal to rounding: V_r back in place)
+            for (int e = tid; e < k * k; e += nthreads) {
+                const int cc = e / k, i = e - cc * k;
+                Vs[(size_t)cc * ks + i] = *reinterpret_cast<const volatile double*>(Vr + e);   // (written by this kernel: not through a stale L1 line)
+            }
         __syncthreads();
     } else {
         // columns of X~ <- W G^-1/2 to first or second order in E: the symmetric factor P in place of the Gram matrix, then one
         // product held in registers across the barrier (it overwrites its own operand).  V_r is in global memory by now: its LDS
         // block serves as scratch for A~ and is read back before the U product.
-        double* Ab = Vs;
+        // (tight layout: P sits in V_r's block already; A~ goes through the order's slot of the output U, written only after this)
+        double* Ab = pad ? Vs : reinterpret_cast<double*>(A.U + (size_t)b * A.xtot + A.xoff[l]);
         for (int e = tid; e < k * k; e += nthreads) {
             const int i = e / k, j = e - i * k;
             const double g = Pm[(size_t)i * kp + j], gi = sh.sig[i] * sh.sig[i], gj = sh.sig[j] * sh.sig[j];
@@ -856,10 +883,10 @@ __device__ __forceinline__ void rp_solve(const RProjArgs& A, int b, int l, RpSha
                 }
             }
         }
-        if (corr2) {                                           // V_r back into its LDS block (its zero padding was never an operand)
+        if (corr2 || v_saved) {                                // V_r back into its LDS block (its zero padding was never an operand)
             for (int e = tid; e < k * k; e += nthreads) {
                 const int cc = e / k, i = e - cc * k;
-                Vs[(size_t)cc * ks + i] = Vr[e];
+                Vs[(size_t)cc * ks + i] = *reinterpret_cast<const volatile double*>(Vr + e);   // (written by this kernel: not through a stale L1 line)
             }
         }
         __syncthreads();
