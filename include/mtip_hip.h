@@ -187,6 +187,12 @@ int mtip_last_deg2_invariant(mtip_ctx* ctx, int batch, mtip_cdouble* Bl);
  *      averaging keeps its batch in HBM between these calls. ---------------------------------------- */
 int mtip_op_sht_forward(mtip_ctx* ctx, const mtip_cdouble* grid, mtip_cdouble* coeff, int prologue);
 int mtip_op_sht_inverse(mtip_ctx* ctx, const mtip_cdouble* coeff, mtip_cdouble* grid);
+/* inverse transform and, on the grid it produced, the forward transform of prologue(grid) -- inverse_harmonic_transform then
+ * [square_grid, misk.py:159-168, then] harmonic_transform, the way three links of a phasing step chain them
+ * (reconstruct.py:518-528, 576-593): grid = iSHT(coeff), coeff_out = SHT(grid) (prologue 0) or SHT(|grid|^2) (prologue 1).
+ * One kernel per shell where the angular grid allows it (csrc/k_sht_chain.hip; profile family "sht_chain"), else the two
+ * transforms one after the other. */
+int mtip_op_sht_inverse_forward(mtip_ctx* ctx, const mtip_cdouble* coeff, mtip_cdouble* grid, mtip_cdouble* coeff_out, int prologue);
 int mtip_op_hankel(mtip_ctx* ctx, const mtip_cdouble* coeff_in, mtip_cdouble* coeff_out, int inverse);
 int mtip_op_fourier_transform(mtip_ctx* ctx, const mtip_cdouble* grid_in, mtip_cdouble* grid_out, int inverse);
 /* approximate_unknowns + mtip_projection (fxs_Projections.py:752-767, 832-872) on 'direct' coefficients */

@@ -37,7 +37,7 @@ def transforms_engine(N, L, lib_path, n_batch=2, mode='midpoint'):
     return e, fp
 
 
-def check_transforms(N, L, lib_path, seed=0, mode='midpoint'):
+def check_transforms(N, L, lib_path, seed=0, mode='midpoint', expect_chain=None):
     e, fp = transforms_engine(N, L, lib_path, mode=mode)
     sht = fp.sht
     assert (e.n_theta, e.n_phi) == (sht.n_theta, sht.n_phi)
@@ -48,6 +48,17 @@ def check_transforms(N, L, lib_path, seed=0, mode='midpoint'):
     assert rel_l2(e.sht_forward(g, 1), sht.forward_d(g * g.conj())) < TOL_SHT
     assert rel_l2(e.sht_forward(g, 2), sht.forward_d(np.abs(g))) < TOL_SHT
     assert rel_l2(e.sht_inverse(co), sht.inverse_d(co)) < TOL_SHT
+    # the chained inverse -> forward kernel: the grid is that of the inverse transform, the coefficients those of the oracle's
+    # two transforms one after the other
+    e.profile(True)
+    for pro in (0, 1):
+        gi, ci = e.sht_inverse_forward(co, pro)
+        ref_g = sht.inverse_d(co)
+        assert rel_l2(gi, ref_g) < TOL_SHT
+        assert rel_l2(ci, sht.forward_d(ref_g * ref_g.conj() if pro else ref_g)) < TOL_SHT
+    if expect_chain is not None:
+        assert (e.profile_get('sht_chain')[1] > 0) == expect_chain, e.profile_get('sht_chain')
+    e.profile(False)
     assert rel_l2(e.hankel(co), fp.hankel(co)) < TOL_OP
     assert rel_l2(e.hankel(co, True), fp.ihankel(co)) < TOL_OP
     assert rel_l2(e.fourier_transform(g), fp.ft(g)) < TOL_SHT

@@ -22,9 +22,12 @@ def emul_lib():
     return EMUL_LIB
 
 
-@pytest.mark.parametrize('N,L', [(16, 4), (10, 7), (8, 2), (6, 12), (4, 24), (3, 32), (3, 44)])   # n_phi = 16, 32, 8, 64, 128, 128, 256
-def test_transforms(emul_lib, N, L):
-    PC.check_transforms(N, L, emul_lib, seed=N + L)
+# n_phi = 16, 32, 8, 64, 128, 128, 256; the chained inverse -> forward kernel exists where the register FFTs do and a shell fits one
+# CU's LDS (k_sht_chain.hip: run-time table variants at 16 / 32 / 64, register-table variants <2, 8> and <3, 8> at 128)
+@pytest.mark.parametrize('N,L,chain', [(16, 4, True), (10, 7, True), (8, 2, False), (6, 12, True), (4, 24, True), (3, 32, True),
+                                       (3, 44, False)])
+def test_transforms(emul_lib, N, L, chain):
+    PC.check_transforms(N, L, emul_lib, seed=N + L, expect_chain=chain)
 
 
 def test_transforms_trapz(emul_lib):

@@ -14,9 +14,10 @@ def test_library_loaded_and_device_present():
     assert lib.mtip_device_count() >= 1
 
 
-@pytest.mark.parametrize('N,L', [(16, 4), (10, 7), (8, 2), (32, 8), (64, 16)])
-def test_transforms(N, L):
-    PC.check_transforms(N, L, None, seed=N + L)
+@pytest.mark.parametrize('N,L,chain', [(16, 4, True), (10, 7, True), (8, 2, False), (32, 8, True), (64, 16, True), (20, 24, True),
+                                       (128, 32, True), (12, 44, False)])
+def test_transforms(N, L, chain):
+    PC.check_transforms(N, L, None, seed=N + L, expect_chain=chain)
 
 
 def test_transforms_trapz():

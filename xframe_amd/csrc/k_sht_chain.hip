@@ -1,0 +1,430 @@
+// Inverse -> forward spherical-harmonic transform of a shell in ONE kernel (rows a4-a6, a10-a12 of SURVEY section 8).
+//
+// In a phasing step the grid an inverse transform produces is, three times, the grid the next forward transform reads
+// (reconstruct.py:518-528, 576-593 as decoded in SURVEY 3.3):
+//     F  = iSHT(Hankel(SHT(rho)))          ->  I_lm  = SHT(|F|^2)                 (square_grid, misk.py:159-168)
+//     F' = F sqrt(iSHT(I'_lm) / |F|^2)     ->  SHT(F')  (first half of IFT(F'))   (fxs_Projections.py:899-909)
+//     rho_new = real-space update          ->  SHT(rho_new) (first half of the next step's FT(rho))
+// With separate kernels each of these grids (16.8 MB per restart at 128 x L32) is written once and read back once, and the
+// forward kernel's own phases (row loads, FFTs, Legendre sums) run while nothing else of that shell is in flight.  Here the
+// shell stays in the workgroup: the inverse transform's pass structure (k_sht_inv_wide: Legendre synthesis of all rows by
+// the in-register three-term recurrence, then per pass of RP rows two register-FFT steps around one LDS transpose, epilogue,
+// coalesced store) hands its step-2 registers -- thread (row r, n2) holds the R1 values x[R2 n1 + n2] of its row, the row of
+// theta_j and its mirror R2 lanes apart -- straight to the forward transform's phase 1 (mirror fold through one lane
+// exchange, R1-point FFTs, twiddle, the SAME transpose buffer, R2-point FFTs, (theta, m) panel, table-driven Legendre sums
+// in registers).  The stores of a pass drain while the forward half of that pass computes.  Per shell: three launches and
+// three grid re-reads per restart-step less (12 -> 9 launches, 173 -> ~123 MB of HBM traffic at 128 x L32).
+// The grid values written are bit-identical to k_sht_inv_wide's; the coefficients differ from k_sht_fwd_pair's only in the
+// order of the theta sum (<= 1e-15 relative).
+#include "mtip_internal.h"
+#include "k_sht_common.h"
+#include "k_sht_legendre.h"
+
+struct ChainArgs {
+    // inverse half (as k_sht_inv_wide, one workgroup per shell)
+    const double2* coeff;
+    double2* grid;
+    const double* P;
+    const double2* AB;
+    const double* cost;
+    const double2* twN_g;
+    const double2* Fin;
+    const int* slot;
+    RealEpi re;
+    int npairs, nt, L, RP, Nq, which, B;
+    // forward half
+    double2* coeff_out;
+    const double* PT;
+    const int* lmtab;
+    const double* gw;
+    double norm;
+    int gsz, thg;                       // threads per accumulation group (a power of two), theta pairs of a pass per group
+};
+
+// EPI: epilogue of the inverse half (EPI_STORE / EPI_MODULUS / EPI_REAL_UPDATE); PRE: prologue of the forward half on the value
+// just written (MTIP_PRE_NONE / MTIP_PRE_SQUARE); MAXI: (l, m) pairs per thread of an accumulation group; THG > 0: theta pairs
+// per pass and group at compile time, their table rows prefetched into registers at the top of the pass; THG == 0: run-time
+// count, table values loaded where they are used (small grids)
+template <int EPI, int PRE, int R1, int R2, int MAXI, int THG>
+__global__ void __launch_bounds__(SW_THREADS) k_sht_chain(ChainArgs a) {
+    constexpr int N = R1 * R2;
+    constexpr int AS = R2 + 1;
+    constexpr int GSR = R1 * AS;                    // panel row stride (>= n_phi + 1 > 2 L + 1)
+    HIP_DYNAMIC_SHARED(double2, sm)
+    const int L = a.L, nt = a.nt, RP = a.RP, npairs = a.npairs, Nq = a.Nq, B = a.B;
+    const int nm = 2 * L + 1;
+    const int nlm = (L + 1) * (L + 1);
+    double2* twN = sm;                              // N
+    double2* Gs = sm + N;                           // nt * nm        spectra: row 2j = theta_j, 2j+1 = its mirror
+    double2* ABs = Gs + (size_t)nt * nm;            // npairs         recurrence coefficients
+    double2* cl = ABs + npairs;                     // nlm            (Legendre phase)
+    double2* Bm = cl;                               // RP * R1 * AS   transpose buffer of both directions, then the (theta, m) panel
+    const int tid = threadIdx.x;
+    const long long shell = blockIdx.x;
+    const int q = (int)(shell % Nq);
+    const double2* csrc = a.coeff + (size_t)shell * nlm;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nw = blockDim.x >> 6;
+    LegendreStart ls;
+    legendre_prefetch_first(ls, a.P, nt, L, nt >> 1, 0, wave, tid & 63);
+    for (int e = tid; e < N; e += blockDim.x) sm[e] = a.twN_g[e];
+    for (int e = tid; e < npairs; e += blockDim.x) ABs[e] = a.AB[e];
+    for (int e = tid; e < nlm; e += blockDim.x) cl[e] = csrc[e];
+    long long dst_shell = shell;
+    if (a.slot != nullptr && a.which >= 0) dst_shell += (long long)a.slot[(shell / Nq) * SL_N + a.which] * B * Nq;
+    double2* gdst = a.grid + (size_t)dst_shell * nt * N;
+    const double2* fsrc = a.Fin ? a.Fin + (size_t)shell * nt * N : nullptr;
+    const double2* rprev = nullptr;
+    const uint8_t* rsup = nullptr;
+    const uint8_t* rS0 = nullptr;
+    double err_num = 0.0, err_den = 0.0;
+    if (EPI == EPI_REAL_UPDATE) {
+        const int bb = (int)(shell / Nq);
+        const int* sl = a.slot + bb * SL_N;
+        const size_t gsh = (size_t)nt * N;
+        rprev = a.re.prev + ((size_t)sl[SL_CUR] * B * Nq + shell) * gsh;
+        gdst = a.re.out + ((size_t)sl[SL_OUT] * B * Nq + shell) * gsh;
+        rsup = a.re.sup + ((size_t)sl[SL_SUP] * B * Nq + shell) * gsh;
+        rS0 = a.re.S0 + (size_t)q * gsh;
+    }
+    // forward half: accumulation group g owns theta pairs [g thg, (g + 1) thg) of every pass, thread t of it the pairs t + u gsz
+    const int gsz = a.gsz;
+    const int thg = THG > 0 ? THG : a.thg;
+    const int TH = RP >> 1;
+    const int grp = tid / gsz, tg = tid - grp * gsz;
+    int my_i[MAXI], my_l[MAXI], my_m[MAXI];
+    double2 accp[MAXI], accm[MAXI];
+#pragma unroll
+    for (int u = 0; u < MAXI; ++u) {
+        my_i[u] = min(tg + u * gsz, npairs - 1);    // clamped: the table loads stay branch-free
+        const int lm = a.lmtab[my_i[u]];
+        my_l[u] = lm & 0xff;
+        my_m[u] = lm >> 8;
+        accp[u] = make_double2(0.0, 0.0);
+        accm[u] = make_double2(0.0, 0.0);
+    }
+    __syncthreads();
+    // ---- Legendre synthesis of every row (k_sht_legendre.h)
+    legendre_synthesis_rows(ls, Gs, cl, ABs, a.P, a.cost, nt, L, nt >> 1, 0, wave, nw, tid & 63);
+    __syncthreads();
+    const int n_pass = nt / RP;
+    for (int pass = 0; pass < n_pass; ++pass) {
+        // epilogue operands of this thread's step-2 outputs: requested now, they arrive behind step 1
+        double2 pre[(EPI == EPI_MODULUS || EPI == EPI_REAL_UPDATE) ? R1 : 1];
+        uint8_t pre_s[EPI == EPI_REAL_UPDATE ? R1 : 1], pre_0[EPI == EPI_REAL_UPDATE ? R1 : 1];
+        if ((EPI == EPI_MODULUS || EPI == EPI_REAL_UPDATE) && tid < RP * R2) {
+            const int r = tid / R2, n2 = tid - r * R2;
+            const int rr = pass * RP + r;
+            const int th = rr >> 1;
+            const int row = (rr & 1) ? (nt - 1 - th) : th;
+#pragma unroll
+            for (int n1 = 0; n1 < R1; ++n1) {
+                const size_t o = (size_t)row * N + R2 * n1 + n2;
+                if (EPI == EPI_MODULUS) pre[n1] = fsrc[o];
+                if (EPI == EPI_REAL_UPDATE) {
+                    pre[n1] = rprev[o];
+                    pre_s[n1] = rsup[o];
+                    pre_0[n1] = a.re.err_use_mask ? rS0[o] : (uint8_t)1;
+                }
+            }
+        }
+        // the forward half's table rows of this pass: they arrive while the FFT steps run
+        double tab[MAXI][THG > 0 ? THG : 1];
+        if (THG > 0) {
+#pragma unroll
+            for (int u = 0; u < MAXI; ++u)
+#pragma unroll
+                for (int jj = 0; jj < (THG > 0 ? THG : 1); ++jj) {
+                    const double* row = a.PT + (size_t)(pass * TH + grp * THG + jj) * npairs;
+                    tab[u][jj] = row[(unsigned)my_i[u]];
+                }
+        }
+        // ---- step 1: inverse R2-point FFTs over k2 of the zero padded spectrum, twiddle, transpose store
+        if (tid < RP * R1) {
+            const int r = tid / R1, k1 = tid - r * R1;
+            const double2* gr = Gs + (size_t)(pass * RP + r) * nm + L;
+            double2 uv[R2];
+#pragma unroll
+            for (int k2 = 0; k2 < R2; ++k2) {
+                const int k = k1 + R1 * k2;
+                double2 v = make_double2(0.0, 0.0);
+                if (k <= L) v = gr[k];
+                else if (k >= N - L) v = gr[k - N];
+                uv[k2] = v;
+            }
+            SmallFFT<R2, true>::run(uv);
+            double2* br = Bm + (size_t)(r * R1 + k1) * AS;
+#pragma unroll
+            for (int n2 = 0; n2 < R2; ++n2) {
+                double2 w = twN[n2 * k1];
+                w.y = -w.y;
+                br[n2] = cmul(uv[n2], w);
+            }
+        }
+        __syncthreads();
+        // ---- step 2: inverse R1-point FFTs over k1
+        const bool act2 = tid < RP * R2;
+        const int r = tid / R2, n2 = tid - r * R2;
+        double2 vv[R1];
+#pragma unroll
+        for (int k1 = 0; k1 < R1; ++k1) vv[k1] = make_double2(0.0, 0.0);
+        if (act2) {
+            const double2* br = Bm + (size_t)r * R1 * AS + n2;
+#pragma unroll
+            for (int k1 = 0; k1 < R1; ++k1) vv[k1] = br[k1 * AS];
+        }
+        __syncthreads();                                // Bm is free: the forward half's transpose goes there
+        if (act2) {
+            SmallFFT<R1, true>::run(vv);
+            const int rr = pass * RP + r;
+            const int th = rr >> 1;
+            const int row = (rr & 1) ? (nt - 1 - th) : th;
+            // epilogue + coalesced store, then the forward half's prologue on the value just written
+#pragma unroll
+            for (int n1 = 0; n1 < R1; ++n1) {
+                double2 v = vv[n1];
+                const size_t o = (size_t)row * N + R2 * n1 + n2;
+                if (EPI == EPI_MODULUS) {
+                    // project_to_modified_intensity, fxs_Projections.py:899-909
+                    const double2 Fv = pre[n1];
+                    const double I = cabs2(Fv);
+                    const bool ok = (I >= 0.0) && (v.x >= 0.0);
+                    const double mult = ok ? sqrt(v.x / I) : 0.0;
+                    v = cscale(Fv, mult);
+                } else if (EPI == EPI_REAL_UPDATE) {
+                    const double2 pv = pre[n1];
+                    const double2 w = (a.re.add_prev && q > 0) ? cadd(v, pv) : v;
+                    double2 Pj;
+                    v = real_update_point(a.re.rp, a.re.method, a.re.beta, w, pv, pre_s[n1] != 0, Pj);
+                    if (pre_0[n1] != 0) {                            // l2_projection_diff, fxs_IO_methods.py:97-128
+                        const double wg = a.re.wr[q] * a.re.wt[row];
+                        const double dx = w.x - Pj.x, dy = w.y - Pj.y;
+                        err_num = fma(wg, dx * dx + dy * dy, err_num);
+                        err_den = fma(wg, w.x * w.x + w.y * w.y, err_den);
+                    }
+                }
+                gdst[o] = v;
+                if (PRE == MTIP_PRE_SQUARE) v = make_double2(cabs2(v), 0.0);       // square_grid, misk.py:159-168
+                vv[n1] = v;
+            }
+        }
+        // ---- forward phase 1: mirror fold (row 2j = theta_j, 2j+1 = its mirror: R2 lanes apart; the exchange runs on whole
+        //      waves, rows come in pairs so a thread with a row has its partner), R1-point FFTs, twiddle
+#pragma unroll
+        for (int n1 = 0; n1 < R1; ++n1) {
+            const double px = __shfl_xor(vv[n1].x, R2, 64), py = __shfl_xor(vv[n1].y, R2, 64);
+            vv[n1] = (r & 1) ? make_double2(px - vv[n1].x, py - vv[n1].y)      // odd part  north - south
+                             : make_double2(vv[n1].x + px, vv[n1].y + py);    // even part north + south
+        }
+        if (act2) {
+            SmallFFT<R1, false>::run(vv);
+            double2* ar = Bm + (size_t)r * R1 * AS + n2;
+#pragma unroll
+            for (int k1 = 0; k1 < R1; ++k1) ar[k1 * AS] = cmul(vv[k1], twN[n2 * k1]);
+        }
+        __syncthreads();
+        // ---- forward phase 2: R2-point FFTs over n2; keep |m| <= L, Gauss weight
+        double2 uv[R2];
+        const bool actf = tid < RP * R1;
+        const int r2 = tid / R1, kf = tid - r2 * R1;
+        if (actf) {
+            const double2* ar = Bm + (size_t)(r2 * R1 + kf) * AS;
+#pragma unroll
+            for (int qq = 0; qq < R2; ++qq) uv[qq] = ar[qq];
+        }
+        __syncthreads();                                // the transpose buffer is dead: the panel overwrites it
+        if (actf) {
+            SmallFFT<R2, false>::run(uv);
+            const double sc = a.gw[pass * TH + (r2 >> 1)] * a.norm;
+            double2* gr = Bm + (size_t)r2 * GSR + L;
+#pragma unroll
+            for (int k2 = 0; k2 < R2; ++k2) {
+                const int k = kf + R1 * k2;
+                if (k <= L) gr[k] = cscale(uv[k2], sc);
+                else if (k >= N - L) gr[k - N] = cscale(uv[k2], sc);
+            }
+        }
+        __syncthreads();
+        // ---- Legendre sums (panel rows 2j = even part, 2j+1 = odd part of theta pair j)
+#pragma unroll
+        for (int u = 0; u < MAXI; ++u) {
+            const int l = my_l[u], m = my_m[u];
+            const double2* srcp = Bm + (size_t)(((l + m) & 1) + 2 * grp * thg) * GSR + L + m;
+            const double2* srcm = srcp - 2 * m;
+            double2 ap = accp[u], am = accm[u];
+            if (THG > 0) {
+#pragma unroll
+                for (int jj = 0; jj < (THG > 0 ? THG : 1); ++jj) {
+                    const double p = tab[u][jj];
+                    const double2 vp = srcp[2 * jj * GSR];
+                    const double2 vm = srcm[2 * jj * GSR];
+                    ap.x = fma(p, vp.x, ap.x);
+                    ap.y = fma(p, vp.y, ap.y);
+                    am.x = fma(p, vm.x, am.x);
+                    am.y = fma(p, vm.y, am.y);
+                }
+            } else {
+                const double* pt = a.PT + (size_t)(pass * TH + grp * thg) * npairs + my_i[u];
+                for (int jj = 0; jj < thg; ++jj) {
+                    const double p = pt[(size_t)jj * npairs];
+                    const double2 vp = srcp[2 * jj * GSR];
+                    const double2 vm = srcm[2 * jj * GSR];
+                    ap.x = fma(p, vp.x, ap.x);
+                    ap.y = fma(p, vp.y, ap.y);
+                    am.x = fma(p, vm.x, am.x);
+                    am.y = fma(p, vm.y, am.y);
+                }
+            }
+            accp[u] = ap;
+            accm[u] = am;
+        }
+        __syncthreads();                                // the next pass rewrites Bm
+    }
+    // every LDS block is dead now: per-shell error sums go to the head, the groups' partial coefficients behind them
+    if (EPI == EPI_REAL_UPDATE) {
+        // fixed order (bitwise reproducible): wave butterflies, then the waves
+        for (int o = 32; o > 0; o >>= 1) {
+            err_num += __shfl_xor(err_num, o, 64);
+            err_den += __shfl_xor(err_den, o, 64);
+        }
+        double* red = reinterpret_cast<double*>(sm);
+        if ((tid & 63) == 0) {
+            red[2 * (tid >> 6)] = err_num;
+            red[2 * (tid >> 6) + 1] = err_den;
+        }
+    }
+    double2* racc = sm + N;                             // (groups, MAXI, 2, gsz)
+#pragma unroll
+    for (int u = 0; u < MAXI; ++u) {
+        racc[(size_t)((grp * MAXI + u) * 2) * gsz + tg] = accp[u];
+        racc[(size_t)((grp * MAXI + u) * 2 + 1) * gsz + tg] = accm[u];
+    }
+    __syncthreads();
+    if (EPI == EPI_REAL_UPDATE && tid == 0) {
+        const double* red = reinterpret_cast<const double*>(sm);
+        double sn = 0.0, sd = 0.0;
+        for (int wv = 0; wv < nw; ++wv) {
+            sn += red[2 * wv];
+            sd += red[2 * wv + 1];
+        }
+        a.re.partial[(size_t)shell * 2] = sn;
+        a.re.partial[(size_t)shell * 2 + 1] = sd;
+    }
+    const int ngrp = blockDim.x / gsz;
+    double2* cdst = a.coeff_out + (size_t)shell * nlm;
+    for (int idx = tid; idx < npairs; idx += blockDim.x) {
+        const int u = idx / gsz, t = idx - u * gsz;
+        double2 sp = make_double2(0.0, 0.0), sq = sp;
+        for (int g = 0; g < ngrp; ++g) {                // fixed order over the groups
+            const double2 vp = racc[(size_t)((g * MAXI + u) * 2) * gsz + t];
+            const double2 vq = racc[(size_t)((g * MAXI + u) * 2 + 1) * gsz + t];
+            sp.x += vp.x; sp.y += vp.y;
+            sq.x += vq.x; sq.y += vq.y;
+        }
+        const int lm = a.lmtab[idx];
+        const int l = lm & 0xff, m = lm >> 8;
+        cdst[l * (l + 1) + m] = sp;
+        if (m > 0) cdst[l * (l + 1) - m] = (m & 1) ? make_double2(-sq.x, -sq.y) : sq;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+struct ChainGeom {
+    int r1 = 0, r2 = 0, rp = 0, gsz = 0, thg = 0, maxi = 0;     // maxi: the kernel's MAXI (>= pairs per thread)
+    bool reg_tab = false;
+    size_t lds = 0;
+    bool ok = false;
+};
+
+static ChainGeom chain_geom(const mtip_ctx* c) {
+    ChainGeom g;
+    if (!sht_reg_supported(c) || !c->sht_wide || c->d_AB == nullptr || c->d_PT == nullptr || c->d_lmtab == nullptr) return g;
+    if (!reg_radices(c->np, &g.r1, &g.r2) || (c->nt & 1)) return g;
+    g.rp = largest_even_divisor_le(c->nt, std::min(SW_THREADS / g.r2, SW_THREADS / g.r1));
+    const size_t fixed = (size_t)c->np + (size_t)c->nt * c->nm + c->npairs;
+    // the transpose buffer / panel aliases the coefficient block: shrink the pass until the shell fits one CU
+    while (g.rp >= 2 && (fixed + std::max((size_t)c->nlm, (size_t)g.rp * g.r1 * (g.r2 + 1))) * sizeof(double2) > 158 * 1024)
+        g.rp = largest_even_divisor_le(c->nt, g.rp - 2);
+    if (g.rp < 2) return g;
+    const int TH = g.rp / 2;
+    // accumulation groups: the smallest power-of-two group whose threads hold <= 3 (l, m) pairs each and whose count divides
+    // the theta pairs of a pass
+    for (int gsz = 64; gsz <= SW_THREADS; gsz *= 2) {
+        const int ngrp = SW_THREADS / gsz;
+        if (TH % ngrp != 0) continue;
+        const int maxi = div_up(c->npairs, gsz);
+        if (maxi > 3) continue;
+        g.gsz = gsz;
+        g.thg = TH / ngrp;
+        // the instantiation launch_chain_r picks: table rows in registers for the 128-point grids, else the run-time variants
+        g.reg_tab = c->np == 128 && g.thg == 8 && maxi >= 2;
+        g.maxi = g.reg_tab ? maxi : (maxi == 1 ? 1 : 3);
+        break;
+    }
+    if (g.gsz == 0) return g;
+    const size_t body = fixed + std::max((size_t)c->nlm, (size_t)g.rp * g.r1 * (g.r2 + 1));
+    const size_t tail = (size_t)c->np + (size_t)SW_THREADS * g.maxi * 2;
+    g.lds = std::max(body, tail) * sizeof(double2);
+    g.ok = g.lds <= 158 * 1024;
+    return g;
+}
+
+bool sht_chain_supported(const mtip_ctx* c) {
+    return c->sht_chain && chain_geom(c).ok;
+}
+
+template <int EPI, int PRE, int R1, int R2>
+static void launch_chain_r(mtip_ctx* c, const ChainGeom& g, const ChainArgs& a) {
+    const dim3 gr((unsigned)(c->B * c->N)), bl(SW_THREADS);
+#define CHAIN_GO(MAXI, THG) hipLaunchKernelGGL((k_sht_chain<EPI, PRE, R1, R2, MAXI, THG>), gr, bl, g.lds, c->stream, a)
+    if (R1 * R2 == 128 && g.reg_tab && g.maxi == 3) CHAIN_GO(3, 8);
+    else if (R1 * R2 == 128 && g.reg_tab && g.maxi == 2) CHAIN_GO(2, 8);
+    else if (g.maxi == 1) CHAIN_GO(1, 0);
+    else CHAIN_GO(3, 0);
+#undef CHAIN_GO
+}
+
+template <int EPI, int PRE>
+static void launch_chain_p(mtip_ctx* c, const ChainGeom& g, const ChainArgs& a) {
+    switch (c->np) {
+        case 16: launch_chain_r<EPI, PRE, 4, 4>(c, g, a); break;
+        case 32: launch_chain_r<EPI, PRE, 4, 8>(c, g, a); break;
+        case 64: launch_chain_r<EPI, PRE, 8, 8>(c, g, a); break;
+        case 128: launch_chain_r<EPI, PRE, 8, 16>(c, g, a); break;
+        default: launch_chain_r<EPI, PRE, 16, 16>(c, g, a); break;
+    }
+}
+
+// grid = epilogue(iSHT(coeff)), coeff_out = SHT(prologue(grid)).  Epilogues: EPI_STORE (prologue |.|^2: the F -> I_lm link of a
+// step), EPI_MODULUS and EPI_REAL_UPDATE (no prologue).  Caller checks sht_chain_supported().
+void launch_sht_chain(mtip_ctx* c, const double2* coeff, double2* grid, const InvEpilogue& epi, int prologue, double2* coeff_out) {
+    ProfScope ps(c, epi.mode == EPI_REAL_UPDATE ? "sht_chain_real" : epi.mode == EPI_MODULUS ? "sht_chain_modulus" : "sht_chain");
+    const ChainGeom g = chain_geom(c);
+    ChainArgs a;
+    a.coeff = coeff;
+    a.grid = grid;
+    a.P = c->d_P;
+    a.AB = c->d_AB;
+    a.cost = c->d_cost;
+    a.twN_g = c->d_twN;
+    a.Fin = epi.F;
+    a.slot = (epi.out_slot >= 0 || epi.mode == EPI_REAL_UPDATE) ? c->d_slot : nullptr;
+    a.re = epi.real;
+    a.npairs = c->npairs;
+    a.nt = c->nt;
+    a.L = c->L;
+    a.RP = g.rp;
+    a.Nq = c->N;
+    a.which = epi.out_slot;
+    a.B = c->B;
+    a.coeff_out = coeff_out;
+    a.PT = c->d_PT;
+    a.lmtab = c->d_lmtab;
+    a.gw = c->d_gw;
+    a.norm = 2.0 * 3.14159265358979323846 / c->np;
+    a.gsz = g.gsz;
+    a.thg = g.thg;
+    if (epi.mode == EPI_REAL_UPDATE) launch_chain_p<EPI_REAL_UPDATE, MTIP_PRE_NONE>(c, g, a);
+    else if (epi.mode == EPI_MODULUS) launch_chain_p<EPI_MODULUS, MTIP_PRE_NONE>(c, g, a);
+    else if (prologue == MTIP_PRE_SQUARE) launch_chain_p<EPI_STORE, MTIP_PRE_SQUARE>(c, g, a);
+    else launch_chain_p<EPI_STORE, MTIP_PRE_NONE>(c, g, a);
+}

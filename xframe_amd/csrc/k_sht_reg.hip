@@ -13,58 +13,8 @@
 // ~4 barriers per 32 (forward) / 16 (inverse) grid rows; ~5x fewer instructions than the LDS Stockham variant
 // (k_sht_fused.hip), which stays as the fallback for other n_phi.
 #include "mtip_internal.h"
-
-#define SR_THREADS 256
-
-// exp(-2 pi i j / 16), j = 0..7
-__device__ __forceinline__ double2 tw16(int j) {
-    const double c1 = 0.92387953251128673848, s1 = 0.38268343236508978178, h = 0.70710678118654752440;
-    switch (j) {
-        case 0: return make_double2(1.0, 0.0);
-        case 1: return make_double2(c1, -s1);
-        case 2: return make_double2(h, -h);
-        case 3: return make_double2(s1, -c1);
-        case 4: return make_double2(0.0, -1.0);
-        case 5: return make_double2(-s1, -c1);
-        case 6: return make_double2(-h, -h);
-        default: return make_double2(-c1, -s1);
-    }
-}
-
-// in-register FFT of R points (natural order in and out), decimation in time, fully unrolled
-template <int R, bool INV>
-struct SmallFFT {
-    static __device__ __forceinline__ void run(double2 (&v)[R]) {
-        double2 e[R / 2], o[R / 2];
-#pragma unroll
-        for (int i = 0; i < R / 2; ++i) {
-            e[i] = v[2 * i];
-            o[i] = v[2 * i + 1];
-        }
-        SmallFFT<R / 2, INV>::run(e);
-        SmallFFT<R / 2, INV>::run(o);
-#pragma unroll
-        for (int k = 0; k < R / 2; ++k) {
-            const int j = k * (16 / R);
-            double2 t;
-            if (j == 0) {
-                t = o[k];
-            } else if (j == 4) {
-                t = INV ? make_double2(-o[k].y, o[k].x) : make_double2(o[k].y, -o[k].x);   // * (+-i)
-            } else {
-                double2 w = tw16(j);
-                if (INV) w.y = -w.y;
-                t = cmul(o[k], w);
-            }
-            v[k] = cadd(e[k], t);
-            v[k + R / 2] = csub(e[k], t);
-        }
-    }
-};
-template <bool INV>
-struct SmallFFT<1, INV> {
-    static __device__ __forceinline__ void run(double2 (&)[1]) {}
-};
+#include "k_sht_common.h"
+#include "k_sht_legendre.h"
 
 // (l, m) pairs per thread from which the table loads of eight theta pairs are requested together: with few rows per
 // pass and many pairs per thread (n_phi = 256) every single load was a full L2 round trip (357 -> 260 us at 256 x L48);
@@ -511,7 +461,6 @@ __global__ void __launch_bounds__(SR_THREADS) k_sht_inv_reg(const double2* __res
 // snake order of decreasing length, which balances them to within one column.  Then the spectra of all rows
 // sit in LDS and the two register-FFT steps run over RP rows per pass as in k_sht_inv_reg.  One 512-thread
 // workgroup per shell and CU (LDS: n_theta (2L+1) spectra + transpose buffer, 147 KB at 64 x 128, L = 32).
-#define SW_THREADS 512
 template <int EPI, int R1, int R2>
 __global__ void __launch_bounds__(SW_THREADS) k_sht_inv_wide(const double2* __restrict__ coeff, double2* __restrict__ grid,
                                                              const double* __restrict__ P, const int* __restrict__ poff,
@@ -539,31 +488,14 @@ __global__ void __launch_bounds__(SW_THREADS) k_sht_inv_wide(const double2* __re
     const int split = (int)(blockIdx.x - shell * nsplit);
     const int q = (int)(shell % Nq);
     const double2* csrc = coeff + (size_t)shell * nlm;
-    // Legendre work items (m, chunk of 32 thetas), dealt to the waves in snake order of decreasing length
-    // the wave index as a scalar: items, m and the l loop are then wave-uniform for the compiler too (scalar loop control)
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nw = blockDim.x >> 6;
+    // Legendre work items (k_sht_legendre.h): the wave index as a scalar, so that items, m and the l loop are wave-uniform for
+    // the compiler too (scalar loop control)
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nw = blockDim.x >> 6;
     const int nth = ntl >> 1;                       // theta pairs of this workgroup, first one j0
     const int j0 = split * nth;
-    const int jj = lane & 31, half_id = lane >> 5;
-    const int n_chunks = (nth + 31) >> 5;
-    // an item = (pair of orders m = 2p, 2p + 1; chunk of 32 thetas): lanes 0-31 run the recurrence of m = 2p for their theta, lanes
-    // 32-63 that of m = 2p + 1, and every lane accumulates the rows of +m AND -m (P_lm is the same for both)
-    const int n_mp = (L + 2) >> 1;
-    const int n_items = n_mp * n_chunks;
     // start values P_mm, P_m+1,m of the first item: in flight while the tables are staged
-    double pmm_n = 0.0, pm1_n = 0.0;
-    {
-        const int i = wave;
-        if (i < n_items) {
-            const int mp = i / n_chunks, ch = i - mp * n_chunks;
-            const int m = min(2 * mp + half_id, L);
-            const int j = ch * 32 + jj;
-            const int jc = j0 + (j < nth ? j : nth - 1);
-            const double* pcol = P + (size_t)(m * (L + 1) - m * (m - 1) / 2) * nt + jc;
-            pmm_n = pcol[0];
-            pm1_n = m < L ? pcol[nt] : 0.0;
-        }
-    }
+    LegendreStart ls;
+    legendre_prefetch_first(ls, P, nt, L, nth, j0, wave, tid & 63);
     if (nsplit == 1)
         for (int e = tid; e < N; e += blockDim.x) sm[e] = twN_g[e];
     for (int e = tid; e < npairs; e += blockDim.x) ABs[e] = AB[e];
@@ -593,111 +525,7 @@ __global__ void __launch_bounds__(SW_THREADS) k_sht_inv_wide(const double2* __re
     }
     __syncthreads();
     // ---- Legendre synthesis of every row: P_lm(theta) by the three-term recurrence in l (registers only)
-    for (int kk = 0;; ++kk) {
-        const int i = kk * nw + ((kk & 1) ? nw - 1 - wave : wave);
-        if (i >= n_items) break;
-        const int mp = i / n_chunks, ch = i - mp * n_chunks;
-        const int m_a = 2 * mp;                                  // the smaller order of the pair: sets the trip count of the wave
-        const bool m_ok = m_a + half_id <= L;
-        const int m = min(m_a + half_id, L);                     // this lane's order (clamped: an odd L + 1 has no partner)
-        const int j = ch * 32 + jj;
-        const bool act = (j < nth) && m_ok;
-        const int jc = j0 + (j < nth ? j : nth - 1);
-        const double x = cost[jc];
-        double p2 = pmm_n, p1 = pm1_n;
-        {   // prefetch the start values of this wave's next item
-            const int i2 = (kk + 1) * nw + (((kk + 1) & 1) ? nw - 1 - wave : wave);
-            if (i2 < n_items) {
-                const int mp2 = i2 / n_chunks, ch2 = i2 - mp2 * n_chunks;
-                const int m2 = min(2 * mp2 + half_id, L);
-                const int j2 = ch2 * 32 + jj;
-                const int jc2 = j0 + (j2 < nth ? j2 : nth - 1);
-                const double* pcol = P + (size_t)(m2 * (L + 1) - m2 * (m2 - 1) / 2) * nt + jc2;
-                pmm_n = pcol[0];
-                pm1_n = m2 < L ? pcol[nt] : 0.0;
-            }
-        }
-        const double2* cp = cl + m;                              // c_l,+m at cp[l (l + 1)]
-        const double2* cm = cl - m;                              // c_l,-m
-        const double2* abm = ABs + (m * (L + 1) - m * (m - 1) / 2) - m;   // abm[l]
-        double2 Ep, Em, Op = make_double2(0.0, 0.0), Om = make_double2(0.0, 0.0);
-        {
-            const double2 a = cp[m * (m + 1)], b = cm[m * (m + 1)];
-            Ep = make_double2(p2 * a.x, p2 * a.y);
-            Em = make_double2(p2 * b.x, p2 * b.y);
-        }
-        if (m < L) {
-            const double2 a = cp[(m + 1) * (m + 2)], b = cm[(m + 1) * (m + 2)];
-            Op = make_double2(p1 * a.x, p1 * a.y);
-            Om = make_double2(p1 * b.x, p1 * b.y);
-        }
-        // The recurrence is a dependent chain and there are only two waves per SIMD: with the operands read at the top of
-        // each iteration an LDS round trip per iteration was most of the loop.  Two operand sets, A and B, alternate; a set is
-        // requested before the other one is used (clamped indices, branch-free) and the empty asm pins it there.  The wave runs
-        // the iterations of its smaller order; a lane whose order is one larger sits out the last one when its l runs out.
-        int l = m + 2;                                           // per lane
-        const int n_it = m_a + 2 <= L ? (L - m_a - 1) >> 1 : 0;  // double steps of the wave (uniform)
-        double2 Aab0, Aab1, Acp, Aop, Acm, Aom, Bab0, Bab1, Bcp, Bop, Bcm, Bom;
-#define LEG_LOAD(S, lq_)                                             \
-        {                                                            \
-            const int q_ = max(min((lq_), L - 1), 0);                \
-            const int o_ = min((q_ + 1) * (q_ + 2), L * (L + 1));    \
-            S##ab0 = abm[q_];                                        \
-            S##ab1 = abm[q_ + 1];                                    \
-            S##cp = cp[q_ * (q_ + 1)];                               \
-            S##op = cp[o_];                                          \
-            S##cm = cm[q_ * (q_ + 1)];                               \
-            S##om = cm[o_];                                          \
-        }
-#define LEG_STEP(S)                                                         \
-        if (l + 1 <= L) {                                                   \
-            const double pa = S##ab0.x * (x * p1 - S##ab0.y * p2);          \
-            const double pb = S##ab1.x * (x * pa - S##ab1.y * p1);          \
-            Ep.x = fma(pa, S##cp.x, Ep.x); Ep.y = fma(pa, S##cp.y, Ep.y);   \
-            Op.x = fma(pb, S##op.x, Op.x); Op.y = fma(pb, S##op.y, Op.y);   \
-            Em.x = fma(pa, S##cm.x, Em.x); Em.y = fma(pa, S##cm.y, Em.y);   \
-            Om.x = fma(pb, S##om.x, Om.x); Om.y = fma(pb, S##om.y, Om.y);   \
-            p2 = pa;                                                        \
-            p1 = pb;                                                        \
-            l += 2;                                                         \
-        }
-#define LEG_PIN(S)                                                  \
-        MTIP_PIN_VGPRS4(S##ab0.x, S##ab0.y, S##ab1.x, S##ab1.y)     \
-        MTIP_PIN_VGPRS4(S##cp.x, S##cp.y, S##op.x, S##op.y)         \
-        MTIP_PIN_VGPRS4(S##cm.x, S##cm.y, S##om.x, S##om.y)
-        LEG_LOAD(A, l)
-        for (int it = 0; it < n_it;) {
-            LEG_LOAD(B, l + 2)
-            LEG_STEP(A)
-            LEG_PIN(B)
-            if (++it >= n_it) break;
-            LEG_LOAD(A, l + 2)
-            LEG_STEP(B)
-            LEG_PIN(A)
-            ++it;
-        }
-#undef LEG_LOAD
-#undef LEG_STEP
-#undef LEG_PIN
-        if (l <= L) {
-            const double2 ab0 = abm[l];
-            const double2 a = cp[l * (l + 1)], b = cm[l * (l + 1)];
-            const double pa = ab0.x * (x * p1 - ab0.y * p2);
-            Ep.x = fma(pa, a.x, Ep.x); Ep.y = fma(pa, a.y, Ep.y);
-            Em.x = fma(pa, b.x, Em.x); Em.y = fma(pa, b.y, Em.y);
-        }
-        if (act) {
-            double2* g_p = Gs + (size_t)(2 * j) * nm + L + m;
-            g_p[0] = make_double2(Ep.x + Op.x, Ep.y + Op.y);
-            g_p[nm] = make_double2(Ep.x - Op.x, Ep.y - Op.y);
-            if (m > 0) {
-                const double sg = (m & 1) ? -1.0 : 1.0;            // Y_l,-m = (-1)^m conj(Y_lm)
-                double2* g_m = Gs + (size_t)(2 * j) * nm + L - m;
-                g_m[0] = make_double2(sg * (Em.x + Om.x), sg * (Em.y + Om.y));
-                g_m[nm] = make_double2(sg * (Em.x - Om.x), sg * (Em.y - Om.y));
-            }
-        }
-    }
+    legendre_synthesis_rows(ls, Gs, cl, ABs, P, cost, nt, L, nth, j0, wave, nw, tid & 63);
     __syncthreads();
     const int n_pass = ntl / RP;
     for (int pass = 0; pass < n_pass; ++pass) {
@@ -809,23 +637,6 @@ __global__ void __launch_bounds__(SW_THREADS) k_sht_inv_wide(const double2* __re
 }
 
 // ------------------------------------------------------------------------------------------------------
-static bool reg_radices(int np, int* r1, int* r2) {
-    switch (np) {
-        case 16: *r1 = 4; *r2 = 4; return true;
-        case 32: *r1 = 4; *r2 = 8; return true;
-        case 64: *r1 = 8; *r2 = 8; return true;
-        case 128: *r1 = 8; *r2 = 16; return true;
-        case 256: *r1 = 16; *r2 = 16; return true;
-        default: return false;
-    }
-}
-
-static int largest_even_divisor_le(int nt, int cap) {
-    for (int v = std::min(nt, cap) & ~1; v >= 2; v -= 2)
-        if (nt % v == 0) return v;
-    return 0;
-}
-
 bool sht_inverse_fuses_real_update(const mtip_ctx* c);
 
 bool sht_reg_supported(const mtip_ctx* c) {

@@ -59,7 +59,7 @@ void mtip_destroy(mtip_ctx* c) {
                     c->d_err_wt, c->d_rho, c->d_Fp, c->d_slot, c->d_best_err, c->d_last_err, c->d_op_err, c->d_gq, c->d_polar_dbg, c->d_so3_d, c->d_so3_tw, c->d_so3_T, c->d_so3_S, c->d_so3_P, c->d_so3_D, c->d_so3_C, c->d_err_hist, c->d_main_hist,
                     c->d_deg2_hist, c->d_F, c->d_T1, c->d_T2, c->d_fixed, c->d_g, c->d_c[0], c->d_c[1], c->d_c[2],
                     c->d_c[3], c->d_c[4], c->d_c[5], c->d_X, c->d_Vr, c->d_U, c->d_partial, c->d_minmax, c->d_Bl,
-                    c->d_rp_DV, c->d_rp_Vt, c->d_rp_slots};
+                    c->d_rp_DV, c->d_rp_Vt, c->d_rp_slots, c->d_c0n};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : c->prof_events) (void)hipEventDestroy(e);
@@ -132,6 +132,7 @@ mtip_ctx* mtip_create(const mtip_cfg* cfg, int device) {
     if (const char* e = std::getenv("MTIP_SHT_FWD_PAIR")) c->sht_fwd_pair = std::atoi(e) != 0;
     if (const char* e = std::getenv("MTIP_FUSE_REAL")) c->fuse_real_update = std::atoi(e) != 0;
     if (const char* e = std::getenv("MTIP_SHT_WIDE")) c->sht_wide = std::atoi(e) != 0;
+    if (const char* e = std::getenv("MTIP_SHT_CHAIN")) c->sht_chain = std::atoi(e) != 0;
     if (const char* e = std::getenv("MTIP_JAC_RESIDENT")) c->jac_resident = std::atoi(e) != 0;
     if (const char* e = std::getenv("MTIP_JAC_TG")) c->jac_tg = std::atoi(e) == 8 ? 8 : 16;
     if (rc == MTIP_OK) rc = build_hankel_tiles(c);
@@ -200,6 +201,7 @@ mtip_ctx* mtip_create(const mtip_cfg* cfg, int device) {
     A(dev_alloc(c, &c->d_fixed, (size_t)B * c->G));
     A(dev_alloc(c, &c->d_g, (size_t)B * N * c->nt * c->nm));
     for (int i = 0; i < 6; ++i) A(dev_alloc(c, &c->d_c[i], (size_t)B * c->C));
+    A(dev_alloc(c, &c->d_c0n, (size_t)B * c->C));
     A(dev_alloc(c, &c->d_X, (size_t)B * c->xtot));
     A(dev_alloc(c, &c->d_Vr, (size_t)B * c->utot));
     A(dev_alloc(c, &c->d_U, (size_t)B * c->xtot));
@@ -525,13 +527,22 @@ static int enqueue_step(mtip_ctx* c, int method, int ft_stab, double beta) {
     const bool fxs = (method == MTIP_HIO || method == MTIP_ER);
     double2 **cc = c->d_c;
     InvEpilogue store;
+    // Chained kernels (k_sht_chain.hip): in the fused step every inverse SHT hands its shell to the forward SHT that reads the
+    // same grid next -- F -> SHT(|F|^2), F' -> SHT(F'), rho_new -> SHT(rho_new) of the NEXT step (kept in d_c0n, valid while
+    // nothing but k_finish_step's rotation touches the current density)
+    const bool one_pass_diff = c->cfg.fused && ft_stab && hankel_has_difference(c) && sht_inverse_fuses_real_update(c);
+    const bool chain = c->cfg.fused && sht_chain_supported(c);
     // 1  F = FT(rho_cur)
-    launch_sht_forward(c, c->d_rho, cc[0], MTIP_PRE_NONE, SL_CUR);
-    launch_hankel(c, cc[0], cc[1], 0);
-    launch_sht_inverse(c, cc[1], c->d_F, store);
+    const double2* c0 = cc[0];
+    if (chain && c->c0n_valid) c0 = c->d_c0n;
+    else launch_sht_forward(c, c->d_rho, cc[0], MTIP_PRE_NONE, SL_CUR);
+    c->c0n_valid = false;
+    launch_hankel(c, c0, cc[1], 0);
+    if (chain && fxs) launch_sht_chain(c, cc[1], c->d_F, store, MTIP_PRE_SQUARE, cc[2]);
+    else launch_sht_inverse(c, cc[1], c->d_F, store);
     if (fxs) {
         // 2-3 I_lm = SHT(|F|^2);  4-5 projection;  6-7 I' = iSHT, F' = F sqrt(I'/I) -> Fp[out]
-        launch_sht_forward(c, c->d_F, cc[2], MTIP_PRE_SQUARE);
+        if (!chain) launch_sht_forward(c, c->d_F, cc[2], MTIP_PRE_SQUARE);
         if (c->deg2_enable) launch_deg2_metric(c, cc[2], c->d_deg2_hist + (size_t)c->n_steps_done * c->B * (c->L + 1));
         if (c->im_which) {
             const int rm = launch_invariant_metrics(c, cc[2], c->n_steps_done);
@@ -543,16 +554,16 @@ static int enqueue_step(mtip_ctx* c, int method, int ft_stab, double beta) {
         mod.mode = EPI_MODULUS;
         mod.F = c->d_F;
         mod.out_slot = SL_OUT;
-        launch_sht_inverse(c, cc[2], c->d_Fp, mod);
+        if (chain) launch_sht_chain(c, cc[2], c->d_Fp, mod, MTIP_PRE_NONE, cc[4]);
+        else launch_sht_inverse(c, cc[2], c->d_Fp, mod);
         launch_reciprocal_l2_metric(c, c->d_F, c->d_Fp, c->n_steps_done);     // (non-default metric; no launch unless enabled)
     } else {
         launch_modulus_fixed_slots(c, c->d_F);
     }
     // 9  rho' = IFT(F')
-    launch_sht_forward(c, c->d_Fp, cc[4], MTIP_PRE_NONE, SL_OUT);
+    if (!(chain && fxs)) launch_sht_forward(c, c->d_Fp, cc[4], MTIP_PRE_NONE, SL_OUT);
     // rho'' = rho + IFT(F' - F) on shells > 0, IFT(F') on shell 0, using SHT(F) == Hankel(SHT(rho)) = cc[1]: with the
     // workgroup-tiled Hankel kernel the difference is taken on load and shell 0 corrected in the same pass
-    const bool one_pass_diff = c->cfg.fused && ft_stab && hankel_has_difference(c) && sht_inverse_fuses_real_update(c);
     if (one_pass_diff) {
         ProfScope ps(c, "hankel");
         launch_hankel_mfma_sub(c, cc[4], cc[1], cc[5], 1);
@@ -579,8 +590,15 @@ static int enqueue_step(mtip_ctx* c, int method, int ft_stab, double beta) {
             ru.real.err_use_mask = c->err_use_mask;
             ru.real.add_prev = 1;
             ru.real.beta = beta;
-            launch_sht_inverse(c, cc[5], nullptr, ru);
-            launch_finish_step(c, c->n_steps_done, sht_inverse_real_update_blocks(c));
+            if (chain && one_pass_diff) {
+                // the new density goes to slot SL_OUT, which k_finish_step makes the current one: its SHT is the next step's
+                launch_sht_chain(c, cc[5], nullptr, ru, MTIP_PRE_NONE, c->d_c0n);
+                launch_finish_step(c, c->n_steps_done, c->N);
+                c->c0n_valid = true;
+            } else {
+                launch_sht_inverse(c, cc[5], nullptr, ru);
+                launch_finish_step(c, c->n_steps_done, sht_inverse_real_update_blocks(c));
+            }
             c->n_steps_done += 1;
             return MTIP_OK;
         }
@@ -718,6 +736,7 @@ int mtip_init_state(mtip_ctx* c) {
     MTIP_HIP_CHECK(c, mtip_copy(c, c->d_last_err, inf.data(), c->B * sizeof(double), hipMemcpyHostToDevice));
     c->n_steps_done = 0;
     c->fixed_valid = false;
+    c->c0n_valid = false;
     c->vr_valid = false;                 // a fresh reconstruction does not warm-start its polar factors
     c->vr_kind = 0;
     c->proj_calls = 0;
@@ -817,6 +836,7 @@ int mtip_select_best_where(mtip_ctx* c, const uint8_t* select) {
     }
     MTIP_HIP_CHECK(c, mtip_copy(c, c->d_slot, slots.data(), slots.size() * sizeof(int), hipMemcpyHostToDevice));
     c->fixed_valid = false;
+    c->c0n_valid = false;                // the current density is another one now
     return MTIP_OK;
 }
 
@@ -888,6 +908,7 @@ int mtip_refresh_reciprocal_density(mtip_ctx* c) {
     MTIP_HIP_CHECK(c, hipStreamSynchronize(c->stream));
     MTIP_HIP_CHECK(c, mtip_copy(c, slots.data(), c->d_slot, slots.size() * sizeof(int), hipMemcpyDeviceToHost));
     InvEpilogue store;
+    c->c0n_valid = false;                // the real half of the latest pair becomes FT(rho)
     ft_pipeline(c, c->d_rho, SL_CUR, c->d_T1, 0, MTIP_PRE_NONE, store, c->d_c[0], c->d_c[1]);
     for (int b = 0; b < c->B; ++b) {
         int* s = slots.data() + (size_t)b * SL_N;
@@ -961,6 +982,26 @@ int mtip_op_sht_inverse(mtip_ctx* c, const mtip_cdouble* coeff, mtip_cdouble* gr
     SYNC();
     D2H(grid, c->d_T1, (size_t)c->B * c->G * sizeof(double2));
     return post_launch(c, "mtip_op_sht_inverse");
+}
+
+int mtip_op_sht_inverse_forward(mtip_ctx* c, const mtip_cdouble* coeff, mtip_cdouble* grid, mtip_cdouble* coeff_out, int prologue) {
+    CTX_CHECK(c);
+    if (!c->have_angular) FAIL(c, MTIP_ESTATE, "mtip_set_angular_grid has not been called");
+    if (!grid || !coeff || !coeff_out || prologue < 0 || prologue > 1) FAIL(c, MTIP_EINVAL, "null buffer / bad prologue");
+    (void)hipSetDevice(c->device);
+    SYNC();
+    H2D(c->d_c[0], coeff, (size_t)c->B * c->C * sizeof(double2));
+    InvEpilogue store;
+    if (sht_chain_supported(c)) {
+        launch_sht_chain(c, c->d_c[0], c->d_T1, store, prologue, c->d_c[1]);
+    } else {
+        launch_sht_inverse(c, c->d_c[0], c->d_T1, store);
+        launch_sht_forward(c, c->d_T1, c->d_c[1], prologue);
+    }
+    SYNC();
+    D2H(grid, c->d_T1, (size_t)c->B * c->G * sizeof(double2));
+    D2H(coeff_out, c->d_c[1], (size_t)c->B * c->C * sizeof(double2));
+    return post_launch(c, "mtip_op_sht_inverse_forward");
 }
 
 int mtip_op_hankel(mtip_ctx* c, const mtip_cdouble* in, mtip_cdouble* out, int inverse) {

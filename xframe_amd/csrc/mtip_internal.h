@@ -167,6 +167,9 @@ struct mtip_ctx {
     long long* d_polar_dbg = nullptr;                 // (B, L+1, 32) phase / round timers of k_rproj, allocated by mtip_debug_polar_timing
     int jac_tg = 16;                                  // env MTIP_JAC_TG=8|16: lanes per Jacobi column pair
     bool sht_fwd_pair = true;                         // env MTIP_SHT_FWD_PAIR=0: k_sht_fwd_reg (table loads inside the accumulation loop)
+    bool sht_chain = true;                            // env MTIP_SHT_CHAIN=0: separate inverse / forward SHT kernels in the fused step (k_sht_chain.hip)
+    double2* d_c0n = nullptr;                         // (B, C) SHT of the current density, written by the chained last kernel of a step
+    bool c0n_valid = false;                           // d_c0n holds SHT(rho[SL_CUR]) of every restart
     void* d_htiles32 = nullptr;                       // workgroup tiles (order, first column) of k_hankel_tile
     int n_htiles32 = 0, htile_ct = 5;                 // 16-column MFMA tiles per workgroup
     double fwd_scale = 0, inv_scale = 0;
@@ -267,6 +270,10 @@ bool sht_inverse_fuses_real_update(const mtip_ctx* c);    // EPI_REAL_UPDATE / c
 int sht_inverse_real_update_blocks(const mtip_ctx* c);   // error partial sums per restart written by that epilogue
 void launch_sht_forward_reg(mtip_ctx* c, const double2* grid, double2* coeff, int prologue, int in_slot);
 void launch_sht_inverse_reg(mtip_ctx* c, const double2* coeff, double2* grid, const InvEpilogue& epi);
+// k_sht_chain.hip: grid = epilogue(iSHT(coeff)) and coeff_out = SHT(prologue(grid)) in one kernel (EPI_STORE with
+// MTIP_PRE_NONE / MTIP_PRE_SQUARE, EPI_MODULUS, EPI_REAL_UPDATE without coeff_sub)
+bool sht_chain_supported(const mtip_ctx* c);
+void launch_sht_chain(mtip_ctx* c, const double2* coeff, double2* grid, const InvEpilogue& epi, int prologue, double2* coeff_out);
 // Hankel
 void launch_hankel(mtip_ctx* c, const double2* in, double2* out, int inverse);
 bool hankel_has_difference(const mtip_ctx* c);       // launch_hankel_mfma_sub is available (workgroup-tiled kernel)

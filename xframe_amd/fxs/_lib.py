@@ -73,6 +73,7 @@ _SIGNATURES = {
     'mtip_last_deg2_invariant': (C.c_int, [c_void, C.c_int, c_void]),
     'mtip_op_sht_forward': (C.c_int, [c_void, c_void, c_void, C.c_int]),
     'mtip_op_sht_inverse': (C.c_int, [c_void, c_void, c_void]),
+    'mtip_op_sht_inverse_forward': (C.c_int, [c_void, c_void, c_void, c_void, C.c_int]),
     'mtip_op_hankel': (C.c_int, [c_void, c_void, c_void, C.c_int]),
     'mtip_op_fourier_transform': (C.c_int, [c_void, c_void, c_void, C.c_int]),
     'mtip_op_project_coefficients': (C.c_int, [c_void, c_void, c_void]),

@@ -215,6 +215,14 @@ class Engine:
         self._ck(self.lib.mtip_op_sht_inverse(self.ctx, _lib.ptr(c), _lib.ptr(out)))
         return out
 
+    def sht_inverse_forward(self, coeff, prologue=0):
+        """grid = iSHT(coeff) and SHT(grid) (prologue 0) / SHT(|grid|^2) (prologue 1) in one kernel per shell."""
+        c = self._bcoef(coeff)
+        grid = np.empty((self.B,) + self.shape, complex)
+        out = np.empty((self.B, self.N, self.nlm), complex)
+        self._ck(self.lib.mtip_op_sht_inverse_forward(self.ctx, _lib.ptr(c), _lib.ptr(grid), _lib.ptr(out), prologue))
+        return grid, out
+
     def hankel(self, coeff, inverse=False):
         c = self._bcoef(coeff)
         out = np.empty_like(c)
