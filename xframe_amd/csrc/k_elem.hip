@@ -352,6 +352,41 @@ void launch_sw_threshold(mtip_ctx* c, const double* tmp_real, double threshold, 
                        (const int*)c->d_slot, (const double*)c->d_last_err, threshold, error_limit, c->B, (long long)c->G);
     hipLaunchKernelGGL(k_sw_commit, dim3((unsigned)div_up(c->B, 64)), dim3(64), 0, c->stream, c->d_slot,
                        (const double*)c->d_last_err, error_limit, c->B);
+    launch_pack_masks(c);
+}
+
+// ---- support masks packed for the chained SHT kernel: its step-2 thread (row, n2) owns the points R2 n1 + n2 of its row and
+//      reads their support / initial-support bits with ONE 16-bit load (16 byte loads and registers otherwise)
+__global__ void __launch_bounds__(256) k_pack_masks(const uint8_t* __restrict__ sup, const uint8_t* __restrict__ S0,
+                                                    uint16_t* __restrict__ mk, long long G, long long n_words, int R1, int R2) {
+    const long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x;      // word (slot * B + b, row of the grid, n2)
+    if (w >= n_words) return;
+    const int n2 = (int)(w % R2);
+    const long long row = w / R2;                                              // global row over (slot, b, shell, theta)
+    const long long Nrow = (long long)R1 * R2;
+    const uint8_t* s = sup + row * Nrow + n2;
+    const uint8_t* s0 = S0 + (row * Nrow) % G + n2;
+    unsigned v = 0;
+    for (int n1 = 0; n1 < R1; ++n1) {
+        if (s[R2 * n1]) v |= 1u << n1;
+        if (s0[R2 * n1]) v |= 1u << (8 + n1);
+    }
+    mk[w] = (uint16_t)v;
+}
+
+void launch_pack_masks(mtip_ctx* c) {
+    if (!c->d_mk) return;
+    int r1 = 8, r2 = c->np / 8;
+    switch (c->np) {                                                           // the register-FFT radix pairs (k_sht_common.h)
+        case 16: r1 = 4; r2 = 4; break;
+        case 32: r1 = 4; r2 = 8; break;
+        case 64: r1 = 8; r2 = 8; break;
+        case 128: r1 = 8; r2 = 16; break;
+        default: return;                                                       // no chained kernel for this grid
+    }
+    const long long n_words = 3LL * c->B * (long long)c->G / r1;
+    hipLaunchKernelGGL(k_pack_masks, dim3((unsigned)div_up(n_words, 256)), dim3(256), 0, c->stream, (const uint8_t*)c->d_sup,
+                       (const uint8_t*)c->d_S0, c->d_mk, (long long)c->G, n_words, r1, r2);
 }
 
 // ---- generic y = M x (GPU-process boundary example of the reference docs/tests) -------------------------

@@ -30,6 +30,7 @@ struct ChainArgs {
     const double2* twN_g;
     const double2* Fin;
     const int* slot;
+    const uint16_t* mk;                 // packed masks (3, B, Nq, nt, R2): bit n1 = support, bit 8 + n1 = initial support of point R2 n1 + n2
     RealEpi re;
     int npairs, nt, L, RP, Nq, which, B;
     // forward half
@@ -38,13 +39,13 @@ struct ChainArgs {
     const int* lmtab;
     const double* gw;
     double norm;
-    int gsz, thg;                       // threads per accumulation group (a power of two), theta pairs of a pass per group
+    int gsz, thg;                       // threads per accumulation group (a power of two), theta pairs of the shell per group
 };
 
 // EPI: epilogue of the inverse half (EPI_STORE / EPI_MODULUS / EPI_REAL_UPDATE); PRE: prologue of the forward half on the value
 // just written (MTIP_PRE_NONE / MTIP_PRE_SQUARE); MAXI: (l, m) pairs per thread of an accumulation group; THG > 0: theta pairs
-// per pass and group at compile time, their table rows prefetched into registers at the top of the pass; THG == 0: run-time
-// count, table values loaded where they are used (small grids)
+// per group at compile time, their table rows requested together into registers; THG == 0: run-time count, table values
+// loaded where they are used (small grids)
 template <int EPI, int PRE, int R1, int R2, int MAXI, int THG>
 __global__ void __launch_bounds__(SW_THREADS) k_sht_chain(ChainArgs a) {
     constexpr int N = R1 * R2;
@@ -74,8 +75,7 @@ __global__ void __launch_bounds__(SW_THREADS) k_sht_chain(ChainArgs a) {
     double2* gdst = a.grid + (size_t)dst_shell * nt * N;
     const double2* fsrc = a.Fin ? a.Fin + (size_t)shell * nt * N : nullptr;
     const double2* rprev = nullptr;
-    const uint8_t* rsup = nullptr;
-    const uint8_t* rS0 = nullptr;
+    const uint16_t* rmk = nullptr;
     double err_num = 0.0, err_den = 0.0;
     if (EPI == EPI_REAL_UPDATE) {
         const int bb = (int)(shell / Nq);
@@ -83,25 +83,17 @@ __global__ void __launch_bounds__(SW_THREADS) k_sht_chain(ChainArgs a) {
         const size_t gsh = (size_t)nt * N;
         rprev = a.re.prev + ((size_t)sl[SL_CUR] * B * Nq + shell) * gsh;
         gdst = a.re.out + ((size_t)sl[SL_OUT] * B * Nq + shell) * gsh;
-        rsup = a.re.sup + ((size_t)sl[SL_SUP] * B * Nq + shell) * gsh;
-        rS0 = a.re.S0 + (size_t)q * gsh;
+        rmk = a.mk + ((size_t)sl[SL_SUP] * B * Nq + shell) * nt * R2;
     }
-    // forward half: accumulation group g owns theta pairs [g thg, (g + 1) thg) of every pass, thread t of it the pairs t + u gsz
+    // forward half: its (theta, m) panel rows overwrite the spectra rows a pass has consumed (same row order: 2j = even part,
+    // 2j+1 = odd part of theta pair j), and ONE Legendre-sum phase follows the last pass: accumulation group g owns theta pairs
+    // [g thg, (g + 1) thg) of the shell, thread t of it the (l, m) pairs t + u gsz.  (Sums per pass were built first: table
+    // rows and accumulators live across the 16-point FFTs spill.)
     const int gsz = a.gsz;
     const int thg = THG > 0 ? THG : a.thg;
     const int TH = RP >> 1;
-    const int grp = tid / gsz, tg = tid - grp * gsz;
-    int my_i[MAXI], my_l[MAXI], my_m[MAXI];
-    double2 accp[MAXI], accm[MAXI];
-#pragma unroll
-    for (int u = 0; u < MAXI; ++u) {
-        my_i[u] = min(tg + u * gsz, npairs - 1);    // clamped: the table loads stay branch-free
-        const int lm = a.lmtab[my_i[u]];
-        my_l[u] = lm & 0xff;
-        my_m[u] = lm >> 8;
-        accp[u] = make_double2(0.0, 0.0);
-        accm[u] = make_double2(0.0, 0.0);
-    }
+    const int grp = __builtin_amdgcn_readfirstlane(tid / gsz);      // wave-uniform (gsz >= 64): table rows through scalar bases
+    const int tg = tid - grp * gsz;
     __syncthreads();
     // ---- Legendre synthesis of every row (k_sht_legendre.h)
     legendre_synthesis_rows(ls, Gs, cl, ABs, a.P, a.cost, nt, L, nt >> 1, 0, wave, nw, tid & 63);
@@ -110,7 +102,7 @@ __global__ void __launch_bounds__(SW_THREADS) k_sht_chain(ChainArgs a) {
     for (int pass = 0; pass < n_pass; ++pass) {
         // epilogue operands of this thread's step-2 outputs: requested now, they arrive behind step 1
         double2 pre[(EPI == EPI_MODULUS || EPI == EPI_REAL_UPDATE) ? R1 : 1];
-        uint8_t pre_s[EPI == EPI_REAL_UPDATE ? R1 : 1], pre_0[EPI == EPI_REAL_UPDATE ? R1 : 1];
+        unsigned pre_m = 0;                             // support / initial-support bits of this thread's R1 points (one load)
         if ((EPI == EPI_MODULUS || EPI == EPI_REAL_UPDATE) && tid < RP * R2) {
             const int r = tid / R2, n2 = tid - r * R2;
             const int rr = pass * RP + r;
@@ -120,23 +112,9 @@ __global__ void __launch_bounds__(SW_THREADS) k_sht_chain(ChainArgs a) {
             for (int n1 = 0; n1 < R1; ++n1) {
                 const size_t o = (size_t)row * N + R2 * n1 + n2;
                 if (EPI == EPI_MODULUS) pre[n1] = fsrc[o];
-                if (EPI == EPI_REAL_UPDATE) {
-                    pre[n1] = rprev[o];
-                    pre_s[n1] = rsup[o];
-                    pre_0[n1] = a.re.err_use_mask ? rS0[o] : (uint8_t)1;
-                }
+                if (EPI == EPI_REAL_UPDATE) pre[n1] = rprev[o];
             }
-        }
-        // the forward half's table rows of this pass: they arrive while the FFT steps run
-        double tab[MAXI][THG > 0 ? THG : 1];
-        if (THG > 0) {
-#pragma unroll
-            for (int u = 0; u < MAXI; ++u)
-#pragma unroll
-                for (int jj = 0; jj < (THG > 0 ? THG : 1); ++jj) {
-                    const double* row = a.PT + (size_t)(pass * TH + grp * THG + jj) * npairs;
-                    tab[u][jj] = row[(unsigned)my_i[u]];
-                }
+            if (EPI == EPI_REAL_UPDATE) pre_m = rmk[row * R2 + n2];
         }
         // ---- step 1: inverse R2-point FFTs over k2 of the zero padded spectrum, twiddle, transpose store
         if (tid < RP * R1) {
@@ -194,8 +172,8 @@ __global__ void __launch_bounds__(SW_THREADS) k_sht_chain(ChainArgs a) {
                     const double2 pv = pre[n1];
                     const double2 w = (a.re.add_prev && q > 0) ? cadd(v, pv) : v;
                     double2 Pj;
-                    v = real_update_point(a.re.rp, a.re.method, a.re.beta, w, pv, pre_s[n1] != 0, Pj);
-                    if (pre_0[n1] != 0) {                            // l2_projection_diff, fxs_IO_methods.py:97-128
+                    v = real_update_point(a.re.rp, a.re.method, a.re.beta, w, pv, ((pre_m >> n1) & 1u) != 0, Pj);
+                    if (!a.re.err_use_mask || ((pre_m >> (8 + n1)) & 1u)) {   // l2_projection_diff, fxs_IO_methods.py:97-128
                         const double wg = a.re.wr[q] * a.re.wt[row];
                         const double dx = w.x - Pj.x, dy = w.y - Pj.y;
                         err_num = fma(wg, dx * dx + dy * dy, err_num);
@@ -222,20 +200,18 @@ __global__ void __launch_bounds__(SW_THREADS) k_sht_chain(ChainArgs a) {
             for (int k1 = 0; k1 < R1; ++k1) ar[k1 * AS] = cmul(vv[k1], twN[n2 * k1]);
         }
         __syncthreads();
-        // ---- forward phase 2: R2-point FFTs over n2; keep |m| <= L, Gauss weight
-        double2 uv[R2];
+        // ---- forward phase 2: R2-point FFTs over n2; keep |m| <= L, Gauss weight; the panel rows go where this pass's
+        //      spectra were (consumed by step 1)
         const bool actf = tid < RP * R1;
         const int r2 = tid / R1, kf = tid - r2 * R1;
         if (actf) {
+            double2 uv[R2];
             const double2* ar = Bm + (size_t)(r2 * R1 + kf) * AS;
 #pragma unroll
             for (int qq = 0; qq < R2; ++qq) uv[qq] = ar[qq];
-        }
-        __syncthreads();                                // the transpose buffer is dead: the panel overwrites it
-        if (actf) {
             SmallFFT<R2, false>::run(uv);
             const double sc = a.gw[pass * TH + (r2 >> 1)] * a.norm;
-            double2* gr = Bm + (size_t)r2 * GSR + L;
+            double2* gr = Gs + (size_t)(pass * RP + r2) * nm + L;
 #pragma unroll
             for (int k2 = 0; k2 < R2; ++k2) {
                 const int k = kf + R1 * k2;
@@ -243,43 +219,9 @@ __global__ void __launch_bounds__(SW_THREADS) k_sht_chain(ChainArgs a) {
                 else if (k >= N - L) gr[k - N] = cscale(uv[k2], sc);
             }
         }
-        __syncthreads();
-        // ---- Legendre sums (panel rows 2j = even part, 2j+1 = odd part of theta pair j)
-#pragma unroll
-        for (int u = 0; u < MAXI; ++u) {
-            const int l = my_l[u], m = my_m[u];
-            const double2* srcp = Bm + (size_t)(((l + m) & 1) + 2 * grp * thg) * GSR + L + m;
-            const double2* srcm = srcp - 2 * m;
-            double2 ap = accp[u], am = accm[u];
-            if (THG > 0) {
-#pragma unroll
-                for (int jj = 0; jj < (THG > 0 ? THG : 1); ++jj) {
-                    const double p = tab[u][jj];
-                    const double2 vp = srcp[2 * jj * GSR];
-                    const double2 vm = srcm[2 * jj * GSR];
-                    ap.x = fma(p, vp.x, ap.x);
-                    ap.y = fma(p, vp.y, ap.y);
-                    am.x = fma(p, vm.x, am.x);
-                    am.y = fma(p, vm.y, am.y);
-                }
-            } else {
-                const double* pt = a.PT + (size_t)(pass * TH + grp * thg) * npairs + my_i[u];
-                for (int jj = 0; jj < thg; ++jj) {
-                    const double p = pt[(size_t)jj * npairs];
-                    const double2 vp = srcp[2 * jj * GSR];
-                    const double2 vm = srcm[2 * jj * GSR];
-                    ap.x = fma(p, vp.x, ap.x);
-                    ap.y = fma(p, vp.y, ap.y);
-                    am.x = fma(p, vm.x, am.x);
-                    am.y = fma(p, vm.y, am.y);
-                }
-            }
-            accp[u] = ap;
-            accm[u] = am;
-        }
-        __syncthreads();                                // the next pass rewrites Bm
+        __syncthreads();                                // the next pass rewrites Bm; the last one completes the panel
     }
-    // every LDS block is dead now: per-shell error sums go to the head, the groups' partial coefficients behind them
+    // the twiddles are dead: the per-shell error sums go to the head of the LDS block
     if (EPI == EPI_REAL_UPDATE) {
         // fixed order (bitwise reproducible): wave butterflies, then the waves
         for (int o = 32; o > 0; o >>= 1) {
@@ -292,7 +234,69 @@ __global__ void __launch_bounds__(SW_THREADS) k_sht_chain(ChainArgs a) {
             red[2 * (tid >> 6) + 1] = err_den;
         }
     }
-    double2* racc = sm + N;                             // (groups, MAXI, 2, gsz)
+    // ---- Legendre sums over the whole panel: c_lm += P_lm(theta_j) E/O[j][m], table rows of the group requested together
+    double2 accp[MAXI], accm[MAXI];
+    {
+        double tab[MAXI][THG > 0 ? THG : 1];
+        if (THG > 0) {
+#pragma unroll
+            for (int u = 0; u < MAXI; ++u)
+#pragma unroll
+                for (int jj = 0; jj < (THG > 0 ? THG : 1); ++jj) {
+                    const double* row = a.PT + (size_t)(grp * THG + jj) * npairs;
+                    tab[u][jj] = row[(unsigned)min(tg + u * gsz, npairs - 1)];       // clamped: branch-free loads
+                }
+        }
+        const double2 *srcp[MAXI], *srcm[MAXI];
+#pragma unroll
+        for (int u = 0; u < MAXI; ++u) {
+            const int lm = a.lmtab[min(tg + u * gsz, npairs - 1)];
+            const int l = lm & 0xff, m = lm >> 8;
+            srcp[u] = Gs + (size_t)(((l + m) & 1) + 2 * grp * thg) * nm + L + m;
+            srcm[u] = srcp[u] - 2 * m;
+            accp[u] = make_double2(0.0, 0.0);
+            accm[u] = make_double2(0.0, 0.0);
+        }
+        if (THG > 0) {
+            // four theta pairs at a time, fenced: left alone the scheduler requests every panel value of the phase first (96 LDS
+            // reads in flight next to the table registers) and spills
+#pragma unroll
+            for (int jc = 0; jc < (THG > 0 ? THG : 1); jc += 4) {
+#pragma unroll
+                for (int u = 0; u < MAXI; ++u)
+#pragma unroll
+                    for (int jj = jc; jj < jc + 4 && jj < (THG > 0 ? THG : 1); ++jj) {
+                        const double p = tab[u][jj];
+                        const double2 vp = srcp[u][2 * jj * nm];
+                        const double2 vm = srcm[u][2 * jj * nm];
+                        accp[u].x = fma(p, vp.x, accp[u].x);
+                        accp[u].y = fma(p, vp.y, accp[u].y);
+                        accm[u].x = fma(p, vm.x, accm[u].x);
+                        accm[u].y = fma(p, vm.y, accm[u].y);
+                    }
+                asm volatile("" ::: "memory");
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < MAXI; ++u) {
+                const double* pt = a.PT + (size_t)(grp * thg) * npairs + min(tg + u * gsz, npairs - 1);
+                double2 ap = accp[u], am = accm[u];
+                for (int jj = 0; jj < thg; ++jj) {
+                    const double p = pt[(size_t)jj * npairs];
+                    const double2 vp = srcp[u][2 * jj * nm];
+                    const double2 vm = srcm[u][2 * jj * nm];
+                    ap.x = fma(p, vp.x, ap.x);
+                    ap.y = fma(p, vp.y, ap.y);
+                    am.x = fma(p, vm.x, am.x);
+                    am.y = fma(p, vm.y, am.y);
+                }
+                accp[u] = ap;
+                accm[u] = am;
+            }
+        }
+    }
+    // the groups' partial coefficients go where the transpose buffer was (other waves may still be reading the panel)
+    double2* racc = Bm;                                 // (groups, MAXI, 2, gsz)
 #pragma unroll
     for (int u = 0; u < MAXI; ++u) {
         racc[(size_t)((grp * MAXI + u) * 2) * gsz + tg] = accp[u];
@@ -345,25 +349,25 @@ static ChainGeom chain_geom(const mtip_ctx* c) {
     while (g.rp >= 2 && (fixed + std::max((size_t)c->nlm, (size_t)g.rp * g.r1 * (g.r2 + 1))) * sizeof(double2) > 158 * 1024)
         g.rp = largest_even_divisor_le(c->nt, g.rp - 2);
     if (g.rp < 2) return g;
-    const int TH = g.rp / 2;
-    // accumulation groups: the smallest power-of-two group whose threads hold <= 3 (l, m) pairs each and whose count divides
-    // the theta pairs of a pass
+    const int TP = c->nt / 2;                       // theta pairs of a shell
+    // accumulation groups of the Legendre-sum phase: the smallest power-of-two group whose threads hold <= 3 (l, m) pairs each
+    // and whose count divides the theta pairs
     for (int gsz = 64; gsz <= SW_THREADS; gsz *= 2) {
         const int ngrp = SW_THREADS / gsz;
-        if (TH % ngrp != 0) continue;
+        if (TP % ngrp != 0) continue;
         const int maxi = div_up(c->npairs, gsz);
         if (maxi > 3) continue;
         g.gsz = gsz;
-        g.thg = TH / ngrp;
+        g.thg = TP / ngrp;
         // the instantiation launch_chain_r picks: table rows in registers for the 128-point grids, else the run-time variants
-        g.reg_tab = c->np == 128 && g.thg == 8 && maxi >= 2;
+        g.reg_tab = c->np == 128 && g.thg == 16 && maxi >= 2;
         g.maxi = g.reg_tab ? maxi : (maxi == 1 ? 1 : 3);
         break;
     }
     if (g.gsz == 0) return g;
-    const size_t body = fixed + std::max((size_t)c->nlm, (size_t)g.rp * g.r1 * (g.r2 + 1));
-    const size_t tail = (size_t)c->np + (size_t)SW_THREADS * g.maxi * 2;
-    g.lds = std::max(body, tail) * sizeof(double2);
+    // transpose buffer / panel staging aliases the coefficient block; the groups' partial sums land there at the end
+    const size_t un = std::max(std::max((size_t)c->nlm, (size_t)g.rp * g.r1 * (g.r2 + 1)), (size_t)SW_THREADS * g.maxi * 2);
+    g.lds = (fixed + un) * sizeof(double2);
     g.ok = g.lds <= 158 * 1024;
     return g;
 }
@@ -376,10 +380,14 @@ template <int EPI, int PRE, int R1, int R2>
 static void launch_chain_r(mtip_ctx* c, const ChainGeom& g, const ChainArgs& a) {
     const dim3 gr((unsigned)(c->B * c->N)), bl(SW_THREADS);
 #define CHAIN_GO(MAXI, THG) hipLaunchKernelGGL((k_sht_chain<EPI, PRE, R1, R2, MAXI, THG>), gr, bl, g.lds, c->stream, a)
-    if (R1 * R2 == 128 && g.reg_tab && g.maxi == 3) CHAIN_GO(3, 8);
-    else if (R1 * R2 == 128 && g.reg_tab && g.maxi == 2) CHAIN_GO(2, 8);
-    else if (g.maxi == 1) CHAIN_GO(1, 0);
-    else CHAIN_GO(3, 0);
+    if constexpr (R1 * R2 == 128) {
+        if (g.reg_tab && g.maxi == 3) { CHAIN_GO(3, 16); return; }
+        if (g.reg_tab && g.maxi == 2) { CHAIN_GO(2, 16); return; }
+    }
+    if constexpr (R1 * R2 < 256) {                  // a 256-point shell does not fit one CU (chain_geom)
+        if (g.maxi == 1) CHAIN_GO(1, 0);
+        else CHAIN_GO(3, 0);
+    }
 #undef CHAIN_GO
 }
 
@@ -408,6 +416,7 @@ void launch_sht_chain(mtip_ctx* c, const double2* coeff, double2* grid, const In
     a.twN_g = c->d_twN;
     a.Fin = epi.F;
     a.slot = (epi.out_slot >= 0 || epi.mode == EPI_REAL_UPDATE) ? c->d_slot : nullptr;
+    a.mk = c->d_mk;
     a.re = epi.real;
     a.npairs = c->npairs;
     a.nt = c->nt;

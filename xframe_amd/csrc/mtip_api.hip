@@ -59,7 +59,7 @@ void mtip_destroy(mtip_ctx* c) {
                     c->d_err_wt, c->d_rho, c->d_Fp, c->d_slot, c->d_best_err, c->d_last_err, c->d_op_err, c->d_gq, c->d_polar_dbg, c->d_so3_d, c->d_so3_tw, c->d_so3_T, c->d_so3_S, c->d_so3_P, c->d_so3_D, c->d_so3_C, c->d_err_hist, c->d_main_hist,
                     c->d_deg2_hist, c->d_F, c->d_T1, c->d_T2, c->d_fixed, c->d_g, c->d_c[0], c->d_c[1], c->d_c[2],
                     c->d_c[3], c->d_c[4], c->d_c[5], c->d_X, c->d_Vr, c->d_U, c->d_partial, c->d_minmax, c->d_Bl,
-                    c->d_rp_DV, c->d_rp_Vt, c->d_rp_slots, c->d_c0n};
+                    c->d_rp_DV, c->d_rp_Vt, c->d_rp_slots, c->d_c0n, c->d_mk};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : c->prof_events) (void)hipEventDestroy(e);
@@ -182,6 +182,7 @@ mtip_ctx* mtip_create(const mtip_cfg* cfg, int device) {
     A(dev_alloc(c, &c->d_deg2_part, (size_t)B * (L + 1) * div_up(N, 16) * div_up(N, 16)));
     A(dev_alloc(c, &c->d_S0, c->G));
     A(dev_alloc(c, &c->d_sup, (size_t)3 * B * c->G));
+    A(dev_alloc(c, &c->d_mk, (size_t)3 * B * c->G / 4));
     A(dev_alloc(c, &c->d_err_wr, N));
     A(dev_alloc(c, &c->d_err_wt, c->nt));
     A(dev_alloc(c, &c->d_rho, (size_t)3 * B * c->G));
@@ -227,6 +228,7 @@ mtip_ctx* mtip_create(const mtip_cfg* cfg, int device) {
     (void)hipMemsetAsync(c->d_rmask, 0, (size_t)(L + 1) * N, c->stream);
     (void)hipMemsetAsync(c->d_sup, 1, (size_t)3 * B * c->G, c->stream);
     (void)hipMemsetAsync(c->d_S0, 1, c->G, c->stream);
+    (void)hipMemsetAsync(c->d_mk, 0xff, (size_t)3 * B * c->G / 4 * sizeof(uint16_t), c->stream);
     // default slots
     std::vector<int> slots((size_t)B * SL_N, 0);
     for (int b = 0; b < B; ++b) {
@@ -433,8 +435,9 @@ int mtip_set_initial_support(mtip_ctx* c, const uint8_t* support) {
         MTIP_HIP_CHECK(c, mtip_copy(c, c->d_sup + (size_t)b * c->G, support, c->G, hipMemcpyHostToDevice));
     }
     MTIP_HIP_CHECK(c, mtip_copy(c, c->d_slot, slots.data(), slots.size() * sizeof(int), hipMemcpyHostToDevice));
+    launch_pack_masks(c);
     c->have_support = true;
-    return MTIP_OK;
+    return post_launch(c, "mtip_set_initial_support");
 }
 
 int mtip_set_error_weights(mtip_ctx* c, const double* radial_w, const double* theta_w, int use_mask) {
@@ -795,7 +798,8 @@ int mtip_set_support(mtip_ctx* c, int batch, const uint8_t* support, int enforce
     s[SL_SUP] = fs;
     s[SL_ENFORCE] = enforce ? 1 : 0;
     MTIP_HIP_CHECK(c, mtip_copy(c, c->d_slot + (size_t)batch * SL_N, s.data(), SL_N * sizeof(int), hipMemcpyHostToDevice));
-    return MTIP_OK;
+    launch_pack_masks(c);
+    return post_launch(c, "mtip_set_support");
 }
 
 int mtip_get_unknowns(mtip_ctx* c, int batch, int l, mtip_cdouble* U) {

@@ -206,6 +206,7 @@ struct mtip_ctx {
     // real-space constraints and error metric
     RealParams rp{RC_SUPPORT | RC_VALUE_LO, RC_SUPPORT | RC_VALUE_LO, 0.0, 0.0, 0.0};
     uint8_t *d_S0 = nullptr, *d_sup = nullptr;        // (G), (3, B, G)
+    uint16_t* d_mk = nullptr;                         // (3, B, Nq, nt, R2) the same masks packed for k_sht_chain: bit n1 = support, bit 8 + n1 = S0 of point R2 n1 + n2 of the row
     double *d_err_wr = nullptr, *d_err_wt = nullptr;
     int err_use_mask = 1;
     // state
@@ -308,6 +309,7 @@ void launch_modulus_fixed_slots(mtip_ctx* c, const double2* F);
 void launch_copy_to_slot(mtip_ctx* c, const double2* src, double2* dst_slots, int which);
 void launch_sw_clamp(mtip_ctx* c, const double2* conv, double* tmp_real);
 void launch_sw_threshold(mtip_ctx* c, const double* tmp_real, double threshold, double error_limit);
+void launch_pack_masks(mtip_ctx* c);                  // d_sup, d_S0 -> d_mk (all slots; after every writer of the two)
 void launch_apply_matrix(mtip_ctx* c, const double* M, const double* x, double* y, int nr, int nc, int nv);
 
 // ---- small utilities ---------------------------------------------------------------------------------
