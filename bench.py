@@ -43,6 +43,9 @@ def parse():
     p.add_argument('--cpu-seconds', type=float, default=20.0, help='budget of the CPU baseline sample')
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--no-roofline', action='store_true')
+    p.add_argument('--repeats', type=int, default=0,
+                   help='timed windows (each: fresh state, W warm-up steps, K timed steps); the line reports the MEDIAN window. '
+                        '0 = 5 when K <= 50 (a 20-step window lasts 13 ms: one shot is not a measurement), 3 up to 1000 steps, else 1')
     p.add_argument('--dist-backend', default='nccl', help="'gloo' + --same-device rehearses the multi-rank path on a one-GPU box")
     p.add_argument('--same-device', action='store_true', help='every rank uses GPU 0 (rehearsal only)')
     return p.parse_args()
@@ -182,11 +185,22 @@ def main():
         for b in range(e.B):                                    # global restart id -> seed 1000 + id
             rho0.append(hs.bump_density(e.rs, e.shape, S.PARTICLE_RADIUS, 0.3, 2, np.random.default_rng(1000 + gid),
                                         e.rsetup.integrated_intensity, e.int_wr, e.int_wt))
-            e.set_density(b, rho0[-1])
             gid += 1
-        e.init_state()
-    for e in engines:
-        e.synchronize()
+
+    def fresh_state():
+        """every restart back to its seeded initial density and the initial support (reconstruct.py:957-979): the timed windows of a
+        run all walk the same trajectory"""
+        i = 0
+        for e in engines:
+            e.reset_support()
+            for b in range(e.B):
+                e.set_density(b, rho0[i])
+                i += 1
+            e.init_state()
+        for e in engines:
+            e.synchronize()
+
+    fresh_state()
     setup_s = time.time() - t_setup
     ramp = hs.ExponentialRamp(0.5, 0.4, -1 / 250, 500)
     limit = 6e-3
@@ -238,26 +252,43 @@ def main():
         idle_streams.append(st)
     torch.cuda.synchronize(dev)
 
-    # ---- warmup, then exactly K timed steps
-    run_schedule(a.warmup)
-    sync_all()
-    if dist is not None:
-        dist.barrier()
-    host['enqueue_s'] = 0.0
-    if not a.no_roofline:
-        e0.profile(True)                                        # resets the timers
-        host['profile'] = True
-    t0 = time.perf_counter()
-    run_schedule(a.steps, start_step=a.warmup)
-    sync_all()
-    t1 = time.perf_counter()
-    if dist is not None:
-        dist.barrier()
-    elapsed = t1 - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if a.dist_backend == 'nccl' else 'cpu')
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    # ---- R windows of (fresh state, W warm-up steps, exactly K timed steps between barrier + synchronize); the line reports the
+    #      median window, so ms_per_step x steps is a time that was measured, and lists them all
+    R = a.repeats if a.repeats > 0 else (5 if a.steps <= 50 else (3 if a.steps <= 1000 else 1))
+    windows = []
+    enqueue = []
+    for rep in range(R):
+        if rep > 0:
+            fresh_state()
+        host['profile'] = False
+        run_schedule(a.warmup)
+        sync_all()
+        if dist is not None:
+            dist.barrier()
+        host['enqueue_s'] = 0.0
+        if not a.no_roofline:
+            if rep == 0:
+                e0.profile(True)                                # resets the timers; they accumulate over the windows
+            host['profile'] = True
+        t0 = time.perf_counter()
+        run_schedule(a.steps, start_step=a.warmup)
+        sync_all()
+        t1 = time.perf_counter()
+        if dist is not None:
+            dist.barrier()
+        el = t1 - t0
+        if dist is not None:
+            t = torch.tensor([el], dtype=torch.float64, device=dev if a.dist_backend == 'nccl' else 'cpu')
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        windows.append(el)
+        enqueue.append(host['enqueue_s'])
+        if not a.no_roofline:
+            engines[0].lib.mtip_profile(engines[0].ctx, 0)
+    order = np.argsort(windows)
+    mid = int(order[(R - 1) // 2])                              # the median window (the lower one of an even count)
+    elapsed = windows[mid]
+    host['enqueue_s'] = enqueue[mid]
     its = world * B * a.steps / elapsed
     ms_per_step = 1e3 * elapsed / a.steps
 
@@ -282,7 +313,8 @@ def main():
     Bp = e0.B
     e0_cus = int(torch.cuda.get_device_properties(dev).multi_processor_count)
     if not a.no_roofline:
-        for fam in ('sht_fwd', 'sht_inv', 'sht_inv_modulus', 'sht_inv_real', 'hankel', 'proj', 'polar', 'real_update', 'deg2_metric'):
+        for fam in ('sht_fwd', 'sht_inv', 'sht_inv_modulus', 'sht_inv_real', 'sht_chain', 'sht_chain_modulus', 'sht_chain_real', 'hankel',
+                    'proj', 'polar', 'real_update', 'deg2_metric'):
             ms, n = e0.profile_get(fam)
             if n:
                 fam_ms[fam] = {'total_ms': ms, 'launches': int(n), 'avg_ms': ms / n}
@@ -296,6 +328,10 @@ def main():
                    'sht_inv': (16 * C + 16 * G) * Bp,                       # coefficients in, grid out
                    'sht_inv_modulus': (16 * C + 2 * 16 * G) * Bp,           # + F in  (F' = F sqrt(I'/I) epilogue)
                    'sht_inv_real': (2 * 16 * C + 2 * 16 * G + 2 * G) * Bp,  # two coefficient sets, rho in/out, 2 masks
+                   # chained inverse -> forward kernels (k_sht_chain.hip): coefficients in, the grid once, coefficients out
+                   'sht_chain': (2 * 16 * C + 16 * G) * Bp,                 # F out
+                   'sht_chain_modulus': (2 * 16 * C + 2 * 16 * G) * Bp,     # F in, F' out
+                   'sht_chain_real': (2 * 16 * C + 2 * 16 * G + G // 4) * Bp,   # rho in / out, packed masks (2 bits per point)
                    'hankel': 2 * 16 * C * Bp + 8 * N * N * (L + 1),
                    'real_update': (3 * 16 + 2) * G * Bp}
             hbm = {k: v for k, v in fam_ms.items() if k in alg}
@@ -340,7 +376,7 @@ def main():
                     per_sweep, prod = 9.0 * ns ** 3, 2.0 * ns ** 2 * (2.0 * N + 2.0 * ns) * active
                     kname = ('polar (k_rproj: the whole reciprocal projection in real arithmetic -- four f64 MFMA products and the '
                              'one-sided Jacobi SVD in LDS, one workgroup per (restart, slot of orders))')
-                    slots = 9 if L == 32 else int(active.sum())                    # workgroups per restart (host-packed slots)
+                    slots = e0.projection_slots() or int(active.sum())            # workgroups per restart (host-packed slots of orders)
                 else:
                     # complex one-sided Jacobi: 16 n flop for the Gram sums and 24 flop per row for the rotations: 32 n^3 per sweep
                     per_sweep, prod = 32.0 * ns ** 3, 0.0 * ns
@@ -378,13 +414,27 @@ def main():
     step_bytes = algorithmic_bytes_per_step(N, L, e0.n_theta, e0.n_phi, True)
     whole_step = {'algorithmic_bytes_per_step_per_restart': step_bytes,
                   'achieved_GBps_per_gpu': step_bytes * B * a.steps / elapsed / 1e9,
-                  'frac_of_8TBps': step_bytes * B * a.steps / elapsed / 8e12}
+                  'frac_of_8TBps': step_bytes * B * a.steps / elapsed / 8e12,
+                  'pmc_bytes_per_step_per_restart': None}
+    try:        # what a step physically moves: FETCH_SIZE x 2 + WRITE_SIZE summed over the kernels of one step (profiles/pmc_traffic.json)
+        with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')) as f:
+            pmc_w = json.load(f)
+        if pmc_w.get('config') == a.config and pmc_w.get('hbm_bytes_per_step_per_restart'):
+            pb = float(pmc_w['hbm_bytes_per_step_per_restart'])
+            whole_step['pmc_bytes_per_step_per_restart'] = pb
+            whole_step['pmc_GBps_per_gpu'] = pb * B * a.steps / elapsed / 1e9
+            whole_step['pmc_frac_of_8TBps'] = pb * B * a.steps / elapsed / 8e12
+    except (OSError, ValueError, KeyError):
+        pass
 
     if rank == 0:
         line = {
             'metric': 'MTIP iterations/sec, 128 q-shells x L_max=32',
             'value': its, 'unit': 'MTIP iterations/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
             'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'repeats': {'windows_ms': [1e3 * w for w in windows], 'reported': 'median', 'spread_rel': (max(windows) - min(windows)) / elapsed,
+                        'note': 'every window: fresh seeded state, W warm-up steps, then exactly K timed steps between barrier + '
+                                'synchronize; value and ms_per_step are the median window'},
             'dtype': 'f64 (complex128)', 'data': 'synthetic',
             'config': {'workload': f'BASELINE config {a.config}: {N} shells x L_max={L}, grid {N}x{e0.n_theta}x{e0.n_phi}, '
                                    f'{B} restarts per GPU on {n_eng} streams, tutorial schedule (HIO/SW/ER, ft_stab on), '

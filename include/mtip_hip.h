@@ -298,6 +298,9 @@ int mtip_profile_reset(mtip_ctx* ctx);
 /* diagnostic of the last polar-factor solve, (n_batch, L+1) int32: bits 0-7 Jacobi sweeps used, bits 8+ the
  * number of columns of X_l that were still non-zero (not deflated) in the final sweep */
 int mtip_debug_jacobi_sweeps(mtip_ctx* ctx, int32_t* out);
+/* diagnostic: workgroups per restart of the real projection kernel (k_rproj: the host-packed slots of orders), 0 before the
+ * first projection or when the general complex kernels are in use; negative = error code */
+int mtip_debug_projection_slots(mtip_ctx* ctx);
 /* diagnostic: in-kernel timers of the real projection kernel (k_rproj), (n_batch, L+1, 32) int64 s_memtime ticks of the last
  * projection per (restart, order): [0..4] phases X~ product, warm start, Jacobi, U, apply; [5] rounds; [6], [7] start / end;
  * [8] hardware id; [10..17] busy and [18..25] LDS drain + barrier per wave and [26..32] the segments of a round of wave 0

@@ -1176,6 +1176,11 @@ int mtip_debug_jacobi_sweeps(mtip_ctx* c, int32_t* out) {
     return MTIP_OK;
 }
 
+int mtip_debug_projection_slots(mtip_ctx* c) {
+    CTX_CHECK(c);
+    return c->vr_kind == 2 ? c->rp_n_slots : 0;
+}
+
 __global__ void k_debug_spin(long long ticks) {
     const long long t0 = wall_clock64();
     while (wall_clock64() - t0 < ticks) {}

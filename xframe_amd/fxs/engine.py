@@ -428,6 +428,12 @@ class Engine:
     def init_state(self):
         self._ck(self.lib.mtip_init_state(self.ctx))
 
+    def reset_support(self):
+        """back to the initial support, enforced, for every restart (the state a fresh reconstruction starts from,
+        fxs_Projections.py:34, 133-155)"""
+        s0 = _lib.as_u8(self.initial_support)
+        self._ck(self.lib.mtip_set_initial_support(self.ctx, _lib.ptr(s0)))
+
     def density(self, batch, best=False):
         out = np.empty(self.shape, complex)
         self._ck(self.lib.mtip_get_density(self.ctx, batch, int(best), _lib.ptr(out)))
@@ -567,6 +573,13 @@ class Engine:
         out = np.zeros((self.B, self.L + 1), np.int32)
         self._ck(self.lib.mtip_debug_jacobi_sweeps(self.ctx, _lib.ptr(out)))
         return (out >> 8) & 0xffff
+
+    def projection_slots(self):
+        """workgroups per restart of the real projection kernel in the last call (0: general complex kernels)"""
+        n = self.lib.mtip_debug_projection_slots(self.ctx)
+        if n < 0:
+            self._ck(n)
+        return int(n)
 
     def jacobi_closing_step(self):
         """how the real-arithmetic projection closed its sweeps in the last call, per (restart, order): 0 = classic confirming sweep,
