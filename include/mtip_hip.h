@@ -298,6 +298,12 @@ int mtip_profile_reset(mtip_ctx* ctx);
 /* diagnostic of the last polar-factor solve, (n_batch, L+1) int32: bits 0-7 Jacobi sweeps used, bits 8+ the
  * number of columns of X_l that were still non-zero (not deflated) in the final sweep */
 int mtip_debug_jacobi_sweeps(mtip_ctx* ctx, int32_t* out);
+/* diagnostic: phase stamps of the chained inverse -> forward SHT kernel (csrc/k_sht_chain.hip), (3 kinds: store / modulus /
+ * real-space epilogue, n_batch * n_radial shells, 18) int64 s_memtime ticks of the last launch of each kind: [0] start, [1]
+ * tables staged, [2] / [3] Legendre synthesis done (wave 0 / all), then per FFT pass p (6 p + 4 ...): step 1 done, barrier,
+ * epilogue + forward phase 1 done, barrier, forward phase 2 done, barrier; [16] Legendre sums done, [17] end.  The first call
+ * switches the stamps on (out may be null). */
+int mtip_debug_chain_timing(mtip_ctx* ctx, int64_t* out);
 /* diagnostic: workgroups per restart of the real projection kernel (k_rproj: the host-packed slots of orders), 0 before the
  * first projection or when the general complex kernels are in use; negative = error code */
 int mtip_debug_projection_slots(mtip_ctx* ctx);

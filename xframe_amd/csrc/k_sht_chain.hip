@@ -20,6 +20,13 @@
 #include "k_sht_common.h"
 #include "k_sht_legendre.h"
 
+// phase stamps exist in the DBG instantiations only: with them in the code the allocator spills the table registers of the last
+// phase (238 of them at 128 x L32), so the stamped build times the phases up to the Legendre sums faithfully and the rest not
+#define CHAIN_STAMP(i)                                                                                  \
+    if constexpr (DBG) {                                                                                \
+        if (a.dbg != nullptr && tid == 0) a.dbg[(size_t)shell * MTIP_CHAIN_DBG_SLOTS + (i)] = clock64(); \
+    }
+
 struct ChainArgs {
     // inverse half (as k_sht_inv_wide, one workgroup per shell)
     const double2* coeff;
@@ -39,6 +46,7 @@ struct ChainArgs {
     const int* lmtab;
     const double* gw;
     double norm;
+    long long* dbg;                     // diagnostic: (shells, CHAIN_DBG_SLOTS) clock64 stamps of wave 0 at the phase boundaries, or null
     int gsz, thg;                       // threads per accumulation group (a power of two), theta pairs of the shell per group
 };
 
@@ -46,7 +54,7 @@ struct ChainArgs {
 // just written (MTIP_PRE_NONE / MTIP_PRE_SQUARE); MAXI: (l, m) pairs per thread of an accumulation group; THG > 0: theta pairs
 // per group at compile time, their table rows requested together into registers; THG == 0: run-time count, table values
 // loaded where they are used (small grids)
-template <int EPI, int PRE, int R1, int R2, int MAXI, int THG>
+template <int EPI, int PRE, int R1, int R2, int MAXI, int THG, bool DBG>
 __global__ void __launch_bounds__(SW_THREADS) k_sht_chain(ChainArgs a) {
     constexpr int N = R1 * R2;
     constexpr int AS = R2 + 1;
@@ -65,6 +73,7 @@ __global__ void __launch_bounds__(SW_THREADS) k_sht_chain(ChainArgs a) {
     const int q = (int)(shell % Nq);
     const double2* csrc = a.coeff + (size_t)shell * nlm;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nw = blockDim.x >> 6;
+    CHAIN_STAMP(0)
     LegendreStart ls;
     legendre_prefetch_first(ls, a.P, nt, L, nt >> 1, 0, wave, tid & 63);
     for (int e = tid; e < N; e += blockDim.x) sm[e] = a.twN_g[e];
@@ -95,9 +104,12 @@ __global__ void __launch_bounds__(SW_THREADS) k_sht_chain(ChainArgs a) {
     const int grp = __builtin_amdgcn_readfirstlane(tid / gsz);      // wave-uniform (gsz >= 64): table rows through scalar bases
     const int tg = tid - grp * gsz;
     __syncthreads();
+    CHAIN_STAMP(1)
     // ---- Legendre synthesis of every row (k_sht_legendre.h)
     legendre_synthesis_rows(ls, Gs, cl, ABs, a.P, a.cost, nt, L, nt >> 1, 0, wave, nw, tid & 63);
+    CHAIN_STAMP(2)
     __syncthreads();
+    CHAIN_STAMP(3)
     const int n_pass = nt / RP;
     for (int pass = 0; pass < n_pass; ++pass) {
         // epilogue operands of this thread's step-2 outputs: requested now, they arrive behind step 1
@@ -138,7 +150,9 @@ __global__ void __launch_bounds__(SW_THREADS) k_sht_chain(ChainArgs a) {
                 br[n2] = cmul(uv[n2], w);
             }
         }
+        CHAIN_STAMP(4 + 6 * (pass & 1))
         __syncthreads();
+        CHAIN_STAMP(5 + 6 * (pass & 1))
         // ---- step 2: inverse R1-point FFTs over k1
         const bool act2 = tid < RP * R2;
         const int r = tid / R2, n2 = tid - r * R2;
@@ -199,7 +213,9 @@ __global__ void __launch_bounds__(SW_THREADS) k_sht_chain(ChainArgs a) {
 #pragma unroll
             for (int k1 = 0; k1 < R1; ++k1) ar[k1 * AS] = cmul(vv[k1], twN[n2 * k1]);
         }
+        CHAIN_STAMP(6 + 6 * (pass & 1))
         __syncthreads();
+        CHAIN_STAMP(7 + 6 * (pass & 1))
         // ---- forward phase 2: R2-point FFTs over n2; keep |m| <= L, Gauss weight; the panel rows go where this pass's
         //      spectra were (consumed by step 1)
         const bool actf = tid < RP * R1;
@@ -219,7 +235,9 @@ __global__ void __launch_bounds__(SW_THREADS) k_sht_chain(ChainArgs a) {
                 else if (k >= N - L) gr[k - N] = cscale(uv[k2], sc);
             }
         }
+        CHAIN_STAMP(8 + 6 * (pass & 1))
         __syncthreads();                                // the next pass rewrites Bm; the last one completes the panel
+        CHAIN_STAMP(9 + 6 * (pass & 1))
     }
     // the twiddles are dead: the per-shell error sums go to the head of the LDS block
     if (EPI == EPI_REAL_UPDATE) {
@@ -295,6 +313,7 @@ __global__ void __launch_bounds__(SW_THREADS) k_sht_chain(ChainArgs a) {
             }
         }
     }
+    CHAIN_STAMP(16)
     // the groups' partial coefficients go where the transpose buffer was (other waves may still be reading the panel)
     double2* racc = Bm;                                 // (groups, MAXI, 2, gsz)
 #pragma unroll
@@ -329,6 +348,7 @@ __global__ void __launch_bounds__(SW_THREADS) k_sht_chain(ChainArgs a) {
         cdst[l * (l + 1) + m] = sp;
         if (m > 0) cdst[l * (l + 1) - m] = (m & 1) ? make_double2(-sq.x, -sq.y) : sq;
     }
+    CHAIN_STAMP(17)
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -379,8 +399,12 @@ bool sht_chain_supported(const mtip_ctx* c) {
 template <int EPI, int PRE, int R1, int R2>
 static void launch_chain_r(mtip_ctx* c, const ChainGeom& g, const ChainArgs& a) {
     const dim3 gr((unsigned)(c->B * c->N)), bl(SW_THREADS);
-#define CHAIN_GO(MAXI, THG) hipLaunchKernelGGL((k_sht_chain<EPI, PRE, R1, R2, MAXI, THG>), gr, bl, g.lds, c->stream, a)
+#define CHAIN_GO(MAXI, THG) hipLaunchKernelGGL((k_sht_chain<EPI, PRE, R1, R2, MAXI, THG, false>), gr, bl, g.lds, c->stream, a)
     if constexpr (R1 * R2 == 128) {
+        if (g.reg_tab && g.maxi == 3 && a.dbg != nullptr) {
+            hipLaunchKernelGGL((k_sht_chain<EPI, PRE, R1, R2, 3, 16, true>), gr, bl, g.lds, c->stream, a);
+            return;
+        }
         if (g.reg_tab && g.maxi == 3) { CHAIN_GO(3, 16); return; }
         if (g.reg_tab && g.maxi == 2) { CHAIN_GO(2, 16); return; }
     }
@@ -432,6 +456,8 @@ void launch_sht_chain(mtip_ctx* c, const double2* coeff, double2* grid, const In
     a.norm = 2.0 * 3.14159265358979323846 / c->np;
     a.gsz = g.gsz;
     a.thg = g.thg;
+    a.dbg = c->d_chain_dbg ? c->d_chain_dbg + (size_t)(epi.mode == EPI_REAL_UPDATE ? 2 : epi.mode == EPI_MODULUS ? 1 : 0) * c->B * c->N * MTIP_CHAIN_DBG_SLOTS
+                           : nullptr;
     if (epi.mode == EPI_REAL_UPDATE) launch_chain_p<EPI_REAL_UPDATE, MTIP_PRE_NONE>(c, g, a);
     else if (epi.mode == EPI_MODULUS) launch_chain_p<EPI_MODULUS, MTIP_PRE_NONE>(c, g, a);
     else if (prologue == MTIP_PRE_SQUARE) launch_chain_p<EPI_STORE, MTIP_PRE_SQUARE>(c, g, a);

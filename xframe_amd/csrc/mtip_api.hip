@@ -59,7 +59,7 @@ void mtip_destroy(mtip_ctx* c) {
                     c->d_err_wt, c->d_rho, c->d_Fp, c->d_slot, c->d_best_err, c->d_last_err, c->d_op_err, c->d_gq, c->d_polar_dbg, c->d_so3_d, c->d_so3_tw, c->d_so3_T, c->d_so3_S, c->d_so3_P, c->d_so3_D, c->d_so3_C, c->d_err_hist, c->d_main_hist,
                     c->d_deg2_hist, c->d_F, c->d_T1, c->d_T2, c->d_fixed, c->d_g, c->d_c[0], c->d_c[1], c->d_c[2],
                     c->d_c[3], c->d_c[4], c->d_c[5], c->d_X, c->d_Vr, c->d_U, c->d_partial, c->d_minmax, c->d_Bl,
-                    c->d_rp_DV, c->d_rp_Vt, c->d_rp_slots, c->d_c0n, c->d_mk};
+                    c->d_rp_DV, c->d_rp_Vt, c->d_rp_slots, c->d_c0n, c->d_mk, c->d_chain_dbg};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : c->prof_events) (void)hipEventDestroy(e);
@@ -1207,6 +1207,20 @@ int mtip_debug_polar_timing(mtip_ctx* c, int64_t* out) {
         MTIP_HIP_CHECK(c, hipMemsetAsync(c->d_polar_dbg, 0, n * sizeof(long long), c->stream));
     }
     if (out) MTIP_HIP_CHECK(c, mtip_copy(c, out, c->d_polar_dbg, n * sizeof(long long), hipMemcpyDeviceToHost));
+    return MTIP_OK;
+}
+
+int mtip_debug_chain_timing(mtip_ctx* c, int64_t* out) {
+    CTX_CHECK(c);
+    (void)hipSetDevice(c->device);
+    const size_t n = (size_t)3 * c->B * c->N * MTIP_CHAIN_DBG_SLOTS;
+    MTIP_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    if (!c->d_chain_dbg) {                       // first call: switch the stamps on (the next chained launches fill them)
+        int r = dev_alloc(c, &c->d_chain_dbg, n);
+        if (r) return r;
+        MTIP_HIP_CHECK(c, hipMemsetAsync(c->d_chain_dbg, 0, n * sizeof(long long), c->stream));
+    }
+    if (out) MTIP_HIP_CHECK(c, mtip_copy(c, out, c->d_chain_dbg, n * sizeof(long long), hipMemcpyDeviceToHost));
     return MTIP_OK;
 }
 

@@ -49,6 +49,7 @@ __device__ __forceinline__ double2 cmul_ipow(double2 a, int l, int sign) {
     }
 }
 
+#define MTIP_CHAIN_DBG_SLOTS 18
 // ---- per-restart slot table (device ints), see DESIGN.md "state" ---------------------------------
 // SL_HIST: the pair the reference's stale local `hist` ends with (reconstruct.py:859, 913): the input pair of the most
 // recent step, or the latest pair when no step has run in the current sub-loop call; read by SW_center (893) and by the
@@ -169,6 +170,7 @@ struct mtip_ctx {
     bool sht_fwd_pair = true;                         // env MTIP_SHT_FWD_PAIR=0: k_sht_fwd_reg (table loads inside the accumulation loop)
     bool sht_chain = true;                            // env MTIP_SHT_CHAIN=0: separate inverse / forward SHT kernels in the fused step (k_sht_chain.hip)
     double2* d_c0n = nullptr;                         // (B, C) SHT of the current density, written by the chained last kernel of a step
+    long long* d_chain_dbg = nullptr;                 // (3 kinds, B * Nq, MTIP_CHAIN_DBG_SLOTS) phase stamps of k_sht_chain, allocated by mtip_debug_chain_timing
     bool c0n_valid = false;                           // d_c0n holds SHT(rho[SL_CUR]) of every restart
     void* d_htiles32 = nullptr;                       // workgroup tiles (order, first column) of k_hankel_tile
     int n_htiles32 = 0, htile_ct = 5;                 // 16-column MFMA tiles per workgroup

@@ -110,6 +110,7 @@ _SIGNATURES = {
     'mtip_profile_reset': (C.c_int, [c_void]),
     'mtip_debug_jacobi_sweeps': (C.c_int, [c_void, c_void]),
     'mtip_debug_projection_slots': (C.c_int, [c_void]),
+    'mtip_debug_chain_timing': (C.c_int, [c_void, c_void]),
     'mtip_debug_check_jacobi_schedule': (C.c_int, [c_void, C.c_int]),
     'mtip_debug_polar_timing': (C.c_int, [c_void, c_void]),
     'mtip_debug_spin': (C.c_int, [c_void, C.c_double]),
