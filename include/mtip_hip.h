@@ -307,10 +307,12 @@ int mtip_debug_chain_timing(mtip_ctx* ctx, int64_t* out);
 /* diagnostic: workgroups per restart of the real projection kernel (k_rproj: the host-packed slots of orders), 0 before the
  * first projection or when the general complex kernels are in use; negative = error code */
 int mtip_debug_projection_slots(mtip_ctx* ctx);
-/* diagnostic: in-kernel timers of the real projection kernel (k_rproj), (n_batch, L+1, 32) int64 s_memtime ticks of the last
- * projection per (restart, order): [0..4] phases X~ product, warm start, Jacobi, U, apply; [5] rounds; [6], [7] start / end;
- * [8] hardware id; [10..17] busy and [18..25] LDS drain + barrier per wave and [26..32] the segments of a round of wave 0
- * (summed over the rounds; largest order of L = 32 only).  The first call (out may be NULL) switches the timers on. */
+/* diagnostic: in-kernel timers of the real projection kernel (k_rproj), (n_batch, L+1, MTIP_POLAR_TIMING_SLOTS = 40) int64
+ * s_memtime ticks of the last projection per (restart, order): [0..4] phases X~ product, warm start, Jacobi, U, apply;
+ * [5] rounds; [6], [7] start / end; [8] hardware id; [10..17] busy and [18..25] LDS drain + barrier per wave, [26..32] the
+ * segments of a round of wave 0 and [33..39] of wave 5 (summed over the rounds; largest order of L = 32 only).  The first call
+ * (out may be NULL) switches the timers on. */
+#define MTIP_POLAR_TIMING_SLOTS 40
 int mtip_debug_polar_timing(mtip_ctx* ctx, int64_t* out);
 /* diagnostic: enqueue a one-workgroup kernel that spins for `microseconds` on the context's stream (asynchronous).  Used to
  * check that the streams of several engines of one process really execute side by side (HIP maps streams onto a limited

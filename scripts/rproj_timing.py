@@ -35,7 +35,7 @@ for _ in range(reps):
 ms, n = e.profile_get('proj')
 print('%s projection: %.1f us per call (B = %d, %d calls, warm start on the same input)' % ('real' if real else 'complex', 1e3 * ms / n, B, n))
 print('sweeps per order (restart 0):', list(e.jacobi_sweeps()[0]))
-out = np.zeros((B, L + 1, 32), np.int64)
+out = np.zeros((B, L + 1, 40), np.int64)      # MTIP_POLAR_TIMING_SLOTS
 e.lib.mtip_debug_polar_timing(e.ctx, _lib.ptr(out))
 t_first = out[:, :, 6][out[:, :, 6] > 0].min() if (out[:, :, 6] > 0).any() else 0
 print('order: cycles of phase A (X~ product) | W (warm start) | J (Jacobi) | U | E (apply);  rounds; cycles per round; start / end (k cycles after the first workgroup); hw id')

@@ -205,7 +205,7 @@ static inline unsigned atomicAdd(unsigned* p, unsigned v) {
     std::lock_guard<std::mutex> g(emul_atomic_mutex);
     unsigned o = *p; *p = o + v; return o;
 }
-static inline long long clock64() { return 0; }
+static inline long long clock64() { static thread_local long long t = 0; return t += 7; }   // a running (per host thread) clock: timers carry values
 static inline unsigned __builtin_amdgcn_s_getreg(int) { return 0u; }
 static inline void __threadfence() { std::atomic_thread_fence(std::memory_order_seq_cst); }
 static inline void __threadfence_block() { std::atomic_thread_fence(std::memory_order_seq_cst); }

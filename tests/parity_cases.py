@@ -465,10 +465,43 @@ def check_projection_vs_oracle(N, L, lib_path=None, n_batch=2, seed=1):
     e.close()
 
 
-def check_projection_real_vs_oracle(N, L, lib_path=None, n_batch=2, seed=1, reciprocal_opt=None, imag_residue=None, so_order=None):
+def check_polar_timing_records(lib_path=None, N=24, L=10):
+    """mtip_debug_polar_timing: every solved (restart, order) has a record of its own (MTIP_POLAR_TIMING_SLOTS wide; the kernel
+    clears and fills slots up to 39 -- with 32-wide records it zeroed the head of its neighbour's and wrote past the buffer)."""
+    from xframe_amd.fxs import _lib
+    sht = SHT(L)
+    fpd = FourierPair(sht, N, S.data_cutoff(N), 2.0)
+    data, _ = S.make_invariants(OracleTransforms(fpd), N, L)
+    B = 2
+    e = Engine(golden_settings(N, L), data, n_batch=B, lib_path=lib_path)
+    rng = np.random.default_rng(3)
+    grid = rng.uniform(0.0, 1.0, (B, N, sht.n_theta, sht.n_phi))
+    Ilm = np.stack([np.concatenate(sht.forward_l(g.astype(complex)), axis=1) for g in grid])
+    e._ck(e.lib.mtip_debug_polar_timing(e.ctx, None))
+    e.project_coefficients(Ilm, real_intensity=True)
+    e.project_coefficients(Ilm, real_intensity=True)
+    W = 40
+    out = np.zeros((B, L + 1, W), np.int64)
+    e._ck(e.lib.mtip_debug_polar_timing(e.ctx, _lib.ptr(out)))
+    solved = (e.jacobi_sweeps() & 0xff) > 0
+    assert solved.any()
+    for b in range(B):
+        for l in range(L + 1):
+            t = out[b, l]
+            if solved[b, l] and l > 0:
+                assert t[6] > 0 and t[7] >= t[6] and t[5] > 0, (b, l, t[:9])      # start / end stamps, rounds
+                assert (t[:5] >= 0).all() and t[:5].sum() > 0, (b, l, t[:5])       # phase times of its own
+            elif l > 0 and not solved[b, l]:
+                assert not t.any(), (b, l, t)
+    e.close()
+
+
+def check_projection_real_vs_oracle(N, L, lib_path=None, n_batch=2, seed=1, reciprocal_opt=None, imag_residue=None, so_order=None,
+                                    closing=None, expect_real=True):
     """The real-arithmetic form of the projection (k_projr.hip: real V_l, coefficients of a real intensity) against the
     oracle's complex numpy-SVD route (fxs_Projections.py:752-767, 832-871): projected coefficients, unknowns, and the
-    general (complex) kernel on the same input; second call = warm start."""
+    general (complex) kernel on the same input; second call = warm start.  closing: what jacobi_closing_step() must have
+    reported over the calls -- 'none' (classic confirming sweep everywhere, MTIP_RP_CORR=0) or 'some' (a closing polar step ran)."""
     from oracle.fourier import FourierPair
     from oracle.sht import SHT
     from helpers import OracleTransforms
@@ -495,12 +528,17 @@ def check_projection_real_vs_oracle(N, L, lib_path=None, n_batch=2, seed=1, reci
         e._ck(e.lib.mtip_set_so_freedom(e.ctx, int(so_order)))
         om.rp.SO_order_id = int(so_order)
     rng = np.random.default_rng(seed)
+    closing_seen, sweeps_seen = set(), set()
     for rep in range(3):                                   # later calls: warm start from the previous V_r
         grid = rng.uniform(0.0, 1.0, (n_batch, N, sht.n_theta, sht.n_phi)) * rng.uniform(0.5, 2.0, (n_batch, N, 1, 1))
         Ilm = np.stack([np.concatenate(sht.forward_l(g.astype(complex)), axis=1) for g in grid])
         # (the general kernel first, and only once: the real kernel's later calls then warm-start from its own V_r)
         proj_c = e.project_coefficients(Ilm) if rep == 0 else None
         proj = e.project_coefficients(Ilm, real_intensity=True)
+        if expect_real:
+            solved = e.jacobi_sweeps() > 0                  # (raises if an order's LDS layout did not fit its launch)
+            closing_seen |= set(np.unique(e.jacobi_closing_step()[solved]).tolist())
+            sweeps_seen |= set(np.unique(e.jacobi_sweeps()[solved]).tolist())
         unk_hip = [e.unknowns(b) for b in range(n_batch)]
         for b in range(n_batch):
             Il = [Ilm[b][:, l * l:(l + 1) ** 2] for l in range(L + 1)]
@@ -514,12 +552,16 @@ def check_projection_real_vs_oracle(N, L, lib_path=None, n_batch=2, seed=1, reci
                 if np.abs(V).max() == 0:
                     continue
                 assert rel_l2(V @ unk_hip[b][l], V @ unk[i]) < TOL_SHT, (rep, b, l)
+    if closing == 'none':
+        assert closing_seen <= {0}, closing_seen
+    elif closing == 'some':
+        assert closing_seen & {1, 2}, (closing_seen, sweeps_seen)
     # which kernel ran: the real one reads only the m >= 0 half of the coefficients
     junk = Ilm.copy()
     for l in range(1, L + 1):
         junk[:, :, l * l:l * l + l] = 1.0 + 2.0j
     same = rel_l2(e.project_coefficients(junk, real_intensity=True), proj) < TOL_SHT
-    assert same, 'the real-arithmetic projection was expected to run'
+    assert same == expect_real, 'the real-arithmetic projection was expected to run' if expect_real else 'the general kernels were expected to run'
     if so_order is not None:
         U = e.unknowns(0)[so_order]
         assert U[4, 2].imag == 0 and np.abs(U[4, 1].imag) > 1e-6       # the one element lost its imaginary part, its neighbours kept theirs

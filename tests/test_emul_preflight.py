@@ -194,6 +194,22 @@ def test_projection_real_vs_oracle(emul_lib, N, L, ropt):
     PC.check_projection_real_vs_oracle(N, L, emul_lib, n_batch=1, reciprocal_opt=ropt)
 
 
+@pytest.mark.parametrize('env,closing', [({'MTIP_RP_CORR': '0'}, 'none'), ({}, 'some'),
+                                         ({'MTIP_RP_EARLY': '0.2', 'MTIP_RP_CORR2_MAX': '5e-4'}, 'some'),
+                                         ({'MTIP_RP_EARLY': '0.2', 'MTIP_RP_CORR2_MAX': '1e-6'}, None),
+                                         ({'MTIP_RP_EARLY': '7', 'MTIP_RP_CORR2_MAX': '1'}, 'some')])
+def test_projection_real_switches(emul_lib, env, closing, monkeypatch):
+    """the closing-step switches of k_rproj: classic confirming sweep (MTIP_RP_CORR=0), the two ends of the tested threshold
+    range, and values beyond it (clamped by mtip_create: the operator keeps its 1e-10)"""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    PC.check_projection_real_vs_oracle(24, 10, emul_lib, n_batch=1, closing=closing)
+
+
+def test_polar_timing_records_do_not_overlap(emul_lib):
+    PC.check_polar_timing_records(emul_lib)
+
+
 def test_so_freedom_on_a_higher_order(emul_lib):
     """SO_freedom (fxs_Projections.py:768-780) forced onto l = 4, where column 2 is m = -2 and the correction is not a no-op"""
     PC.check_projection_real_vs_oracle(16, 6, emul_lib, n_batch=1, so_order=4)

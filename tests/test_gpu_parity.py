@@ -108,6 +108,29 @@ def test_projection_real_vs_oracle(N, L):
     PC.check_projection_real_vs_oracle(N, L)
 
 
+@pytest.mark.parametrize('env,closing', [({'MTIP_RP_CORR': '0'}, 'none'), ({}, 'some'),
+                                         ({'MTIP_RP_EARLY': '0.2', 'MTIP_RP_CORR2_MAX': '5e-4'}, 'some'),
+                                         ({'MTIP_RP_EARLY': '0.2', 'MTIP_RP_CORR2_MAX': '1e-6'}, None),
+                                         ({'MTIP_RP_EARLY': '7', 'MTIP_RP_CORR2_MAX': '1'}, 'some')])
+@pytest.mark.parametrize('N,L', [(66, 32), (100, 48)])
+def test_projection_real_switches(N, L, env, closing, monkeypatch):
+    """the closing-step switches of k_rproj on the padded (65-column) and the tight (97-column, Gram matrix in V_r's place) layout:
+    classic confirming sweep, both ends of the tested threshold range, values beyond it (clamped by mtip_create)"""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    PC.check_projection_real_vs_oracle(N, L, closing=closing)
+
+
+def test_projection_order_49_takes_the_general_kernels():
+    """l = 49 (99 columns) needs 832 threads in the real kernel's pairing -- beyond its 768-thread instantiation: the launcher must
+    refuse it (rproj_supported) and the general kernels run; odd orders active"""
+    PC.check_projection_real_vs_oracle(100, 49, n_batch=1, reciprocal_opt={'odd_orders_to_0': False}, expect_real=False)
+
+
+def test_polar_timing_records_do_not_overlap():
+    PC.check_polar_timing_records(None)
+
+
 @pytest.mark.parametrize('ropt', [{'odd_orders_to_0': False}, {'use_averaged_intensity': False}, {'used_order_ids': np.arange(3)},
                                   {'SO_freedom': {'use': True, 'radial_high_pass': 0.2}}])
 def test_projection_real_option_variants(ropt):
@@ -246,7 +269,7 @@ def test_config5_properties_full_size():
 # ---- every MTIP_* switch that selects another kernel of the shipping library gets a forced parity case ------------------
 _TRAJ_SWITCHES = [('MTIP_SHT_MODE', '0'), ('MTIP_SHT_MODE', '1'), ('MTIP_SHT_WIDE', '0'), ('MTIP_FUSE_REAL', '0'),
                   ('MTIP_DEG2_SIMPLE', '1'), ('MTIP_SHT_FWD_PAIR', '0'),
-                  ('MTIP_PROJ_FUSE', '0'), ('MTIP_PROJ_REAL', '0')]
+                  ('MTIP_PROJ_FUSE', '0'), ('MTIP_PROJ_REAL', '0'), ('MTIP_SHT_CHAIN', '0'), ('MTIP_RP_CORR', '0')]
 
 
 @pytest.mark.parametrize('name,value', _TRAJ_SWITCHES)

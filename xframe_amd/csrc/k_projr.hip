@@ -206,37 +206,54 @@ __device__ __forceinline__ void rp_sweep(double* Xs, double* Vs, int ns, int ks,
 //   * the pairing table is translated once per sweep into {resident offset << 2 | write-back << 1 | load, mover offset} (through
 //     the compaction of the deflated columns), flags made self-contained: a resident is written back before an idle round;
 //   * a pair that is orthogonal already takes the identity rotation through the same instructions.
-// nc = blocks of 16 columns (= row slots of 16 rows: 2l+2 <= 16 nc); TG = lanes per column pair (16, or 32: twice the waves
-// per round with shorter chains each, conflict-free 32-lane column reads; up to 32 pairs = 1024 threads)
+// nc = blocks of 16 columns (= row slots of 16 rows: 2l+2 <= 16 nc); TG = lanes per column pair (16; a 32-lane variant -- twice
+// the waves per round with shorter chains each -- measured 3520 against 2440 ticks per round and was removed in round 4)
 #define RP_PAD_MAX_NR 5
 __host__ __device__ __forceinline__ constexpr int rp_pad_nrt(int nc, int tg) { return (16 * nc + tg - 1) / tg; }      // row slots per lane
 __host__ __device__ __forceinline__ constexpr int rp_pad_ns(int nc, int tg) { return rp_pad_nrt(nc, tg) * tg + 1; }   // column stride (odd)
 __host__ __device__ __forceinline__ constexpr int rp_pad_voff(int nc, int tg) { return 16 * nc * rp_pad_ns(nc, tg); } // doubles from X~ to V_r
 
-// value of the same lane in the neighbouring row of 16 lanes (row ^ 1): v_permlane16_swap (gfx950) exchanges the odd rows of its
-// first operand with the even rows of its second
-__device__ __forceinline__ double rp_xrow(double v) {
-    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
-    const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);      // {[r0 r0 r2 r2], [r1 r1 r3 r3]}
-    const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
-    const bool odd = ((threadIdx.x >> 4) & 1) != 0;
-    return __hiloint2double((int)(odd ? b[0] : b[1]), (int)(odd ? a[0] : a[1]));
-}
 // sums over the TG lanes of a pair-group, every lane receives them
+// The carve-up of a workgroup's dynamic LDS for one order (k columns, n2 = 2l+2 rows): the ONE definition the launcher sizes the
+// block from and the kernel takes its pointers from (gfx950 drops stores beyond the allocation silently -- two rounds in a row a
+// hand-kept second copy of this arithmetic went out of step).  Offsets in doubles from the start of the block.
+struct RpLayout {
+    bool pad;                 // zero-padded columns, one stride (up to RP_PAD_MAX_NR row slots); else tight columns
+    int ns, ks;               // column strides of X~ and V_r (odd)
+    size_t v_off;             // V_r
+    size_t tab_off;           // padded layout: raw pairing table (ints), behind it the per-sweep translation (int2 per round and
+                              // group); the Gram matrix / symmetric factor of the closing step overlays both.  Tight layout: end of
+                              // the matrices (+ slack); the Gram matrix overlays V_r there
+    size_t end_bytes;         // bytes of dynamic LDS this order needs
+};
+__host__ __device__ __forceinline__ RpLayout rp_layout(int k, int n2, int tg, int tab_ints, int tab2_entries) {
+    RpLayout y;
+    const int nc = (n2 + 15) >> 4;
+    y.pad = nc <= RP_PAD_MAX_NR;
+    y.ns = y.pad ? rp_pad_ns(nc, tg) : (n2 | 1);
+    y.ks = y.pad ? y.ns : (k | 1);
+    y.v_off = y.pad ? (size_t)rp_pad_voff(nc, tg) : (size_t)k * y.ns;
+    y.tab_off = (y.pad ? 2 * (size_t)rp_pad_voff(nc, tg) : (size_t)k * y.ns + (size_t)k * y.ks) + RP_SLACK;
+    size_t end = y.tab_off * sizeof(double);
+    if (y.pad) {
+        const size_t tables = end + (size_t)tab_ints * sizeof(int) + (size_t)tab2_entries * sizeof(int2);
+        const size_t gram = end + (size_t)k * (k | 1) * sizeof(double);
+        end = tables > gram ? tables : gram;
+    }
+    y.end_bytes = end;
+    return y;
+}
+#define RP_LAYOUT_ERROR 0x7fffffff     // sweeps_out marker: the kernel's layout did not fit the launch's LDS (order skipped)
+
 template <int TG>
 __device__ __forceinline__ void rp_sum3(double& a, double& b, double& g) {
+    static_assert(TG == 16, "16 lanes per column pair (the 32-lane variant measured slower and was removed)");
     double z = 0.0;
     group_sum4<16>(a, b, g, z);
-    if (TG == 32) {
-        a += rp_xrow(a);
-        b += rp_xrow(b);
-        g += rp_xrow(g);
-    }
 }
 template <int TG>
 __device__ __forceinline__ double rp_sum1(double v) {
     v = group_sum<16>(v);
-    if (TG == 32) v += rp_xrow(v);
     return v;
 }
 
@@ -347,6 +364,7 @@ struct RProjArgs {
     int slot_len;
     const int *sched, *sched_off, *sched_rounds;
     int sched_ps, tab_ints;       // tab_ints: ints reserved in LDS for the raw pairing table (even)
+    int tab2_entries, lds_bytes;  // int2 entries reserved behind it for the per-sweep translation; dynamic LDS of the launch
     int N, L, nlm, utot, xtot, warm, corr;
     double rp_early, rp_corr2_max;   // closing step: stop sweeping below this rotation size / accept the second-order step below this |E|
     double tabs2, inv_sqrt_np;
@@ -446,12 +464,17 @@ __device__ __forceinline__ void rp_solve(const RProjArgs& A, int b, int l, RpSha
     const int nr = TG == 16 ? nc : rp_pad_nrt(nc, TG);   // row slots per lane (the same for the k rows of V_r: k = 2l+1)
     // up to RP_PAD_MAX_NR row slots: zero-padded columns, one stride, V_r a fixed distance behind X~ (rp_sweep_pad); beyond
     // (config 5) the matrices fill the CU: tight columns, predicates on the last row slot (rp_sweep)
-    const bool pad = nc <= RP_PAD_MAX_NR;
-    const int ns = pad ? rp_pad_ns(nc, TG) : (n2 | 1), ks = pad ? ns : (k | 1);      // odd column strides
+    const RpLayout lay = rp_layout(k, n2, TG, A.tab_ints, A.tab2_entries);
+    if (lay.end_bytes > (size_t)A.lds_bytes) {           // never with the launcher of this file: host and device share rp_layout
+        if (tid == 0) A.sweeps_out[b * (A.L + 1) + l] = RP_LAYOUT_ERROR;
+        return;
+    }
+    const bool pad = lay.pad;
+    const int ns = lay.ns, ks = lay.ks;                  // odd column strides
     double* Xs = sm;
-    double* Vs = sm + (pad ? (size_t)rp_pad_voff(nc, TG) : (size_t)k * ns);
+    double* Vs = sm + lay.v_off;
     // behind the matrices: the pairing table of the current column count (raw, and translated per sweep in pad mode)
-    int* s_tab = reinterpret_cast<int*>(sm + (pad ? 2 * (size_t)rp_pad_voff(nc, TG) : (size_t)k * ns + (size_t)k * ks) + RP_SLACK);
+    int* s_tab = reinterpret_cast<int*>(sm + lay.tab_off);
     int2* s_tab2 = reinterpret_cast<int2*>(s_tab + A.tab_ints);
     const double* DV = A.DV + A.voff[l];
     const double* Vt = A.Vt + A.voff[l];
@@ -459,7 +482,7 @@ __device__ __forceinline__ void rp_solve(const RProjArgs& A, int b, int l, RpSha
     const size_t cstride = (size_t)A.nlm * 2;                                   // doubles between shells
     double* Vr = A.Vr + (size_t)b * A.utot + A.uoff[l];
     const int ntm_k = (k + 15) >> 4, ntn = (n2 + 15) >> 4;
-    long long* dbg = A.dbg ? A.dbg + ((size_t)b * (A.L + 1) + l) * 32 : nullptr;
+    long long* dbg = A.dbg ? A.dbg + ((size_t)b * (A.L + 1) + l) * MTIP_POLAR_DBG_SLOTS : nullptr;
     long long t0 = 0, t1 = 0;
     long long n_rounds_done = 0;
     if (dbg) t0 = clock64();
@@ -469,6 +492,7 @@ __device__ __forceinline__ void rp_solve(const RProjArgs& A, int b, int l, RpSha
         if (tid == 0) dbg[SLOT] = t1 - t0;              \
         t0 = t1;                                        \
     }
+    static_assert(MTIP_POLAR_DBG_SLOTS >= 40, "slots 10..39 hold the per-wave and per-segment sums");
     if (dbg && tid < 30) dbg[10 + tid] = 0;
     if (dbg && tid == 0) {
         dbg[6] = t0;
@@ -1047,7 +1071,8 @@ __global__ void __launch_bounds__(MAXT) k_rproj(RProjArgs A) {
 // RP_PAD_MAX_NR blocks of 16 columns, behind them the raw pairing table and its per-sweep translation (one int2 per round and
 // group); tight layout beyond (table read from L2) -- whichever needs more; tab_ints = ints reserved for the raw table
 struct RpGeom {
-    int tg = 16, threads = 256, tab_ints = 0, acc = RP_ACC_MAX;
+    int tg = 16, threads = 256, tab_ints = 0, tab2_entries = 0, acc = RP_ACC_MAX;
+    bool big = false;                  // some order has the tight layout (k_rproj<768, ...>)
     size_t lds = 0;
 };
 static RpGeom rp_launch_geometry(const mtip_ctx* c) {
@@ -1061,24 +1086,20 @@ static RpGeom rp_launch_geometry(const mtip_ctx* c) {
     const int kmax = std::max(kpad, kbig);
     const int ps = kmax >= 2 ? std::max(c->jsched_ps, 1) : 1;        // row length of the pairing table (it may have been built for more columns)
     const int groups = kmax >= 2 ? std::max(jacobi_groups(kmax), 1) : 1; // pair-groups the largest order keeps busy
-    // 32 lanes per pair when every order has the padded layout and all pairs of a round fit 1024 threads: four waves per SIMD
-    // with three row slots each instead of two with five
-    // (measured at k = 65: 3520 ticks per round against 2440 with 16 lanes: the youngest of four waves per SIMD starve; MTIP_RP_TG=32 selects it)
-    g.tg = (c->rp_tg == 32 && kbig == 0 && groups * 32 <= 1024 && kmax >= 34) ? 32 : 16;
+    g.tg = 16;
+    g.big = kbig > 0;
     g.threads = std::max(256, (groups * g.tg + 63) / 64 * 64);
-    g.lds = RP_SLACK * sizeof(double);
     if (kpad >= 2) {
         int nrd = 1;                                             // (the schedule has more rounds than columns: 70 at k = 65)
         for (int ke = 2; ke <= kpad && ke < (int)c->jsched_nrd.size(); ++ke) nrd = std::max(nrd, c->jsched_nrd[ke]);
         g.tab_ints = (nrd * ps + 1) & ~1;
-        const int nc = (kpad + 1 + 15) / 16;
-        g.lds = (2 * (size_t)rp_pad_voff(nc, g.tg) + RP_SLACK) * sizeof(double) + (size_t)g.tab_ints * sizeof(int) +
-                (size_t)nrd * (g.threads / g.tg) * sizeof(int2);
-        // the Gram matrix of the closing first-order step takes the place of the tables
-        g.lds = std::max(g.lds, (2 * (size_t)rp_pad_voff(nc, g.tg) + RP_SLACK + (size_t)kpad * (kpad | 1)) * sizeof(double));
+        g.tab2_entries = nrd * (g.threads / g.tg);
     }
-    if (kbig >= 2)
-        g.lds = std::max(g.lds, ((size_t)kbig * ((kbig + 1) | 1) + (size_t)kbig * (kbig | 1) + RP_SLACK) * sizeof(double));
+    // the block holds the largest layout among the solved orders (rp_layout: the definition the kernel takes its pointers from)
+    g.lds = RP_SLACK * sizeof(double);
+    for (int l = 1; l <= c->L; ++l)
+        if (c->active[l] && c->kl[l] >= 2)
+            g.lds = std::max(g.lds, rp_layout(c->kl[l], 2 * l + 2, g.tg, g.tab_ints, g.tab2_entries).end_bytes);
     // the in-place products hold all their 16 x 16 tiles in registers across a barrier
     const int nt16 = (kmax + 1 + 15) / 16;
     g.acc = div_up(nt16 * nt16, g.threads / 64);
@@ -1101,9 +1122,10 @@ bool rproj_supported(mtip_ctx* c) {
     if (kmax >= 2) {
         if (build_jacobi_schedule(c, kmax) != MTIP_OK) return false;
         const RpGeom g = rp_launch_geometry(c);
-        if (g.threads > RP_MAX_THREADS) return false;
+        // the instantiations of launch_rproj: <512, ...> up to 512 threads, <768, ...> (tight layout, config 5) up to 768
+        if (g.threads > 768) return false;             // (l = 49: 49 pair-groups = 832 threads -> the general kernels)
         if (g.lds + sizeof(RpShared) + 256 > 160 * 1024) return false;
-        if (g.acc > (g.tg == 32 ? 2 : (g.threads <= 512 ? 4 : RP_ACC_MAX))) return false;   // tiles per wave of the instantiations below
+        if (g.acc > (g.threads <= 512 ? 4 : RP_ACC_MAX)) return false;    // tiles per wave of those instantiations
     }
     return true;
 }
@@ -1234,16 +1256,21 @@ int launch_rproj(mtip_ctx* c, double2* coef) {
     a.dbg = c->d_polar_dbg;
     const RpGeom g = rp_launch_geometry(c);
     a.tab_ints = g.tab_ints;
+    a.tab2_entries = g.tab2_entries;
+    a.lds_bytes = (int)g.lds;
     ProfScope pp(c, "polar");                                    // (the whole projection is this one kernel)
     const dim3 grid((unsigned)c->B, (unsigned)c->rp_n_slots), block((unsigned)g.threads);
-    // registers by launch bound: 1024 threads (32 lanes per pair) = four waves per SIMD, 128 registers; 512 = two, 256 each; 768
-    // (the 97-column orders of config 5) = three, 168 each
-    if (g.tg == 32)
-        hipLaunchKernelGGL((k_rproj<1024, 1, 2, false, 32>), grid, block, g.lds, c->stream, a);
-    else if (g.threads <= 512)
+    // registers by launch bound: 512 threads = two waves per SIMD, 256 registers each; 768 (the 97-column orders of config 5) =
+    // three, 168 each
+    if (g.threads <= 512)
         hipLaunchKernelGGL((k_rproj<512, 2, 4, false, 16>), grid, block, g.lds, c->stream, a);
     else
         hipLaunchKernelGGL((k_rproj<768, 1, RP_ACC_MAX, true, 16>), grid, block, g.lds, c->stream, a);
+    const hipError_t le = hipGetLastError();
+    if (le != hipSuccess) {
+        c->err = std::string("k_rproj launch: ") + hipGetErrorString(le);
+        return MTIP_EHIP;
+    }
     c->vr_kind = 2;
     c->proj_calls += 1;
     return MTIP_OK;

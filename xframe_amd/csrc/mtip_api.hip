@@ -153,10 +153,11 @@ mtip_ctx* mtip_create(const mtip_cfg* cfg, int device) {
     c->have_V.assign(L + 1, 0);
     c->v_real.assign(L + 1, 1);
     if (const char* e = std::getenv("MTIP_PROJ_REAL")) c->proj_real = std::atoi(e) != 0;
-    if (const char* e = std::getenv("MTIP_RP_TG")) c->rp_tg = std::atoi(e);
     if (const char* e = std::getenv("MTIP_RP_CORR")) c->rp_corr = std::atoi(e) != 0;
-    if (const char* e = std::getenv("MTIP_RP_EARLY")) c->rp_early = std::atof(e);
-    if (const char* e = std::getenv("MTIP_RP_CORR2_MAX")) c->rp_corr2_max = std::atof(e);
+    // closing-step thresholds: A/B switches, held to the range the parity cases cover (test_projection_real_switches) -- a stray
+    // shell variable must not loosen the 1e-10 operator
+    if (const char* e = std::getenv("MTIP_RP_EARLY")) c->rp_early = std::min(std::max(std::atof(e), 1e-3), 0.2);
+    if (const char* e = std::getenv("MTIP_RP_CORR2_MAX")) c->rp_corr2_max = std::min(std::max(std::atof(e), 1e-6), 5e-4);
     for (int l = 0; l <= L; ++l) {
         const int n = 2 * l + 1, k = std::min(n, N);
         c->kl[l] = k;                               // default; mtip_set_projection_matrix may give a smaller k_l
@@ -1173,6 +1174,8 @@ int mtip_debug_jacobi_sweeps(mtip_ctx* c, int32_t* out) {
     (void)hipSetDevice(c->device);
     MTIP_HIP_CHECK(c, hipStreamSynchronize(c->stream));
     MTIP_HIP_CHECK(c, mtip_copy(c, out, c->d_sweeps, (size_t)c->B * (c->L + 1) * sizeof(int), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < (size_t)c->B * (c->L + 1); ++i)
+        if (out[i] == 0x7fffffff) FAIL(c, MTIP_ESTATE, "k_rproj: an order's LDS layout exceeded the launch's allocation and was skipped");
     return MTIP_OK;
 }
 
@@ -1199,7 +1202,7 @@ int mtip_debug_spin(mtip_ctx* c, double microseconds) {
 int mtip_debug_polar_timing(mtip_ctx* c, int64_t* out) {
     CTX_CHECK(c);
     (void)hipSetDevice(c->device);
-    const size_t n = (size_t)c->B * (c->L + 1) * 32;
+    const size_t n = (size_t)c->B * (c->L + 1) * MTIP_POLAR_DBG_SLOTS;
     MTIP_HIP_CHECK(c, hipStreamSynchronize(c->stream));
     if (!c->d_polar_dbg) {                       // first call: switch the timers on (the next projections fill them)
         int r = dev_alloc(c, &c->d_polar_dbg, n);

@@ -50,6 +50,7 @@ __device__ __forceinline__ double2 cmul_ipow(double2 a, int l, int sign) {
 }
 
 #define MTIP_CHAIN_DBG_SLOTS 18
+#define MTIP_POLAR_DBG_SLOTS MTIP_POLAR_TIMING_SLOTS   // int64 per (restart, order) of the k_rproj timers (include/mtip_hip.h)
 // ---- per-restart slot table (device ints), see DESIGN.md "state" ---------------------------------
 // SL_HIST: the pair the reference's stale local `hist` ends with (reconstruct.py:859, 913): the input pair of the most
 // recent step, or the latest pair when no step has run in the current sub-loop call; read by SW_center (893) and by the
@@ -165,7 +166,7 @@ struct mtip_ctx {
     int n_jorder = 0;
     int* d_pg_tiles[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // (order, tile) lists of the projection GEMMs (4, 5: fused pairs)
     int n_pg_tiles[6] = {0, 0, 0, 0, 0, 0};
-    long long* d_polar_dbg = nullptr;                 // (B, L+1, 32) phase / round timers of k_rproj, allocated by mtip_debug_polar_timing
+    long long* d_polar_dbg = nullptr;                 // (B, L+1, MTIP_POLAR_DBG_SLOTS) phase / round timers of k_rproj, allocated by mtip_debug_polar_timing
     int jac_tg = 16;                                  // env MTIP_JAC_TG=8|16: lanes per Jacobi column pair
     bool sht_fwd_pair = true;                         // env MTIP_SHT_FWD_PAIR=0: k_sht_fwd_reg (table loads inside the accumulation loop)
     bool sht_chain = true;                            // env MTIP_SHT_CHAIN=0: separate inverse / forward SHT kernels in the fused step (k_sht_chain.hip)
@@ -183,7 +184,6 @@ struct mtip_ctx {
     bool vr_valid = false;                            // d_Vr holds (complex) right singular vectors of the previous call
     int vr_kind = 0;                                  // 2: d_Vr holds the REAL right singular vectors of the previous k_rproj call
     bool proj_real = true;                            // env MTIP_PROJ_REAL=0: never take the real form of the projection (k_projr.hip)
-    int rp_tg = 0;                                    // env MTIP_RP_TG=32: 32 lanes per column pair in k_rproj where 1024 threads hold a round (default 16; slower as measured)
     std::vector<char> v_real;                         // per order: V_l has no imaginary part
     std::vector<double2> h_V;                         // host copy of the concatenated V_l (tables of the real projection)
     double *d_rp_DV = nullptr, *d_rp_Vt = nullptr;    // q^2 V_l (N x k) and V_l^T (k x N), real, at voff[l]
