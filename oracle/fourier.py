@@ -20,6 +20,14 @@ def radial_grid_midpoint(max_q, n_radial_points, reciprocity_coefficient):
     return rs, qs
 
 
+def radial_grid_gauss(max_q, n_radial_points, reciprocity_coefficient):
+    """ft_grid_pairs.py:293-300: Gauss-Legendre nodes mapped to [0, R] and [0, Q]."""
+    from scipy.special import roots_legendre
+    r_max = reciprocity_coefficient * n_radial_points / max_q
+    xs, _ = roots_legendre(n_radial_points)
+    return r_max / 2 * xs + r_max / 2, max_q / 2 * xs + max_q / 2
+
+
 def radial_grid_trapz(max_q, n_radial_points, reciprocity_coefficient):
     """ft_grid_pairs.py:274-281 (uniformGrid_func with endpoint)."""
     N = n_radial_points
@@ -52,16 +60,22 @@ class FourierPair:
         if mode == 'midpoint':
             self.rs, self.qs = radial_grid_midpoint(max_q, N, reciprocity_coefficient)
             wraw = _hk.spherical_mid_weights(sht.l_max, N, reciprocity_coefficient)
-        elif mode in ('trapz', 'Zernike'):
+        elif mode == 'trapz':
             self.rs, self.qs = radial_grid_trapz(max_q, N, reciprocity_coefficient)
             wraw = _hk.spherical_trapz_weights(sht.l_max, N, reciprocity_coefficient)
+        elif mode == 'Zernike':                     # the trapz grid (ft_grid_pairs.py:545), its own weights
+            self.rs, self.qs = radial_grid_trapz(max_q, N, reciprocity_coefficient)
+            wraw = _hk.zernike_weights_as_loaded(sht.l_max, N, reciprocity_coefficient)
+        elif mode == 'gauss':
+            self.rs, self.qs = radial_grid_gauss(max_q, N, reciprocity_coefficient)
+            wraw = _hk.spherical_gauss_weights(sht.l_max, N, reciprocity_coefficient)
         else:
             raise AssertionError(mode)
         # reconstruct.py:329 r_max = max(real_radial_points) -- NOT the cutoff R:
         self.r_max = np.max(self.rs)
         self.raw_weights = wraw
-        self.w = _hk.assemble_weights(wraw, self.r_max, reciprocity_coefficient)
-        self.trapz = mode != 'midpoint'
+        self.w = _hk.assemble_weights_mode(wraw, self.r_max, reciprocity_coefficient, mode)
+        self.trapz = mode in ('trapz', 'Zernike')       # sums skip shell 0 of the input (hankel_transforms.py:647-652: ht_modes[:2])
         self.grid = GridPair(self.rs, self.qs, sht.theta, sht.phi)
 
     def hankel(self, c):

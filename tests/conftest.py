@@ -51,6 +51,11 @@ def golden_polar2d():
 
 
 @pytest.fixture(scope='session')
+def golden_radial():
+    return np.load(os.path.join(GOLDEN, 'radial_rules.npz'))
+
+
+@pytest.fixture(scope='session')
 def golden_cfg1():
     return np.load(os.path.join(GOLDEN, 'mtip_cfg1_N32_L8.npz'))
 

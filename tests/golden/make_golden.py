@@ -1425,6 +1425,72 @@ def main_mtip2d():
     print('2-D loop fixture:', len(out), 'arrays; final error', res['final_error'], 'steps', len(res['error_dict']['main']))
 
 
+def main_radial_rules():
+    """tests/golden/radial_rules.npz (G21): the radial rules beyond midpoint / trapz for 3-D grids, from the reference's own functions:
+    `gauss` -- calc_spherical_gauss_weights, assemble_weights_gauss (hankel_transforms.py:477-490, 509-535), the grid of
+    radial_grid_gauss / spherical_ft_grid_pair_gauss (ft_grid_pairs.py:293-300, 394-399; selected for dim == 3 at 551-552) -- and
+    `Zernike` -- calc_spherical_zernike_weights, assemble_weights_zernike (88-131, 270-300) on the trapz grid (274-281, 545) --
+    each with the Hankel pair of generate_ht (602-658) on seeded 'ml' lists and the Fourier pair of generate_ft
+    (fourier_transforms.py:49-86) on a seeded grid.
+    The Zernike weights are generated the way the loader reaches them: load_fourier_transform_weights (fourier_transforms.py:17-35)
+    calls generate_weightDict(max_order, n, reciprocity_coefficient=rc, ...), which hands rc to generate_weightDict_zernike as its
+    THIRD POSITIONAL argument (hankel_transforms.py:26) -- that is `expansion_limit` (52); so the expansion limit is max(rc, max_order)
+    (62) and the weights' own reciprocity coefficient stays at its default pi (52), while the assembly uses rc (270-283)."""
+    mods = bootstrap()
+    ml = mods['xframe.library.mathLibrary']
+    ml.shtns = ShAdapter
+    from xframe_amd.fxs import synthetic as S
+    pre = 'xframe.projects.fxs.projectLibrary.'
+    ht = importlib.import_module(pre + 'hankel_transforms')
+    hts = importlib.import_module(pre + 'harmonic_transforms')
+    fts = importlib.import_module(pre + 'fourier_transforms')
+    gp = importlib.import_module(pre + 'ft_grid_pairs')
+    out = {}
+    N, L, kappa = 12, 5, 2.0
+    out['N'], out['L'], out['kappa'] = N, L, kappa
+    rng = np.random.default_rng(2104)
+    ht_opt = {'dimensions': 3, 'max_order': L, 'n_phi': 0, 'n_theta': 0, 'n_radial_points': N}
+    cht = hts.HarmonicTransform('complex', ht_opt)
+    sh = cht._sh
+    nlm = (L + 1) ** 2
+    max_q = float(np.max(S.midpoint_points(S.data_cutoff(N), N)))
+    out['max_q'] = max_q
+    orders = np.arange(L + 1)
+    c_direct = cplx(rng, (N, nlm))
+    g_in = cplx(rng, (N, len(cht.grid_param['thetas']), len(cht.grid_param['phis'])))
+    out['coeff_in'], out['grid_in'] = c_direct, g_in
+    c_ml = [np.array(c_direct[:, idx]) for idx in sh.cplx_m_indices]
+
+    def to_direct(ml_list):
+        d = np.zeros((N, nlm), complex)
+        for m_id, idx in enumerate(sh.cplx_m_indices):
+            d[:, idx] = ml_list[m_id]
+        return d
+
+    for mode in ('gauss', 'Zernike'):
+        grid_pair = gp.get_grid({'type': mode, 'reciprocity_coefficient': kappa, **ht_opt, **cht.grid_param,
+                                 'max_q': max_q, 'n_radial_points_from_data': N})
+        rs = np.array(grid_pair.realGrid[:, 0, 0, 0], dtype=float)
+        qs = np.array(grid_pair.reciprocalGrid[:, 0, 0, 0], dtype=float)
+        out[mode + '_rs'], out[mode + '_qs'] = rs, qs
+        if mode == 'gauss':
+            wraw = ht.calc_spherical_gauss_weights(orders, N, kappa)
+        else:
+            wraw = ht.calc_spherical_zernike_weights(orders, N, max(kappa, L), np.pi)      # (the call chain of the docstring)
+        out[mode + '_raw'] = wraw
+        r_max = float(np.max(rs))                                # reconstruct.py:329
+        out[mode + '_r_max'] = r_max
+        a = ht.assemble_weights(wraw, orders, r_max, reciprocity_coefficient=kappa, dimensions=3, mode=mode)
+        out[mode + '_fwd'], out[mode + '_inv'] = a['forward'], a['inverse']
+        zht, izht = ht.generate_ht(wraw, orders, r_max, reciprocity_coefficient=kappa, dimensions=3, use_gpu=False, mode=mode)
+        out[mode + '_hankel'], out[mode + '_ihankel'] = to_direct(zht(c_ml)), to_direct(izht(c_ml))
+        wd = {'weights': wraw, 'posHarmOrders': orders}
+        ft, ift = fts.generate_ft(r_max, wd, cht, 3, pos_orders=orders, reciprocity_coefficient=kappa, use_gpu=False, mode=mode)
+        out[mode + '_ft'], out[mode + '_ift'] = ft(g_in), ift(g_in)
+    np.savez_compressed(os.path.join(HERE, 'radial_rules.npz'), **out)
+    print('radial rules fixture:', len(out), 'arrays;', {k: np.shape(v) for k, v in out.items() if k.endswith('_raw')})
+
+
 if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'io':
         main_io()
@@ -1440,6 +1506,8 @@ if __name__ == '__main__':
         main_metrics()
     elif len(sys.argv) > 1 and sys.argv[1] == 'mtip2d':
         main_mtip2d()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'radial_rules':
+        main_radial_rules()
     elif len(sys.argv) > 1 and sys.argv[1] == 'variants':
         main_variants()
     else:

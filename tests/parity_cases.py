@@ -94,6 +94,28 @@ def check_transforms_golden(golden_ops, lib_path):
     e.close()
 
 
+def check_radial_rules_golden(g, lib_path):
+    """G21: the `gauss` and `Zernike` radial rules -- grids, raw weights (host setup), Hankel pair and Fourier pair of the device
+    against the outputs of the reference's own functions (tests/golden/radial_rules.npz), and against the oracle at a second size."""
+    import xframe_amd.fxs.hostsetup as hs
+    N, L, kappa, max_q = int(g['N']), int(g['L']), float(g['kappa']), float(g['max_q'])
+    for mode in ('gauss', 'Zernike'):
+        e = Engine({'grid': {'n_radial_points': N, 'max_order': L}, 'fourier_transform': {'type': mode, 'reciprocity_coefficient': kappa}},
+                   None, n_batch=1, lib_path=lib_path, max_q=max_q)
+        assert rel_l2(e.rs, g[mode + '_rs']) < 1e-14 and rel_l2(e.qs, g[mode + '_qs']) < 1e-14
+        assert rel_l2(e.raw_weights, g[mode + '_raw']) < 1e-13
+        fs, ivs = hs.hankel_scales(e.r_max, N, kappa, mode)
+        orders = np.arange(L + 1)
+        assert rel_l2(np.moveaxis(e.raw_weights, 0, 2) * ((-1j) ** orders * fs), g[mode + '_fwd']) < 1e-13
+        assert rel_l2(np.moveaxis(e.raw_weights, 0, 2) * ((1j) ** orders * ivs), g[mode + '_inv']) < 1e-13
+        assert rel_l2(e.hankel(g['coeff_in'])[0], g[mode + '_hankel']) < TOL_OP
+        assert rel_l2(e.hankel(g['coeff_in'], True)[0], g[mode + '_ihankel']) < TOL_OP
+        assert rel_l2(e.fourier_transform(g['grid_in'])[0], g[mode + '_ft']) < TOL_SHT
+        assert rel_l2(e.fourier_transform(g['grid_in'], True)[0], g[mode + '_ift']) < TOL_SHT
+        e.close()
+        check_transforms(10, 7, lib_path, seed=4, mode=mode)
+
+
 def _engine_and_oracle(g, lib_path, prefix='data_', n_batch=1, fused=False, extra=None):
     N, L = (int(g['N']), int(g['L'])) if 'N' in g else (16, 4)
     data = data_from_golden(g, L, prefix=prefix)
@@ -285,6 +307,7 @@ SETTINGS_VARIANTS = {
         'enforce_initial_support': {'apply': False, 'if_error_bigger_than': 6e-3}}}}}},
     'hio_considers_support_only': {'projections': {'real': {'HIO': {'considered_projections': ['support']}}}},
     'trapz': {'fourier_transform': {'type': 'trapz'}},
+    'gauss': {'fourier_transform': {'type': 'gauss'}},                  # hankel_transforms.py:477-535, ft_grid_pairs.py:293-300, 551-552
     'pi_in_q': {'fourier_transform': {'pi_in_q': True}},
     'history5': {'main_loop': {'history_length': 5}},
 }
@@ -430,6 +453,43 @@ def check_non_fxs_trajectory_vs_oracle(g, lib_path, fused, n_restarts=2):
     m.engine.close()
 
 
+def check_zernike_rule_trajectories(g, lib_path, fused=True):
+    """The `Zernike` radial rule (hankel_transforms.py:88-131, 270-300) inside the loop.  Its transform pair is numerically singular
+    (condition of the weight matrices 1e20 .. 1e36 at 16 x L4), and with it the Procrustes matrices V_l^+ D^2 I_l of the very first
+    step are rank deficient to rounding (singular-value ratios 5e-17 at l = 2, 3e-20 at l = 4, measured on this problem): their
+    polar factor is not unique and LAPACK's SVD (oracle) and the Jacobi kernel complete it differently (3e-5 in V_l U_l) -- DESIGN
+    section 1, intrinsic limit.  So: (1) a schedule WITHOUT the B_l projection (*_non_FXS steps with and without ft_stab: Fourier
+    pair, modulus step, real-space stage, error metric, shrink wrap) at the usual 1e-8, and (2) the FXS schedule with the error trace
+    to 1e-3 over its first six steps and 5e-2 over all ten (the two completions drift apart: 1e-4 after three steps, 1e-2 after nine)."""
+    N, L = int(g['N']), int(g['L'])
+    data = data_from_golden(g, L)
+    for fxs in (False, True):
+        opt = golden_settings(N, L, {'fourier_transform': {'type': 'Zernike'}})
+        main = opt['main_loop']['sub_loops']['main']
+        if fxs:
+            main['methods']['HIO']['iterations'] = 3
+            main['methods']['ER']['iterations'] = 2
+        else:
+            main['methods'] = {'HIO_non_FXS': {'iterations': 3, 'ft_stab': True}, 'ER_non_FXS': {'iterations': 2, 'ft_stab': False},
+                               'SW': main['methods']['SW']}
+            main['order'] = ['HIO_non_FXS', 'SW', 'ER_non_FXS']
+        main['iterations'] = 2
+        ref = OM.MTIP(opt, data).phasing_loop(rho0=g['rho0'])
+        R.MTIP.preinit(opt, data)
+        m = R.MTIP(n_restarts=1, initial_densities=[g['rho0']], lib_path=lib_path, fused=fused)
+        m.generate_phasing_loop()
+        r = m.phasing_loop()[0]
+        if fxs:
+            assert np.allclose(r['error_dict']['main'][:6], ref['error_dict']['main'][:6], rtol=1e-3)
+            assert np.allclose(r['error_dict']['main'], ref['error_dict']['main'], rtol=5e-2)
+        else:
+            assert np.allclose(r['error_dict']['main'], ref['error_dict']['main'], rtol=1e-8)
+            for k in ('real_density', 'last_real_density', 'reciprocal_density', 'last_reciprocal_density'):
+                assert rel_l2(r[k], ref[k]) < 1e-8, k
+            assert (r['support_mask'] != ref['support_mask']).sum() == 0
+        m.engine.close()
+
+
 def synthetic_problem(cfg, lib_path=None, N=None, L=None):
     """Synthetic invariants for a BASELINE config, generated with the HIP transforms (product path)."""
     n, l = S._SIZES[cfg]
@@ -462,6 +522,23 @@ def check_projection_vs_oracle(N, L, lib_path=None, n_batch=2, seed=1):
             unk = om.rp.approximate_unknowns(Il)
             ref = np.concatenate(om.rp.mtip_projection(Il, unk), axis=1)
             assert rel_l2(proj[b], ref) < TOL_SHT, (rep, b)
+    e.close()
+
+
+def check_find_rotation_nan(lib_path=None, N=6, L=4):
+    """arg-max of the SO(3) correlation as numpy's (average.py:936): a NaN is the maximum, the first one in reading order wins --
+    a restart whose coefficients hold a NaN comes back with index (0, 0, 0) and a NaN maximum, the others are untouched"""
+    import torch
+    e, _ = transforms_engine(N, L, lib_path, n_batch=2)
+    rng = np.random.default_rng(11)
+    dev = e.torch_device()
+    ref = torch.from_numpy(cplx(rng, (N, e.nlm))).to(dev)
+    sig = cplx(rng, (2, N, e.nlm))
+    arg0, v0, _ = e.t_find_rotation(ref, torch.from_numpy(sig).to(dev))
+    sig[1, 2, 5] = np.nan
+    arg1, v1, _ = e.t_find_rotation(ref, torch.from_numpy(sig).to(dev))
+    assert (arg1[0] == arg0[0]).all() and v1[0] == v0[0] and np.isfinite(v0).all()
+    assert (arg1[1] == 0).all() and np.isnan(v1[1])
     e.close()
 
 

@@ -34,6 +34,10 @@ def test_transforms_trapz(emul_lib):
     PC.check_transforms(12, 3, emul_lib, seed=3, mode='trapz')
 
 
+def test_radial_rules_golden(emul_lib, golden_radial):
+    PC.check_radial_rules_golden(golden_radial, emul_lib)
+
+
 def test_transforms_golden(emul_lib, golden_ops):
     PC.check_transforms_golden(golden_ops, emul_lib)
 
@@ -69,6 +73,11 @@ def test_reciprocal_option_variants_vs_oracle(emul_lib, golden_mtip16, ropt):
 @pytest.mark.parametrize('name', sorted(PC.SETTINGS_VARIANTS))
 def test_settings_variants_vs_oracle(emul_lib, golden_mtip16, name):
     PC.check_settings_variant_vs_oracle(golden_mtip16, emul_lib, name)
+
+
+@pytest.mark.parametrize('fused', [True, False])
+def test_zernike_rule_trajectories(emul_lib, golden_mtip16, fused):
+    PC.check_zernike_rule_trajectories(golden_mtip16, emul_lib, fused)
 
 
 def test_split_shell_steps_vs_oracle(emul_lib):
@@ -204,6 +213,10 @@ def test_projection_real_switches(emul_lib, env, closing, monkeypatch):
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     PC.check_projection_real_vs_oracle(24, 10, emul_lib, n_batch=1, closing=closing)
+
+
+def test_find_rotation_nan_is_the_maximum(emul_lib):
+    PC.check_find_rotation_nan(emul_lib)
 
 
 def test_polar_timing_records_do_not_overlap(emul_lib):

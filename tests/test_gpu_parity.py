@@ -24,6 +24,11 @@ def test_transforms_trapz():
     PC.check_transforms(12, 3, None, seed=3, mode='trapz')
 
 
+def test_radial_rules_golden(golden_radial):
+    """`gauss` and `Zernike` radial rules: device Hankel / Fourier pairs against the reference's own outputs (G21) and the oracle"""
+    PC.check_radial_rules_golden(golden_radial, None)
+
+
 def test_transforms_golden(golden_ops):
     PC.check_transforms_golden(golden_ops, None)
 
@@ -125,6 +130,10 @@ def test_projection_order_49_takes_the_general_kernels():
     """l = 49 (99 columns) needs 832 threads in the real kernel's pairing -- beyond its 768-thread instantiation: the launcher must
     refuse it (rproj_supported) and the general kernels run; odd orders active"""
     PC.check_projection_real_vs_oracle(100, 49, n_batch=1, reciprocal_opt={'odd_orders_to_0': False}, expect_real=False)
+
+
+def test_find_rotation_nan_is_the_maximum():
+    PC.check_find_rotation_nan(None)
 
 
 def test_polar_timing_records_do_not_overlap():
@@ -251,6 +260,10 @@ def test_config2_properties():
     PC.check_full_size_properties(2)
 
 
+def test_zernike_rule_trajectories(golden_mtip16):
+    PC.check_zernike_rule_trajectories(golden_mtip16, None)
+
+
 def test_config3_properties_full_size():
     """128 shells x L_max = 32 (the metric's configuration)."""
     errs = PC.check_full_size_properties(3, n_steps=8)
@@ -259,9 +272,12 @@ def test_config3_properties_full_size():
 
 def test_config5_properties_full_size():
     """256 shells x L_max = 48 (BASELINE config 5, 128 x 256 angular grid): the inverse SHT shares a shell between two
-    workgroups (fused epilogues, two error partial sums per shell), the forward SHT takes the pass-wise table kernel and the
-    97-column polar factors the X_l-only Jacobi with the rotation log + V_r replay; same size-independent properties as at
-    the metric's size (fused == reference order, round trips, B_l of the projection == data B_l)."""
+    workgroups (fused epilogues, two error partial sums per shell; no chained inverse -> forward kernel: a shell of this grid
+    does not fit one CU), the forward SHT takes the pass-wise table kernel with prefetched rows, and the 97-column polar factors
+    run in k_rproj's tight layout (768 threads, pairing table from L2, the closing step's Gram matrix in V_r's place); same
+    size-independent properties as at the metric's size (fused == reference order, round trips, B_l of the projection ==
+    data B_l).  Its oracle coverage: test_projection_real_vs_oracle[100-48], test_projection_real_switches[100-48-*],
+    test_split_shell_steps_vs_oracle."""
     errs = PC.check_full_size_properties(5, n_steps=4)
     assert np.isfinite(errs).all()
 

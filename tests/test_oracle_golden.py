@@ -189,6 +189,24 @@ def _mtip_from_golden(g, extra=None):
     return OM.MTIP(o, data)
 
 
+@pytest.mark.parametrize('mode', ['gauss', 'Zernike'])
+def test_G21_radial_rules(golden_radial, mode):
+    """the oracle's `gauss` / `Zernike` radial rules against the reference's own functions: grids, raw weights, assembled weights,
+    the Hankel pair of generate_ht and the Fourier pair of generate_ft (the SHT in it is the oracle's own double)"""
+    from oracle.fourier import FourierPair
+    from oracle.sht import SHT
+    g = golden_radial
+    N, L, kappa = int(g['N']), int(g['L']), float(g['kappa'])
+    fp = FourierPair(SHT(L), N, float(g['max_q']), kappa, mode)
+    assert rel_l2(fp.rs, g[mode + '_rs']) < TIGHT and rel_l2(fp.qs, g[mode + '_qs']) < TIGHT
+    assert np.isclose(fp.r_max, float(g[mode + '_r_max']), rtol=1e-15)
+    assert rel_l2(fp.raw_weights, g[mode + '_raw']) < TIGHT
+    assert rel_l2(fp.w['forward'], g[mode + '_fwd']) < TIGHT and rel_l2(fp.w['inverse'], g[mode + '_inv']) < TIGHT
+    assert rel_l2(fp.hankel(g['coeff_in']), g[mode + '_hankel']) < TIGHT
+    assert rel_l2(fp.ihankel(g['coeff_in']), g[mode + '_ihankel']) < TIGHT
+    assert rel_l2(fp.ft(g['grid_in']), g[mode + '_ft']) < TIGHT and rel_l2(fp.ift(g['grid_in']), g[mode + '_ift']) < TIGHT
+
+
 def test_G10_single_steps(golden_mtip16):
     g = golden_mtip16
     m = _mtip_from_golden(g)

@@ -119,7 +119,12 @@ __global__ void __launch_bounds__(256) k_so3_build_D(const double* __restrict__ 
 // arg-max of the correlation in the order the reference reads it in (average.py:936-940: [beta, alpha, gamma], tabulated at
 // the angles whose flip alpha -> 2 pi - alpha, gamma -> 2 pi - gamma is the aligning rotation -- oracle/alignment.py
 // mean_C_layout): the key of element C[j][bi][k] is bi nb^2 + ((-j) mod nb) nb + ((-k) mod nb); the first maximum in that order
-// wins, as numpy's argmax does.  One workgroup per restart.
+// wins, as numpy's argmax does -- and like numpy's, a NaN counts as the maximum (the first NaN in reading order is returned).
+// One workgroup per restart.
+__device__ __forceinline__ bool so3_better(double v2, long long k2, double v, long long k) {
+    if (v2 != v2) return (v == v) || k2 < k;
+    return (v == v) && (v2 > v || (v2 == v && k2 < k));
+}
 __global__ void __launch_bounds__(1024) k_so3_argmax(const double* __restrict__ C, int nb, long long* __restrict__ arg, double* __restrict__ vmax) {
     __shared__ double s_v[16];
     __shared__ long long s_k[16];
@@ -131,7 +136,7 @@ __global__ void __launch_bounds__(1024) k_so3_argmax(const double* __restrict__ 
         const int j = e / (nb * nb), bi = (e / nb) % nb, k = e % nb;
         const long long kk = (long long)bi * nb * nb + (long long)((nb - j) % nb) * nb + (nb - k) % nb;
         const double v = Cb[e];
-        if (v > best || (v == best && kk < key)) {
+        if (so3_better(v, kk, best, key)) {
             best = v;
             key = kk;
         }
@@ -139,7 +144,7 @@ __global__ void __launch_bounds__(1024) k_so3_argmax(const double* __restrict__ 
     for (int o = 32; o > 0; o >>= 1) {
         const double v2 = __shfl_xor(best, o, 64);
         const long long k2 = __shfl_xor(key, o, 64);
-        if (v2 > best || (v2 == best && k2 < key)) {
+        if (so3_better(v2, k2, best, key)) {
             best = v2;
             key = k2;
         }
@@ -151,7 +156,7 @@ __global__ void __launch_bounds__(1024) k_so3_argmax(const double* __restrict__ 
     __syncthreads();
     if (threadIdx.x == 0) {
         for (int wv = 1; wv < (int)(blockDim.x >> 6); ++wv)
-            if (s_v[wv] > best || (s_v[wv] == best && s_k[wv] < key)) {
+            if (so3_better(s_v[wv], s_k[wv], best, key)) {
                 best = s_v[wv];
                 key = s_k[wv];
             }

@@ -399,8 +399,13 @@ int mtip_op_invariant_metrics(mtip_ctx* c, const mtip_cdouble* Ilm, double* II, 
     const size_t rowlen = (size_t)c->B * (2 + c->N);
     double* d_row = nullptr;
     MTIP_HIP_CHECK(c, hipMalloc((void**)&d_row, rowlen * sizeof(double)));
-    MTIP_HIP_CHECK(c, hipMemsetAsync(d_row, 0, rowlen * sizeof(double), c->stream));
-    MTIP_HIP_CHECK(c, mtip_copy(c, c->d_c[2], Ilm, (size_t)c->B * c->C * sizeof(double2), hipMemcpyHostToDevice));
+    hipError_t he = hipMemsetAsync(d_row, 0, rowlen * sizeof(double), c->stream);
+    if (he == hipSuccess) he = mtip_copy(c, c->d_c[2], Ilm, (size_t)c->B * c->C * sizeof(double2), hipMemcpyHostToDevice);
+    if (he != hipSuccess) {                                  // (the row buffer must not outlive a failed call)
+        (void)hipFree(d_row);
+        c->err = std::string("op_invariant_metrics: ") + hipGetErrorString(he);
+        return MTIP_EHIP;
+    }
     int rc = launch_invariant_metrics_row(c, c->d_c[2], d_row);
     std::vector<double> row(rowlen);
     if (rc == MTIP_OK && mtip_copy(c, row.data(), d_row, rowlen * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) rc = MTIP_EHIP;

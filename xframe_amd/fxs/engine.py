@@ -42,7 +42,7 @@ class Engine:
         self.fused = bool(fused)
         if self.lib.mtip_device_count() <= 0:
             raise _lib.MtipError('no HIP device visible: the MTIP engine needs an MI355X (no CPU fallback)')
-        cfg = _lib.MtipCfg(self.N, self.L, self.n_theta, self.n_phi, self.B, 0 if self.mode == 'midpoint' else 1,
+        cfg = _lib.MtipCfg(self.N, self.L, self.n_theta, self.n_phi, self.B, 1 if hs.hankel_skips_first_shell(self.mode) else 0,
                            1 if fused else 0, 0)
         self.ctx = self.lib.mtip_create(C.byref(cfg), int(device))
         if not self.ctx:
@@ -54,7 +54,7 @@ class Engine:
         self._ck(self.lib.mtip_set_radial_grid(self.ctx, _lib.ptr(self.rs), _lib.ptr(self.qs)))
         self.r_max = float(np.max(self.rs))                          # reconstruct.py:329
         self.raw_weights = hs.hankel_raw_weights(self.L, self.N, self.kappa, self.mode)
-        fs, ivs = hs.hankel_scales(self.r_max, self.N, self.kappa)
+        fs, ivs = hs.hankel_scales(self.r_max, self.N, self.kappa, self.mode)
         self._ck(self.lib.mtip_set_hankel_weights(self.ctx, _lib.ptr(self.raw_weights), fs, ivs))
         self.int_wr, self.int_wt = hs.integrator_weights(self.rs, self.n_theta)
         self.default_sigma = np.pi / np.max(self.qs)                 # fxs_Projections.py:189-193

@@ -2,7 +2,7 @@
 
 Each helper mirrors a reference routine (file:line relative to the reference checkout, under xframe/):
   angular grid        externalLibraries/shtns_plugin.py:94-101, 121-133
-  radial grids        projects/fxs/projectLibrary/ft_grid_pairs.py:282-291 (midpoint), 274-281 (trapz)
+  radial grids        projects/fxs/projectLibrary/ft_grid_pairs.py:282-291 (midpoint), 274-281 (trapz, Zernike), 293-300 (gauss)
   Hankel weights      projects/fxs/projectLibrary/hankel_transforms.py:399-410, 322-333, 426-452
   projection matrices projects/fxs/projectLibrary/fxs_Projections.py:471-537, 578-714
   initial support     fxs_Projections.py:133-155
@@ -40,11 +40,12 @@ def radial_grids(max_q, n, kappa, mode='midpoint'):
         dr, dq = r_cut / n, max_q / n
         return (np.linspace(dr / 2, r_cut - dr / 2, num=n, endpoint=True),
                 np.linspace(dq / 2, max_q - dq / 2, num=n, endpoint=True))
-    if mode == 'trapz':
+    if mode in ('trapz', 'Zernike'):                    # ft_grid_pairs.py:274-281, selected for both at 545
         return np.linspace(0, r_cut, n), np.linspace(0, max_q, n)
-    # 'Zernike' shares the trapz grid upstream (ft_grid_pairs.py:545-547) but has its own weights, which are not built here;
-    # 'gauss' has no spherical grid upstream
-    raise NotImplementedError(f'fourier_transform.type {mode!r} is not supported (midpoint, trapz)')
+    if mode == 'gauss':                                 # ft_grid_pairs.py:293-300 (dim == 3: 551-552): Gauss-Legendre nodes on [0, R], [0, Q]
+        xs = roots_legendre(n)[0]
+        return r_cut / 2 * xs + r_cut / 2, max_q / 2 * xs + max_q / 2
+    raise NotImplementedError(f'fourier_transform.type {mode!r} is not supported (midpoint, trapz, gauss, Zernike)')
 
 
 _HANKEL_W = {}
@@ -71,16 +72,63 @@ def _hankel_raw_weights(l_max, n, kappa, mode='midpoint'):
     elif mode == 'trapz':
         ps = np.arange(1, n)
         ks = np.arange(n)
+    elif mode == 'gauss':
+        # calc_spherical_gauss_weights, hankel_transforms.py:477-490: Gauss-Legendre nodes and weights, p = k = x + 1
+        xi, wg = roots_legendre(n)
+        ps = ks = xi + 1
+        arg = ks[None, :] * ps[:, None] * kappa * n / 4
+        return np.ascontiguousarray(ps[None, :, None] ** 2 * spherical_jn(ls[:, None, None], arg[None, :, :]) * wg[None, :, None])
+    elif mode == 'Zernike':
+        return _zernike_raw_weights(l_max, n, kappa)
     else:
-        raise NotImplementedError(f'fourier_transform.type {mode!r} is not supported (midpoint, trapz)')
+        raise NotImplementedError(f'fourier_transform.type {mode!r} is not supported (midpoint, trapz, gauss, Zernike)')
     arg = ks[None, :] * ps[:, None] * kappa / n
     return np.ascontiguousarray(ps[None, :, None] ** 2 * spherical_jn(ls[:, None, None], arg[None, :, :]))
 
 
-def hankel_scales(r_max, n, kappa):
-    """(forward, inverse) real prefactors; the (-/+ i)^l phases are applied by the kernel."""
+def _zernike_raw_weights(l_max, n, kappa):
+    """calc_spherical_zernike_weights (hankel_transforms.py:88-131) with the arguments the reference's loader gives it: its
+    generate_weightDict hands the reciprocity coefficient on as the third POSITIONAL argument of generate_weightDict_zernike (26),
+    which is `expansion_limit` (52) -- so the Zernike expansion stops at max(kappa, l_max) (62) and the Bessel arguments use that
+    function's default reciprocity coefficient pi, whatever the settings say; only the assembly (hankel_scales) sees kappa.
+    w[l,p,k] = (p^2 / k) sum_{s = l, l+2, ..} (-1)^((s-l)/2) (2s+3) R^l_s(p/n) j_{s+1}(pi k) for p = 1..n-1, k = 1..n-1, with the
+    3-D Zernike radial polynomials R^l_s(x) = (-1)^((s-l)/2) x^l P^{(l+1/2, 0)}_{(s-l)/2}(1 - 2 x^2) (mathLibrary.py:805-819); column
+    k = 0: p^2 pi for l = 0, else 0."""
+    from scipy.special import eval_jacobi
+    lim = max(kappa, l_max)
+    rc = np.pi
+    ps = np.arange(1, n)
+    ks = np.arange(n)
+    x = ps / n
+    w = np.zeros((l_max + 1, n - 1, n))
+    for l in range(l_max + 1):
+        s = np.arange(l, lim + 1, 2)
+        half = (s - l) / 2
+        R = ((-1) ** half)[:, None] * (x ** l)[None, :] * eval_jacobi(half[:, None], l + 0.5, 0, (1 - 2 * x ** 2)[None, :])
+        pref = (-1) ** half * (2 * s + 3)
+        jp = spherical_jn((s + 1)[:, None], (ks[1:] * rc)[None, :])
+        w[l, :, 1:] = np.einsum('s,sp,sk->pk', pref, R, jp)
+        if l == 0:
+            w[0, :, 0] = rc
+    c_kp = np.empty((n - 1, n))
+    c_kp[:, 1:] = np.square(ps)[:, None] / ks[None, 1:]
+    c_kp[:, 0] = np.square(ps)
+    return np.ascontiguousarray(w * c_kp[None, :, :])
+
+
+def hankel_skips_first_shell(mode):
+    """the sums of the trapz and Zernike rules leave out shell 0 of their input (hankel_transforms.py:647-652, 671-700: ht_modes[:2])"""
+    return mode in ('trapz', 'Zernike')
+
+
+def hankel_scales(r_max, n, kappa, mode='midpoint'):
+    """(forward, inverse) real prefactors; the (-/+ i)^l phases are applied by the kernel.  midpoint / trapz:
+    hankel_transforms.py:426-452, 349-375; gauss 509-535; Zernike 270-300."""
     q_max = kappa * n / r_max
-    c = np.sqrt(2 / np.pi)
+    if mode == 'gauss':
+        c = np.sqrt(2 / np.pi)
+        return (r_max / 2) ** 3 * c, (q_max / 2) ** 3 * c
+    c = np.sqrt(2 / np.pi ** 3) if mode == 'Zernike' else np.sqrt(2 / np.pi)
     return (r_max / n) ** 3 * c, (q_max / n) ** 3 * c
 
 
