@@ -42,6 +42,11 @@ out = {{'rank': rank, 'n_results': int(len(result)), 'mine': mine,
        'errs': [float(r['final_error']) for r in result], 'engines': len(w.mtip_instances),
        'kinds': [r.get('gathered', 'own') for r in result],
        'dens_norm': [float(np.linalg.norm(r['real_density'])) if 'real_density' in r else -1.0 for r in result],
+       # order-sensitive checksums of every grid-sized array of a full dict: what arrived on rank 0 must be what the owner holds
+       'sums': [[float(np.vdot(np.arange(1, r[k].size + 1) % 97, np.asarray(r[k], dtype=complex).ravel()).real) for k in
+                 ('real_density', 'last_real_density', 'reciprocal_density', 'last_reciprocal_density', 'support_mask', 'last_support_mask',
+                  'initial_density', 'last_deg2_invariant')] if 'real_density' in r else [] for r in result],
+       'from_hbm': int(getattr(P, 'SENT_FROM_DEVICE', 0)),
        'sorted': [int(i) for i in w.results.get('sorted_ids', [])]}}
 print('RESULT ' + json.dumps(out), flush=True)
 dist.destroy_process_group()
@@ -82,6 +87,8 @@ def test_two_rank_gloo_worker(emul_lib, tmp_path):
     r0, r1 = _run_two_ranks(tmp_path, 29571, n_total=3, n_eng=1, n_full=8)
     assert r0['mine'] == [0, 2] and r1['mine'] == [1]
     assert r0['kinds'] == ['own', 'full', 'own'] and r0['dens_norm'][1] > 0     # restart 1 arrived with its arrays
+    assert r0['sums'][1] == r1['sums'][0]            # ... bit for bit what its owner holds
+    assert r1['from_hbm'] == 6 and r0['from_hbm'] == 0    # densities and masks went out of the owner's engine buffers, not its host copies
     assert r0['n_results'] == 3                      # rank 0 holds every restart after the gather
     assert r0['gathered'] == [[2.0, 0.0], [1.0, 1.0]] == r1['gathered']
     assert np.isclose(r0['bl_trace'], r1['bl_trace'], rtol=1e-12)       # all-reduced mean B_l identical on both ranks

@@ -392,6 +392,21 @@ class Engine:
         self._ck(self.lib.mtip_op_sht_inverse(self.ctx, self._tp(c), self._tp(out)))
         return out
 
+    def t_state(self, kind, batch, best=False):
+        """a grid of the loop state -- 'density', 'reciprocal_density' (complex128) or 'support' (uint8), current or best pair -- as a
+        tensor ON THE ENGINE'S DEVICE (device-to-device copy out of the slot arrays; the getters of the C ABI take a device
+        destination as well as a host one).  What the end-of-run gather sends from (parallel.gather_results)."""
+        import torch
+        dev = self.torch_device()
+        if kind == 'support':
+            out = torch.empty(self.shape, dtype=torch.uint8, device=dev)
+            self._ck(self.lib.mtip_get_support(self.ctx, int(batch), int(best), self._tp(out)))
+            return out
+        fn = {'density': self.lib.mtip_get_density, 'reciprocal_density': self.lib.mtip_get_reciprocal_density}[kind]
+        out = torch.empty(self.shape, dtype=torch.complex128, device=dev)
+        self._ck(fn(self.ctx, int(batch), int(best), self._tp(out)))
+        return out
+
     def t_find_rotation(self, ref_coeff, sig_coeff, r_limit_ids=None, keep_metric=False):
         """find_rotation (average.py:920-947) for a batch: (arg-max in the reference's reading order as (i_beta, i_alpha, i_gamma)
         per restart, the maxima, the correlation (B, nb, nb, nb) [alpha, beta, gamma] on the device or None)"""

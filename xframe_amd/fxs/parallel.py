@@ -54,17 +54,25 @@ def _heavy_keys(res):
     return sorted(k for k, v in res.items() if _is_heavy(v))
 
 
-def gather_results(local_results, local_ids, n_total, rank, world_size, n_full=8, device=None):
+SENT_FROM_DEVICE = 0          # arrays the last gathers of this process sent out of engine buffers (diagnostic, tests)
+
+
+def gather_results(local_results, local_ids, n_total, rank, world_size, n_full=8, device=None, device_source=None):
     """End-of-run gather (reference: Manager Queue + argsort of the final errors, reconstruct.py:160-177).
 
     1. all_gather of the per-restart scalars (last main error) -> every rank knows the global ranking;
     2. the light parts of the result dicts (scalars, error histories, unknowns: a few KB each) go to rank 0 as objects;
     3. the grid-sized arrays (densities, supports, B_l: ~7 x 16 MiB per restart at 128 x L32) travel only for the ``n_full``
        best restarts, as tensors point to point to rank 0 (RCCL send / recv over xGMI with the nccl backend; gloo on CPU in the
-       tests).  The result dicts hold host arrays (the engine has already copied them back): with the nccl backend each array is
-       staged host -> device tensor -> send -> device tensor -> host on the receiver.
+       tests).  With the nccl backend the owner sends the arrays that are engine state -- the four densities and the two support
+       masks, 6 of the ~7 grids -- straight out of HBM: ``device_source[restart id](key)`` hands back a device tensor (a
+       device-to-device copy out of the engine's slot arrays, Engine.t_state), so nothing of grid size crosses PCIe on the sending
+       side; what the engine does not hold in that form (B_l, the initial density, arrays an output modifier has changed) is
+       staged from the host copy of the result dict.  The receiver copies each tensor to the host once (the result dicts are host
+       arrays, as the reference's).
     Rank 0 returns an object array of all restarts -- full dicts for its own and for the selected ones, light dicts (flagged
     ``'gathered': 'light'``) for the rest; other ranks return their own results unchanged."""
+    global SENT_FROM_DEVICE
     if world_size == 1:
         return local_results
     dist = _dist()
@@ -98,14 +106,21 @@ def gather_results(local_results, local_ids, n_total, rank, world_size, n_full=8
         for i, r in zip(local_ids, local_results):
             out[i] = r
     # heavy arrays of the selected restarts, in a fixed order on both ends
-    use_dev = device is not None and dist.get_backend() == 'nccl'
+    # tensors of `device` travel as they are: the GPU with nccl (= RCCL); a CPU `device` (gloo rehearsal of the same code path)
+    use_dev = device is not None and (dist.get_backend() == 'nccl' or getattr(device, 'type', None) == 'cpu')
     for i in selected:
         owner = i % world_size
         if owner == 0:
             continue
         if rank == owner:
             res = local_results[local_ids.index(i)]
+            src = (device_source or {}).get(i) if use_dev else None
             for k in _heavy_keys(res):
+                t = src(k) if src is not None else None
+                if t is not None and tuple(t.shape) == tuple(res[k].shape) and t.element_size() == res[k].dtype.itemsize:
+                    dist.send(t.contiguous().view(torch.uint8).reshape(-1), dst=0)           # from the engine's HBM
+                    SENT_FROM_DEVICE += 1
+                    continue
                 a = np.ascontiguousarray(res[k])
                 t = torch.from_numpy(a.view(np.uint8).reshape(-1).copy())
                 dist.send(t.to(device) if use_dev else t, dst=0)

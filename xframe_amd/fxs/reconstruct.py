@@ -299,6 +299,12 @@ class MTIP:
         # the reference's metric has one entry per used order (fxs_IO_methods.py:413, 425-427)
         order_array = np.array(tuple(e.rsetup.used_orders.values()), dtype=int)
         shift = bool(self.opt.get('output_density_modifiers', {}).get('shift_to_center', False))
+        # grids of the result dicts that are the engine's state as it stands (no output modifier touched them): the end-of-run
+        # gather sends those from HBM (device_source)
+        self._state_keys = {} if shift else {'real_density': ('density', True), 'last_real_density': ('density', False),
+                                             'reciprocal_density': ('reciprocal_density', True),
+                                             'last_reciprocal_density': ('reciprocal_density', False)}
+        self._state_keys.update({'support_mask': ('support', True), 'last_support_mask': ('support', False)})
         B = self.n_restarts
         recip = {best: np.stack([e.reciprocal_density(b, best=best) for b in range(B)]) for best in (True, False)}
         real = {best: np.stack([e.density(b, best=best) for b in range(B)]) for best in (True, False)}
@@ -339,6 +345,17 @@ class MTIP:
                 'grid_pair': {'real_grid': real_grid, 'reciprocal_grid': reciprocal_grid},
                 'projection_matrices': masked_pm, 'last_deg2_invariant': last_deg2[b]}
         return out
+
+
+def _device_source(mtip, batch):
+    """key -> device tensor of restart `batch` of that MTIP instance's engine, or None when the dict's array is not engine state"""
+    def get(key):
+        spec = getattr(mtip, '_state_keys', {}).get(key)
+        if spec is None or mtip.engine is None:
+            return None
+        t = mtip.engine.t_state(spec[0], batch, best=spec[1])
+        return t.bool() if spec[0] == 'support' else t
+    return get
 
 
 class ProjectWorker:
@@ -404,14 +421,16 @@ class ProjectWorker:
                 with ThreadPoolExecutor(n_eng) as pool:             # ctypes calls release the GIL
                     outs = list(pool.map(run_group, groups))
             result = np.empty(len(mine), dtype=object)
+            sources = {}
             for local_ids, (m, res) in zip(groups, outs):
                 for j, i in enumerate(local_ids):
                     result[i] = res[j]
+                    sources[mine[i]] = _device_source(m, j)
             self.mtip_instance = outs[0][0]
             self.mtip_instances = [m for m, _ in outs]
             self.results['stats']['groups'] = [dict(m.timing, restarts=len(g)) for (m, _), g in zip(outs, groups)]
         result = gather_results(result, mine, total, self.rank, self.world_size, n_full=self.n_gather_full,
-                                device=self._torch_device())
+                                device=self._torch_device(), device_source=sources if len(mine) else None)
         self.results['MTIP'] = result
         self.results['stats']['run_time'] = time.time() - start
         self.post_processing()
@@ -426,6 +445,8 @@ class ProjectWorker:
             import torch.distributed as dist
             if dist.is_initialized() and dist.get_backend() == 'nccl':
                 return torch.device('cuda', self.device)
+            if dist.is_initialized() and self.lib_path is not None:     # CPU emulation of the kernels (tests): same gather path, CPU tensors
+                return torch.device('cpu')
         except Exception:
             pass
         return None
