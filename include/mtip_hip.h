@@ -243,6 +243,25 @@ int mtip_op_so3_find_rotation(mtip_ctx* ctx, const mtip_cdouble* ref, const mtip
 int mtip_op_rotate_coefficients_grid(mtip_ctx* ctx, const mtip_cdouble* coeff, const int32_t* beta_index, const double* alpha,
                                      const double* gamma, mtip_cdouble* out);
 
+/* ---- grid arithmetic of the averaging worker (average.py:359-627, 721-727) between the transforms: csrc/k_average.hip.  Stacks of
+ * n grids (n, Nq, n_theta, n_phi) complex128; every buffer may be host memory or memory of the context's device.
+ * mtip_op_grid_stats: per grid 12 doubles -- [0] sum w Re, [1..3] sum w Re {x, y, z} (the centre of mass of misk.py:295-312 is
+ *   [1..3] / [0]), [4] sum w Re^2, [5] sum w (Re ref - Re)^2 (0 without ref), [6] max Re, [7] min Re, [8], [9] the sum and [10] the
+ *   count of the entries numpy calls > 0 (Re > 0, or Re == 0 and Im > 0; average.py:432-435), [11] 0; w = radial_w[q] theta_w[t]
+ *   (the SphericalIntegrator's weights, mathLibrary.py:1223-1237, without its 1 / volume)
+ * mtip_op_grid_phase_ramp: grid b *= exp(-i sign k . c_b), k the cartesian reciprocal grid vector, c_b = centers_cartesian[b]
+ *   (generate_shift_by_operator, fxs_Projections.py:1419-1444; sign -1 = opposite direction), in place
+ * mtip_op_grid_combine: op 0 dst[b] = conj(a[b]); 1 dst[b] = a[b] * scalars[b]; 2 dst = sum_b a[b] (one grid); 3 dst = sum_b |a[b]|^2;
+ *   4 dst[b] = (a[b] - scalars[0]) * scalars[1] (average.py:721-727); dst may be a
+ * mtip_op_prtf: resolution_metrics.py:62-78 -- nd = sqrt(a1 conj(a2) / (b1 b2)), b = sqrt(Re I), with the reference's rules for
+ *   vanishing b; per shell the mean (complex, (Nq)) and the standard deviation ((Nq)) over the sphere */
+int mtip_op_grid_stats(mtip_ctx* ctx, const mtip_cdouble* grids, int n, const mtip_cdouble* ref, const double* radial_w,
+                       const double* theta_w, double* out);
+int mtip_op_grid_phase_ramp(mtip_ctx* ctx, mtip_cdouble* grids, int n, const double* centers_cartesian, double sign);
+int mtip_op_grid_combine(mtip_ctx* ctx, int op, mtip_cdouble* dst, const mtip_cdouble* a, int n, const mtip_cdouble* scalars);
+int mtip_op_prtf(mtip_ctx* ctx, const mtip_cdouble* a1, const mtip_cdouble* a2, const mtip_cdouble* I1, const mtip_cdouble* I2,
+                 mtip_cdouble* mean, double* std_dev);
+
 /* ---- upstream step `extract`: B_l -> V_l (fxs_invariant_tools.py:1079-1131, 1171-1207) -------------------------------
  * eigen-decomposition of n_mat Hermitian n x n matrices A (row-major, only their Hermitian part matters): eigvals (n_mat, n)
  * unsorted, eigvecs (n_mat, n, n) with eigenvector i of matrix k in eigvecs[k][i][:] (one eigenvector per row).  Sorting,

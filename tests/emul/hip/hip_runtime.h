@@ -237,6 +237,10 @@ using std::max;
 // ---- runtime API ----------------------------------------------------------------------------
 static inline const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "hipSuccess" : "emul error"; }
 static inline hipError_t hipGetLastError() { return hipSuccess; }
+// every pointer of the emulation is "device" memory (host arrays are used in place)
+enum hipMemoryType { hipMemoryTypeHost = 1, hipMemoryTypeDevice = 2 };
+struct hipPointerAttribute_t { hipMemoryType type; };
+static inline hipError_t hipPointerGetAttributes(hipPointerAttribute_t* a, const void*) { a->type = hipMemoryTypeDevice; return hipSuccess; }
 static inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
 static inline hipError_t hipSetDevice(int) { return hipSuccess; }
 static inline hipError_t hipMalloc(void** p, size_t n) { *p = std::calloc(1, n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }

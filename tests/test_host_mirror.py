@@ -176,9 +176,12 @@ def test_reference_sw_and_shift_sketches_on_registry(emul_lib, golden_mtip16):
 
 
 def test_unsupported_radial_rules_raise():
-    """'Zernike' has its own weights upstream (not built), 'gauss' no spherical grid: neither may fall through to the trapz weights"""
+    """the four rules of the reference exist (midpoint, trapz, gauss, Zernike: hankel_transforms.py:15); anything else -- e.g. the
+    lower-case 'zernike' of default_0.01.yaml:25, which the reference's mode test does not know either -- raises"""
     from xframe_amd.fxs import hostsetup as hs
-    for mode in ('Zernike', 'zernike', 'gauss'):
+    for mode in ('midpoint', 'trapz', 'gauss', 'Zernike'):
+        assert len(hs.radial_grids(1.0, 8, 2.0, mode)[0]) == 8 and hs.hankel_raw_weights(2, 8, 2.0, mode).shape[0] == 3
+    for mode in ('zernike', 'PNAS', 'simpson'):
         with pytest.raises(NotImplementedError):
             hs.radial_grids(1.0, 8, 2.0, mode)
         with pytest.raises(NotImplementedError):

@@ -83,6 +83,10 @@ _SIGNATURES = {
     'mtip_op_real_space_update': (C.c_int, [c_void, c_void, c_void, C.c_int, C.c_double, c_void, c_void]),
     'mtip_op_deg2_invariants': (C.c_int, [c_void, c_void, c_void]),
     'mtip_op_apply_matrix': (C.c_int, [c_void, c_void, c_void, c_void, C.c_int, C.c_int, C.c_int]),
+    'mtip_op_grid_stats': (C.c_int, [c_void, c_void, C.c_int, c_void, c_void, c_void, c_void]),
+    'mtip_op_grid_phase_ramp': (C.c_int, [c_void, c_void, C.c_int, c_void, C.c_double]),
+    'mtip_op_grid_combine': (C.c_int, [c_void, C.c_int, c_void, c_void, C.c_int, c_void]),
+    'mtip_op_prtf': (C.c_int, [c_void, c_void, c_void, c_void, c_void, c_void, c_void]),
     'mtip_set_so3_tables': (C.c_int, [c_void, C.c_int, c_void]),
     'mtip_op_so3_correlation': (C.c_int, [c_void, c_void, c_void, C.c_int, C.c_int, c_void]),
     'mtip_op_rotate_coefficients': (C.c_int, [c_void, c_void, c_void, c_void]),

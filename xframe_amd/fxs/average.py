@@ -3,11 +3,13 @@
 the reference by the SO(3) correlation of their harmonic coefficients, average the aligned ones and compute the PRTF.
 
 Where the reference forks one process per reconstruction and runs numpy / shtns / pysofft in each, here the batch of
-reconstructions stays in HBM from the first upload to the last download: torch tensors own the memory, the transforms (FT, SHT),
-the SO(3) correlation with its arg-max and the rotation of the coefficients are the engine's HIP kernels working on those tensors
-in place (``csrc/k_align.hip``, ``Engine.t_*``), and the glue between them -- centre-of-mass and error integrals (weighted sums),
-phase ramps, scaling, the sums over the selected alignments, the PRTF shell statistics -- is elementwise / reduction arithmetic on
-the same device tensors.  What crosses PCIe: the inputs once (unless they are device tensors already), a few scalars per
+reconstructions stays in HBM from the first upload to the last download: torch tensors OWN THE MEMORY (allocation, stacking,
+slicing, the collectives) and every piece of arithmetic on it is a HIP kernel of the engine behind the C ABI, working on those
+tensors in place (``Engine.t_*``): the transforms (FT, SHT), the SO(3) correlation with its arg-max and the rotation of the
+coefficients (``csrc/k_align.hip``), and the glue between them -- centre-of-mass and error integrals, extrema and the
+normalisation factors (``mtip_op_grid_stats``), phase ramps (``mtip_op_grid_phase_ramp``), conjugation / scaling / the sums over the
+selected alignments / normalisation (``mtip_op_grid_combine``), the PRTF shell statistics (``mtip_op_prtf``; ``csrc/k_average.hip``).
+What crosses PCIe: the inputs once (unless they are device tensors already), a few scalars per
 reconstruction (centres, maxima, arg-max indices, errors -- the decisions are host logic, as they depend on each other in the
 reference's order), and the results.  With several ranks (``torch.distributed``: one process per GPU) every rank aligns its own
 restarts against the reference, which its owner broadcasts, and the sums of the aligned densities are all-reduced from the
@@ -47,16 +49,8 @@ class Alignment:
         self.dev = torch.device(device) if device is not None else e.torch_device()
         self.soft_grid = np.stack(np.meshgrid(*hs.euler_grid(self.L + 1), indexing='ij'), -1)     # make_SO3_grid; edited in place
         self.results = {}
-        # weights of the plain SphericalIntegrator (mathLibrary.py:1223-1232) and of the centre of mass (misk.py:295-312), the
-        # cartesian components of the reciprocal grid points for the shift phases (fxs_Projections.py:1436-1443): device constants
-        wr, wt = hs.integrator_weights(e.rs, e.n_theta)       # (the same weights integrate_normed_weights() below is tested with, G14)
-        st, ct = np.sin(e.theta)[None, :, None], np.cos(e.theta)[None, :, None]
-        cp, sp = np.cos(e.phi)[None, None, :], np.sin(e.phi)[None, None, :]
-        w0 = np.broadcast_to(wr[:, None, None] * wt[None, :, None], e.shape)
-        r = np.asarray(e.rs)[:, None, None]
-        self.W = torch.from_numpy(np.stack([w0, w0 * r * st * cp, w0 * r * st * sp, w0 * r * ct * np.ones_like(cp)])).to(self.dev)
-        q = np.asarray(e.qs)[:, None, None]
-        self.K = torch.from_numpy(np.stack([q * st * cp, q * st * sp, q * ct * np.ones_like(cp)])).to(self.dev)
+        # integrals, centres of mass, phase ramps, sums and the PRTF statistics are kernels of the engine (csrc/k_average.hip,
+        # Engine.t_grid_stats / t_phase_ramp / t_combine / t_prtf): torch only owns the memory of the stacks
         self.volume = 4 / 3 * np.pi * np.max(e.rs) ** 3
 
     # -- helpers
@@ -90,31 +84,25 @@ class Alignment:
     def isht(self, Cf):
         return self._batched(lambda c: self.e.t_sht_inverse(c), Cf)
 
-    def integrate_normed(self, V):
-        """SphericalIntegrator.integrate_normed (mathLibrary.py:1223-1237) of real stacks (n, ...): (n,) on the host"""
-        return ((V * self.W[0]).sum(dim=(1, 2, 3)) / self.volume).cpu().numpy()
+    def stats(self, X, ref=None):
+        """mtip_op_grid_stats of a stack (any length): (n, 12) on the host"""
+        return self.e.t_grid_stats(X.contiguous(), ref)
 
     def centers(self, R):
         """generate_calc_center (misk.py:295-312): centres of mass of Re(rho), spherical coordinates, (n, 3) on the host"""
-        # (elementwise product + sum: einsum would hand this 4 x 10^6 contraction to a BLAS GEMM of a hopeless shape, 112 ms)
-        re = R.real
-        m = self.torch.stack([(re * self.W[k]).sum(dim=(1, 2, 3)) for k in range(4)], dim=1).cpu().numpy()
+        m = self.stats(R)[:, :4]
         total = np.where(m[:, 0] == 0, 1.0, m[:, 0])
         return np.stack([hs.cartesian_to_spherical(m[i, 1:] / total[i]) for i in range(len(m))])
 
-    def phases(self, vectors, opposite_direction=False):
-        """generate_shift_by_operator (fxs_Projections.py:1419-1444): exp(-i s k.c) for spherical vectors (n, 3)"""
-        t = self.torch
-        pre = -1.0 if opposite_direction else 1.0
-        c = t.from_numpy(np.stack([hs.spherical_to_cartesian(np.asarray(v, dtype=float)) for v in vectors])).to(self.dev)
-        kc = sum(self.K[k][None] * c[:, k, None, None, None] for k in range(3))
-        return t.polar(t.ones_like(kc), -pre * kc)
+    def shift(self, X, vectors, opposite_direction=False):
+        """generate_shift_by_operator (fxs_Projections.py:1419-1444): X[b] *= exp(-i s k.c_b) for spherical vectors (n, 3), in place"""
+        c = np.stack([hs.spherical_to_cartesian(np.asarray(v, dtype=float)) for v in vectors])
+        return self.e.t_phase_ramp(X, c, -1.0 if opposite_direction else 1.0)
 
     def shift_to_center(self, R, F):
         """assemble_shift_to_center (1007-1020) for stacks: (IFT(FT(rho) e^{i k c}), F e^{i k c}, c)"""
         c = self.centers(R)
-        ph = self.phases(c, opposite_direction=True)
-        return self.ift(self.ft(R) * ph), F * ph, c
+        return self.ift(self.shift(self.ft(R), c, True)), self.shift(F.clone(), c, True), c
 
     def pick_rotation(self, am):
         """find_rotation (936-946), literally: the grid entry at the arg-max (i_beta, i_alpha, i_gamma) is a VIEW and is flipped in place"""
@@ -139,10 +127,10 @@ class Alignment:
         t, e = self.torch, self.e
         n = S_rho.shape[0]
         keep_metric = bool(self.opt.get('keep_rotation_metrics', True))
-        inv_d = self.ift(self.ft(S_rho).conj().resolve_conj())
+        inv_d = self.ift(e.t_combine('conj', self.ft(S_rho)))
         both_rho = t.cat([S_rho, inv_d])
-        both_F = t.cat([S_F, S_F.conj().resolve_conj()])
-        norm = float(self.integrate_normed(reference.real[None] ** 2)[0])
+        both_F = t.cat([S_F, e.t_combine('conj', S_F.contiguous())])
+        norm = float(self.stats(reference[None])[0, 4]) / self.volume       # integrate_normed(Re(reference)^2)
         norm = norm if norm != 0 else 1
         ref_c = self.sht(reference[None])[0].contiguous()
         sig_c = self.sht(both_rho)
@@ -178,7 +166,7 @@ class Alignment:
             return t.cat(out) if len(out) > 1 else out[0]
         dens = self.isht(rotate(sig_c))
         fts = self.isht(rotate(ft_c))
-        errs = self.integrate_normed((reference.real[None] - dens.real) ** 2) / norm
+        errs = self.stats(dens, reference.contiguous())[:, 5] / self.volume / norm          # integrate_normed((Re ref - Re d)^2) / norm
         res = []
         for i in range(n):
             k = i if errs[i] < errs[n + i] else n + i
@@ -194,24 +182,12 @@ def integrate_normed_weights(rs, n_theta):
     return wr[:, None] * wt[None, :] / (4 / 3 * np.pi * np.max(rs) ** 3)
 
 
-def _prtf(t, a1, a2, b1, b2):
-    """resolution_metrics.py:62-78 on device tensors: per-shell mean and standard deviation, on the host"""
-    nd = t.ones_like(a1)
-    nz = (b1 != 0) & (b2 != 0)
-    den = t.where(nz, b1 * b2.conj(), t.ones_like(b1))
-    nd = t.where(nz, a1 * a2.conj() / den, nd)
-    nd = t.where(~nz & (a1 != 0) & (a2 != 0), t.zeros_like(nd), nd)
-    nd = t.sqrt(nd)
-    mean = nd.mean(dim=(1, 2))
-    std = t.sqrt(((nd - mean[:, None, None]).abs() ** 2).mean(dim=(1, 2)))
-    return mean.cpu().numpy(), std.cpu().numpy()
-
-
-def _normalize(t, d, d_min=False):
-    """average.py:721-727"""
+def _normalize(al, d, d_min=False):
+    """average.py:721-727 on a device grid: (d - min) / (max - min) of the real parts"""
+    st = al.stats(d[None])[0]
     if isinstance(d_min, bool):
-        d_min = float(d.real.min())
-    return (d - d_min) / (float(d.real.max()) - d_min)
+        d_min = float(st[7])
+    return al.e.t_combine('affine', d[None].contiguous(), [d_min, 1.0 / (float(st[6]) - d_min)])[0]
 
 
 def average_reconstructions(engine, reconstructions, errors, opt=None, dist=None, device=None):
@@ -238,18 +214,17 @@ def average_reconstructions(engine, reconstructions, errors, opt=None, dist=None
     scales = np.ones(n_in)
     if o['normalize_reconstructions']['use'] and n_in:
         fac = np.ones(n_in, complex)
+        st = al.stats(R)
         if o['normalize_reconstructions']['mode'] == 'max':
             # 424-429: skipped when np.max (lexicographic on complex) has a real part <= 0; else the largest real part
-            mx = R.real.amax(dim=(1, 2, 3)).cpu().numpy()
+            mx = st[:, 6]
             fac = np.where(mx > 0, mx, 1.0).astype(complex)
         else:
             # 432-435: the mean over the entries > 0 (numpy compares complex numbers lexicographically); complex, and only its
             # real part reaches scaling_factors
-            pos = (R.real > 0) | ((R.real == 0) & (R.imag > 0))
-            fac = ((R * pos).sum(dim=(1, 2, 3)) / pos.sum(dim=(1, 2, 3))).cpu().numpy()
+            fac = (st[:, 8] + 1j * st[:, 9]) / st[:, 10]
         scales = np.real(fac).astype(float)
-        ft_ = t.from_numpy(np.ascontiguousarray(fac)).to(dv)[:, None, None, None]
-        R, F = R / ft_, F / ft_
+        R, F = e.t_combine('scale', R.contiguous(), 1.0 / fac), e.t_combine('scale', F.contiguous(), 1.0 / fac)
     # ---- reference: the reconstruction with the lowest error (of all ranks)
     world = dist.get_world_size() if dist is not None else 1
     rank = dist.get_rank() if dist is not None else 0
@@ -274,7 +249,7 @@ def average_reconstructions(engine, reconstructions, errors, opt=None, dist=None
         reference = [R[ref_arg].clone(), F[ref_arg].clone()]
     S_rho, S_F = R[keep], F[keep]
     if o.get('pointinvert_reference', False):
-        ri = reference[1].conj().resolve_conj()
+        ri = e.t_combine('conj', reference[1][None].contiguous())[0]
         reference = [al.ift(ri[None])[0], ri]
     # ---- align
     outs = al.apply_to(reference[0], S_rho, S_F) if len(keep) else []
@@ -317,9 +292,9 @@ def average_reconstructions(engine, reconstructions, errors, opt=None, dist=None
     if aligned:
         A_rho, A_F = t.stack([a[0] for a in aligned]), t.stack([a[1] for a in aligned])
         ftd = al.ft(A_rho)
-        sums[0], sums[1] = A_rho.sum(0), A_F.sum(0)
-        sums[2] = (A_F.abs() ** 2).sum(0)
-        sums[3] = (ftd.abs() ** 2).sum(0)
+        sums[0], sums[1] = e.t_combine('sum', A_rho), e.t_combine('sum', A_F)
+        sums[2] = e.t_combine('abs2sum', A_F)
+        sums[3] = e.t_combine('abs2sum', ftd.contiguous())
     count = float(len(aligned))
     if world > 1:
         tr = t.view_as_real(sums)
@@ -327,8 +302,9 @@ def average_reconstructions(engine, reconstructions, errors, opt=None, dist=None
         dist.all_reduce(tr)
         dist.all_reduce(nn)
         count = float(nn.cpu()[0])
-    average = [sums[0] / count, sums[1] / count]
-    I_ft, I_d = (sums[2] / count).real, (sums[3] / count).real
+    mean4 = e.t_combine('scale', sums, np.full(4, 1.0 / count))          # the four sums over the selected alignments -> means
+    average = [mean4[0], mean4[1]]
+    I_ft, I_d = mean4[2], mean4[3]                                       # (real values in complex grids)
     # average.py:538: the averaged pair is centred BEFORE the metrics and the reference's shift operator multiplies its argument in
     # place (fxs_Projections.py:1442): the averaged reciprocal density that is saved and that enters 'PRTF' is the shifted one
     cen = al.shift_to_center(average[0][None], average[1][None])
@@ -336,10 +312,10 @@ def average_reconstructions(engine, reconstructions, errors, opt=None, dist=None
     ft_avg = al.ft(average[0][None])[0]
     metrics = {}
     if o['resolution_metrics'].get('PRTF', False):
-        sd, sf = t.sqrt(I_d).to(t.complex128), t.sqrt(I_ft).to(t.complex128)
-        for name, args in (('PRTF', (ft_avg, average[1], sd, sf)), ('PRTF_from_density', (ft_avg, ft_avg, sd, sd)),
-                           ('PRTF_from_ft_density', (average[1], average[1], sf, sf)), ('PRTF_ftI', (ft_avg, ft_avg, sf, sf))):
-            metrics[name], metrics[name + '_std'] = _prtf(t, *args)
+        a_ft, a_d, i_d, i_f = average[1].contiguous(), ft_avg.contiguous(), I_d.contiguous(), I_ft.contiguous()
+        for name, args in (('PRTF', (a_d, a_ft, i_d, i_f)), ('PRTF_from_density', (a_d, a_d, i_d, i_d)),
+                           ('PRTF_from_ft_density', (a_ft, a_ft, i_f, i_f)), ('PRTF_ftI', (a_d, a_d, i_f, i_f))):
+            metrics[name], metrics[name + '_std'] = e.t_prtf(*args)       # b = sqrt(I) inside the kernel
     dmin = o.get('average_normalization_min', False)
     on_dev = bool(o.get('keep_on_device', False))
 
@@ -349,10 +325,11 @@ def average_reconstructions(engine, reconstructions, errors, opt=None, dist=None
     def host(x):
         return x.cpu().numpy()
     return {
-        'average': {'real_density': host(average[0]), 'normalized_real_density': host(_normalize(t, average[0], dmin)),
-                    'reciprocal_density': host(average[1]), 'intensity_from_densities': host(I_d), 'intensity_from_ft_densities': host(I_ft)},
+        'average': {'real_density': host(average[0]), 'normalized_real_density': host(_normalize(al, average[0], dmin)),
+                    'reciprocal_density': host(average[1]), 'intensity_from_densities': host(I_d).real.copy(),
+                    'intensity_from_ft_densities': host(I_ft).real.copy()},
         'resolution_metrics': metrics,
-        'centered_average': {'real_density': host(cen[0][0]), 'normalized_real_density': host(_normalize(t, cen[0][0], dmin)),
+        'centered_average': {'real_density': host(cen[0][0]), 'normalized_real_density': host(_normalize(al, cen[0][0], dmin)),
                              'reciprocal_density': host(cen[1][0])},
         'aligned': {str(i): {'real_density': out(a[0]), 'reciprocal_density': out(a[1])} for i, a in enumerate(aligned)},
         'n_averaged': int(count), 'alignment_errors': loc_err, 'reference_owner': owner, 'reference_arg': ref_arg,

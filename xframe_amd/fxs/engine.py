@@ -392,6 +392,45 @@ class Engine:
         self._ck(self.lib.mtip_op_sht_inverse(self.ctx, self._tp(c), self._tp(out)))
         return out
 
+    # ---- grid arithmetic of the averaging worker on device stacks (csrc/k_average.hip): torch owns the memory, nothing else
+    def t_grid_stats(self, X, ref=None):
+        """(n, 12) host array per grid of the stack X (n, Nq, n_theta, n_phi): integrals, moments, extrema (mtip_op_grid_stats)"""
+        import torch
+        assert X.dtype == torch.complex128 and tuple(X.shape[1:]) == self.shape and X.is_contiguous()
+        out = np.zeros((X.shape[0], 12))
+        wr, wt = _lib.as_f64(self.int_wr), _lib.as_f64(self.int_wt)
+        self._ck(self.lib.mtip_op_grid_stats(self.ctx, self._tp(X), int(X.shape[0]), self._tp(ref) if ref is not None else None,
+                                             _lib.ptr(wr), _lib.ptr(wt), _lib.ptr(out)))
+        return out
+
+    def t_phase_ramp(self, X, centers_cartesian, sign):
+        """X[b] *= exp(-i sign k . c_b) in place (generate_shift_by_operator, fxs_Projections.py:1419-1444)"""
+        import torch
+        assert X.dtype == torch.complex128 and tuple(X.shape[1:]) == self.shape and X.is_contiguous()
+        cc = np.ascontiguousarray(centers_cartesian, dtype=np.float64)
+        assert cc.shape == (X.shape[0], 3)
+        self._ck(self.lib.mtip_op_grid_phase_ramp(self.ctx, self._tp(X), int(X.shape[0]), _lib.ptr(cc), float(sign)))
+        return X
+
+    def t_combine(self, op, A, scalars=None):
+        """mtip_op_grid_combine on a stack A (n, ...): 'conj', 'scale' (complex per grid), 'sum', 'abs2sum' (one grid out), 'affine'"""
+        import torch
+        code = {'conj': 0, 'scale': 1, 'sum': 2, 'abs2sum': 3, 'affine': 4}[op]
+        assert A.dtype == torch.complex128 and tuple(A.shape[1:]) == self.shape and A.is_contiguous()
+        out = torch.empty(self.shape if code in (2, 3) else tuple(A.shape), dtype=torch.complex128, device=A.device)
+        sc = None if scalars is None else np.ascontiguousarray(scalars, dtype=np.complex128)
+        self._ck(self.lib.mtip_op_grid_combine(self.ctx, code, self._tp(out), self._tp(A), int(A.shape[0]), _lib.ptr(sc) if sc is not None else None))
+        return out
+
+    def t_prtf(self, a1, a2, I1, I2):
+        """resolution_metrics.py:62-78: per-shell mean (complex) and standard deviation of sqrt(a1 conj(a2) / sqrt(I1 I2))"""
+        mean = np.zeros(self.N, complex)
+        std = np.zeros(self.N)
+        for x in (a1, a2, I1, I2):
+            assert tuple(x.shape) == self.shape and x.is_contiguous()
+        self._ck(self.lib.mtip_op_prtf(self.ctx, self._tp(a1), self._tp(a2), self._tp(I1), self._tp(I2), _lib.ptr(mean), _lib.ptr(std)))
+        return mean, std
+
     def t_state(self, kind, batch, best=False):
         """a grid of the loop state -- 'density', 'reciprocal_density' (complex128) or 'support' (uint8), current or best pair -- as a
         tensor ON THE ENGINE'S DEVICE (device-to-device copy out of the slot arrays; the getters of the C ABI take a device
