@@ -128,9 +128,14 @@ __global__ void __launch_bounds__(SW_THREADS) k_sht_chain(ChainArgs a) {
             }
             if (EPI == EPI_REAL_UPDATE) pre_m = rmk[row * R2 + n2];
         }
-        // ---- step 1: inverse R2-point FFTs over k2 of the zero padded spectrum, twiddle, transpose store
-        if (tid < RP * R1) {
-            const int r = tid / R1, k1 = tid - r * R1;
+        // ---- step 1: inverse R2-point FFTs over k2 of the zero padded spectrum, twiddle, transpose store.  SPLIT (16-point
+        //      transforms that would occupy half of the workgroup): two threads per transform, the upper half of the workgroup
+        //      takes the odd outputs (half_fft, k_sht_common.h)
+        constexpr bool SPLIT = R2 == 16;
+        if (SPLIT ? (tid < 2 * RP * R1) : (tid < RP * R1)) {
+            const int hf = SPLIT ? __builtin_amdgcn_readfirstlane(tid / (RP * R1)) : 0;
+            const int t1 = SPLIT ? tid - hf * RP * R1 : tid;
+            const int r = t1 / R1, k1 = t1 - r * R1;
             const double2* gr = Gs + (size_t)(pass * RP + r) * nm + L;
             double2 uv[R2];
 #pragma unroll
@@ -141,13 +146,25 @@ __global__ void __launch_bounds__(SW_THREADS) k_sht_chain(ChainArgs a) {
                 else if (k >= N - L) v = gr[k - N];
                 uv[k2] = v;
             }
-            SmallFFT<R2, true>::run(uv);
             double2* br = Bm + (size_t)(r * R1 + k1) * AS;
+            if constexpr (SPLIT) {
+                double2 yv[R2 / 2];
+                half_fft<R2, true>(uv, hf, yv);
 #pragma unroll
-            for (int n2 = 0; n2 < R2; ++n2) {
-                double2 w = twN[n2 * k1];
-                w.y = -w.y;
-                br[n2] = cmul(uv[n2], w);
+                for (int j = 0; j < R2 / 2; ++j) {
+                    const int n2 = 2 * j + hf;
+                    double2 w = twN[n2 * k1];
+                    w.y = -w.y;
+                    br[n2] = cmul(yv[j], w);
+                }
+            } else {
+                SmallFFT<R2, true>::run(uv);
+#pragma unroll
+                for (int n2 = 0; n2 < R2; ++n2) {
+                    double2 w = twN[n2 * k1];
+                    w.y = -w.y;
+                    br[n2] = cmul(uv[n2], w);
+                }
             }
         }
         CHAIN_STAMP(4 + 6 * (pass & 1))
@@ -217,22 +234,34 @@ __global__ void __launch_bounds__(SW_THREADS) k_sht_chain(ChainArgs a) {
         __syncthreads();
         CHAIN_STAMP(7 + 6 * (pass & 1))
         // ---- forward phase 2: R2-point FFTs over n2; keep |m| <= L, Gauss weight; the panel rows go where this pass's
-        //      spectra were (consumed by step 1)
-        const bool actf = tid < RP * R1;
-        const int r2 = tid / R1, kf = tid - r2 * R1;
-        if (actf) {
+        //      spectra were (consumed by step 1); split over two threads like step 1
+        if (SPLIT ? (tid < 2 * RP * R1) : (tid < RP * R1)) {
+            const int hf = SPLIT ? __builtin_amdgcn_readfirstlane(tid / (RP * R1)) : 0;
+            const int t2 = SPLIT ? tid - hf * RP * R1 : tid;
+            const int r2 = t2 / R1, kf = t2 - r2 * R1;
             double2 uv[R2];
             const double2* ar = Bm + (size_t)(r2 * R1 + kf) * AS;
 #pragma unroll
             for (int qq = 0; qq < R2; ++qq) uv[qq] = ar[qq];
-            SmallFFT<R2, false>::run(uv);
             const double sc = a.gw[pass * TH + (r2 >> 1)] * a.norm;
             double2* gr = Gs + (size_t)(pass * RP + r2) * nm + L;
+            if constexpr (SPLIT) {
+                double2 yv[R2 / 2];
+                half_fft<R2, false>(uv, hf, yv);
 #pragma unroll
-            for (int k2 = 0; k2 < R2; ++k2) {
-                const int k = kf + R1 * k2;
-                if (k <= L) gr[k] = cscale(uv[k2], sc);
-                else if (k >= N - L) gr[k - N] = cscale(uv[k2], sc);
+                for (int j = 0; j < R2 / 2; ++j) {
+                    const int k = kf + R1 * (2 * j + hf);
+                    if (k <= L) gr[k] = cscale(yv[j], sc);
+                    else if (k >= N - L) gr[k - N] = cscale(yv[j], sc);
+                }
+            } else {
+                SmallFFT<R2, false>::run(uv);
+#pragma unroll
+                for (int k2 = 0; k2 < R2; ++k2) {
+                    const int k = kf + R1 * k2;
+                    if (k <= L) gr[k] = cscale(uv[k2], sc);
+                    else if (k >= N - L) gr[k - N] = cscale(uv[k2], sc);
+                }
             }
         }
         CHAIN_STAMP(8 + 6 * (pass & 1))

@@ -57,6 +57,34 @@ struct SmallFFT<1, INV> {
 };
 
 
+// Half of an R-point FFT: the outputs n = 2 j + half (j < R / 2, returned in y[j]) of the inputs x[0..R) -- one radix-2
+// decimation-in-frequency stage, then an R/2-point FFT.  Two threads share one transform (`half` is wave-uniform where this is
+// used: no divergence); each does a little more than half of its work and, more to the point, every wave of the workgroup has work
+// in the two FFT steps that 16-point transforms otherwise leave to half of them.
+template <int R, bool INV>
+__device__ __forceinline__ void half_fft(const double2 (&x)[R], int half, double2 (&y)[R / 2]) {
+    static_assert(R == 16 || R == 8, "twiddles come from tw16");
+#pragma unroll
+    for (int k = 0; k < R / 2; ++k) {
+        if (half == 0) {
+            y[k] = cadd(x[k], x[k + R / 2]);
+        } else {
+            const double2 d = csub(x[k], x[k + R / 2]);
+            const int j = k * (16 / R);                 // exp(-/+ 2 pi i k / R) = tw16(k 16 / R)
+            if (j == 0) {
+                y[k] = d;
+            } else if (j == 4) {
+                y[k] = INV ? make_double2(-d.y, d.x) : make_double2(d.y, -d.x);
+            } else {
+                double2 w = tw16(j);
+                if (INV) w.y = -w.y;
+                y[k] = cmul(d, w);
+            }
+        }
+    }
+    SmallFFT<R / 2, INV>::run(y);
+}
+
 #define SW_THREADS 512
 
 static inline bool reg_radices(int np, int* r1, int* r2) {
