@@ -38,6 +38,7 @@ def parse():
     p.add_argument('--warmup', type=int, default=20)
     p.add_argument('--restarts-per-gpu', type=int, default=8)
     p.add_argument('--streams', type=int, default=3, help='engines (HIP streams) the restarts of a rank are split over')
+    p.add_argument('--engine-sizes', default='', help="restarts per engine, e.g. '4,2,2' (overrides the even split of --streams)")
     p.add_argument('--config', type=int, default=4, help='BASELINE config id (sizes): 1..5')
     p.add_argument('--exact', action='store_true', help='reference operator order instead of the fused step')
     p.add_argument('--cpu-seconds', type=float, default=20.0, help='budget of the CPU baseline sample')
@@ -177,6 +178,11 @@ def main():
     data, rho_true = S.make_invariants(eng_d, N, L, eigh=eng_d)     # simulate + extract front half on the device
     eng_d.close()
     sizes = [B // n_eng + (1 if i < B % n_eng else 0) for i in range(n_eng)]
+    if a.engine_sizes:
+        sizes = [int(x) for x in a.engine_sizes.split(',')]
+        if sum(sizes) != B or min(sizes) < 1:
+            raise SystemExit(f'--engine-sizes {a.engine_sizes} must add up to --restarts-per-gpu {B}')
+        n_eng = len(sizes)
     engines = [Engine(opt, data, n_batch=nb, device=local_rank, fused=not a.exact) for nb in sizes]
     e0 = engines[0]
     rho0 = []

@@ -38,24 +38,20 @@ if os.environ.get('CHAIN_STAMPS', '1') == '0':
 SL = 18
 out = np.zeros((3, B * N, SL), np.int64)
 e._ck(e.lib.mtip_debug_chain_timing(e.ctx, _lib.ptr(out)))
-names = ['tables staged', 'synthesis (wave 0)', 'synthesis barrier']
-for p in range(2):
-    names += ['p%d inverse step 1' % p, 'p%d barrier' % p, 'p%d step 2 + epilogue + fwd phase 1' % p, 'p%d barrier' % p, 'p%d fwd phase 2' % p, 'p%d barrier' % p]
-names += ['Legendre sums (+ error sums)', 'reduce + store']
-idx = list(range(1, 18))
 for k, kind in enumerate(('store + |.|^2', 'modulus', 'real-space')):
     t = out[k]
     ok = t[:, 17] > 0
     if not ok.any():
         continue
-    t = t[ok]
-    d = np.diff(t[:, [0] + idx], axis=1)
+    t = t[ok].astype(float)
     tot = t[:, 17] - t[:, 0]
-    span = t[:, 17].max() - t[:, 0].min()
-    print('\n%s: %d shells; workgroup lifetime mean %.0f ticks (min %.0f, max %.0f); launch span %.0f ticks' % (kind, len(t), tot.mean(), tot.min(), tot.max(), span))
-    for nm, col in zip(names, d.T):
-        print('   %-40s %8.0f  (%4.1f %%)' % (nm, col.mean(), 100 * col.mean() / tot.mean()))
-    # how many workgroups started late (second round on their CU)
-    st = t[:, 0] - t[:, 0].min()
-    print('   start offsets: %d workgroups within 200 ticks of the first, median of the rest %.0f ticks' % ((st < 200).sum(), np.median(st[st >= 200]) if (st >= 200).any() else 0))
+    rows = [('tables staged', t[:, 1] - t[:, 0]), ('Legendre synthesis (wave 0)', t[:, 2] - t[:, 1]), ('   its barrier', t[:, 3] - t[:, 2]),
+            ('passes: inverse step 1', t[:, 4]), ('   barrier', t[:, 5]), ('passes: step 2 + epilogue + forward phase 1', t[:, 6]),
+            ('   barrier', t[:, 7]), ('passes: forward phase 2', t[:, 8]), ('   barrier', t[:, 9]),
+            ('Legendre sums (+ error sums), wave 0', t[:, 16] - t[:, 3] - t[:, 4:10].sum(1)), ('reduce + store (incl. waiting for the other waves)', t[:, 17] - t[:, 16])]
+    print('\n%s: %d shells; workgroup lifetime mean %.0f ticks (min %.0f, max %.0f)' % (kind, len(t), tot.mean(), tot.min(), tot.max()))
+    for nm, col in rows:
+        print('   %-52s %8.0f  (%4.1f %%)' % (nm, col.mean(), 100 * col.mean() / tot.mean()))
+    st = np.sort(t[:, 0] - t[:, 0].min())
+    print('   start offsets (ticks after the first workgroup): median %.0f, 75 %% %.0f, max %.0f' % (np.median(st), st[int(0.75 * len(st))], st[-1]))
 e.close()

@@ -20,11 +20,17 @@
 #include "k_sht_common.h"
 #include "k_sht_legendre.h"
 
-// phase stamps exist in the DBG instantiations only: with them in the code the allocator spills the table registers of the last
-// phase (238 of them at 128 x L32), so the stamped build times the phases up to the Legendre sums faithfully and the rest not
-#define CHAIN_STAMP(i)                                                                                  \
-    if constexpr (DBG) {                                                                                \
-        if (a.dbg != nullptr && tid == 0) a.dbg[(size_t)shell * MTIP_CHAIN_DBG_SLOTS + (i)] = clock64(); \
+// phase stamps (DBG instantiations only): s_memtime into scalar registers at the phase boundaries, no branch and no store
+// until the kernel's last instruction -- stamps that branched and stored on the spot made the allocator spill the table registers
+// of the last phase (238 of them), which is not what one wants to time
+#define CHAIN_STAMP(i)                           \
+    if constexpr (DBG) stamp[i] = clock64();
+// inside the pass loop: durations of the six segments of a pass, summed over the passes (static slots 4..9)
+#define CHAIN_SEG(i)                             \
+    if constexpr (DBG) {                         \
+        const long long n_ = clock64();          \
+        stamp[i] += n_ - tprev;                  \
+        tprev = n_;                              \
     }
 
 struct ChainArgs {
@@ -60,6 +66,12 @@ __global__ void __launch_bounds__(SW_THREADS) k_sht_chain(ChainArgs a) {
     constexpr int AS = R2 + 1;
     constexpr int GSR = R1 * AS;                    // panel row stride (>= n_phi + 1 > 2 L + 1)
     HIP_DYNAMIC_SHARED(double2, sm)
+    long long stamp[DBG ? MTIP_CHAIN_DBG_SLOTS : 1];
+    long long tprev = 0;
+    if constexpr (DBG) {
+#pragma unroll
+        for (int i = 0; i < MTIP_CHAIN_DBG_SLOTS; ++i) stamp[i] = 0;
+    }
     const int L = a.L, nt = a.nt, RP = a.RP, npairs = a.npairs, Nq = a.Nq, B = a.B;
     const int nm = 2 * L + 1;
     const int nlm = (L + 1) * (L + 1);
@@ -103,19 +115,15 @@ __global__ void __launch_bounds__(SW_THREADS) k_sht_chain(ChainArgs a) {
     const int TH = RP >> 1;
     const int grp = __builtin_amdgcn_readfirstlane(tid / gsz);      // wave-uniform (gsz >= 64): table rows through scalar bases
     const int tg = tid - grp * gsz;
-    __syncthreads();
-    CHAIN_STAMP(1)
-    // ---- Legendre synthesis of every row (k_sht_legendre.h)
-    legendre_synthesis_rows(ls, Gs, cl, ABs, a.P, a.cost, nt, L, nt >> 1, 0, wave, nw, tid & 63);
-    CHAIN_STAMP(2)
-    __syncthreads();
-    CHAIN_STAMP(3)
-    const int n_pass = nt / RP;
-    for (int pass = 0; pass < n_pass; ++pass) {
-        // epilogue operands of this thread's step-2 outputs: requested now, they arrive behind step 1
-        double2 pre[(EPI == EPI_MODULUS || EPI == EPI_REAL_UPDATE) ? R1 : 1];
-        unsigned pre_m = 0;                             // support / initial-support bits of this thread's R1 points (one load)
-        if ((EPI == EPI_MODULUS || EPI == EPI_REAL_UPDATE) && tid < RP * R2) {
+    // epilogue operands of a thread's step-2 outputs in pass p (previous density / F: R1 values, the packed masks: one load).
+    // Software-pipelined: those of pass 0 are requested before the Legendre synthesis (which touches no global memory), those of
+    // pass p + 1 as soon as the epilogue of pass p has consumed its own -- the loads share the CU's memory pipe with the stores
+    // of a pass and the table rows, and issuing 64 KB of them at the top of a pass held step 1 up (3.4 k cycles per pass)
+    constexpr bool HAS_PRE = EPI == EPI_MODULUS || EPI == EPI_REAL_UPDATE;
+    double2 pre[HAS_PRE ? R1 : 1];
+    unsigned pre_m = 0;
+    auto load_pre = [&](int pass) {
+        if (HAS_PRE && tid < RP * R2) {
             const int r = tid / R2, n2 = tid - r * R2;
             const int rr = pass * RP + r;
             const int th = rr >> 1;
@@ -128,6 +136,18 @@ __global__ void __launch_bounds__(SW_THREADS) k_sht_chain(ChainArgs a) {
             }
             if (EPI == EPI_REAL_UPDATE) pre_m = rmk[row * R2 + n2];
         }
+    };
+    load_pre(0);
+    __syncthreads();
+    CHAIN_STAMP(1)
+    // ---- Legendre synthesis of every row (k_sht_legendre.h)
+    legendre_synthesis_rows(ls, Gs, cl, ABs, a.P, a.cost, nt, L, nt >> 1, 0, wave, nw, tid & 63);
+    CHAIN_STAMP(2)
+    __syncthreads();
+    CHAIN_STAMP(3)
+    const int n_pass = nt / RP;
+    if constexpr (DBG) tprev = stamp[3];
+    for (int pass = 0; pass < n_pass; ++pass) {
         // ---- step 1: inverse R2-point FFTs over k2 of the zero padded spectrum, twiddle, transpose store.  SPLIT (16-point
         //      transforms that would occupy half of the workgroup): two threads per transform, the upper half of the workgroup
         //      takes the odd outputs (half_fft, k_sht_common.h)
@@ -167,9 +187,9 @@ __global__ void __launch_bounds__(SW_THREADS) k_sht_chain(ChainArgs a) {
                 }
             }
         }
-        CHAIN_STAMP(4 + 6 * (pass & 1))
+        CHAIN_SEG(4)
         __syncthreads();
-        CHAIN_STAMP(5 + 6 * (pass & 1))
+        CHAIN_SEG(5)
         // ---- step 2: inverse R1-point FFTs over k1
         const bool act2 = tid < RP * R2;
         const int r = tid / R2, n2 = tid - r * R2;
@@ -216,6 +236,7 @@ __global__ void __launch_bounds__(SW_THREADS) k_sht_chain(ChainArgs a) {
                 vv[n1] = v;
             }
         }
+        if (pass + 1 < n_pass) load_pre(pass + 1);
         // ---- forward phase 1: mirror fold (row 2j = theta_j, 2j+1 = its mirror: R2 lanes apart; the exchange runs on whole
         //      waves, rows come in pairs so a thread with a row has its partner), R1-point FFTs, twiddle
 #pragma unroll
@@ -230,9 +251,9 @@ __global__ void __launch_bounds__(SW_THREADS) k_sht_chain(ChainArgs a) {
 #pragma unroll
             for (int k1 = 0; k1 < R1; ++k1) ar[k1 * AS] = cmul(vv[k1], twN[n2 * k1]);
         }
-        CHAIN_STAMP(6 + 6 * (pass & 1))
+        CHAIN_SEG(6)
         __syncthreads();
-        CHAIN_STAMP(7 + 6 * (pass & 1))
+        CHAIN_SEG(7)
         // ---- forward phase 2: R2-point FFTs over n2; keep |m| <= L, Gauss weight; the panel rows go where this pass's
         //      spectra were (consumed by step 1); split over two threads like step 1
         if (SPLIT ? (tid < 2 * RP * R1) : (tid < RP * R1)) {
@@ -264,9 +285,9 @@ __global__ void __launch_bounds__(SW_THREADS) k_sht_chain(ChainArgs a) {
                 }
             }
         }
-        CHAIN_STAMP(8 + 6 * (pass & 1))
+        CHAIN_SEG(8)
         __syncthreads();                                // the next pass rewrites Bm; the last one completes the panel
-        CHAIN_STAMP(9 + 6 * (pass & 1))
+        CHAIN_SEG(9)
     }
     // the twiddles are dead: the per-shell error sums go to the head of the LDS block
     if (EPI == EPI_REAL_UPDATE) {
@@ -284,6 +305,9 @@ __global__ void __launch_bounds__(SW_THREADS) k_sht_chain(ChainArgs a) {
     // ---- Legendre sums over the whole panel: c_lm += P_lm(theta_j) E/O[j][m], table rows of the group requested together
     double2 accp[MAXI], accm[MAXI];
     {
+        // table rows of this thread's (l, m) pairs and theta pairs, requested together.  (Requested before the passes instead --
+        // they fit beside them since the 16-point FFTs are split -- the sums get 4 k cycles shorter and step 1 of the passes 4 k
+        // longer: measured, workgroup lifetime unchanged, profiles/r04_chain_phase_timers.txt.)
         double tab[MAXI][THG > 0 ? THG : 1];
         if (THG > 0) {
 #pragma unroll
@@ -378,6 +402,12 @@ __global__ void __launch_bounds__(SW_THREADS) k_sht_chain(ChainArgs a) {
         if (m > 0) cdst[l * (l + 1) - m] = (m & 1) ? make_double2(-sq.x, -sq.y) : sq;
     }
     CHAIN_STAMP(17)
+    if constexpr (DBG) {
+        if (a.dbg != nullptr && tid == 0) {
+#pragma unroll
+            for (int i = 0; i < MTIP_CHAIN_DBG_SLOTS; ++i) a.dbg[(size_t)shell * MTIP_CHAIN_DBG_SLOTS + i] = stamp[i];
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------
