@@ -46,8 +46,8 @@ for k, kind in enumerate(('store + |.|^2', 'modulus', 'real-space')):
     t = t[ok].astype(float)
     tot = t[:, 17] - t[:, 0]
     rows = [('tables staged', t[:, 1] - t[:, 0]), ('Legendre synthesis (wave 0)', t[:, 2] - t[:, 1]), ('   its barrier', t[:, 3] - t[:, 2]),
-            ('passes: inverse step 1', t[:, 4]), ('   barrier', t[:, 5]), ('passes: step 2 + epilogue + forward phase 1', t[:, 6]),
-            ('   barrier', t[:, 7]), ('passes: forward phase 2', t[:, 8]), ('   barrier', t[:, 9]),
+            ('row groups of wave 0: inverse step 1', t[:, 4]), ('row groups of wave 0: step 2 + epilogue + forward phase 1', t[:, 6]),
+            ('row groups of wave 0: forward phase 2', t[:, 8]), ('   barrier (the other waves finish their groups)', t[:, 9]),
             ('Legendre sums (+ error sums), wave 0', t[:, 16] - t[:, 3] - t[:, 4:10].sum(1)), ('reduce + store (incl. waiting for the other waves)', t[:, 17] - t[:, 16])]
     print('\n%s: %d shells; workgroup lifetime mean %.0f ticks (min %.0f, max %.0f)' % (kind, len(t), tot.mean(), tot.min(), tot.max()))
     for nm, col in rows:

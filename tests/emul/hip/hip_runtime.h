@@ -169,6 +169,7 @@ static inline emul_u2 __builtin_amdgcn_permlane32_swap(unsigned a, unsigned b, b
 static inline int __builtin_amdgcn_readlane(int v, int src_lane) { return __shfl(v, src_lane, 64); }
 #define MTIP_PIN_VGPRS4(a, b, c, d)      // register-scheduling fence of the device build: nothing to do on the host
 #define MTIP_WAIT_LDS()
+#define MTIP_WAVE_LDS_SYNC() emul::wave_barrier()
 static inline long long wall_clock64() { static thread_local long long t = 0; return t += 1000; }
 static inline int __builtin_amdgcn_readfirstlane(int v) { return __shfl(v, 0, 64); }
 // workgroup-scope atomics on LDS words: the fibers of a block share one OS thread, plain accesses are atomic enough

@@ -45,7 +45,7 @@ struct ChainArgs {
     const int* slot;
     const uint16_t* mk;                 // packed masks (3, B, Nq, nt, R2): bit n1 = support, bit 8 + n1 = initial support of point R2 n1 + n2
     RealEpi re;
-    int npairs, nt, L, RP, Nq, which, B;
+    int npairs, nt, L, Nq, which, B;
     // forward half
     double2* coeff_out;
     const double* PT;
@@ -72,14 +72,14 @@ __global__ void __launch_bounds__(SW_THREADS) k_sht_chain(ChainArgs a) {
 #pragma unroll
         for (int i = 0; i < MTIP_CHAIN_DBG_SLOTS; ++i) stamp[i] = 0;
     }
-    const int L = a.L, nt = a.nt, RP = a.RP, npairs = a.npairs, Nq = a.Nq, B = a.B;
+    const int L = a.L, nt = a.nt, npairs = a.npairs, Nq = a.Nq, B = a.B;
     const int nm = 2 * L + 1;
     const int nlm = (L + 1) * (L + 1);
     double2* twN = sm;                              // N
     double2* Gs = sm + N;                           // nt * nm        spectra: row 2j = theta_j, 2j+1 = its mirror
     double2* ABs = Gs + (size_t)nt * nm;            // npairs         recurrence coefficients
     double2* cl = ABs + npairs;                     // nlm            (Legendre phase)
-    double2* Bm = cl;                               // RP * R1 * AS   transpose buffer of both directions, then the (theta, m) panel
+    double2* Bm = cl;                               // nw * RW * R1 * AS   the waves' transpose buffers (both directions); at the end the groups' partial sums
     const int tid = threadIdx.x;
     const long long shell = blockIdx.x;
     const int q = (int)(shell % Nq);
@@ -112,20 +112,37 @@ __global__ void __launch_bounds__(SW_THREADS) k_sht_chain(ChainArgs a) {
     // rows and accumulators live across the 16-point FFTs spill.)
     const int gsz = a.gsz;
     const int thg = THG > 0 ? THG : a.thg;
-    const int TH = RP >> 1;
     const int grp = __builtin_amdgcn_readfirstlane(tid / gsz);      // wave-uniform (gsz >= 64): table rows through scalar bases
     const int tg = tid - grp * gsz;
-    // epilogue operands of a thread's step-2 outputs in pass p (previous density / F: R1 values, the packed masks: one load).
-    // Software-pipelined: those of pass 0 are requested before the Legendre synthesis (which touches no global memory), those of
-    // pass p + 1 as soon as the epilogue of pass p has consumed its own -- the loads share the CU's memory pipe with the stores
-    // of a pass and the table rows, and issuing 64 KB of them at the top of a pass held step 1 up (3.4 k cycles per pass)
+    // ---- the FFT steps: WAVE-PRIVATE row groups.  A wave owns RW = 64 / R2 whole rows (theta pairs with their mirrors) through all
+    // four FFT steps -- inverse R2-point FFTs over k2, transpose, inverse R1-point FFTs + epilogue + store, mirror fold, forward
+    // R1-point FFTs, transpose, forward R2-point FFTs -- and a private slice of the transpose buffer, so nothing between the
+    // Legendre synthesis and the Legendre sums needs a workgroup barrier: LDS operations of one wave complete in order.  (With
+    // workgroup-wide passes of 32 rows, eight barriers per shell kept the eight waves in lock step: one resource at a time --
+    // LDS, vector ALU, memory pipe -- and a fifth of the workgroup's lifetime waiting for the slowest wave,
+    // profiles/r04_chain_phase_timers.txt.)  Lane roles: steps 2 / forward 1: (row, n2); steps 1 / forward 2: (half, row, k1)
+    // where the 16-point transforms are split over two lanes (half_fft).
+    constexpr bool SPLIT = R2 == 16;
+    constexpr int RW = 64 / R2;                             // rows per group
+    constexpr int S1 = RW * R1;                             // lanes of one half in steps 1 / forward 2
+    static_assert(S1 * (SPLIT ? 2 : 1) <= 64, "lane roles");
+    const int lane = tid & 63;
+    const int n_grp = (nt + RW - 1) / RW;
+    double2* Bw = Bm + (size_t)wave * (RW * R1 * AS);       // this wave's transpose buffer
+    const int r2l = lane / R2, n2 = lane - r2l * R2;
+    const int hf = SPLIT ? lane / S1 : 0;
+    const int t1 = lane - hf * S1;
+    const bool role1 = SPLIT || lane < S1;
+    const int r1l = (t1 / R1) % RW, k1 = t1 % R1;
+    // epilogue operands of a lane's step-2 outputs in group g (previous density / F: R1 values, the packed masks: one load),
+    // requested a group ahead: those of the wave's first group before the Legendre synthesis (which touches no global memory),
+    // those of the next group as soon as the epilogue has consumed its own
     constexpr bool HAS_PRE = EPI == EPI_MODULUS || EPI == EPI_REAL_UPDATE;
     double2 pre[HAS_PRE ? R1 : 1];
     unsigned pre_m = 0;
-    auto load_pre = [&](int pass) {
-        if (HAS_PRE && tid < RP * R2) {
-            const int r = tid / R2, n2 = tid - r * R2;
-            const int rr = pass * RP + r;
+    auto load_pre = [&](int g) {
+        const int rr = g * RW + r2l;
+        if (HAS_PRE && g < n_grp && rr < nt) {
             const int th = rr >> 1;
             const int row = (rr & 1) ? (nt - 1 - th) : th;
 #pragma unroll
@@ -137,77 +154,74 @@ __global__ void __launch_bounds__(SW_THREADS) k_sht_chain(ChainArgs a) {
             if (EPI == EPI_REAL_UPDATE) pre_m = rmk[row * R2 + n2];
         }
     };
-    load_pre(0);
+    // (l, m) of this thread's pairs in the Legendre sums: loaded here, used 40 k cycles later (a global round trip at that point
+    // was most of the closing loop)
+    int my_lm[MAXI];
+#pragma unroll
+    for (int u = 0; u < MAXI; ++u) my_lm[u] = a.lmtab[min(tg + u * gsz, npairs - 1)];
     __syncthreads();
     CHAIN_STAMP(1)
+    // (behind the staging copies: vmcnt counts in order, requested before them these loads made the copies wait)
+    load_pre(wave);
     // ---- Legendre synthesis of every row (k_sht_legendre.h)
     legendre_synthesis_rows(ls, Gs, cl, ABs, a.P, a.cost, nt, L, nt >> 1, 0, wave, nw, tid & 63);
     CHAIN_STAMP(2)
     __syncthreads();
     CHAIN_STAMP(3)
-    const int n_pass = nt / RP;
     if constexpr (DBG) tprev = stamp[3];
-    for (int pass = 0; pass < n_pass; ++pass) {
-        // ---- step 1: inverse R2-point FFTs over k2 of the zero padded spectrum, twiddle, transpose store.  SPLIT (16-point
-        //      transforms that would occupy half of the workgroup): two threads per transform, the upper half of the workgroup
-        //      takes the odd outputs (half_fft, k_sht_common.h)
-        constexpr bool SPLIT = R2 == 16;
-        if (SPLIT ? (tid < 2 * RP * R1) : (tid < RP * R1)) {
-            const int hf = SPLIT ? __builtin_amdgcn_readfirstlane(tid / (RP * R1)) : 0;
-            const int t1 = SPLIT ? tid - hf * RP * R1 : tid;
-            const int r = t1 / R1, k1 = t1 - r * R1;
-            const double2* gr = Gs + (size_t)(pass * RP + r) * nm + L;
-            double2 uv[R2];
+    for (int g = wave; g < n_grp; g += nw) {
+        // ---- step 1: inverse R2-point FFTs over k2 of the zero padded spectrum, twiddle, transpose store
+        {
+            const int rr = g * RW + r1l;
+            if (role1 && rr < nt) {
+                const double2* gr = Gs + (size_t)rr * nm + L;
+                double2 uv[R2];
 #pragma unroll
-            for (int k2 = 0; k2 < R2; ++k2) {
-                const int k = k1 + R1 * k2;
-                double2 v = make_double2(0.0, 0.0);
-                if (k <= L) v = gr[k];
-                else if (k >= N - L) v = gr[k - N];
-                uv[k2] = v;
-            }
-            double2* br = Bm + (size_t)(r * R1 + k1) * AS;
-            if constexpr (SPLIT) {
-                double2 yv[R2 / 2];
-                half_fft<R2, true>(uv, hf, yv);
-#pragma unroll
-                for (int j = 0; j < R2 / 2; ++j) {
-                    const int n2 = 2 * j + hf;
-                    double2 w = twN[n2 * k1];
-                    w.y = -w.y;
-                    br[n2] = cmul(yv[j], w);
+                for (int k2 = 0; k2 < R2; ++k2) {
+                    // branch-free (clamped index + select): a `cond ? load : 0` compiles to a branch with a full wait at its
+                    // join, sixteen LDS round trips one after the other
+                    const int k = k1 + R1 * k2;
+                    const bool lo = k <= L, hi = k >= N - L;
+                    const double2 v = gr[lo ? k : (hi ? k - N : 0)];
+                    uv[k2] = (lo || hi) ? v : make_double2(0.0, 0.0);
                 }
-            } else {
-                SmallFFT<R2, true>::run(uv);
+                double2* br = Bw + (size_t)(r1l * R1 + k1) * AS;
+                if constexpr (SPLIT) {
+                    double2 yv[R2 / 2];
+                    half_fft<R2, true>(uv, hf, yv);
 #pragma unroll
-                for (int n2 = 0; n2 < R2; ++n2) {
-                    double2 w = twN[n2 * k1];
-                    w.y = -w.y;
-                    br[n2] = cmul(uv[n2], w);
+                    for (int j = 0; j < R2 / 2; ++j) {
+                        const int m2 = 2 * j + hf;
+                        double2 w = twN[m2 * k1];
+                        w.y = -w.y;
+                        br[m2] = cmul(yv[j], w);
+                    }
+                } else {
+                    SmallFFT<R2, true>::run(uv);
+#pragma unroll
+                    for (int m2 = 0; m2 < R2; ++m2) {
+                        double2 w = twN[m2 * k1];
+                        w.y = -w.y;
+                        br[m2] = cmul(uv[m2], w);
+                    }
                 }
             }
         }
+        MTIP_WAVE_LDS_SYNC();
         CHAIN_SEG(4)
-        __syncthreads();
-        CHAIN_SEG(5)
-        // ---- step 2: inverse R1-point FFTs over k1
-        const bool act2 = tid < RP * R2;
-        const int r = tid / R2, n2 = tid - r * R2;
+        // ---- step 2: inverse R1-point FFTs over k1, epilogue + coalesced store, the forward half's prologue
+        const int rr2 = g * RW + r2l;
+        const bool act2 = rr2 < nt;
         double2 vv[R1];
 #pragma unroll
-        for (int k1 = 0; k1 < R1; ++k1) vv[k1] = make_double2(0.0, 0.0);
+        for (int q1 = 0; q1 < R1; ++q1) vv[q1] = make_double2(0.0, 0.0);
         if (act2) {
-            const double2* br = Bm + (size_t)r * R1 * AS + n2;
+            const double2* br = Bw + (size_t)r2l * R1 * AS + n2;
 #pragma unroll
-            for (int k1 = 0; k1 < R1; ++k1) vv[k1] = br[k1 * AS];
-        }
-        __syncthreads();                                // Bm is free: the forward half's transpose goes there
-        if (act2) {
+            for (int q1 = 0; q1 < R1; ++q1) vv[q1] = br[q1 * AS];
             SmallFFT<R1, true>::run(vv);
-            const int rr = pass * RP + r;
-            const int th = rr >> 1;
-            const int row = (rr & 1) ? (nt - 1 - th) : th;
-            // epilogue + coalesced store, then the forward half's prologue on the value just written
+            const int th = rr2 >> 1;
+            const int row = (rr2 & 1) ? (nt - 1 - th) : th;
 #pragma unroll
             for (int n1 = 0; n1 < R1; ++n1) {
                 double2 v = vv[n1];
@@ -236,59 +250,58 @@ __global__ void __launch_bounds__(SW_THREADS) k_sht_chain(ChainArgs a) {
                 vv[n1] = v;
             }
         }
-        if (pass + 1 < n_pass) load_pre(pass + 1);
-        // ---- forward phase 1: mirror fold (row 2j = theta_j, 2j+1 = its mirror: R2 lanes apart; the exchange runs on whole
-        //      waves, rows come in pairs so a thread with a row has its partner), R1-point FFTs, twiddle
+        load_pre(g + nw);
+        // ---- forward phase 1: mirror fold (row 2j = theta_j, 2j+1 = its mirror: R2 lanes apart, same wave), R1-point FFTs, twiddle
 #pragma unroll
         for (int n1 = 0; n1 < R1; ++n1) {
             const double px = __shfl_xor(vv[n1].x, R2, 64), py = __shfl_xor(vv[n1].y, R2, 64);
-            vv[n1] = (r & 1) ? make_double2(px - vv[n1].x, py - vv[n1].y)      // odd part  north - south
-                             : make_double2(vv[n1].x + px, vv[n1].y + py);    // even part north + south
+            vv[n1] = (r2l & 1) ? make_double2(px - vv[n1].x, py - vv[n1].y)      // odd part  north - south
+                               : make_double2(vv[n1].x + px, vv[n1].y + py);    // even part north + south
         }
         if (act2) {
             SmallFFT<R1, false>::run(vv);
-            double2* ar = Bm + (size_t)r * R1 * AS + n2;
+            double2* ar = Bw + (size_t)r2l * R1 * AS + n2;
 #pragma unroll
-            for (int k1 = 0; k1 < R1; ++k1) ar[k1 * AS] = cmul(vv[k1], twN[n2 * k1]);
+            for (int q1 = 0; q1 < R1; ++q1) ar[q1 * AS] = cmul(vv[q1], twN[n2 * q1]);
         }
+        MTIP_WAVE_LDS_SYNC();
         CHAIN_SEG(6)
-        __syncthreads();
-        CHAIN_SEG(7)
-        // ---- forward phase 2: R2-point FFTs over n2; keep |m| <= L, Gauss weight; the panel rows go where this pass's
-        //      spectra were (consumed by step 1); split over two threads like step 1
-        if (SPLIT ? (tid < 2 * RP * R1) : (tid < RP * R1)) {
-            const int hf = SPLIT ? __builtin_amdgcn_readfirstlane(tid / (RP * R1)) : 0;
-            const int t2 = SPLIT ? tid - hf * RP * R1 : tid;
-            const int r2 = t2 / R1, kf = t2 - r2 * R1;
-            double2 uv[R2];
-            const double2* ar = Bm + (size_t)(r2 * R1 + kf) * AS;
+        // ---- forward phase 2: R2-point FFTs over n2; keep |m| <= L, Gauss weight; the panel rows go where this group's spectra
+        //      were (consumed by step 1 of the same wave)
+        {
+            const int rr = g * RW + r1l;
+            if (role1 && rr < nt) {
+                double2 uv[R2];
+                const double2* ar = Bw + (size_t)(r1l * R1 + k1) * AS;
 #pragma unroll
-            for (int qq = 0; qq < R2; ++qq) uv[qq] = ar[qq];
-            const double sc = a.gw[pass * TH + (r2 >> 1)] * a.norm;
-            double2* gr = Gs + (size_t)(pass * RP + r2) * nm + L;
-            if constexpr (SPLIT) {
-                double2 yv[R2 / 2];
-                half_fft<R2, false>(uv, hf, yv);
+                for (int qq = 0; qq < R2; ++qq) uv[qq] = ar[qq];
+                const double sc = a.gw[rr >> 1] * a.norm;
+                double2* gr = Gs + (size_t)rr * nm + L;
+                if constexpr (SPLIT) {
+                    double2 yv[R2 / 2];
+                    half_fft<R2, false>(uv, hf, yv);
 #pragma unroll
-                for (int j = 0; j < R2 / 2; ++j) {
-                    const int k = kf + R1 * (2 * j + hf);
-                    if (k <= L) gr[k] = cscale(yv[j], sc);
-                    else if (k >= N - L) gr[k - N] = cscale(yv[j], sc);
-                }
-            } else {
-                SmallFFT<R2, false>::run(uv);
+                    for (int j = 0; j < R2 / 2; ++j) {
+                        const int k = k1 + R1 * (2 * j + hf);
+                        if (k <= L) gr[k] = cscale(yv[j], sc);
+                        else if (k >= N - L) gr[k - N] = cscale(yv[j], sc);
+                    }
+                } else {
+                    SmallFFT<R2, false>::run(uv);
 #pragma unroll
-                for (int k2 = 0; k2 < R2; ++k2) {
-                    const int k = kf + R1 * k2;
-                    if (k <= L) gr[k] = cscale(uv[k2], sc);
-                    else if (k >= N - L) gr[k - N] = cscale(uv[k2], sc);
+                    for (int k2 = 0; k2 < R2; ++k2) {
+                        const int k = k1 + R1 * k2;
+                        if (k <= L) gr[k] = cscale(uv[k2], sc);
+                        else if (k >= N - L) gr[k - N] = cscale(uv[k2], sc);
+                    }
                 }
             }
         }
+        MTIP_WAVE_LDS_SYNC();
         CHAIN_SEG(8)
-        __syncthreads();                                // the next pass rewrites Bm; the last one completes the panel
-        CHAIN_SEG(9)
     }
+    __syncthreads();                                    // the panel of the shell is complete
+    CHAIN_SEG(9)
     // the twiddles are dead: the per-shell error sums go to the head of the LDS block
     if (EPI == EPI_REAL_UPDATE) {
         // fixed order (bitwise reproducible): wave butterflies, then the waves
@@ -321,8 +334,7 @@ __global__ void __launch_bounds__(SW_THREADS) k_sht_chain(ChainArgs a) {
         const double2 *srcp[MAXI], *srcm[MAXI];
 #pragma unroll
         for (int u = 0; u < MAXI; ++u) {
-            const int lm = a.lmtab[min(tg + u * gsz, npairs - 1)];
-            const int l = lm & 0xff, m = lm >> 8;
+            const int l = my_lm[u] & 0xff, m = my_lm[u] >> 8;
             srcp[u] = Gs + (size_t)(((l + m) & 1) + 2 * grp * thg) * nm + L + m;
             srcm[u] = srcp[u] - 2 * m;
             accp[u] = make_double2(0.0, 0.0);
@@ -367,12 +379,15 @@ __global__ void __launch_bounds__(SW_THREADS) k_sht_chain(ChainArgs a) {
         }
     }
     CHAIN_STAMP(16)
-    // the groups' partial coefficients go where the transpose buffer was (other waves may still be reading the panel)
-    double2* racc = Bm;                                 // (groups, MAXI, 2, gsz)
+    // the other groups' partial coefficients go where the transpose buffers were (other waves may still be reading the panel);
+    // group 0 adds them to its own in a fixed order and stores
+    double2* racc = Bm;                                 // (groups - 1, MAXI, 2, gsz)
+    if (grp > 0) {
 #pragma unroll
-    for (int u = 0; u < MAXI; ++u) {
-        racc[(size_t)((grp * MAXI + u) * 2) * gsz + tg] = accp[u];
-        racc[(size_t)((grp * MAXI + u) * 2 + 1) * gsz + tg] = accm[u];
+        for (int u = 0; u < MAXI; ++u) {
+            racc[(size_t)(((grp - 1) * MAXI + u) * 2) * gsz + tg] = accp[u];
+            racc[(size_t)(((grp - 1) * MAXI + u) * 2 + 1) * gsz + tg] = accm[u];
+        }
     }
     __syncthreads();
     if (EPI == EPI_REAL_UPDATE && tid == 0) {
@@ -385,21 +400,24 @@ __global__ void __launch_bounds__(SW_THREADS) k_sht_chain(ChainArgs a) {
         a.re.partial[(size_t)shell * 2] = sn;
         a.re.partial[(size_t)shell * 2 + 1] = sd;
     }
-    const int ngrp = blockDim.x / gsz;
-    double2* cdst = a.coeff_out + (size_t)shell * nlm;
-    for (int idx = tid; idx < npairs; idx += blockDim.x) {
-        const int u = idx / gsz, t = idx - u * gsz;
-        double2 sp = make_double2(0.0, 0.0), sq = sp;
-        for (int g = 0; g < ngrp; ++g) {                // fixed order over the groups
-            const double2 vp = racc[(size_t)((g * MAXI + u) * 2) * gsz + t];
-            const double2 vq = racc[(size_t)((g * MAXI + u) * 2 + 1) * gsz + t];
-            sp.x += vp.x; sp.y += vp.y;
-            sq.x += vq.x; sq.y += vq.y;
+    if (grp == 0) {
+        const int ngrp = blockDim.x / gsz;
+        double2* cdst = a.coeff_out + (size_t)shell * nlm;
+#pragma unroll
+        for (int u = 0; u < MAXI; ++u) {
+            double2 sp = accp[u], sq = accm[u];
+            for (int g = 1; g < ngrp; ++g) {
+                const double2 vp = racc[(size_t)(((g - 1) * MAXI + u) * 2) * gsz + tg];
+                const double2 vq = racc[(size_t)(((g - 1) * MAXI + u) * 2 + 1) * gsz + tg];
+                sp.x += vp.x; sp.y += vp.y;
+                sq.x += vq.x; sq.y += vq.y;
+            }
+            if (tg + u * gsz < npairs) {
+                const int l = my_lm[u] & 0xff, m = my_lm[u] >> 8;
+                cdst[l * (l + 1) + m] = sp;
+                if (m > 0) cdst[l * (l + 1) - m] = (m & 1) ? make_double2(-sq.x, -sq.y) : sq;
+            }
         }
-        const int lm = a.lmtab[idx];
-        const int l = lm & 0xff, m = lm >> 8;
-        cdst[l * (l + 1) + m] = sp;
-        if (m > 0) cdst[l * (l + 1) - m] = (m & 1) ? make_double2(-sq.x, -sq.y) : sq;
     }
     CHAIN_STAMP(17)
     if constexpr (DBG) {
@@ -412,8 +430,9 @@ __global__ void __launch_bounds__(SW_THREADS) k_sht_chain(ChainArgs a) {
 
 // ------------------------------------------------------------------------------------------------------
 struct ChainGeom {
-    int r1 = 0, r2 = 0, rp = 0, gsz = 0, thg = 0, maxi = 0;     // maxi: the kernel's MAXI (>= pairs per thread)
+    int r1 = 0, r2 = 0, gsz = 0, thg = 0, maxi = 0;     // maxi: the kernel's MAXI (>= pairs per thread)
     bool reg_tab = false;
+    size_t tb = 0;                      // double2 of the waves' transpose buffers
     size_t lds = 0;
     bool ok = false;
 };
@@ -422,12 +441,9 @@ static ChainGeom chain_geom(const mtip_ctx* c) {
     ChainGeom g;
     if (!sht_reg_supported(c) || !c->sht_wide || c->d_AB == nullptr || c->d_PT == nullptr || c->d_lmtab == nullptr) return g;
     if (!reg_radices(c->np, &g.r1, &g.r2) || (c->nt & 1)) return g;
-    g.rp = largest_even_divisor_le(c->nt, std::min(SW_THREADS / g.r2, SW_THREADS / g.r1));
+    // every wave owns 64 / R2 rows at a time and a transpose buffer for them; it aliases the coefficient block
+    g.tb = (size_t)(SW_THREADS / 64) * (64 / g.r2) * g.r1 * (g.r2 + 1);
     const size_t fixed = (size_t)c->np + (size_t)c->nt * c->nm + c->npairs;
-    // the transpose buffer / panel aliases the coefficient block: shrink the pass until the shell fits one CU
-    while (g.rp >= 2 && (fixed + std::max((size_t)c->nlm, (size_t)g.rp * g.r1 * (g.r2 + 1))) * sizeof(double2) > 158 * 1024)
-        g.rp = largest_even_divisor_le(c->nt, g.rp - 2);
-    if (g.rp < 2) return g;
     const int TP = c->nt / 2;                       // theta pairs of a shell
     // accumulation groups of the Legendre-sum phase: the smallest power-of-two group whose threads hold <= 3 (l, m) pairs each
     // and whose count divides the theta pairs
@@ -445,7 +461,7 @@ static ChainGeom chain_geom(const mtip_ctx* c) {
     }
     if (g.gsz == 0) return g;
     // transpose buffer / panel staging aliases the coefficient block; the groups' partial sums land there at the end
-    const size_t un = std::max(std::max((size_t)c->nlm, (size_t)g.rp * g.r1 * (g.r2 + 1)), (size_t)SW_THREADS * g.maxi * 2);
+    const size_t un = std::max(std::max((size_t)c->nlm, g.tb), (size_t)SW_THREADS * g.maxi * 2);
     g.lds = (fixed + un) * sizeof(double2);
     g.ok = g.lds <= 158 * 1024;
     return g;
@@ -504,7 +520,6 @@ void launch_sht_chain(mtip_ctx* c, const double2* coeff, double2* grid, const In
     a.npairs = c->npairs;
     a.nt = c->nt;
     a.L = c->L;
-    a.RP = g.rp;
     a.Nq = c->N;
     a.which = epi.out_slot;
     a.B = c->B;

@@ -18,6 +18,18 @@
 #endif
 
 
+// LDS data handed from some lanes of a wave to others of the SAME wave: LDS operations of one wave complete in the order they were
+// issued, so only the compiler has to keep them in order (the emulation runs the lanes one after the other and needs a real
+// rendezvous: tests/emul defines its own)
+#ifndef MTIP_WAVE_LDS_SYNC
+#define MTIP_WAVE_LDS_SYNC()                        \
+    do {                                            \
+        asm volatile("" ::: "memory");              \
+        __builtin_amdgcn_wave_barrier();            \
+        asm volatile("" ::: "memory");              \
+    } while (0)
+#endif
+
 typedef double v4f64 __attribute__((vector_size(32)));   // accumulator of v_mfma_f64_16x16x4_f64
 
 // ---- complex helpers (complex128 = double2, interleaved like numpy) ----------------------------
