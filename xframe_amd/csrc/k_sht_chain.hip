@@ -163,6 +163,8 @@ __global__ void __launch_bounds__(SW_THREADS) k_sht_chain(ChainArgs a) {
     CHAIN_STAMP(1)
     // (behind the staging copies: vmcnt counts in order, requested before them these loads made the copies wait)
     load_pre(wave);
+    const RealFlags rflags = real_flags(a.re.rp, a.re.method);
+    const double wr_q = EPI == EPI_REAL_UPDATE ? a.re.wr[q] : 0.0;
     // ---- Legendre synthesis of every row (k_sht_legendre.h)
     legendre_synthesis_rows(ls, Gs, cl, ABs, a.P, a.cost, nt, L, nt >> 1, 0, wave, nw, tid & 63);
     CHAIN_STAMP(2)
@@ -237,9 +239,9 @@ __global__ void __launch_bounds__(SW_THREADS) k_sht_chain(ChainArgs a) {
                     const double2 pv = pre[n1];
                     const double2 w = (a.re.add_prev && q > 0) ? cadd(v, pv) : v;
                     double2 Pj;
-                    v = real_update_point(a.re.rp, a.re.method, a.re.beta, w, pv, ((pre_m >> n1) & 1u) != 0, Pj);
+                    v = real_update_point_flat(a.re.rp, rflags, a.re.beta, w, pv, ((pre_m >> n1) & 1u) != 0, Pj);
                     if (!a.re.err_use_mask || ((pre_m >> (8 + n1)) & 1u)) {   // l2_projection_diff, fxs_IO_methods.py:97-128
-                        const double wg = a.re.wr[q] * a.re.wt[row];
+                        const double wg = wr_q * a.re.wt[row];
                         const double dx = w.x - Pj.x, dy = w.y - Pj.y;
                         err_num = fma(wg, dx * dx + dy * dy, err_num);
                         err_den = fma(wg, w.x * w.x + w.y * w.y, err_den);

@@ -114,6 +114,48 @@ __device__ __forceinline__ double2 real_update_point(const RealParams& rp, int m
     return nw;
 }
 
+// The same point update with the settings decoded once (uniform booleans) and no short-circuit logic: in the chained kernel the
+// flag tests of real_update_point became scalar branches around every grid point (157 branches in the kernel, eight points per
+// lane and row group).  Bit-identical results: the same comparisons and the same arithmetic in the same order.
+struct RealFlags {
+    bool support, lo, hi, both, imag, hio, h_support, h_value, h_imag;
+};
+__device__ __forceinline__ RealFlags real_flags(const RealParams& rp, int method) {
+    RealFlags f;
+    f.support = (rp.flags & RC_SUPPORT) != 0;
+    f.lo = (rp.flags & RC_VALUE_LO) != 0;
+    f.hi = (rp.flags & RC_VALUE_HI) != 0;
+    f.both = f.lo && f.hi;
+    f.imag = (rp.flags & RC_LIMIT_IMAG) != 0;
+    f.hio = method == MTIP_HIO || method == MTIP_HIO_NON_FXS;
+    uint32_t hm = rp.hio_flags;
+    if (hm & (RC_VALUE_LO | RC_VALUE_HI)) hm |= RC_VALUE_LO;          // both bounds share one mask
+    f.h_support = (hm & RC_SUPPORT) != 0;
+    f.h_value = (hm & RC_VALUE_LO) != 0;
+    f.h_imag = (hm & RC_LIMIT_IMAG) != 0;
+    return f;
+}
+__device__ __forceinline__ double2 real_update_point_flat(const RealParams& rp, const RealFlags& f, double beta, double2 w, double2 pv,
+                                                          bool S, double2& P_out) {
+    double2 P = w;
+    const bool v_s = f.support & !S;
+    P.x = v_s ? 0.0 : P.x;
+    P.y = v_s ? 0.0 : P.y;
+    // (with both bounds the upper one is tested on the value the lower one may have replaced, as in real_update_point)
+    const bool c_lo = f.lo & (P.x < rp.lo);
+    P.x = c_lo ? rp.lo : P.x;
+    const bool c_hi = f.hi & (P.x > rp.hi);
+    P.x = c_hi ? rp.hi : P.x;
+    const bool v_i = f.imag & (fabs(P.y) >= rp.imag_thr);
+    P.y = v_i ? 0.0 : P.y;
+    const bool take = f.hio & ((f.h_support & v_s) | (f.h_value & (c_lo | c_hi)) | (f.h_imag & v_i));
+    double2 nw;
+    nw.x = take ? pv.x - beta * (w.x - P.x) : P.x;
+    nw.y = take ? pv.y - beta * (w.y - P.y) : P.y;
+    P_out = P;
+    return nw;
+}
+
 // real-space stage fused into the last inverse SHT of a step (EPI_REAL_UPDATE): w = iSHT value (+ previous density on
 // shells > 0: the ft_stab add-back), densities and support read / written through the slot table, error partial
 // sums per shell
