@@ -40,7 +40,8 @@ for tot, k, n, fk, wk in rows[:24]:
 if len(sys.argv) > 3:
     import json
     fam_of = [("k_sht_fwd_pair", "sht_fwd"), ("k_sht_fwd_reg", "sht_fwd"), ("k_sht_inv_wide<0", "sht_inv"), ("k_sht_inv_wide<1", "sht_inv_modulus"),
-              ("k_sht_inv_wide<4", "sht_inv_real"), ("k_hankel", "hankel"), ("k_real_update", "real_update"), ("k_rproj", "polar")]
+              ("k_sht_inv_wide<4", "sht_inv_real"), ("k_hankel", "hankel"), ("k_real_update", "real_update"), ("k_rproj", "polar"),
+              ("k_sht_chain<0", "sht_chain"), ("k_sht_chain<1", "sht_chain_modulus"), ("k_sht_chain<4", "sht_chain_real")]
     fam = defaultdict(lambda: [0.0, 0])
     for k in fetch:
         for pat, name in fam_of:
@@ -49,7 +50,19 @@ if len(sys.argv) > 3:
                 # per-launch mean of (2 x FETCH_SIZE + WRITE_SIZE), weighting the variants of a family by their calls
                 fam[name][0] += 2 * fetch[k][0] * 1024 + wb * fetch[k][1] / max(write[k][1], 1) if k in write else 2 * fetch[k][0] * 1024
                 fam[name][1] += fetch[k][1]
-    out = {"restarts_per_launch": int(sys.argv[4]), "config": int(sys.argv[5]),
+    # what one phasing step of one restart physically moves: every kernel of the loop (chained / plain SHTs, Hankel, projection, finish,
+    # shrink wrap, copies) summed over the run, divided by the restart-steps the run made (k_finish_step: one 256-thread block per restart)
+    def all_rows(d, counter):
+        f = max(glob.glob(d + "/*/*counter_collection.csv"), key=os.path.getmtime)
+        return [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter]
+    loop = ("k_sht_", "k_hankel", "k_rproj", "k_finish_step", "k_sw_", "k_proj", "k_polar", "k_real_update", "k_coeff", "k_modulus", "k_deg2", "copyBuffer", "fillBuffer", "k_pack_masks")
+    fr, wr_ = all_rows(sys.argv[1], "FETCH_SIZE"), all_rows(sys.argv[2], "WRITE_SIZE")
+    tot_f = sum(float(r["Counter_Value"]) for r in fr if any(p in r["Kernel_Name"] for p in loop)) * 1024
+    tot_w = sum(float(r["Counter_Value"]) for r in wr_ if any(p in r["Kernel_Name"] for p in loop)) * 1024
+    rsteps = sum(int(r["Grid_Size"]) // 256 for r in fr if "k_finish_step" in r["Kernel_Name"])
+    per_rs = (2 * tot_f + tot_w) / max(rsteps, 1)
+    print("loop kernels: fetch x2 %.1f MB + write %.1f MB over %d restart-steps = %.1f MB per restart-step" % (2 * tot_f / 1e6, tot_w / 1e6, rsteps, per_rs / 1e6))
+    out = {"restarts_per_launch": int(sys.argv[4]), "config": int(sys.argv[5]), "hbm_bytes_per_step_per_restart": per_rs,
            "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of bench.py; KiB units; FETCH_SIZE doubled (gfx950 "
                      "tallies 128-byte read requests at 64 bytes); Infinity-Cache hits are included in FETCH_SIZE",
            "hbm_bytes_per_launch": {k: v[0] / v[1] for k, v in fam.items()}}
