@@ -13,7 +13,7 @@ rows = list(csv.DictReader(open(f)))
 
 def fam(name):
     for key, label in (('k_rproj', 'projection (k_rproj)'), ('k_polar', 'polar (complex)'), ('k_proj', 'projection products'),
-                       ('k_sht_fwd', 'forward SHT'), ('k_sht_inv', 'inverse SHT'), ('k_hankel', 'Hankel'), ('k_finish', 'finish_step'),
+                       ('k_sht_chain', 'chained inverse -> forward SHT'), ('k_sht_fwd', 'forward SHT'), ('k_sht_inv', 'inverse SHT'), ('k_hankel', 'Hankel'), ('k_finish', 'finish_step'),
                        ('k_sw_', 'shrink-wrap'), ('k_deg2', 'B_l')):
         if key in name:
             return label
@@ -22,7 +22,7 @@ def fam(name):
 
 # workgroups of a kernel that fit one CU (dynamic LDS is not in the trace: from the launchers -- k_rproj 113 KB, the inverse SHT
 # keeps a shell's spectra (one workgroup per CU), the forward SHT two, the Hankel tiles one or two)
-PER_CU = {'k_rproj': 1, 'k_polar': 1, 'k_sht_inv': 1, 'k_sht_fwd': 2, 'k_hankel': 2, 'k_proj': 4}
+PER_CU = {'k_rproj': 1, 'k_polar': 1, 'k_sht_chain': 1, 'k_sht_inv': 1, 'k_sht_fwd': 2, 'k_hankel': 2, 'k_proj': 4}
 ev = []
 for r in rows:
     s, e = int(r['Start_Timestamp']), int(r['End_Timestamp'])
@@ -50,7 +50,7 @@ n_proj = sum(1 for x in win if x['fam'].startswith('projection (k_rproj)') or x[
 queues = sorted({x['q'] for x in win})
 steps = n_proj / max(len(queues), 1)
 print('window: %.1f us, %d kernel launches on %d queues, %.1f steps per engine -> %.1f us per step' % (span, len(win), len(queues), steps, span / max(steps, 1)))
-print('\n%-24s %8s %9s %9s %10s %12s %9s' % ('family', 'launches', 'wg/launch', 'CUs held', 'avg us', 'CU x us/step', 'of chip'))
+print('\n%-32s %8s %9s %9s %10s %12s %9s' % ('family', 'launches', 'wg/launch', 'CUs held', 'avg us', 'CU x us/step', 'of chip'))
 acc = defaultdict(lambda: [0, 0, 0, 0.0, 0.0, 0])
 for x in win:
     a = acc[x['fam']]
