@@ -237,7 +237,7 @@ int build_hankel_tiles(mtip_ctx* c) {
             const int ncols = c->B * (4 * l + 2);
             for (int c0 = 0; c0 < ncols; c0 += 16 * cts[ci]) t32.push_back(HankelTile32{l, c0});
         }
-        if ((int)t32.size() * div_up(c->N, HT_ROWS) * 5 >= c->n_cu * 4) break;
+        if (c->htile_force > 0 ? cts[ci] == c->htile_force : (int)t32.size() * div_up(c->N, HT_ROWS) * 5 >= c->n_cu * 4) break;
     }
     {
         // XCD-aware order: consecutive workgroup ids go round-robin to the 8 XCDs (one L2 each), so the tiles of one order

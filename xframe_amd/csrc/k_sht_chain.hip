@@ -60,7 +60,9 @@ struct ChainArgs {
 // just written (MTIP_PRE_NONE / MTIP_PRE_SQUARE); MAXI: (l, m) pairs per thread of an accumulation group; THG > 0: theta pairs
 // per group at compile time, their table rows requested together into registers; THG == 0: run-time count, table values
 // loaded where they are used (small grids)
-template <int EPI, int PRE, int R1, int R2, int MAXI, int THG, bool DBG>
+// LC: L_max at compile time (0: run-time value).  With the benchmark's L = 32 the row strides of the spectra / panel become immediates, the
+// zero-padded inputs of the inverse 16-point FFTs (7 of 16) and the unused outputs of the forward ones fold away, loop bounds are constants.
+template <int EPI, int PRE, int R1, int R2, int MAXI, int THG, bool DBG, int LC>
 __global__ void __launch_bounds__(SW_THREADS) k_sht_chain(ChainArgs a) {
     constexpr int N = R1 * R2;
     constexpr int AS = R2 + 1;
@@ -72,7 +74,7 @@ __global__ void __launch_bounds__(SW_THREADS) k_sht_chain(ChainArgs a) {
 #pragma unroll
         for (int i = 0; i < MTIP_CHAIN_DBG_SLOTS; ++i) stamp[i] = 0;
     }
-    const int L = a.L, nt = a.nt, npairs = a.npairs, Nq = a.Nq, B = a.B;
+    const int L = LC > 0 ? LC : a.L, nt = a.nt, npairs = LC > 0 ? (LC + 1) * (LC + 2) / 2 : a.npairs, Nq = a.Nq, B = a.B;
     const int nm = 2 * L + 1;
     const int nlm = (L + 1) * (L + 1);
     double2* twN = sm;                              // N
@@ -476,10 +478,14 @@ bool sht_chain_supported(const mtip_ctx* c) {
 template <int EPI, int PRE, int R1, int R2>
 static void launch_chain_r(mtip_ctx* c, const ChainGeom& g, const ChainArgs& a) {
     const dim3 gr((unsigned)(c->B * c->N)), bl(SW_THREADS);
-#define CHAIN_GO(MAXI, THG) hipLaunchKernelGGL((k_sht_chain<EPI, PRE, R1, R2, MAXI, THG, false>), gr, bl, g.lds, c->stream, a)
+#define CHAIN_GO(MAXI, THG) hipLaunchKernelGGL((k_sht_chain<EPI, PRE, R1, R2, MAXI, THG, false, 0>), gr, bl, g.lds, c->stream, a)
     if constexpr (R1 * R2 == 128) {
         if (g.reg_tab && g.maxi == 3 && a.dbg != nullptr) {
-            hipLaunchKernelGGL((k_sht_chain<EPI, PRE, R1, R2, 3, 16, true>), gr, bl, g.lds, c->stream, a);
+            hipLaunchKernelGGL((k_sht_chain<EPI, PRE, R1, R2, 3, 16, true, 0>), gr, bl, g.lds, c->stream, a);
+            return;
+        }
+        if (g.reg_tab && g.maxi == 3 && c->L == 32 && c->nt == 64 && c->sht_chain_lc) {       // the metric's grid: L at compile time
+            hipLaunchKernelGGL((k_sht_chain<EPI, PRE, R1, R2, 3, 16, false, 32>), gr, bl, g.lds, c->stream, a);
             return;
         }
         if (g.reg_tab && g.maxi == 3) { CHAIN_GO(3, 16); return; }

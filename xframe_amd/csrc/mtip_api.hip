@@ -133,8 +133,13 @@ mtip_ctx* mtip_create(const mtip_cfg* cfg, int device) {
     if (const char* e = std::getenv("MTIP_FUSE_REAL")) c->fuse_real_update = std::atoi(e) != 0;
     if (const char* e = std::getenv("MTIP_SHT_WIDE")) c->sht_wide = std::atoi(e) != 0;
     if (const char* e = std::getenv("MTIP_SHT_CHAIN")) c->sht_chain = std::atoi(e) != 0;
+    if (const char* e = std::getenv("MTIP_SHT_CHAIN_LC")) c->sht_chain_lc = std::atoi(e) != 0;
     if (const char* e = std::getenv("MTIP_JAC_RESIDENT")) c->jac_resident = std::atoi(e) != 0;
     if (const char* e = std::getenv("MTIP_JAC_TG")) c->jac_tg = std::atoi(e) == 8 ? 8 : 16;
+    if (const char* e = std::getenv("MTIP_HANKEL_CT")) {
+        const int v = std::atoi(e);
+        c->htile_force = (v == 1 || v == 2 || v == 3 || v == 5) ? v : 0;
+    }
     if (rc == MTIP_OK) rc = build_hankel_tiles(c);
     A(dev_alloc(c, &c->d_twN, c->np));
     if (const char* e = std::getenv("MTIP_SHT_MODE")) c->sht_mode = std::atoi(e);

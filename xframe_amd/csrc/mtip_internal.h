@@ -223,11 +223,13 @@ struct mtip_ctx {
     long long* d_polar_dbg = nullptr;                 // (B, L+1, MTIP_POLAR_DBG_SLOTS) phase / round timers of k_rproj, allocated by mtip_debug_polar_timing
     int jac_tg = 16;                                  // env MTIP_JAC_TG=8|16: lanes per Jacobi column pair
     bool sht_fwd_pair = true;                         // env MTIP_SHT_FWD_PAIR=0: k_sht_fwd_reg (table loads inside the accumulation loop)
+    bool sht_chain_lc = true;                         // env MTIP_SHT_CHAIN_LC=0: run-time L also at L = 32 (A/B of the compile-time instantiation)
     bool sht_chain = true;                            // env MTIP_SHT_CHAIN=0: separate inverse / forward SHT kernels in the fused step (k_sht_chain.hip)
     double2* d_c0n = nullptr;                         // (B, C) SHT of the current density, written by the chained last kernel of a step
     long long* d_chain_dbg = nullptr;                 // (3 kinds, B * Nq, MTIP_CHAIN_DBG_SLOTS) phase stamps of k_sht_chain, allocated by mtip_debug_chain_timing
     bool c0n_valid = false;                           // d_c0n holds SHT(rho[SL_CUR]) of every restart
     void* d_htiles32 = nullptr;                       // workgroup tiles (order, first column) of k_hankel_tile
+    int htile_force = 0;                              // env MTIP_HANKEL_CT=1|2|3|5: tile width of k_hankel_tile instead of the occupancy rule (A/B)
     int n_htiles32 = 0, htile_ct = 5;                 // 16-column MFMA tiles per workgroup
     double fwd_scale = 0, inv_scale = 0;
     bool have_angular = false, have_radial = false, have_weights = false, have_support = false, have_errw = false;
