@@ -212,6 +212,7 @@ def main():
     limit = 6e-3
     sw_sigma = hs.LinearRamp(20, [False, 5], -2, default_start=e0.default_sigma, default_stop=e0.default_sigma)
     CHUNK = 10                                                  # steps enqueued per engine before switching
+    BRACKET_CHUNKS = int(os.environ.get('BENCH_BRACKET_CHUNKS', '4'))  # bracketed steps per bracketed window
 
     host = {'enqueue_s': 0.0, 'profile': False, 'chunks': 0}
 
@@ -229,17 +230,21 @@ def main():
                 c = min(CHUNK, k - done)
                 betas = np.array([ramp.eval(step + done + i) for i in range(c)])
                 th = time.perf_counter()
-                # family timers (hipEvent brackets on engine 0's stream) on for the FIRST step of every chunk of the timed region:
-                # two event records around each of a step's seven kernels make that step ~12 % slower (measured: 50 % of the
-                # steps bracketed cost 6 % of the headline), so the brackets sample one step in ten
-                if host['profile'] and c > 1:
+                # family timers (hipEvent brackets on engine 0's stream): the first step of the first BRACKET_CHUNKS chunks of a
+                # bracketed window.  A bracketed step costs ~0.5 ms -- eighteen event records drain engine 0's queue between its
+                # kernels and the other engines run ahead (measured: one bracketed step per 20-step window = 5 % of the window) --
+                # so the brackets are a SAMPLE inside the timed region, in the first windows only (the line says which), and the
+                # reported time is the median window
+                if host['profile'] and c > 1 and host['chunks'] < BRACKET_CHUNKS:
                     engines[0].lib.mtip_profile(engines[0].ctx, 1)
                     for e in engines:
                         e.run(kind, True, betas[:1], fetch=False)
                     engines[0].lib.mtip_profile(engines[0].ctx, 0)
                     for e in engines:
                         e.run(kind, True, betas[1:], fetch=False)
+                    host['chunks'] += 1
                 else:
+                    host['chunks'] += 1 if host['profile'] else 0
                     for e in engines:
                         e.run(kind, True, betas, fetch=False)
                 host['enqueue_s'] += time.perf_counter() - th
@@ -269,6 +274,7 @@ def main():
     R = a.repeats if a.repeats > 0 else (5 if a.steps <= 50 else (3 if a.steps <= 1000 else 1))
     windows = []
     enqueue = []
+    n_bracketed = max(1, R // 2)                                # windows that carry family brackets: fewer than half, so the median has none
     for rep in range(R):
         if rep > 0:
             fresh_state()
@@ -278,10 +284,12 @@ def main():
         if dist is not None:
             dist.barrier()
         host['enqueue_s'] = 0.0
+        host['chunks'] = 0
         if not a.no_roofline:
             if rep == 0:
-                e0.profile(True)                                # resets the timers; they accumulate over the windows
-            host['profile'] = True
+                e0.profile(True)                                # resets the timers; they accumulate over the bracketed windows
+                e0.lib.mtip_profile(e0.ctx, 0)
+            host['profile'] = rep < n_bracketed
         t0 = time.perf_counter()
         run_schedule(a.steps, start_step=a.warmup)
         sync_all()
@@ -445,8 +453,10 @@ def main():
             'value': its, 'unit': 'MTIP iterations/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
             'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'repeats': {'windows_ms': [1e3 * w for w in windows], 'reported': 'median', 'spread_rel': (max(windows) - min(windows)) / elapsed,
+                        'bracketed_windows': list(range(n_bracketed)) if not a.no_roofline else [],
                         'note': 'every window: fresh seeded state, W warm-up steps, then exactly K timed steps between barrier + '
-                                'synchronize; value and ms_per_step are the median window'},
+                                'synchronize; value and ms_per_step are the median window; the hipEvent family brackets behind `roofline` '
+                                'sample the first step of up to four chunks of the bracketed windows (a bracketed step costs ~0.5 ms)'},
             'dtype': 'f64 (complex128)', 'data': 'synthetic',
             'config': {'workload': f'BASELINE config {a.config}: {N} shells x L_max={L}, grid {N}x{e0.n_theta}x{e0.n_phi}, '
                                    f'{B} restarts per GPU on {n_eng} streams, tutorial schedule (HIO/SW/ER, ft_stab on), '

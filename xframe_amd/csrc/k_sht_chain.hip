@@ -480,8 +480,8 @@ static void launch_chain_r(mtip_ctx* c, const ChainGeom& g, const ChainArgs& a) 
     const dim3 gr((unsigned)(c->B * c->N)), bl(SW_THREADS);
 #define CHAIN_GO(MAXI, THG) hipLaunchKernelGGL((k_sht_chain<EPI, PRE, R1, R2, MAXI, THG, false, 0>), gr, bl, g.lds, c->stream, a)
     if constexpr (R1 * R2 == 128) {
-        if (g.reg_tab && g.maxi == 3 && a.dbg != nullptr) {
-            hipLaunchKernelGGL((k_sht_chain<EPI, PRE, R1, R2, 3, 16, true, 0>), gr, bl, g.lds, c->stream, a);
+        if (g.reg_tab && g.maxi == 3 && c->L == 32 && c->nt == 64 && a.dbg != nullptr) {       // phase stamps: the metric's grid only
+            hipLaunchKernelGGL((k_sht_chain<EPI, PRE, R1, R2, 3, 16, true, 32>), gr, bl, g.lds, c->stream, a);
             return;
         }
         if (g.reg_tab && g.maxi == 3 && c->L == 32 && c->nt == 64 && c->sht_chain_lc) {       // the metric's grid: L at compile time
