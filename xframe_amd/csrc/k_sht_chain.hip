@@ -142,6 +142,7 @@ __global__ void __launch_bounds__(SW_THREADS) k_sht_chain(ChainArgs a) {
     constexpr bool HAS_PRE = EPI == EPI_MODULUS || EPI == EPI_REAL_UPDATE;
     double2 pre[HAS_PRE ? R1 : 1];
     unsigned pre_m = 0;
+    double pre_w = 0.0;                                     // theta weight of the error integral of this lane's row
     auto load_pre = [&](int g) {
         const int rr = g * RW + r2l;
         if (HAS_PRE && g < n_grp && rr < nt) {
@@ -153,7 +154,10 @@ __global__ void __launch_bounds__(SW_THREADS) k_sht_chain(ChainArgs a) {
                 if (EPI == EPI_MODULUS) pre[n1] = fsrc[o];
                 if (EPI == EPI_REAL_UPDATE) pre[n1] = rprev[o];
             }
-            if (EPI == EPI_REAL_UPDATE) pre_m = rmk[row * R2 + n2];
+            if (EPI == EPI_REAL_UPDATE) {
+                pre_m = rmk[row * R2 + n2];
+                pre_w = a.re.wt[row];
+            }
         }
     };
     // (l, m) of this thread's pairs in the Legendre sums: loaded here, used 40 k cycles later (a global round trip at that point
@@ -243,7 +247,7 @@ __global__ void __launch_bounds__(SW_THREADS) k_sht_chain(ChainArgs a) {
                     double2 Pj;
                     v = real_update_point_flat(a.re.rp, rflags, a.re.beta, w, pv, ((pre_m >> n1) & 1u) != 0, Pj);
                     if (!a.re.err_use_mask || ((pre_m >> (8 + n1)) & 1u)) {   // l2_projection_diff, fxs_IO_methods.py:97-128
-                        const double wg = wr_q * a.re.wt[row];
+                        const double wg = wr_q * pre_w;
                         const double dx = w.x - Pj.x, dy = w.y - Pj.y;
                         err_num = fma(wg, dx * dx + dy * dy, err_num);
                         err_den = fma(wg, w.x * w.x + w.y * w.y, err_den);
