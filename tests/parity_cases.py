@@ -525,6 +525,34 @@ def check_projection_vs_oracle(N, L, lib_path=None, n_batch=2, seed=1):
     e.close()
 
 
+def check_prtf_golden(lib_path=None):
+    """G14: the device PRTF (mtip_op_prtf, resolution_metrics.py:62-78) against values of the reference's own function -- per-shell
+    complex mean and standard deviation, the general case and the single-input case"""
+    import torch
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'average_ops.npz'))
+    N, nt, nph = g['G14_a1'].shape
+    e = Engine({'grid': {'n_radial_points': int(N), 'max_order': 1, 'n_theta': int(nt), 'n_phi': int(nph)}}, None, n_batch=1,
+               lib_path=lib_path, max_q=1.0)
+    dev = e.torch_device()
+
+    def T(x):
+        return torch.from_numpy(np.ascontiguousarray(x, dtype=complex)).to(dev)
+    a1, a2, I1, I2 = T(g['G14_a1']), T(g['G14_a2']), T(g['G14_I1']), T(g['G14_I2'])
+    p, sd = e.t_prtf(a1, a2, I1, I2)
+    assert np.allclose(p, g['G14_prtf'], rtol=1e-12) and np.allclose(sd, g['G14_prtf_std'], rtol=1e-12)
+    p, sd = e.t_prtf(a1, a1, I1, I1)
+    assert np.allclose(p, g['G14_prtf_single'], rtol=1e-12) and np.allclose(sd, g['G14_prtf_single_std'], rtol=1e-12)
+    # the zero rules (b = 0 with both a non-zero -> 0, b = 0 with an a = 0 -> 1) against the oracle's restatement
+    from oracle import alignment as OA
+    z = torch.zeros_like(I1)
+    zero = np.zeros(g['G14_a1'].shape)
+    for x1, n1 in ((a1, g['G14_a1']), (torch.zeros_like(a1), zero.astype(complex))):
+        p, sd = e.t_prtf(x1, a2, z, z)
+        po, so = OA.PRTF(n1, g['G14_a2'], zero, zero)
+        assert np.allclose(p, po, rtol=1e-12, atol=1e-15) and np.allclose(sd, so, rtol=1e-12, atol=1e-15)
+    e.close()
+
+
 def check_find_rotation_nan(lib_path=None, N=6, L=4):
     """arg-max of the SO(3) correlation as numpy's (average.py:936): a NaN is the maximum, the first one in reading order wins --
     a restart whose coefficients hold a NaN comes back with index (0, 0, 0) and a NaN maximum, the others are untouched"""

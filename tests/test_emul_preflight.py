@@ -215,6 +215,10 @@ def test_projection_real_switches(emul_lib, env, closing, monkeypatch):
     PC.check_projection_real_vs_oracle(24, 10, emul_lib, n_batch=1, closing=closing)
 
 
+def test_prtf_golden(emul_lib):
+    PC.check_prtf_golden(emul_lib)
+
+
 def test_find_rotation_nan_is_the_maximum(emul_lib):
     PC.check_find_rotation_nan(emul_lib)
 

@@ -132,6 +132,10 @@ def test_projection_order_49_takes_the_general_kernels():
     PC.check_projection_real_vs_oracle(100, 49, n_batch=1, reciprocal_opt={'odd_orders_to_0': False}, expect_real=False)
 
 
+def test_prtf_golden():
+    PC.check_prtf_golden(None)
+
+
 def test_find_rotation_nan_is_the_maximum():
     PC.check_find_rotation_nan(None)
 
