@@ -56,6 +56,34 @@ void build_legendre_tables(mtip_ctx* c, const double* cos_theta) {
             }
         (void)mtip_copy(c, c->d_PT, PT.data(), PT.size() * sizeof(double), hipMemcpyHostToDevice);
         (void)mtip_copy(c, c->d_lmtab, lmtab.data(), lmtab.size() * sizeof(int), hipMemcpyHostToDevice);
+        // the same table in the CHUNK layout of the chained kernel's Legendre sums (k_sht_chain.hip, CHK): a thread owns up to three
+        // orders l of ONE (m, parity of l - m), so the panel values G[theta][+-m] it multiplies them with are read from LDS once for
+        // the three -- slot u * 256 + t = order u of chunk t (l | m << 8, or -1: no such order, table entry 0)
+        c->chain_chunks = 0;
+        if (c->d_PTc != nullptr) {
+            std::vector<int> lmc(3 * 256, -1);
+            std::vector<double> PTc((size_t)nth * 3 * 256, 0.0);
+            int t = 0;
+            bool fits = true;
+            for (int m = 0; m <= L && fits; ++m)
+                for (int par = 0; par < 2 && fits; ++par)
+                    for (int l0 = m + par; l0 <= L; l0 += 6) {
+                        if (t >= 256) { fits = false; break; }
+                        for (int u = 0; u < 3; ++u) {
+                            const int l = l0 + 2 * u;
+                            if (l > L) break;
+                            const size_t idx = (size_t)poff[m] + l - m;
+                            lmc[u * 256 + t] = l | (m << 8);
+                            for (int th = 0; th < nth; ++th) PTc[(size_t)th * 768 + u * 256 + t] = P[idx * nt + th];
+                        }
+                        ++t;
+                    }
+            if (fits) {
+                c->chain_chunks = t;
+                (void)mtip_copy(c, c->d_PTc, PTc.data(), PTc.size() * sizeof(double), hipMemcpyHostToDevice);
+                (void)mtip_copy(c, c->d_lmc, lmc.data(), lmc.size() * sizeof(int), hipMemcpyHostToDevice);
+            }
+        }
     }
     // twiddles exp(-2 pi i j / n_phi), j < n_phi/2
     std::vector<double2> tw(c->np / 2);

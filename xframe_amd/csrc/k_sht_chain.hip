@@ -50,6 +50,8 @@ struct ChainArgs {
     double2* coeff_out;
     const double* PT;
     const int* lmtab;
+    const double* PTc;                  // chunk layout of PT and lmtab (CHK instantiations)
+    const int* lmc;
     const double* gw;
     double norm;
     long long* dbg;                     // diagnostic: (shells, CHAIN_DBG_SLOTS) clock64 stamps of wave 0 at the phase boundaries, or null
@@ -62,7 +64,8 @@ struct ChainArgs {
 // loaded where they are used (small grids)
 // LC: L_max at compile time (0: run-time value).  With the benchmark's L = 32 the row strides of the spectra / panel become immediates, the
 // zero-padded inputs of the inverse 16-point FFTs (7 of 16) and the unused outputs of the forward ones fold away, loop bounds are constants.
-template <int EPI, int PRE, int R1, int R2, int MAXI, int THG, bool DBG, int LC>
+// CHK: chunk layout of the Legendre sums (a thread = up to three orders l of one (m, parity): one pair of LDS reads per theta serves all three)
+template <int EPI, int PRE, int R1, int R2, int MAXI, int THG, bool DBG, int LC, bool CHK>
 __global__ void __launch_bounds__(SW_THREADS) k_sht_chain(ChainArgs a) {
     constexpr int N = R1 * R2;
     constexpr int AS = R2 + 1;
@@ -164,7 +167,7 @@ __global__ void __launch_bounds__(SW_THREADS) k_sht_chain(ChainArgs a) {
     // was most of the closing loop)
     int my_lm[MAXI];
 #pragma unroll
-    for (int u = 0; u < MAXI; ++u) my_lm[u] = a.lmtab[min(tg + u * gsz, npairs - 1)];
+    for (int u = 0; u < MAXI; ++u) my_lm[u] = CHK ? a.lmc[u * 256 + tg] : a.lmtab[min(tg + u * gsz, npairs - 1)];
     __syncthreads();
     CHAIN_STAMP(1)
     // (behind the staging copies: vmcnt counts in order, requested before them these loads made the copies wait)
@@ -335,14 +338,19 @@ __global__ void __launch_bounds__(SW_THREADS) k_sht_chain(ChainArgs a) {
             for (int u = 0; u < MAXI; ++u)
 #pragma unroll
                 for (int jj = 0; jj < (THG > 0 ? THG : 1); ++jj) {
-                    const double* row = a.PT + (size_t)(grp * THG + jj) * npairs;
-                    tab[u][jj] = row[(unsigned)min(tg + u * gsz, npairs - 1)];       // clamped: branch-free loads
+                    if constexpr (CHK) {
+                        tab[u][jj] = a.PTc[(size_t)(grp * THG + jj) * 768 + u * 256 + tg];
+                    } else {
+                        const double* row = a.PT + (size_t)(grp * THG + jj) * npairs;
+                        tab[u][jj] = row[(unsigned)min(tg + u * gsz, npairs - 1)];   // clamped: branch-free loads
+                    }
                 }
         }
         const double2 *srcp[MAXI], *srcm[MAXI];
 #pragma unroll
         for (int u = 0; u < MAXI; ++u) {
-            const int l = my_lm[u] & 0xff, m = my_lm[u] >> 8;
+            const int lm = CHK ? max(my_lm[0], 0) : my_lm[u];                 // (CHK: the chunk's orders share m and the parity of l - m)
+            const int l = lm & 0xff, m = lm >> 8;
             srcp[u] = Gs + (size_t)(((l + m) & 1) + 2 * grp * thg) * nm + L + m;
             srcm[u] = srcp[u] - 2 * m;
             accp[u] = make_double2(0.0, 0.0);
@@ -353,18 +361,34 @@ __global__ void __launch_bounds__(SW_THREADS) k_sht_chain(ChainArgs a) {
             // reads in flight next to the table registers) and spills
 #pragma unroll
             for (int jc = 0; jc < (THG > 0 ? THG : 1); jc += 4) {
-#pragma unroll
-                for (int u = 0; u < MAXI; ++u)
+                if constexpr (CHK) {
 #pragma unroll
                     for (int jj = jc; jj < jc + 4 && jj < (THG > 0 ? THG : 1); ++jj) {
-                        const double p = tab[u][jj];
-                        const double2 vp = srcp[u][2 * jj * nm];
-                        const double2 vm = srcm[u][2 * jj * nm];
-                        accp[u].x = fma(p, vp.x, accp[u].x);
-                        accp[u].y = fma(p, vp.y, accp[u].y);
-                        accm[u].x = fma(p, vm.x, accm[u].x);
-                        accm[u].y = fma(p, vm.y, accm[u].y);
+                        const double2 vp = srcp[0][2 * jj * nm];
+                        const double2 vm = srcm[0][2 * jj * nm];
+#pragma unroll
+                        for (int u = 0; u < MAXI; ++u) {
+                            const double p = tab[u][jj];
+                            accp[u].x = fma(p, vp.x, accp[u].x);
+                            accp[u].y = fma(p, vp.y, accp[u].y);
+                            accm[u].x = fma(p, vm.x, accm[u].x);
+                            accm[u].y = fma(p, vm.y, accm[u].y);
+                        }
                     }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < MAXI; ++u)
+#pragma unroll
+                        for (int jj = jc; jj < jc + 4 && jj < (THG > 0 ? THG : 1); ++jj) {
+                            const double p = tab[u][jj];
+                            const double2 vp = srcp[u][2 * jj * nm];
+                            const double2 vm = srcm[u][2 * jj * nm];
+                            accp[u].x = fma(p, vp.x, accp[u].x);
+                            accp[u].y = fma(p, vp.y, accp[u].y);
+                            accm[u].x = fma(p, vm.x, accm[u].x);
+                            accm[u].y = fma(p, vm.y, accm[u].y);
+                        }
+                }
                 asm volatile("" ::: "memory");
             }
         } else {
@@ -420,7 +444,7 @@ __global__ void __launch_bounds__(SW_THREADS) k_sht_chain(ChainArgs a) {
                 sp.x += vp.x; sp.y += vp.y;
                 sq.x += vq.x; sq.y += vq.y;
             }
-            if (tg + u * gsz < npairs) {
+            if (CHK ? my_lm[u] >= 0 : tg + u * gsz < npairs) {
                 const int l = my_lm[u] & 0xff, m = my_lm[u] >> 8;
                 cdst[l * (l + 1) + m] = sp;
                 if (m > 0) cdst[l * (l + 1) - m] = (m & 1) ? make_double2(-sq.x, -sq.y) : sq;
@@ -482,14 +506,15 @@ bool sht_chain_supported(const mtip_ctx* c) {
 template <int EPI, int PRE, int R1, int R2>
 static void launch_chain_r(mtip_ctx* c, const ChainGeom& g, const ChainArgs& a) {
     const dim3 gr((unsigned)(c->B * c->N)), bl(SW_THREADS);
-#define CHAIN_GO(MAXI, THG) hipLaunchKernelGGL((k_sht_chain<EPI, PRE, R1, R2, MAXI, THG, false, 0>), gr, bl, g.lds, c->stream, a)
+#define CHAIN_GO(MAXI, THG) hipLaunchKernelGGL((k_sht_chain<EPI, PRE, R1, R2, MAXI, THG, false, 0, false>), gr, bl, g.lds, c->stream, a)
     if constexpr (R1 * R2 == 128) {
-        if (g.reg_tab && g.maxi == 3 && c->L == 32 && c->nt == 64 && a.dbg != nullptr) {       // phase stamps: the metric's grid only
-            hipLaunchKernelGGL((k_sht_chain<EPI, PRE, R1, R2, 3, 16, true, 32>), gr, bl, g.lds, c->stream, a);
+        const bool metric_grid = g.reg_tab && g.maxi == 3 && c->L == 32 && c->nt == 64 && c->chain_chunks > 0;
+        if (metric_grid && a.dbg != nullptr) {                   // phase stamps: the metric's grid only
+            hipLaunchKernelGGL((k_sht_chain<EPI, PRE, R1, R2, 3, 16, true, 32, true>), gr, bl, g.lds, c->stream, a);
             return;
         }
-        if (g.reg_tab && g.maxi == 3 && c->L == 32 && c->nt == 64 && c->sht_chain_lc) {       // the metric's grid: L at compile time
-            hipLaunchKernelGGL((k_sht_chain<EPI, PRE, R1, R2, 3, 16, false, 32>), gr, bl, g.lds, c->stream, a);
+        if (metric_grid && c->sht_chain_lc) {                   // the metric's grid: L at compile time, chunk layout of the sums
+            hipLaunchKernelGGL((k_sht_chain<EPI, PRE, R1, R2, 3, 16, false, 32, true>), gr, bl, g.lds, c->stream, a);
             return;
         }
         if (g.reg_tab && g.maxi == 3) { CHAIN_GO(3, 16); return; }
@@ -538,6 +563,8 @@ void launch_sht_chain(mtip_ctx* c, const double2* coeff, double2* grid, const In
     a.coeff_out = coeff_out;
     a.PT = c->d_PT;
     a.lmtab = c->d_lmtab;
+    a.PTc = c->d_PTc;
+    a.lmc = c->d_lmc;
     a.gw = c->d_gw;
     a.norm = 2.0 * 3.14159265358979323846 / c->np;
     a.gsz = g.gsz;

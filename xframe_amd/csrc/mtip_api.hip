@@ -59,7 +59,7 @@ void mtip_destroy(mtip_ctx* c) {
                     c->d_err_wt, c->d_rho, c->d_Fp, c->d_slot, c->d_best_err, c->d_last_err, c->d_op_err, c->d_gq, c->d_polar_dbg, c->d_so3_d, c->d_so3_tw, c->d_so3_T, c->d_so3_S, c->d_so3_P, c->d_so3_D, c->d_so3_C, c->d_err_hist, c->d_main_hist,
                     c->d_deg2_hist, c->d_F, c->d_T1, c->d_T2, c->d_fixed, c->d_g, c->d_c[0], c->d_c[1], c->d_c[2],
                     c->d_c[3], c->d_c[4], c->d_c[5], c->d_X, c->d_Vr, c->d_U, c->d_partial, c->d_minmax, c->d_Bl,
-                    c->d_rp_DV, c->d_rp_Vt, c->d_rp_slots, c->d_c0n, c->d_mk, c->d_chain_dbg};
+                    c->d_rp_DV, c->d_rp_Vt, c->d_rp_slots, c->d_c0n, c->d_mk, c->d_chain_dbg, c->d_PTc, c->d_lmc};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : c->prof_events) (void)hipEventDestroy(e);
@@ -127,6 +127,8 @@ mtip_ctx* mtip_create(const mtip_cfg* cfg, int device) {
     A(dev_alloc(c, &c->d_PT, (size_t)(c->nt / 2 + 1) * c->npairs));
     A(dev_alloc(c, &c->d_AB, (size_t)c->npairs));
     A(dev_alloc(c, &c->d_lmtab, c->npairs));
+    A(dev_alloc(c, &c->d_PTc, (size_t)(c->nt / 2 + 1) * 768));
+    A(dev_alloc(c, &c->d_lmc, 768));
     if (const char* e = std::getenv("MTIP_PROJ_FUSE")) c->proj_fuse = std::atoi(e) != 0;
     if (const char* e = std::getenv("MTIP_DEG2_SIMPLE")) c->deg2_simple = std::atoi(e) != 0;
     if (const char* e = std::getenv("MTIP_SHT_FWD_PAIR")) c->sht_fwd_pair = std::atoi(e) != 0;

@@ -189,6 +189,9 @@ struct mtip_ctx {
     int* d_poff = nullptr;
     double2* d_AB = nullptr;                          // (npairs) three-term recurrence coefficients (a_lm, b_lm), (l,m)-major
     double* d_PT = nullptr;                           // (nt/2, npairs) theta-major Legendre table (fused SHT)
+    double* d_PTc = nullptr;                          // (nt/2, 768) the same table in the chunk layout of k_sht_chain's Legendre sums
+    int* d_lmc = nullptr;                             // (768) l | m << 8 of slot u * 256 + t, -1: none
+    int chain_chunks = 0;                             // chunks (threads of an accumulation group with work) in that layout; 0: it does not fit 256
     int* d_lmtab = nullptr;                           // (npairs) l | m << 8
     int npairs = 0;
     bool sht_unfused = false;                         // MTIP_SHT_MODE=0: two-kernel SHT (A/B testing)
