@@ -40,6 +40,7 @@ def parse():
     p.add_argument('--streams', type=int, default=3, help='engines (HIP streams) the restarts of a rank are split over')
     p.add_argument('--engine-sizes', default='', help="restarts per engine, e.g. '4,2,2' (overrides the even split of --streams)")
     p.add_argument('--config', type=int, default=4, help='BASELINE config id (sizes): 1..5')
+    p.add_argument('--no-turns', action='store_true', help='enqueue every engine on its own instead of mtip_run_group_async')
     p.add_argument('--exact', action='store_true', help='reference operator order instead of the fused step')
     p.add_argument('--cpu-seconds', type=float, default=20.0, help='budget of the CPU baseline sample')
     p.add_argument('--no-cpu-baseline', action='store_true')
@@ -216,6 +217,18 @@ def main():
 
     host = {'enqueue_s': 0.0, 'profile': False, 'chunks': 0}
 
+    # the engines' steps go through mtip_run_group_async, as ProjectWorker's restart groups do (EngineGroup): the contexts take
+    # turns at the chip-filling transforms; --no-turns enqueues every engine on its own (what rounds 1-3 timed)
+    from xframe_amd.fxs.engine import EngineGroup
+    turns = None if (a.no_turns or len(engines) == 1) else EngineGroup(engines)
+
+    def run_all(kind, betas):
+        if turns is not None:
+            turns.run(kind, True, betas)
+        else:
+            for e in engines:
+                e.run(kind, True, betas, fetch=False)
+
     def run_schedule(n_steps, start_step=0):
         step = start_step
         sw_count = 0
@@ -237,16 +250,13 @@ def main():
                 # reported time is the median window
                 if host['profile'] and c > 1 and host['chunks'] < BRACKET_CHUNKS:
                     engines[0].lib.mtip_profile(engines[0].ctx, 1)
-                    for e in engines:
-                        e.run(kind, True, betas[:1], fetch=False)
+                    run_all(kind, betas[:1])
                     engines[0].lib.mtip_profile(engines[0].ctx, 0)
-                    for e in engines:
-                        e.run(kind, True, betas[1:], fetch=False)
+                    run_all(kind, betas[1:])
                     host['chunks'] += 1
                 else:
                     host['chunks'] += 1 if host['profile'] else 0
-                    for e in engines:
-                        e.run(kind, True, betas, fetch=False)
+                    run_all(kind, betas)
                 host['enqueue_s'] += time.perf_counter() - th
                 done += c
             step += k
@@ -463,6 +473,7 @@ def main():
                                    f'{"reference-order" if a.exact else "fused"} step',
                        'restarts_per_gpu': B, 'restarts_total': B * world, 'streams_per_gpu': n_eng,
                        'streams_side_by_side': round(side_by_side, 2),
+                       'engines_take_turns': turns is not None,      # mtip_run_group_async (ProjectWorker's default) / --no-turns
                        'parallelism': f'restart-sharded x{world}', 'step_mode': 'exact' if a.exact else 'fused'},
             'roofline': roofline, 'cpu_baseline': cpu, 'whole_step': whole_step, 'kernel_families_ms': fam_ms,
             'phase': phase_of(a.warmup, a.steps),

@@ -161,6 +161,12 @@ int mtip_run(mtip_ctx* ctx, int method, int ft_stab, int n_steps, const double* 
              double* real_err, double* deg2_err);
 /* same, but only enqueues (no download, no sync): errors stay on the device until mtip_fetch_errors */
 int mtip_run_async(mtip_ctx* ctx, int method, int ft_stab, int n_steps, const double* betas);
+/* mtip_run_async for the n_ctx contexts of ONE device that a worker runs side by side (the restart groups of
+ * reconstruct.py:104 `n_gpu_workers`, one stream each): the same steps, every context's results bit-identical to its own
+ * mtip_run_async, enqueued so that the contexts take turns at the transforms of a step (which fill the chip) while the
+ * projections of the others (a long chain on a few CUs) run beside them -- see mtip_api.hip.  All contexts must be in the
+ * same loop state a mtip_run_async call would need; n_ctx = 1 is mtip_run_async. */
+int mtip_run_group_async(mtip_ctx* const* ctxs, int n_ctx, int method, int ft_stab, int n_steps, const double* betas);
 int mtip_fetch_errors(mtip_ctx* ctx, int64_t first_step, int64_t n_steps, double* real_err, double* deg2_err);
 /* the main error per step (n_steps x n_batch): what best-pair tracking and the enforce_initial_support decision use */
 int mtip_fetch_main_errors(mtip_ctx* ctx, int64_t first_step, int64_t n_steps, double* main_err);

@@ -268,6 +268,87 @@ def check_short_trajectory_vs_oracle(g, lib_path, fused, n_hio=3, n_er=2, n_rest
     m.engine.close()
 
 
+def check_group_run_identical(g, lib_path, fused=True, sizes=(2, 1, 1)):
+    """mtip_run_group_async (contexts of one GPU taking turns at the transforms of a step) against mtip_run_async per context:
+    HIO + SW + ER + a non-FXS block, every density, error history and support bit-identical; the direct form of EngineGroup."""
+    from xframe_amd.fxs.engine import EngineGroup
+    N, L = int(g['N']), int(g['L'])
+    data = data_from_golden(g, L)
+    opt = golden_settings(N, L)
+    rng = np.random.default_rng(5)
+    rho0 = [g['rho0'] * (1.0 + 0.1 * rng.standard_normal(g['rho0'].shape)) for _ in range(sum(sizes))]
+    out = {}
+    for mode in ('group', 'single'):
+        engines = [Engine(opt, data, n_batch=b, lib_path=lib_path, fused=fused) for b in sizes]
+        i = 0
+        for e in engines:
+            for b in range(e.B):
+                e.set_density(b, rho0[i])
+                i += 1
+            e.init_state()
+        grp = EngineGroup(engines)
+
+        def run(kind, ft_stab, betas):
+            if mode == 'group':
+                grp.run(kind, ft_stab, betas)
+            else:
+                for e in engines:
+                    e.run(kind, ft_stab, betas, fetch=False)
+        run('HIO', True, np.full(3, 0.45))
+        run('HIO', True, np.full(1, 0.5))                        # one step per call: prologue and last turn in one
+        for e in engines:
+            e.shrinkwrap(e.default_sigma, 0.09, 1e9)
+        run('ER', True, np.full(2, 0.5))
+        run('ER', False, np.full(2, 0.5))
+        run('HIO_non_FXS', True, np.full(2, 0.4))
+        n = 3 + 1 + 2 + 2 + 2
+        out[mode] = [(e.fetch_errors(0, n)[0], [e.density(b) for b in range(e.B)], [e.support(b) for b in range(e.B)])
+                     for e in engines]
+        assert grp.calls['group'] == (5 if mode == 'group' else 0)
+        for e in engines:
+            e.close()
+    for (ea, da, sa), (eb, db, sb) in zip(out['group'], out['single']):
+        assert np.array_equal(ea, eb)
+        for x, y in zip(da, db):
+            assert np.array_equal(x, y)
+        for x, y in zip(sa, sb):
+            assert np.array_equal(x, y)
+
+
+def check_group_run_identical_synthetic(cfg, lib_path=None, sizes=(2, 1, 1), n_hio=4, n_er=3):
+    """check_group_run_identical at a BASELINE size on synthetic invariants (GPU: the chained kernels and k_rproj of the metric)"""
+    import xframe_amd.fxs.hostsetup as hs
+    from xframe_amd.fxs.engine import EngineGroup
+    data, _ = synthetic_problem(cfg, lib_path)
+    out = {}
+    for mode in ('group', 'single'):
+        engines = [Engine(S.config_overrides(cfg), data, n_batch=b, lib_path=lib_path) for b in sizes]
+        i = 0
+        for e in engines:
+            for b in range(e.B):
+                e.set_density(b, hs.bump_density(e.rs, e.shape, S.PARTICLE_RADIUS, 0.3, 2, np.random.default_rng(1000 + i),
+                                                 e.rsetup.integrated_intensity, e.int_wr, e.int_wt))
+                i += 1
+            e.init_state()
+        grp = EngineGroup(engines)
+        for kind, betas in (('HIO', np.full(n_hio, 0.45)), ('SW', None), ('ER', np.full(n_er, 0.5))):
+            if kind == 'SW':
+                for e in engines:
+                    e.shrinkwrap(e.default_sigma, 0.09, 1e9)
+            elif mode == 'group':
+                grp.run(kind, True, betas)
+            else:
+                for e in engines:
+                    e.run(kind, True, betas, fetch=False)
+        out[mode] = [(e.fetch_errors(0, n_hio + n_er)[0], [e.density(b) for b in range(e.B)]) for e in engines]
+        for e in engines:
+            e.close()
+    for (ea, da), (eb, db) in zip(out['group'], out['single']):
+        assert np.array_equal(ea, eb) and np.isfinite(ea).all()
+        for x, y in zip(da, db):
+            assert np.array_equal(x, y)
+
+
 def check_split_shell_steps_vs_oracle(lib_path, N=6, L=44, fused=True):
     """Angular size of config 5 (128 x 256, L > 40) with few shells: the inverse SHT shares a shell between two
     workgroups there (two error partial sums per shell in the fused real-space epilogue).  2 HIO + SW + 1 ER against
@@ -848,6 +929,10 @@ def check_config4_worker(lib_path=None, cfg=4, n_restarts=8, n_workers=3, n_hio=
         w = R.ProjectWorker(o, data, seeds=seeds, lib_path=lib_path)
         res, _ = w.run()
         assert len(res) == n_restarts and len(w.mtip_instances) == workers
+        # the groups step through mtip_run_group_async (their `run` calls meet in EngineGroup): every block of the loop was
+        # enqueued by group calls -- and the restarts still come out bit-identical to the single engine below
+        tc = w.results['stats']['turn_calls']
+        assert (tc is None) == (workers == 1) and (tc is None or (tc['group'] >= 2 and tc['single'] == 0)), tc
         groups = w.results['stats']['groups']                     # where the run spent its time, per engine group
         assert len(groups) == workers and sum(g['restarts'] for g in groups) == n_restarts
         assert all(g[k] >= 0 for g in groups for k in ('engine_seconds', 'setup_seconds', 'loop_seconds', 'output_seconds'))

@@ -57,6 +57,11 @@ def test_short_trajectory_vs_oracle(emul_lib, golden_mtip16, fused):
 
 
 @pytest.mark.parametrize('fused', [False, True])
+def test_group_run_identical(emul_lib, golden_mtip16, fused):
+    PC.check_group_run_identical(golden_mtip16, emul_lib, fused)
+
+
+@pytest.mark.parametrize('fused', [False, True])
 def test_non_fxs_variants_vs_oracle(emul_lib, golden_mtip16, fused):
     PC.check_non_fxs_trajectory_vs_oracle(golden_mtip16, emul_lib, fused)
 

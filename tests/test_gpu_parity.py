@@ -168,6 +168,23 @@ def test_config3_short_trajectory_vs_oracle():
     PC.check_config_trajectory_vs_oracle(3, fused=True, n_hio=10, n_er=10)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('fused', [False, True])
+def test_group_run_identical(golden_mtip16, fused):
+    """mtip_run_group_async (engines of one GPU taking turns at the transforms) == mtip_run_async per engine, bit for bit"""
+    PC.check_group_run_identical(golden_mtip16, None, fused)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('lag', ['1', '2'])
+def test_group_run_identical_metric_grid(lag, monkeypatch):
+    """the same at the benchmark's grid (chained kernels, k_rproj): three engines {2, 1, 1} of 128 x L32; both turn orders
+    (MTIP_TURN_LAG: strict turns / at most two contexts in their transforms)"""
+    monkeypatch.setenv('MTIP_TURN_LAG', lag)
+    PC.check_group_run_identical_synthetic(3, sizes=(2, 1, 1))
+
+
+@pytest.mark.gpu
 def test_config4_worker_three_engines_vs_single_and_oracle():
     """128 x L32, eight distinct restarts on three engines (BASELINE config 4 as bench.py runs it on one GPU): bit-equal to
     one engine holding all eight, restarts 0 and 5 (different engine groups) against the oracle."""

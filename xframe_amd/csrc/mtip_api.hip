@@ -65,6 +65,7 @@ void mtip_destroy(mtip_ctx* c) {
     for (hipEvent_t e : c->prof_events) (void)hipEventDestroy(e);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->turn_ev) (void)hipEventDestroy(c->turn_ev);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -533,8 +534,11 @@ static int ensure_hist(mtip_ctx* c, long long need) {
     return MTIP_OK;
 }
 
-// one phasing step for the whole batch (reference operator order), see file header
-static int enqueue_step(mtip_ctx* c, int method, int ft_stab, double beta) {
+// one phasing step for the whole batch (reference operator order), see file header.  `phases` selects the part to enqueue, so
+// that mtip_run_group_async can put other contexts' launches between them: HEAD = F = FT(rho) and I_lm = SHT(|F|^2) (+ metrics),
+// PROJ = the reciprocal-space projection of the coefficients (the long latency chain on few CUs), TAIL = everything after it
+enum { STEP_HEAD = 1, STEP_PROJ = 2, STEP_TAIL = 4, STEP_ALL = 7 };
+static int enqueue_step(mtip_ctx* c, int method, int ft_stab, double beta, int phases = STEP_ALL) {
     const bool fxs = (method == MTIP_HIO || method == MTIP_ER);
     double2 **cc = c->d_c;
     InvEpilogue store;
@@ -543,24 +547,37 @@ static int enqueue_step(mtip_ctx* c, int method, int ft_stab, double beta) {
     // nothing but k_finish_step's rotation touches the current density)
     const bool one_pass_diff = c->cfg.fused && ft_stab && hankel_has_difference(c) && sht_inverse_fuses_real_update(c);
     const bool chain = c->cfg.fused && sht_chain_supported(c);
-    // 1  F = FT(rho_cur)
-    const double2* c0 = cc[0];
-    if (chain && c->c0n_valid) c0 = c->d_c0n;
-    else launch_sht_forward(c, c->d_rho, cc[0], MTIP_PRE_NONE, SL_CUR);
-    c->c0n_valid = false;
-    launch_hankel(c, c0, cc[1], 0);
-    if (chain && fxs) launch_sht_chain(c, cc[1], c->d_F, store, MTIP_PRE_SQUARE, cc[2]);
-    else launch_sht_inverse(c, cc[1], c->d_F, store);
-    if (fxs) {
-        // 2-3 I_lm = SHT(|F|^2);  4-5 projection;  6-7 I' = iSHT, F' = F sqrt(I'/I) -> Fp[out]
-        if (!chain) launch_sht_forward(c, c->d_F, cc[2], MTIP_PRE_SQUARE);
-        if (c->deg2_enable) launch_deg2_metric(c, cc[2], c->d_deg2_hist + (size_t)c->n_steps_done * c->B * (c->L + 1));
-        if (c->im_which) {
-            const int rm = launch_invariant_metrics(c, cc[2], c->n_steps_done);
-            if (rm != MTIP_OK) return rm;
+    if (phases & STEP_HEAD) {
+        // 1  F = FT(rho_cur)
+        const double2* c0 = cc[0];
+        if (chain && c->c0n_valid) c0 = c->d_c0n;
+        else launch_sht_forward(c, c->d_rho, cc[0], MTIP_PRE_NONE, SL_CUR);
+        c->c0n_valid = false;
+        launch_hankel(c, c0, cc[1], 0);
+        if (chain && fxs) launch_sht_chain(c, cc[1], c->d_F, store, MTIP_PRE_SQUARE, cc[2]);
+        else launch_sht_inverse(c, cc[1], c->d_F, store);
+        if (fxs) {
+            // 2-3 I_lm = SHT(|F|^2)
+            if (!chain) launch_sht_forward(c, c->d_F, cc[2], MTIP_PRE_SQUARE);
+            if (c->deg2_enable) launch_deg2_metric(c, cc[2], c->d_deg2_hist + (size_t)c->n_steps_done * c->B * (c->L + 1));
+            if (c->im_which) {
+                const int rm = launch_invariant_metrics(c, cc[2], c->n_steps_done);
+                if (rm != MTIP_OK) return rm;
+            }
         }
-        const int rp = launch_project_coefficients(c, cc[2], cc[2], true);    // in place: I_lm is not needed afterwards; SHT of the real |F|^2
-        if (rp != MTIP_OK) return rp;
+    }
+    if (phases & STEP_PROJ) {
+        // 4-5 projection
+        if (fxs) {
+            const int rp = launch_project_coefficients(c, cc[2], cc[2], true);    // in place: I_lm is not needed afterwards; SHT of the real |F|^2
+            if (rp != MTIP_OK) return rp;
+        } else {
+            launch_modulus_fixed_slots(c, c->d_F);
+        }
+    }
+    if (!(phases & STEP_TAIL)) return MTIP_OK;
+    if (fxs) {
+        // 6-7 I' = iSHT, F' = F sqrt(I'/I) -> Fp[out]
         InvEpilogue mod;
         mod.mode = EPI_MODULUS;
         mod.F = c->d_F;
@@ -568,8 +585,6 @@ static int enqueue_step(mtip_ctx* c, int method, int ft_stab, double beta) {
         if (chain) launch_sht_chain(c, cc[2], c->d_Fp, mod, MTIP_PRE_NONE, cc[4]);
         else launch_sht_inverse(c, cc[2], c->d_Fp, mod);
         launch_reciprocal_l2_metric(c, c->d_F, c->d_Fp, c->n_steps_done);     // (non-default metric; no launch unless enabled)
-    } else {
-        launch_modulus_fixed_slots(c, c->d_F);
     }
     // 9  rho' = IFT(F')
     if (!(chain && fxs)) launch_sht_forward(c, c->d_Fp, cc[4], MTIP_PRE_NONE, SL_OUT);
@@ -634,8 +649,8 @@ static int enqueue_step(mtip_ctx* c, int method, int ft_stab, double beta) {
     return MTIP_OK;
 }
 
-int mtip_run_async(mtip_ctx* c, int method, int ft_stab, int n_steps, const double* betas) {
-    CTX_CHECK(c);
+// checks and one-time work in front of the steps of a run (shared by mtip_run_async and mtip_run_group_async)
+static int run_prelude(mtip_ctx* c, int method, int ft_stab, int n_steps, const double* betas) {
     int r = require_loop(c);
     if (r) return r;
     if (method < 0 || method > 3) FAIL(c, MTIP_EINVAL, "unknown method");
@@ -662,11 +677,85 @@ int mtip_run_async(mtip_ctx* c, int method, int ft_stab, int n_steps, const doub
     // coefficients); the epilogue path does not use T2 at all
     if (c->cfg.fused && ft_stab && !sht_inverse_fuses_real_update(c))
         MTIP_HIP_CHECK(c, hipMemsetAsync(c->d_T2, 0, (size_t)c->B * c->G * sizeof(double2), c->stream));
+    return MTIP_OK;
+}
+
+int mtip_run_async(mtip_ctx* c, int method, int ft_stab, int n_steps, const double* betas) {
+    CTX_CHECK(c);
+    int r = run_prelude(c, method, ft_stab, n_steps, betas);
+    if (r) return r;
     for (int s = 0; s < n_steps; ++s) {
         r = enqueue_step(c, method, ft_stab, betas[s]);
         if (r) return r;
     }
     return post_launch(c, "mtip_run");
+}
+
+// The same steps for SEVERAL contexts of one device (restart groups of one worker, each on its own stream), enqueued so that the
+// contexts take TURNS at the chip-filling part of a step.  A step of a context is a long projection on a few CUs (k_rproj:
+// ~0.3 ms, <= 27 workgroups) followed by transforms that want every CU (TAIL of the step + HEAD of the next: ~0.15 ms); contexts
+// that run side by side overlap the projection of one with the transforms of the others.  Left to themselves their transform
+// blocks collide, the chip serves colliding kernels by sharing CUs, both blocks finish late and both projections start late
+// (measured: one 3-restart context alone 474 us per step; {3, 3, 2} side by side 588 us, the sum of their transform blocks being
+// 476 us).  Here block (i, s) = TAIL(i, s) + HEAD(i, s + 1) waits for the block before it in the ring (i - 1, s) / (last, s - 1)
+// (or, by default, for the one before that: MTIP_TURN_LAG below) through an event recorded on that context's stream: first come,
+// first served.  Events only order work that has been enqueued
+// already (this function enqueues in ring order), so nothing can wait for a record that never comes.
+int mtip_run_group_async(mtip_ctx* const* ctxs, int n_ctx, int method, int ft_stab, int n_steps, const double* betas) {
+    if (!ctxs || n_ctx < 1) return MTIP_EINVAL;
+    for (int i = 0; i < n_ctx; ++i) {
+        if (!ctxs[i]) return MTIP_EINVAL;
+        if (ctxs[i]->device != ctxs[0]->device) FAIL(ctxs[i], MTIP_EINVAL, "contexts of a group must live on one device");
+        for (int j = 0; j < i; ++j)
+            if (ctxs[j] == ctxs[i]) FAIL(ctxs[i], MTIP_EINVAL, "a context appears twice in the group");
+    }
+    if (n_ctx == 1) return mtip_run_async(ctxs[0], method, ft_stab, n_steps, betas);
+    for (int i = 0; i < n_ctx; ++i) {
+        mtip_ctx* c = ctxs[i];
+        const int r = run_prelude(c, method, ft_stab, n_steps, betas);
+        if (r) return r;
+        if (!c->turn_ev) MTIP_HIP_CHECK(c, hipEventCreateWithFlags(&c->turn_ev, hipEventDisableTiming | hipEventDisableSystemFence));
+    }
+    hipEvent_t prev = nullptr, prev2 = nullptr;     // end of the block before this one in the ring, and of the one before that
+    // MTIP_TURN_LAG = 1: a block waits for the block right before it (strict turns: the launch gaps inside a block, ~7 us x 6 kernels,
+    // are then idle chip time); 2 (default): for the one before that -- at most two contexts are in their transforms at a time, one
+    // fills the other's gaps and tails.  Measured, {3, 3, 2} restarts at 128 x L32: schedule 0.543 ms per step without turns, 0.592 with
+    // lag 1, 0.528 with lag 2; the HIO window (bound by one context's chain, not by the chip) 0.60 in all three.
+    const int lag = getenv("MTIP_TURN_LAG") && atoi(getenv("MTIP_TURN_LAG")) == 1 ? 1 : 2;
+    auto turn = [&](mtip_ctx* c, bool tail, bool head, int s) -> int {
+        hipEvent_t w = lag >= 2 ? prev2 : prev;
+        if (w && w != c->turn_ev) MTIP_HIP_CHECK(c, hipStreamWaitEvent(c->stream, w, 0));
+        if (tail) {
+            const int r = enqueue_step(c, method, ft_stab, betas[s], STEP_TAIL);
+            if (r) return r;
+        }
+        if (head) {
+            const int r = enqueue_step(c, method, ft_stab, betas[s + (tail ? 1 : 0)], STEP_HEAD);
+            if (r) return r;
+        }
+        MTIP_HIP_CHECK(c, hipEventRecord(c->turn_ev, c->stream));
+        prev2 = prev;
+        prev = c->turn_ev;
+        return MTIP_OK;
+    };
+    if (n_steps > 0)
+        for (int i = 0; i < n_ctx; ++i) {
+            const int r = turn(ctxs[i], false, true, 0);
+            if (r) return r;
+        }
+    for (int s = 0; s < n_steps; ++s)
+        for (int i = 0; i < n_ctx; ++i) {
+            mtip_ctx* c = ctxs[i];
+            int r = enqueue_step(c, method, ft_stab, betas[s], STEP_PROJ);
+            if (r) return r;
+            r = turn(c, true, s + 1 < n_steps, s);
+            if (r) return r;
+        }
+    for (int i = 0; i < n_ctx; ++i) {
+        const int r = post_launch(ctxs[i], "mtip_run_group");
+        if (r) return r;
+    }
+    return MTIP_OK;
 }
 
 int mtip_fetch_errors(mtip_ctx* c, int64_t first, int64_t n, double* real_err, double* deg2_err) {

@@ -191,6 +191,7 @@ struct mtip_ctx {
     double* d_PT = nullptr;                           // (nt/2, npairs) theta-major Legendre table (fused SHT)
     double* d_PTc = nullptr;                          // (nt/2, 768) the same table in the chunk layout of k_sht_chain's Legendre sums
     int* d_lmc = nullptr;                             // (768) l | m << 8 of slot u * 256 + t, -1: none
+    hipEvent_t turn_ev = nullptr;                     // mtip_run_group_async: end of this context's latest transform block
     int chain_chunks = 0;                             // chunks (threads of an accumulation group with work) in that layout; 0: it does not fit 256
     int* d_lmtab = nullptr;                           // (npairs) l | m << 8
     int npairs = 0;

@@ -45,6 +45,7 @@ class Engine:
         cfg = _lib.MtipCfg(self.N, self.L, self.n_theta, self.n_phi, self.B, 1 if hs.hankel_skips_first_shell(self.mode) else 0,
                            1 if fused else 0, 0)
         self.ctx = self.lib.mtip_create(C.byref(cfg), int(device))
+        self.group = None                                            # EngineGroup this engine steps with (side-by-side restart groups)
         if not self.ctx:
             raise _lib.MtipError('mtip_create: ' + self.lib.mtip_last_error(None).decode())
         # ---- transforms
@@ -177,6 +178,8 @@ class Engine:
         return self.fourier_transform(self.sht_inverse(c), inverse=True)[0].real
 
     def close(self):
+        if getattr(self, 'group', None) is not None:
+            self.group.leave(self)
         if getattr(self, 'ctx', None):
             self.lib.mtip_destroy(self.ctx)
             self.ctx = None
@@ -534,6 +537,16 @@ class Engine:
     def run(self, method, ft_stab, betas, fetch=True):
         betas = _lib.as_f64(np.atleast_1d(betas))
         n = len(betas)
+        if self.group is not None:
+            # side by side with other engines of this GPU: the group enqueues everybody's steps in turn order (EngineGroup)
+            best = np.empty(self.B)
+            first = C.c_int64(0)
+            if fetch:
+                self._ck(self.lib.mtip_get_best_error(self.ctx, _lib.ptr(best), C.byref(first)))
+            self.group.member_run(self, method, ft_stab, betas)
+            if not fetch:
+                return None, None
+            return self.fetch_errors(first.value, n)
         if not fetch:
             self._ck(self.lib.mtip_run_async(self.ctx, METHOD_ID[method], int(bool(ft_stab)), n, _lib.ptr(betas)))
             return None, None
@@ -658,6 +671,104 @@ class Engine:
     def forward_l(self, grid):
         c = self.sht_forward(grid)[0]
         return [np.array(c[:, l * l:(l + 1) ** 2]) for l in range(self.L + 1)]
+
+
+class EngineGroup:
+    """Engines of one GPU that step side by side (the reference's `GPU.n_gpu_workers` restart groups, reconstruct.py:104), run
+    through mtip_run_group_async: the same steps per engine, enqueued so that the engines take turns at the chip-filling
+    transforms while the others' projections run beside them (mtip_api.hip).
+
+    ``run(method, ft_stab, betas)`` is the direct form (one host thread drives all engines: bench.py).  A worker whose restart
+    groups run the reference's loop each in their own host thread attaches the engines (``attach``): every ``Engine.run`` then
+    meets the others here, and the last one to arrive enqueues for all that asked for the same steps (engines that asked for
+    something else -- a data-dependent ft_stab decision, say -- are enqueued on their own).  A member that is done ``leave``s;
+    nobody waits for a member that has left, and a wait that lasts longer than `patience` seconds stops waiting and enqueues alone."""
+
+    def __init__(self, engines=(), patience=30.0):
+        import threading
+        self.engines = list(engines)
+        self.cond = threading.Condition()
+        self.members = []
+        self.pending = {}
+        self.generation = 0
+        self.patience = patience
+        self.calls = {'group': 0, 'single': 0}
+
+    # -- direct form
+    def run(self, method, ft_stab, betas):
+        betas = _lib.as_f64(np.atleast_1d(betas))
+        self._enqueue(self.engines, method, ft_stab, betas)
+
+    def _enqueue(self, engines, method, ft_stab, betas):
+        e0 = engines[0]
+        if len(engines) == 1:
+            e0._ck(e0.lib.mtip_run_async(e0.ctx, METHOD_ID[method], int(bool(ft_stab)), len(betas), _lib.ptr(betas)))
+            self.calls['single'] += 1
+            return
+        import ctypes as C
+        arr = (C.c_void_p * len(engines))(*[e.ctx for e in engines])
+        rc = e0.lib.mtip_run_group_async(arr, len(engines), METHOD_ID[method], int(bool(ft_stab)), len(betas), _lib.ptr(betas))
+        self.calls['group'] += 1
+        if rc != 0:
+            for e in engines:                       # the context that failed holds the message
+                msg = e.lib.mtip_last_error(e.ctx).decode()
+                if msg:
+                    raise RuntimeError('mtip_run_group_async: %s' % msg)
+            raise RuntimeError('mtip_run_group_async failed with code %d' % rc)
+
+    # -- rendezvous form (one host thread per engine)
+    def attach(self, engine):
+        with self.cond:
+            self.members.append(engine)
+            engine.group = self
+
+    def leave(self, engine):
+        with self.cond:
+            if engine in self.members:
+                self.members.remove(engine)
+            engine.group = None
+            self.pending.pop(id(engine), None)
+            self._flush_if_complete()
+
+    def _flush_if_complete(self):
+        if not self.pending or len(self.pending) < len(self.members):
+            return
+        self._flush()
+
+    def _flush(self):
+        todo = list(self.pending.values())
+        self.pending.clear()
+        self.generation += 1
+        errors = []
+        while todo:
+            e, method, ft_stab, betas = todo[0]
+            same = [t for t in todo if t[1] == method and t[2] == ft_stab and np.array_equal(t[3], betas)]
+            todo = [t for t in todo if not any(t is u for u in same)]
+            try:
+                self._enqueue([t[0] for t in same], method, ft_stab, betas)
+            except Exception as ex:                 # delivered to every waiting member: nobody is left hanging
+                errors.append(ex)
+        self.error = errors[0] if errors else None
+        self.cond.notify_all()
+
+    def member_run(self, engine, method, ft_stab, betas):
+        import time
+        with self.cond:
+            self.pending[id(engine)] = (engine, method, bool(ft_stab), betas)
+            gen = self.generation
+            if len(self.pending) >= len(self.members):
+                self._flush()
+            else:
+                deadline = time.monotonic() + self.patience
+                while self.generation == gen:
+                    left = deadline - time.monotonic()
+                    if left <= 0:                    # the others are busy elsewhere: go alone
+                        self.pending.pop(id(engine), None)
+                        self._enqueue([engine], method, ft_stab, betas)
+                        return
+                    self.cond.wait(left)
+            if getattr(self, 'error', None) is not None:
+                raise self.error
 
 
 def streams_side_by_side(engines, microseconds=2000.0, reps=3):

@@ -407,12 +407,36 @@ class ProjectWorker:
             n_eng = max(1, min(n_eng, 3, len(mine) // 2))
             groups = [list(range(g, len(mine), n_eng)) for g in range(n_eng)]
 
+            # the groups' engines step through mtip_run_group_async (EngineGroup): every group runs the reference's loop in its
+            # own thread, their `run` calls meet and are enqueued in turn order -- each group's results are those of its own
+            # mtip_run_async; GPU.take_turns = False leaves the groups to themselves
+            turns = None
+            if n_eng > 1 and self.opt['GPU'].get('take_turns', True):
+                import threading
+                from .engine import EngineGroup
+                turns = EngineGroup()
+                ready = threading.Barrier(n_eng)
+
             def run_group(local_ids):
                 gseeds = None if seeds is None else [seeds[i] for i in local_ids]
-                m = MTIP(self.process_factory, n_restarts=len(local_ids), device=self.device, seeds=gseeds,
-                         lib_path=self.lib_path)
-                m.generate_phasing_loop()
-                return m, m.phasing_loop()
+                m = None
+                try:
+                    m = MTIP(self.process_factory, n_restarts=len(local_ids), device=self.device, seeds=gseeds,
+                             lib_path=self.lib_path)
+                    m.generate_phasing_loop()
+                    if turns is not None and m.engine is not None and MTIP.dimensions != 2:
+                        turns.attach(m.engine)
+                finally:
+                    if turns is not None:
+                        try:
+                            ready.wait(120.0)            # nobody steps before everybody is attached (or has failed)
+                        except threading.BrokenBarrierError:
+                            pass
+                try:
+                    return m, m.phasing_loop()
+                finally:
+                    if turns is not None and m is not None and m.engine is not None:
+                        turns.leave(m.engine)
 
             if n_eng == 1:
                 outs = [run_group(groups[0])]
@@ -429,6 +453,7 @@ class ProjectWorker:
             self.mtip_instance = outs[0][0]
             self.mtip_instances = [m for m, _ in outs]
             self.results['stats']['groups'] = [dict(m.timing, restarts=len(g)) for (m, _), g in zip(outs, groups)]
+            self.results['stats']['turn_calls'] = None if turns is None else dict(turns.calls)
         result = gather_results(result, mine, total, self.rank, self.world_size, n_full=self.n_gather_full,
                                 device=self._torch_device(), device_source=sources if len(mine) else None)
         self.results['MTIP'] = result
