@@ -310,6 +310,14 @@ int mtip2d_set_error_weights(mtip2d_ctx* ctx, const double* weights);
  * (n_batch, Nq, n_phi) in; F' and the new density, the error per restart and the unknowns (n_batch, n_used; or NULL) out */
 int mtip2d_op_step(mtip2d_ctx* ctx, int method, int ft_stab, double beta, const mtip_cdouble* rho, const uint8_t* support,
                    mtip_cdouble* F_new, mtip_cdouble* rho_new, double* err, mtip_cdouble* unknowns);
+/* the same with the loop's sub-variants: method 2 / 3 = HIO_non_FXS / ER_non_FXS (sketch MTIP_start_non_FXS, reconstruct.py:530-535,
+ * 899-904: F' = F sqrt(fixed / |F|^2) with fixed_intensity (n_batch, Nq, n_phi), no harmonic transform, no unknowns), and the inputs
+ * of the reciprocal error metrics (fxs_IO_methods.py:301-310, 370-400) when asked for: F_out = FT(rho) (n_batch, Nq, n_phi), I_out =
+ * the harmonic coefficients of |F|^2 (n_batch, Nq, M + 1; FXS methods only); any of fixed_intensity / F_out / I_out / unknowns
+ * may be NULL */
+int mtip2d_op_step_ex(mtip2d_ctx* ctx, int method, int ft_stab, double beta, const mtip_cdouble* rho, const uint8_t* support,
+                      const double* fixed_intensity, mtip_cdouble* F_new, mtip_cdouble* rho_new, double* err, mtip_cdouble* unknowns,
+                      mtip_cdouble* F_out, mtip_cdouble* I_out);
 /* the SW sketch (reconstruct.py:598-605, fxs_Projections.py:245-258, 294-298): support mask (n_batch, Nq, n_phi) from rho */
 int mtip2d_op_shrinkwrap(mtip2d_ctx* ctx, const mtip_cdouble* rho, double sigma, double threshold, uint8_t* mask);
 

@@ -112,6 +112,31 @@ class ShrinkWrap2D(P.ShrinkWrap):
         self.gaussian_values = P.gaussian_fourier_transformed_spherical(self.qgrid, self._sigma)
 
 
+class Deg2InvariantDiff2D:
+    """_generate_deg2_invariant_diff_2d, fxs_IO_methods.py:370-400: per used order sum |B_ref - B_m|^2 / sum |B_ref|^2 with
+    B_m = I_m (x) I_m^* (fxs_invariant_tools.py:906-914), -1 where the reference invariant is zero; the zero order's reference is
+    divided by the number of particles; no q weights and no mask (both are commented out upstream)"""
+
+    def __init__(self, reference_invariant, used_orders, n_particles):
+        self.ref = np.array(reference_invariant)[np.array(list(used_orders.keys())).astype(int)].copy()
+        self.reference = self.ref.copy()
+        self.norm = np.sum(self.ref * self.ref.conj(), axis=(1, 2)).real
+        self.order_array = np.array(tuple(used_orders.values()))
+        self.zero_id = used_orders[0]
+        self.n_particles = n_particles
+
+    def __call__(self, Im):
+        Im = np.asarray(Im)                                            # (Nq, M + 1)
+        Bm = np.array([v[:, None] * v[None, :].conj() for v in Im.T])[self.order_array]
+        self.reference[self.zero_id] = self.ref[self.zero_id] / self.n_particles[0]
+        diff = self.reference - Bm
+        nd = np.sum((diff * diff.conj()).real, axis=(1, 2))
+        err = np.full(len(self.norm), -1.0)
+        nz = self.norm != 0
+        err[nz] = nd[nz] / self.norm[nz]
+        return err
+
+
 class MTIP2D(OM.MTIP):
     def __init__(self, opt, data):
         self.opt = opt
@@ -143,26 +168,56 @@ class MTIP2D(OM.MTIP):
         em = opt['main_loop']['error']['methods']
         self.real_metrics = list(em['real']['calculate'])
         self.reciprocal_metrics = list(em['reciprocal']['calculate'])
-        if self.reciprocal_metrics:
-            raise NotImplementedError('2-D reciprocal metrics')
+        for name in self.reciprocal_metrics:
+            if name not in ('deg2_invariant_l2_diff', 'l2_projection_diff'):
+                raise NotImplementedError('2-D reciprocal metric %r' % (name,))
         self.inside_initial = em['real'].get('l2_projection_diff', {}).get('inside_initial_support', False)
         self.initial_mask = self.real_pr.initial_support
         gen = opt.get('general', {})
         self.real_error_mask = P.select_real_error_mask(self.shape, self.inside_initial, self.initial_mask, gen.get('cache_aware', True),
                                                         gen.get('L2_cache', 512))
         self.deg2_diff = None
+        self._ranked_id = None
+        if 'deg2_invariant_l2_diff' in self.reciprocal_metrics:
+            self.deg2_diff = Deg2InvariantDiff2D(self.rp.deg2_invariants, self.rp.used_orders, self.rp.number_of_particles_list)
         self.results = {}
         self._init_sw_ramps()
 
     def autocorrelation_guess(self):
-        """reconstruct.py:421-423: ift(icht(pr.T)).real with the complex inverse transform of the (Nq, M + 1) vectors zero padded?  The
-        reference hands the (Nq, M + 1) array to the COMPLEX inverse transform of n_phi points: only defined when M + 1 == n_phi"""
-        raise NotImplementedError('2-D auto-correlation support')
+        """reconstruct.py:400-403, 421-423: ift(icht(pr.T)).real, pr = the (n_orders, Nq) `full_projection_matrices` (before the
+        odd-order / average-intensity modifications), icht = the inverse of the REAL harmonic transform (the loop's
+        'inverse_harmonic_transform', reconstruct.py:370), ift the polar inverse Fourier transform"""
+        return self.fp.ift(self.sht.inverse_l(np.array(self.rp.full_projection_matrices).T).astype(complex)).real
 
     def output_modifier(self, pair):
-        if self.opt.get('output_density_modifiers', {}).get('shift_to_center', False):
-            raise NotImplementedError('2-D shift_to_center')
-        return pair
+        """assemble_output_modifier, reconstruct.py:721-755 with the 2-D operators (454, misk.py:295-312, fxs_Projections.py:1419-1432):
+        (reciprocal, real) -> (reciprocal * phases, IFT(FT(real) * phases)), phases = exp(+i k.c), c = centre of mass of Re(real) by
+        the PolarIntegrator, returned in polar coordinates with phi in [0, 2 pi)"""
+        if not self.opt.get('output_density_modifiers', {}).get('shift_to_center', False):
+            return pair
+        recip, real = np.array(pair[0]), np.array(pair[1])
+        ft = self.fp.ft(real)
+        r, ph = np.meshgrid(self.fp.rs, self.fp.phis, indexing='ij')
+        cart = np.stack((r * np.cos(ph), r * np.sin(ph)), -1)
+        integral = self.integrator.integrate(real.real)
+        if integral == 0:
+            integral = 1
+        c = np.array([self.integrator.integrate(cart[..., i] * real.real) for i in range(2)]) / integral
+        phi_c = np.arctan2(c[1], c[0])
+        center = np.array([np.hypot(c[0], c[1]), phi_c + 2 * np.pi if phi_c < 0 else phi_c])
+        self.results['neg_center_pos'] = center
+        cv = np.array([center[0] * np.cos(center[1]), center[0] * np.sin(center[1])])                     # spherical_to_cartesian(vector)
+        q, pq = np.meshgrid(self.fp.qs, self.fp.phis, indexing='ij')
+        phases = np.exp(1j * (q * np.cos(pq) * cv[0] + q * np.sin(pq) * cv[1]))                            # opposite_direction = True
+        return (recip * phases, self.fp.ift(ft * phases))
+
+    def _reciprocal_errors(self, F, F_new, Im):
+        for name in self.reciprocal_metrics:
+            if name == 'deg2_invariant_l2_diff':
+                val = self.deg2_diff(Im)
+            else:                                                     # l2_projection_diff: fxs_IO_methods.py:301-310 (see oracle/mtip.py)
+                val = P.l2_rel_diff_error(self.integrator, np.array(F), np.array(F_new), True)
+            self.errors['reciprocal'][name].append(val)
 
     def phasing_loop(self, rho0=None, rng=None, step_hook=None):
         if rho0 is None:
@@ -183,7 +238,8 @@ class MTIP2D(OM.MTIP):
         n_steps = len(self.errors['main'])
         grids = {'real_grid': np.stack(np.meshgrid(self.fp.rs, self.fp.phis, indexing='ij'), -1),
                  'reciprocal_grid': np.stack(np.meshgrid(self.fp.qs, self.fp.phis, indexing='ij'), -1)}
-        err = {'main': np.array(self.errors['main']), 'real': {k: np.array(v) for k, v in self.errors['real'].items()}, 'reciprocal': {}}
+        err = {'main': np.array(self.errors['main']), 'real': {k: np.array(v) for k, v in self.errors['real'].items()},
+               'reciprocal': {k: np.array(v) for k, v in self.errors['reciprocal'].items()}}
         return {'real_density': best[1], 'last_real_density': last[1], 'reciprocal_density': best[0], 'last_reciprocal_density': last[0],
                 'final_error': state['best_error'], 'initial_density': initial_densities[1], 'initial_support': initial_mask,
                 'error_dict': err, 'support_mask': state['best_mask'], 'last_support_mask': state['mask'],

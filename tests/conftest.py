@@ -41,6 +41,11 @@ def golden_mtip2d():
 
 
 @pytest.fixture(scope='session')
+def golden_mtip2d_variants():
+    return np.load(os.path.join(GOLDEN, 'mtip2d_variants_N12_M6.npz'))
+
+
+@pytest.fixture(scope='session')
 def golden_metrics():
     return np.load(os.path.join(GOLDEN, 'metrics_ops.npz'))
 

@@ -1284,7 +1284,7 @@ def main_metrics():
 
 
 # ---- (f-4) the 2-D phasing loop through the reference's own MTIP class --------------------------------------------------------
-def main_mtip2d():
+def run_mtip2d_golden(extra=None, with_steps=True, save=True):
     """tests/golden/mtip2d_N12_M6.npz (G20): the reference's real `reconstruct.MTIP(...).generate_phasing_loop() / phasing_loop()` with
     `dimensions: 2` on seeded 2-D invariants (projection vectors (n_orders, Nq), average intensity) and a stored initial density:
     single HIO / ER (+ft_stab) steps and the shrink-wrap mask from a stored state, and a short trajectory (errors, densities,
@@ -1337,6 +1337,8 @@ def main_mtip2d():
     main['methods']['HIO']['iterations'] = 4
     main['methods']['ER']['iterations'] = 3
     main['iterations'] = 2
+    if extra:
+        o = OM.deep_update(o, extra)
     settings.project = pl.DictNamespace.dict_to_dictnamespace(o)
     for k in list(sys.modules):
         if k.endswith('fxs.reconstruct'):
@@ -1378,6 +1380,8 @@ def main_mtip2d():
     out['rp_radial_points'] = np.asarray(rp.radial_points)
     real_pr = m.projection_objects['real']
     out['initial_support'] = np.asarray(real_pr.initial_support)
+    if not with_steps:
+        out = {'rho0': rho0}
     # single steps from a stored state
     F0 = ops['fourier_transform'](rho0)
     rho_s = ops['inverse_fourier_transform'](F0)
@@ -1385,7 +1389,7 @@ def main_mtip2d():
     out['step_F0'] = np.array(F0)
     hio = m.projection_objects['hio']
     sup = np.random.default_rng(5).random(rho_s.shape) > 0.3
-    for enforce in (True, False):
+    for enforce in ((True, False) if with_steps else ()):
         real_pr.enforce_initial_support = enforce
         real_pr.support = sup
         for meth in ('HIO', 'ER', 'HIO_ft_stab', 'ER_ft_stab'):
@@ -1396,20 +1400,26 @@ def main_mtip2d():
             tag = f'step_{meth}_enf{int(enforce)}'
             out[tag + '_F'], out[tag + '_rho'] = np.array(Fn), np.array(rn)
             out[tag + '_err'] = np.array(m.results['errors']['real']['l2_projection_diff'][-1])
-    out['step_support'] = sup
-    sw = m.projection_objects['sw']
-    sw.gaussian_sigma = 20.0
-    sw.threshold = 0.09
-    out['step_SW_mask'] = np.array(m.routines['SW'].run(np.array(rho_s)))
-    real_pr.enforce_initial_support = True
-    real_pr.support = real_pr.initial_support
+    if with_steps:
+        out['step_support'] = sup
+        sw = m.projection_objects['sw']
+        sw.gaussian_sigma = 20.0
+        sw.threshold = 0.09
+        out['step_SW_mask'] = np.array(m.routines['SW'].run(np.array(rho_s)))
+        real_pr.enforce_initial_support = True
+        real_pr.support = real_pr.initial_support
     # full trajectory with the stored rho0
     m2 = MT(pl.RecipeFactory({}))
-    m2.generate_density_guess_method = lambda *a, **k: (lambda: np.array(rho0))
+    if not (extra or {}).get('_reference_guess', False):
+        m2.generate_density_guess_method = lambda *a, **k: (lambda: np.array(rho0))
+    else:
+        np.random.seed(4242)                         # the reference's guess draws from the global numpy state
     m2.generate_phasing_loop()
     res = m2.phasing_loop()
     out['traj_main'] = res['error_dict']['main']
     out['traj_real_err'] = res['error_dict']['real']['l2_projection_diff']
+    for mk, mv in res['error_dict'].get('reciprocal', {}).items():
+        out['traj_reciprocal_' + mk] = np.asarray(mv)
     for k in ('last_real_density', 'real_density', 'last_reciprocal_density', 'reciprocal_density', 'support_mask', 'last_support_mask',
               'initial_density'):
         out['traj_' + k] = np.asarray(res[k])
@@ -1421,8 +1431,43 @@ def main_mtip2d():
     out['traj_n_particles'] = np.asarray(res['n_particles'])
     out['traj_real_grid'] = np.array(res['grid_pair']['real_grid'][:], dtype=float)
     out['traj_reciprocal_grid'] = np.array(res['grid_pair']['reciprocal_grid'][:], dtype=float)
-    np.savez_compressed(os.path.join(HERE, 'mtip2d_N12_M6.npz'), **out)
+    if save:
+        np.savez_compressed(os.path.join(HERE, 'mtip2d_N12_M6.npz'), **out)
     print('2-D loop fixture:', len(out), 'arrays; final error', res['final_error'], 'steps', len(res['error_dict']['main']))
+    return out
+
+
+def main_mtip2d():
+    run_mtip2d_golden()
+
+
+sys.path.insert(0, HERE)
+from variants2d import VARIANTS_2D          # noqa: E402  (tests/golden/variants2d.py: settings only, shared with tests/parity_cases.py)
+
+
+def main_mtip2d_variants():
+    """tests/golden/mtip2d_variants_N12_M6.npz: '<variant>/<key>' trajectories of the reference's 2-D loop; a variant the
+    reference itself cannot run in 2-D is recorded as '<variant>/raises' = the exception text"""
+    path = os.path.join(HERE, 'mtip2d_variants_N12_M6.npz')
+    names = sys.argv[2:] or list(VARIANTS_2D)
+    out = dict(np.load(path)) if (sys.argv[2:] and os.path.exists(path)) else {}
+    import traceback
+    for name in names:
+        for k in [k for k in out if k.startswith(name + '/')]:
+            del out[k]
+        try:
+            r = run_mtip2d_golden(extra=VARIANTS_2D[name], with_steps=False, save=False)
+        except Exception as ex:
+            tb = traceback.extract_tb(ex.__traceback__)[-1]
+            msg = '%s: %s (%s:%d)' % (type(ex).__name__, ex, os.path.basename(tb.filename), tb.lineno)
+            print('   variant', name, 'raises upstream:', msg)
+            out[name + '/raises'] = np.array(msg)
+            continue
+        for k, v in r.items():
+            out[name + '/' + k] = v
+    np.savez_compressed(path, **out)
+    print('2-D variants fixture:', len(out), 'arrays')
+
 
 
 def main_radial_rules():
@@ -1506,6 +1551,8 @@ if __name__ == '__main__':
         main_metrics()
     elif len(sys.argv) > 1 and sys.argv[1] == 'mtip2d':
         main_mtip2d()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'mtip2d_variants':
+        main_mtip2d_variants()
     elif len(sys.argv) > 1 and sys.argv[1] == 'radial_rules':
         main_radial_rules()
     elif len(sys.argv) > 1 and sys.argv[1] == 'variants':

@@ -1329,6 +1329,67 @@ def check_mtip2d_golden_hip(g, lib_path=None):
     m.close()
 
 
+MTIP2D_VARIANTS = ('nonfxs', 'swcenter', 'shift', 'recip_deg2', 'recip_l2', 'autocorr_support')
+
+
+def mtip2d_variant_problem(g, gv, name):
+    """settings of the 2-D sub-variant `name` (tests/golden/make_golden.py VARIANTS_2D; same data and rho0 as G20) and its arrays"""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden'))
+    import variants2d as mg
+    data, o = mtip2d_problem(g)
+    o = OM.deep_update(o, {k: w for k, w in mg.VARIANTS_2D[name].items() if not k.startswith('_')})
+    ref = {k[len(name) + 1:]: w for k, w in gv.items() if k.startswith(name + '/')}
+    return data, o, ref
+
+
+def _compare_mtip2d_variant(res, ref, tol_e, tol_d):
+    assert len(res['error_dict']['main']) == len(ref['traj_main'])
+    assert np.allclose(res['error_dict']['main'], ref['traj_main'], rtol=tol_e, atol=1e-300)
+    assert np.allclose(res['error_dict']['real']['l2_projection_diff'], ref['traj_real_err'], rtol=tol_e)
+    for k in [k for k in ref if k.startswith('traj_reciprocal_') and k != 'traj_reciprocal_grid' and k != 'traj_reciprocal_density']:
+        got = np.asarray(res['error_dict']['reciprocal'][k[len('traj_reciprocal_'):]])
+        assert got.shape == ref[k].shape and np.allclose(got, ref[k], rtol=tol_e * 10, atol=1e-300), k
+    for k in ('last_real_density', 'real_density', 'last_reciprocal_density', 'reciprocal_density', 'initial_density'):
+        assert rel_l2(res[k], ref['traj_' + k]) < tol_d, k
+    assert (res['support_mask'] != ref['traj_support_mask']).sum() == 0 and (res['last_support_mask'] != ref['traj_last_support_mask']).sum() == 0
+    assert np.isclose(res['final_error'], float(ref['traj_final_error']), rtol=tol_e)
+    assert int(res['loop_iterations']) == int(ref['traj_loop_iterations'])
+    assert rel_l2(res['last_deg2_invariant'], ref['traj_last_deg2_invariant']) < tol_d
+
+
+def check_mtip2d_variant_golden_oracle(g, gv, name):
+    """oracle/mtip2d.py on a sub-variant of the 2-D loop against the reference's own run of it"""
+    from oracle import mtip2d as O2
+    data, o, ref = mtip2d_variant_problem(g, gv, name)
+    _compare_mtip2d_variant(O2.MTIP2D(o, data).phasing_loop(rho0=g['rho0']), ref, 1e-10, 1e-10)
+
+
+def check_mtip2d_variant_golden_hip(g, gv, name, lib_path=None):
+    """the product's 2-D loop on a sub-variant (SW_center, *_non_FXS, reciprocal metrics, auto-correlation support, shift_to_center)
+    against the reference's own run of it; two restarts per call"""
+    from xframe_amd.fxs.reconstruct2d import MTIP2D
+    data, o, ref = mtip2d_variant_problem(g, gv, name)
+    m = MTIP2D(o, data, n_restarts=2, initial_densities=[g['rho0'], g['rho0']], lib_path=lib_path)
+    res = m.phasing_loop()
+    for r in res:
+        _compare_mtip2d_variant(r, ref, 1e-8, 1e-8)
+    m.close()
+
+
+def check_mtip2d_unbuildable_variants(g, gv, lib_path=None):
+    """what the reference cannot run in 2-D raises here too: the low-resolution auto-correlation guess (recorded upstream exception)"""
+    from xframe_amd.fxs.reconstruct2d import MTIP2D
+    import pytest
+    assert 'TypeError' in str(gv['autocorr_guess/raises'])
+    data, o = mtip2d_problem(g)
+    o = OM.deep_update(o, {'density_guess': {'type': 'low_resolution_autocorrelation'}})
+    m = MTIP2D(o, data, n_restarts=1, lib_path=lib_path)
+    with pytest.raises(NotImplementedError):
+        m.phasing_loop()
+    m.close()
+
+
 def check_mtip2d_worker_vs_oracle(g, lib_path=None, N=None, M=None, n_restarts=3):
     """`fxs reconstruct` with `dimensions: 2` through ProjectWorker: seeded density guesses (bump), each restart against the oracle's
     loop run from the same generator; sizes of the fixture unless N, M are given (then data interpolated from the fixture's)"""
@@ -1348,6 +1409,41 @@ def check_mtip2d_worker_vs_oracle(g, lib_path=None, N=None, M=None, n_restarts=3
         assert (res[b]['support_mask'] != ref['support_mask']).sum() == 0 and (res[b]['last_support_mask'] != ref['last_support_mask']).sum() == 0
     for m in w.mtip_instances:
         m.engine.close()
+
+
+def check_mtip2d_ft_stab_disagreement(g, lib_path=None):
+    """two restarts of one batch that DISAGREE on the ft_stab link (one has its initial support enforced by the shrink-wrap, the other
+    not: the reference decides per reconstruction process, reconstruct.py:836-850): every restart against the oracle's own run of it"""
+    from oracle import mtip2d as O2
+    from xframe_amd.fxs.reconstruct2d import MTIP2D
+    data, o = mtip2d_problem(g)
+    o = OM.deep_update(o, {'main_loop': {'sub_loops': {'main': {'iterations': 3, 'order': ['HIO', 'SW', 'ER'], 'methods': {
+        'HIO': {'iterations': 3, 'ft_stab': 'link_to_enforce_initial_support', 'link_to_enforce_initial_support': {'delay': 1}},
+        'SW': 1, 'ER': {'iterations': 2, 'ft_stab': 'link_to_enforce_initial_support', 'link_to_enforce_initial_support': {'delay': 1}}}}}}})
+    rho_a = np.asarray(g['rho0'])
+    rho_b = rho_a * (1.0 + 2.0 * np.random.default_rng(9).random(rho_a.shape)) + 0.3 * np.abs(rho_a).max() * np.random.default_rng(10).random(rho_a.shape)
+    refs = [O2.MTIP2D(o, data).phasing_loop(rho0=r) for r in (rho_a, rho_b)]
+    e3 = [r['error_dict']['main'][2] for r in refs]
+    assert max(e3) > 1.3 * min(e3)
+    eis = o['projections']['real']['projections']['support']['enforce_initial_support']
+    eis['apply'], eis['if_error_bigger_than'] = True, float(np.sqrt(e3[0] * e3[1]))
+    refs = [O2.MTIP2D(o, data).phasing_loop(rho0=r) for r in (rho_a, rho_b)]
+    m = MTIP2D(o, data, n_restarts=2, initial_densities=[rho_a, rho_b], lib_path=lib_path)
+    seen = []
+    orig = m._step
+
+    def spy(key, ft_stab, *a):
+        seen.append(ft_stab)
+        return orig(key, ft_stab, *a)
+    m._step = spy
+    res = m.phasing_loop()
+    m.close()
+    assert any(isinstance(f, np.ndarray) for f in seen)              # the restarts did disagree in some block
+    for r, ref in zip(res, refs):
+        assert np.allclose(r['error_dict']['main'], ref['error_dict']['main'], rtol=1e-8)
+        for k in ('real_density', 'last_real_density', 'reciprocal_density', 'last_reciprocal_density', 'fxs_unknowns'):
+            assert rel_l2(r[k], ref[k]) < 1e-8, k
+        assert (r['last_support_mask'] != ref['last_support_mask']).sum() == 0
 
 
 SETTINGS_VARIANTS_2D = dict(

@@ -182,6 +182,19 @@ def test_mtip2d_loop_golden(emul_lib, golden_mtip2d):
     PC.check_mtip2d_golden_hip(golden_mtip2d, emul_lib)
 
 
+@pytest.mark.parametrize('name', PC.MTIP2D_VARIANTS)
+def test_mtip2d_variants_golden(emul_lib, golden_mtip2d, golden_mtip2d_variants, name):
+    PC.check_mtip2d_variant_golden_hip(golden_mtip2d, golden_mtip2d_variants, name, emul_lib)
+
+
+def test_mtip2d_ft_stab_disagreement(emul_lib, golden_mtip2d):
+    PC.check_mtip2d_ft_stab_disagreement(golden_mtip2d, emul_lib)
+
+
+def test_mtip2d_unbuildable_variants(emul_lib, golden_mtip2d, golden_mtip2d_variants):
+    PC.check_mtip2d_unbuildable_variants(golden_mtip2d, golden_mtip2d_variants, emul_lib)
+
+
 def test_mtip2d_worker_vs_oracle(emul_lib, golden_mtip2d):
     PC.check_mtip2d_worker_vs_oracle(golden_mtip2d, emul_lib)
 

@@ -246,6 +246,21 @@ def test_mtip2d_loop_golden(golden_mtip2d):
     PC.check_mtip2d_golden_hip(golden_mtip2d)
 
 
+@pytest.mark.parametrize('name', PC.MTIP2D_VARIANTS)
+def test_mtip2d_variants_golden(golden_mtip2d, golden_mtip2d_variants, name):
+    """the 2-D loop's sub-variants on the device operators against the reference's own 2-D runs (fixture G22)"""
+    PC.check_mtip2d_variant_golden_hip(golden_mtip2d, golden_mtip2d_variants, name)
+
+
+def test_mtip2d_ft_stab_disagreement(golden_mtip2d):
+    """restarts of one batch that disagree on the ft_stab link: each one follows the oracle's run of it"""
+    PC.check_mtip2d_ft_stab_disagreement(golden_mtip2d)
+
+
+def test_mtip2d_unbuildable_variants(golden_mtip2d, golden_mtip2d_variants):
+    PC.check_mtip2d_unbuildable_variants(golden_mtip2d, golden_mtip2d_variants)
+
+
 @pytest.mark.parametrize('N,M', [(None, None), (64, 30)])
 def test_mtip2d_worker_vs_oracle(golden_mtip2d, N, M):
     """`dimensions: 2` through ProjectWorker with seeded guesses, every restart against the oracle's loop"""

@@ -309,3 +309,10 @@ def test_g20_mtip2d_oracle(golden_mtip2d):
     """oracle/mtip2d.py reproduces the reference's own 2-D phasing loop (reconstruct.MTIP with dimensions: 2)"""
     import parity_cases as PC
     PC.check_mtip2d_golden_oracle(golden_mtip2d)
+
+
+@pytest.mark.parametrize('name', _PC.MTIP2D_VARIANTS)
+def test_g22_mtip2d_variants_oracle(golden_mtip2d, golden_mtip2d_variants, name):
+    """G22: the 2-D loop's sub-variants (SW_center, *_non_FXS, reciprocal metrics, auto-correlation support, shift_to_center) -- the
+    oracle against the reference's own 2-D runs of them"""
+    _PC.check_mtip2d_variant_golden_oracle(golden_mtip2d, golden_mtip2d_variants, name)

@@ -505,13 +505,24 @@ int mtip2d_set_error_weights(mtip2d_ctx* c, const double* weights) {
  * (n_batch, n_used) or NULL. */
 int mtip2d_op_step(mtip2d_ctx* c, int method, int ft_stab, double beta, const mtip_cdouble* rho, const uint8_t* support,
                    mtip_cdouble* F_new, mtip_cdouble* rho_new, double* err, mtip_cdouble* unknowns) {
+    return mtip2d_op_step_ex(c, method, ft_stab, beta, rho, support, nullptr, F_new, rho_new, err, unknowns, nullptr, nullptr);
+}
+
+int mtip2d_op_step_ex(mtip2d_ctx* c, int method, int ft_stab, double beta, const mtip_cdouble* rho, const uint8_t* support,
+                      const double* fixed_intensity, mtip_cdouble* F_new, mtip_cdouble* rho_new, double* err, mtip_cdouble* unknowns,
+                      mtip_cdouble* F_out, mtip_cdouble* I_out) {
     if (!c) return MTIP_EINVAL;
     if (!c->have_weights || c->n_used == 0 || !c->have_errw) {
         c->err = "step: hankel weights, projection and error weights must be set first";
         return MTIP_ESTATE;
     }
-    if ((method != MTIP_HIO && method != MTIP_ER) || !rho || !support || !F_new || !rho_new || !err) {
-        c->err = "step: method 0 (HIO) or 1 (ER), buffers not null";
+    const bool fxs = (method == MTIP_HIO || method == MTIP_ER);
+    if (method < 0 || method > 3 || !rho || !support || !F_new || !rho_new || !err) {
+        c->err = "step: method 0 (HIO), 1 (ER), 2 (HIO_non_FXS) or 3 (ER_non_FXS), buffers not null";
+        return MTIP_EINVAL;
+    }
+    if (!fxs && !fixed_intensity) {
+        c->err = "step: the *_non_FXS methods need the fixed intensity grid";
         return MTIP_EINVAL;
     }
     (void)hipSetDevice(c->device);
@@ -526,13 +537,21 @@ int mtip2d_op_step(mtip2d_ctx* c, int method, int ft_stab, double beta, const mt
     c2_dft(c, c->d_e, c->d_a, 0);
     c2_hankel(c, c->d_a, c->d_b, 0);
     c2_dft(c, c->d_b, c->d_c, 1);
+    if (F_out) C2_CHECK(c, c2_copy(c, F_out, c->d_c, BG * sizeof(double2)));
+    if (!fxs) {
+        // MTIP_start_non_FXS (reconstruct.py:530-535): F' = F sqrt(fixed / |F|^2), no harmonic transform and no unknowns
+        C2_CHECK(c, c2_copy(c, c->d_a, fixed_intensity, BG * sizeof(double)));
+        unknowns = nullptr;
+    } else {
     // I_m of |F|^2 -> d_a (B, N, M + 1); projection -> d_b; I' (real grid) -> d_a (as doubles)
     hipLaunchKernelGGL(k2d_dft, dim3(rows), dim3(256), lds, c->stream, (const double2*)c->d_c, c->d_a, (const double2*)c->d_tw, n, M1, -1, 1.0 / n, 2);
+    if (I_out) C2_CHECK(c, c2_copy(c, I_out, c->d_a, (size_t)B * N * M1 * sizeof(double2)));
     hipLaunchKernelGGL(k2d_project, dim3((unsigned)B), dim3(256), (size_t)c->n_used * sizeof(double2), c->stream, (const double2*)c->d_a, c->d_b,
                        c->d_unk, (const double2*)c->d_pm, (const uint8_t*)c->d_rmask, (const int*)c->d_order_ids, (const double*)c->d_q, N, M1,
                        c->n_used, c->zero_pos, c->zero_id, 1.0 / std::sqrt(c->n_particles));
     hipLaunchKernelGGL(k2d_irdft, dim3(rows), dim3(256), lds, c->stream, (const double2*)c->d_b, reinterpret_cast<double*>(c->d_a),
                        (const double2*)c->d_tw, n, c->M);
+    }
     // F' -> d_d
     hipLaunchKernelGGL(k2d_modulus, dim3((unsigned)div_up(total, 256)), dim3(256), 0, c->stream, (const double2*)c->d_c,
                        (const double*)reinterpret_cast<double*>(c->d_a), c->d_d, total);
@@ -547,7 +566,7 @@ int mtip2d_op_step(mtip2d_ctx* c, int method, int ft_stab, double beta, const mt
         c2_dft(c, c->d_d, c->d_b, 1);
     }
     hipLaunchKernelGGL(k2d_real_update, dim3((unsigned)B), dim3(256), 0, c->stream, (const double2*)c->d_a, (const double2*)c->d_e,
-                       (const double2*)c->d_b, (const uint8_t*)c->d_sup, (const double*)c->d_errw, c->d_d, c->d_red, c->rp, method, beta,
+                       (const double2*)c->d_b, (const uint8_t*)c->d_sup, (const double*)c->d_errw, c->d_d, c->d_red, c->rp, method & 1, beta,
                        ft_stab ? 1 : 0, N, n);
     C2_CHECK(c, c2_copy(c, rho_new, c->d_d, BG * sizeof(double2)));
     std::vector<double> red((size_t)B * 2);

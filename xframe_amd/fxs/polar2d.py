@@ -143,15 +143,26 @@ class Engine2D:
         assert w.shape == (self.N, self.n_phi)
         self._ck(self.lib.mtip2d_set_error_weights(self.ctx, _lib.ptr(w)))
 
-    def step(self, method, ft_stab, beta, rho, support):
-        """one HIO / ER step for the batch: (F_new, rho_new, errors (B,), unknowns (B, n_used))"""
+    def step(self, method, ft_stab, beta, rho, support, fixed_intensity=None, want_inputs=False):
+        """one HIO / ER (or HIO_non_FXS / ER_non_FXS: `fixed_intensity` (B, Nq, n_phi)) step for the batch:
+        (F_new, rho_new, errors (B,), unknowns (B, n_used) or None); with want_inputs also (F = FT(rho), I_m of |F|^2 or None),
+        the arguments of the reciprocal error metrics"""
         r = self._grid(rho)
         sup = np.ascontiguousarray(np.broadcast_to(np.asarray(support, dtype=np.uint8), (self.B,) + self.shape))
         F_new, rho_new = np.empty_like(r), np.empty_like(r)
         err = np.empty(self.B)
-        unk = np.empty((self.B, self.n_used), complex)
-        self._ck(self.lib.mtip2d_op_step(self.ctx, {'HIO': 0, 'ER': 1}[method], int(bool(ft_stab)), float(beta), _lib.ptr(r), _lib.ptr(sup),
-                                         _lib.ptr(F_new), _lib.ptr(rho_new), _lib.ptr(err), _lib.ptr(unk)))
+        mid = {'HIO': 0, 'ER': 1, 'HIO_non_FXS': 2, 'ER_non_FXS': 3}[method]
+        fxs = mid < 2
+        unk = np.empty((self.B, self.n_used), complex) if fxs else None
+        fixed = None
+        if not fxs:
+            fixed = np.ascontiguousarray(np.broadcast_to(np.asarray(fixed_intensity, dtype=np.float64), (self.B,) + self.shape))
+        F_in = np.empty_like(r) if want_inputs else None
+        I_in = np.empty((self.B, self.N, self.M + 1), complex) if (want_inputs and fxs) else None
+        self._ck(self.lib.mtip2d_op_step_ex(self.ctx, mid, int(bool(ft_stab)), float(beta), _lib.ptr(r), _lib.ptr(sup), _lib.ptr(fixed),
+                                            _lib.ptr(F_new), _lib.ptr(rho_new), _lib.ptr(err), _lib.ptr(unk), _lib.ptr(F_in), _lib.ptr(I_in)))
+        if want_inputs:
+            return F_new, rho_new, err, unk, F_in, I_in
         return F_new, rho_new, err, unk
 
     def shrinkwrap(self, rho, sigma, threshold):

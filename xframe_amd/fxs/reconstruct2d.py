@@ -7,8 +7,11 @@ every phasing step (Fourier pair, real harmonic transform of |F|^2, unknowns + p
 with the ft_stab add-back, real-space projection + HIO / ER, error sums) is ONE call into the device operators for the whole
 batch of restarts (`mtip2d_op_step`, csrc/k_polar2d.hip), the shrink-wrap another (`mtip2d_op_shrinkwrap`); schedule, beta and
 shrink-wrap ramps, support bookkeeping, history and best tracking are the host logic of the reference.  Pinned by fixture G20 (the
-reference's own 2-D `MTIP` run).  Not built for 2-D: `SW_center`, the `*_non_FXS` variants, reciprocal metrics, `SO_freedom`,
-the auto-correlation support / guess, `shift_to_center` -- they raise."""
+reference's own 2-D `MTIP` run) and, for the loop's sub-variants -- `SW_center`, `HIO_non_FXS` / `ER_non_FXS`, the reciprocal metrics
+`deg2_invariant_l2_diff` / `l2_projection_diff` (and main errors over them), the auto-correlation initial support, `shift_to_center`
+-- by `tests/golden/mtip2d_variants_N12_M6.npz` (the reference's own 2-D runs of each).  Not built for 2-D: `SO_freedom`, the other
+reciprocal metrics; the `low_resolution_autocorrelation` guess raises upstream in 2-D (reconstruct.py:1186 iterates over
+`low_resolution_intensity_coefficients`, which is False for dimensions == 2) and raises here."""
 import numpy as np
 
 from . import hostsetup as hs
@@ -49,6 +52,9 @@ class ReciprocalSetup2D:
             aint = hs._regrid(aint, q_d, self.qs, interp)
             pm = np.array([hs._regrid(v, q_d, self.qs, interp) for v in pm])
         self.average_intensity = aint
+        self.full_projection_matrices = np.zeros((max_order + 1, len(self.qs)), dtype=complex)              # 508-511
+        for oid, p in zip(used_ids, pm):
+            self.full_projection_matrices[int(oid)] = p
         proj = pm.copy()                                                                                    # 679-714, 2-D branches
         keys = np.array(tuple(self.used_orders))
         if opt.get('odd_orders_to_0', False):
@@ -56,6 +62,7 @@ class ReciprocalSetup2D:
         if opt.get('use_averaged_intensity', False) and 0 in self.used_orders:
             proj[self.used_orders[0]] = aint.astype(complex)
         self.projection_matrices = proj
+        self.deg2_invariants = np.array([v[:, None] * v[None, :].conj() for v in proj])                     # 631-633, fxs_invariant_tools.py:906-914
         self.radial_mask = hs.reciprocal_radial_mask(self.qs, q_d, max_order, opt.get('q_mask', None), data)
 
 
@@ -85,16 +92,24 @@ class MTIP2D:
         popt = opt['projections']['real']['projections']
         considered = opt['projections']['real']['HIO'].get('considered_projections', ['all'])
         e.set_real_constraints(*hs.real_constraint_flags(popt, considered))
-        sup = popt['support']['initial_support']
-        if sup['type'] != 'max_radius':
-            raise NotImplementedError('2-D initial support %r' % (sup['type'],))
-        self.initial_support = np.ascontiguousarray(np.broadcast_to(e.rs[:, None] < sup['max_radius'], self.shape))
+        self.initial_support = np.ascontiguousarray(self._initial_support(popt['support']['initial_support']))
         em = opt['main_loop']['error']['methods']
-        if list(em['reciprocal'].get('calculate', [])) or list(em['real'].get('calculate', [])) != ['l2_projection_diff']:
-            raise NotImplementedError('2-D error metrics other than the real l2_projection_diff')
+        self.reciprocal_metrics = list(em['reciprocal'].get('calculate', []))
+        for name in self.reciprocal_metrics:
+            if name not in ('deg2_invariant_l2_diff', 'l2_projection_diff'):
+                raise NotImplementedError('2-D reciprocal metric %r' % (name,))
+        if list(em['real'].get('calculate', [])) != ['l2_projection_diff']:
+            raise NotImplementedError('2-D real error metrics other than l2_projection_diff')
         main = em.get('main', {'metrics': {'real': ['l2_projection_diff'], 'reciprocal': []}, 'type': 'mean'})
-        if list(main['metrics'].get('real', [])) != ['l2_projection_diff'] or list(main['metrics'].get('reciprocal', [])):
-            raise NotImplementedError('2-D main error over other metrics than l2_projection_diff')
+        self.main_real = list(main['metrics'].get('real', []))
+        self.main_reciprocal = list(main['metrics'].get('reciprocal', []))
+        if any(n != 'l2_projection_diff' for n in self.main_real) or any(n not in self.reciprocal_metrics for n in self.main_reciprocal):
+            raise NotImplementedError('2-D main error over metrics that are not calculated')
+        self.main_type = main.get('type', 'mean')
+        if 'deg2_invariant_l2_diff' in self.reciprocal_metrics:
+            ids = np.array(list(rs_.used_orders.keys())).astype(int)
+            self._deg2_ref = rs_.deg2_invariants[ids].copy()
+            self._deg2_norm = np.sum(self._deg2_ref * self._deg2_ref.conj(), axis=(1, 2)).real
         # l2_projection_diff (fxs_IO_methods.py:97-128) with the PolarIntegrator; which mask the reference really uses: hostsetup.error_weights
         inside = em['real'].get('l2_projection_diff', {}).get('inside_initial_support', False)
         gen = opt.get('general', {})
@@ -115,6 +130,9 @@ class MTIP2D:
         if self.initial_densities is not None:
             return np.asarray(self.initial_densities[i], dtype=complex)
         dg = self.opt['density_guess']
+        if dg['type'] == 'low_resolution_autocorrelation':
+            raise NotImplementedError("2-D density guess 'low_resolution_autocorrelation': the reference raises for dimensions == 2 "
+                                      '(reconstruct.py:1186: low_resolution_intensity_coefficients is False)')
         rng = np.random.default_rng(None if self.seeds is None else self.seeds[i])
         e = self.engine
         radius = dg['radius']
@@ -137,6 +155,83 @@ class MTIP2D:
             raise NotImplementedError('2-D density guess %r' % (dg['type'],))
         total_sq = np.sum(polar_integrator_weights(e.rs, e.phis) * density * density)
         return (density * np.sqrt(self.rsetup.integrated_intensity / total_sq)).astype(complex)
+
+    def _initial_support(self, sup):
+        """RealProjection's initial support (fxs_Projections.py:60-93): a radius, or the thresholded auto-correlation
+        ift(icht(pr.T)).real of the full projection vectors (reconstruct.py:400-403, 421-423; icht = the inverse REAL harmonic
+        transform, ift the polar inverse Fourier transform -- both on the device)"""
+        e = self.engine
+        if sup['type'] == 'max_radius':
+            return np.broadcast_to(e.rs[:, None] < sup['max_radius'], self.shape)
+        if sup['type'] == 'auto_correlation':
+            pr = np.array(self.rsetup.full_projection_matrices).T                                       # (Nq, M + 1)
+            auto = e.fourier_transform(e.real_harmonic_inverse(pr)[0].astype(complex), True)[0].real
+            m = np.array(auto >= sup['auto_correlation']['threshold'] * np.max(auto))                  # fxs_Projections.py:77-84
+            m[np.broadcast_to(e.rs[:, None], self.shape) > self.opt['particle_radius']] = False
+            return m
+        raise NotImplementedError('2-D initial support %r' % (sup['type'],))
+
+    def _reciprocal_errors(self, F, F_new, Im):
+        """the reciprocal metrics of one step per restart: {name: (B,) or (B, n_used)} (fxs_IO_methods.py:301-310, 370-400)"""
+        out = {}
+        for name in self.reciprocal_metrics:
+            if name == 'deg2_invariant_l2_diff':
+                ref = self._deg2_ref.copy()
+                zero_id = self.rsetup.used_orders[0]
+                ref[zero_id] = self._deg2_ref[zero_id] / self.rsetup.number_of_particles
+                order_array = np.array(tuple(self.rsetup.used_orders.values()))
+                vals = np.full((self.B, len(self._deg2_norm)), -1.0)
+                nz = self._deg2_norm != 0
+                for b in range(self.B):
+                    Bm = np.einsum('qm,pm->mqp', Im[b], Im[b].conj())[order_array]
+                    diff = ref - Bm
+                    nd = np.sum((diff * diff.conj()).real, axis=(1, 2))
+                    vals[b, nz] = nd[nz] / self._deg2_norm[nz]
+                out[name] = vals
+            else:
+                # l2_projection_diff of (F, F'): the cache-aware branch asks for type 'reziprocal' and gets the REAL grid's integrator
+                # (fxs_IO_methods.py:131-140), `square[~True] = 0` drops shell N - 2
+                W = polar_integrator_weights(self.engine.rs, self.engine.phis)
+                W[self.N - 2, :] = 0.0
+                num = np.sum(W * np.abs(F - F_new) ** 2, axis=(1, 2))
+                den = np.sum(W * np.abs(F) ** 2, axis=(1, 2))
+                out[name] = np.where(den != 0, num / np.where(den != 0, den, 1), np.inf)
+        return out
+
+    def _main_error(self, err_real, recip):
+        """generate_main_error_routine (fxs_IO_methods.py:746-765): mean / min / max / prod of np.array(last values of the chosen
+        metrics); a scalar metric next to a per-order one makes that array ragged upstream (ValueError) and here"""
+        method = {'mean': np.mean, 'min': np.min, 'max': np.max, 'prod': np.prod}[self.main_type]
+        out = np.empty(self.B)
+        for b in range(self.B):
+            vals = [err_real[b] for _ in self.main_real] + [recip[n][b] for n in self.main_reciprocal]
+            if len({np.shape(v) for v in vals}) > 1:
+                raise ValueError('main error over metrics of different shapes (inhomogeneous array upstream, fxs_IO_methods.py:758)')
+            out[b] = method(np.array(vals))
+        return out
+
+    def _shift_to_center(self, F, rho):
+        """assemble_output_modifier's shift_center for dimensions == 2 (reconstruct.py:454, 721-735; misk.py:295-312;
+        fxs_Projections.py:1419-1432): (F, rho) -> (F phases, IFT(FT(rho) phases)), phases = exp(+i k.c), c = centre of mass of
+        Re(rho) by the PolarIntegrator; transforms on the device, the moments are weighted sums on the host"""
+        e = self.engine
+        W = polar_integrator_weights(e.rs, e.phis)
+        r, ph = np.meshgrid(e.rs, e.phis, indexing='ij')
+        q, pq = np.meshgrid(e.qs, e.phis, indexing='ij')
+        ft = e.fourier_transform(rho)
+        phases = np.empty(rho.shape, complex)
+        centers = []
+        for b in range(self.B):
+            re = rho[b].real
+            integral = np.sum(W * re)
+            if integral == 0:
+                integral = 1
+            cx, cy = np.sum(W * r * np.cos(ph) * re) / integral, np.sum(W * r * np.sin(ph) * re) / integral
+            rad, phi_c = np.hypot(cx, cy), np.arctan2(cy, cx)
+            phi_c = phi_c + 2 * np.pi if phi_c < 0 else phi_c
+            centers.append(np.array([rad, phi_c]))
+            phases[b] = np.exp(1j * (q * np.cos(pq) * rad * np.cos(phi_c) + q * np.sin(pq) * rad * np.sin(phi_c)))
+        return F * phases, e.fourier_transform(ft * phases, True), centers
 
     def _sw_ramps(self):
         sw_opt = self.opt['projections']['real']['shrink_wrap']
@@ -162,7 +257,7 @@ class MTIP2D:
 
     @staticmethod
     def _change_to_ft_stab(popt, name, eis_list):
-        """reconstruct.py:836-850 (one decision per batch, as in the 3-D worker)"""
+        """reconstruct.py:836-850: one decision per restart; a bool when they agree"""
         if name[-8:] == '_ft_stab' or 'ft_stab' not in popt:
             return False
         v = popt['ft_stab']
@@ -173,9 +268,26 @@ class MTIP2D:
             if len(eis_list) >= delay:
                 flags = ~(np.array(eis_list[-delay:]) == True).any(axis=0)          # noqa: E712
                 if flags.all() != flags.any():
-                    raise NotImplementedError('restarts of one batch disagree on ft_stab linking')
+                    return flags                                    # restarts of one batch disagree: per restart (see _step)
                 return bool(flags.all())
         return False
+
+    def _step(self, key, ft_stab, beta, rho, support, fixed, want):
+        """Engine2D.step for the batch; when the restarts disagree on ft_stab (the reference decides per reconstruction process) the
+        step runs once with and once without the add-back and every restart takes its own"""
+        e = self.engine
+        if not isinstance(ft_stab, np.ndarray):
+            return e.step(key, ft_stab, beta, rho, support, fixed_intensity=fixed, want_inputs=want)
+        on = e.step(key, True, beta, rho, support, fixed_intensity=fixed, want_inputs=want)
+        off = e.step(key, False, beta, rho, support, fixed_intensity=fixed, want_inputs=want)
+        out = []
+        for a, b in zip(on, off):
+            if a is None:
+                out.append(None)
+            else:
+                sel = ft_stab.reshape((-1,) + (1,) * (a.ndim - 1))
+                out.append(np.where(sel, a, b))
+        return tuple(out)
 
     def phasing_loop(self):
         """create_initial_state + the sub-loops + generate_output (reconstruct.py:957-1035) for the batch: list of result dicts"""
@@ -189,6 +301,7 @@ class MTIP2D:
         support = init_sup.copy()                                     # effective support (what RealProjection's mask holds)
         best = {'pair': (F0.copy(), rho0.copy()), 'err': np.full(B, np.inf), 'iter': np.zeros(B, int), 'mask': init_sup.copy()}
         err_real, err_main, unknowns = [], [], None
+        err_recip = {n: [] for n in self.reciprocal_metrics}
         self._sig_ramps, self._thr_ramps = self._sw_ramps()
         self.sw_sigma, self.sw_threshold = self.default_sigma, 0.06
         hio_opt = opt['projections']['real']['HIO']
@@ -196,19 +309,27 @@ class MTIP2D:
         limit = eis_opt['if_error_bigger_than'] if eis_opt['apply'] else np.inf
         loops = opt['main_loop']['sub_loops']
         eis_list, iterations = [], []
+        want = bool(self.reciprocal_metrics)
         for loop_number, loop_name in enumerate(loops['order']):
             lo = loops[loop_name]
             methods = {}
             for key in lo['order']:
                 mo = lo['methods'][key]
                 methods[key] = ({'iterations': mo.get('iterations', 0), 'options': mo} if isinstance(mo, dict) else {'iterations': mo, 'options': {}})
-                if key not in ('HIO', 'ER', 'SW'):
+                if key not in ('HIO', 'ER', 'SW', 'SW_center', 'HIO_non_FXS', 'ER_non_FXS'):
                     raise NotImplementedError('2-D loop method %r' % (key,))
+                if key.endswith('_non_FXS') and self.reciprocal_metrics:
+                    # (upstream the *_non_FXS start sketch hands the reciprocal metrics a grid instead of I_m and raises)
+                    raise NotImplementedError('2-D %s with reciprocal metrics enabled: the reference raises' % key)
             beta_cfg = hio_opt['beta'][loop_number] if len(hio_opt['beta']) - 1 >= loop_number else [0.5, 0.5, -1 / 700, 1600]
             ramp = hs.ExponentialRamp(*beta_cfg)
             if 'SW' in methods:
                 self._update_shrink_wrap(0, loop_number)
             step = sw_step = iteration = 0
+            # reconstruct.py:859: `hist` is a local that is re-read from the state only at the top of every phasing step (913); SW_center
+            # (893) and the *_non_FXS intensity (901) read it as it was left there -- the history BEFORE the most recent step
+            stale = hist
+            latest_intensity = None
             for iteration in range(1, lo['iterations'] + 1):
                 for key in lo['order']:
                     if key == 'SW':                                   # 877-885
@@ -220,18 +341,46 @@ class MTIP2D:
                         sw_step += 1
                         self._update_shrink_wrap(sw_step, loop_number)
                         continue
+                    if key == 'SW_center':
+                        # reconstruct.py:606-613, 886-897: one enforce decision, then `iterations` support updates; the sketch shifts
+                        # nothing and hands its outputs back in swapped order -- the pair appended to the (stale) history is (rho, FT(rho))
+                        if not err_main:
+                            raise IndexError("SW_center before any phasing step: error_dict['main'][-1] of an empty list (reconstruct.py:887)")
+                        enforce = np.asarray(err_main[-1]) > limit
+                        eis_list.append(enforce)
+                        for _ in range(methods[key]['iterations']):
+                            rho = hist[-1][1]
+                            new_sup = e.shrinkwrap(rho, self.sw_sigma, self.sw_threshold)
+                            support = np.where(enforce[:, None, None], new_sup & init_sup, new_sup)
+                            hist = stale[1:] + [(rho.copy(), e.fourier_transform(rho))]
+                            sw_step += 1
+                            self._update_shrink_wrap(sw_step, loop_number)
+                        continue
+                    if key.endswith('_non_FXS'):
+                        if latest_intensity is None:
+                            latest_intensity = np.abs(stale[-1][0])       # |F| of the stale pair, used as the intensity (899-902)
+                    else:
+                        latest_intensity = None
                     ft_stab = self._change_to_ft_stab(methods[key]['options'], key, eis_list)
                     for _ in range(methods[key]['iterations']):
-                        F_new, rho_new, err, unknowns = e.step(key, ft_stab, ramp.eval(step), hist[-1][1], support)
+                        stale = hist
+                        res = self._step(key, ft_stab, ramp.eval(step), hist[-1][1], support, latest_intensity, want)
+                        F_new, rho_new, err, unk = res[:4]
+                        if unk is not None:
+                            unknowns = unk
                         hist = hist[1:] + [(F_new, rho_new)]
                         err_real.append(err)
-                        err_main.append(err)                          # main = mean over [l2_projection_diff]
-                        better = best['err'] > err
+                        recip = self._reciprocal_errors(res[4], F_new, res[5]) if want else {}
+                        for n_, v_ in recip.items():
+                            err_recip[n_].append(v_)
+                        main_err = self._main_error(err, recip)
+                        err_main.append(main_err)
+                        better = best['err'] > main_err
                         if better.any():
                             sel = better[:, None, None]
                             best['pair'] = (np.where(sel, F_new, best['pair'][0]), np.where(sel, rho_new, best['pair'][1]))
                             best['mask'] = np.where(sel, support, best['mask'])
-                            best['err'] = np.where(better, err, best['err'])
+                            best['err'] = np.where(better, main_err, best['err'])
                             best['iter'] = np.where(better, iteration, best['iter'])
                         step += 1
             n_first = lo.get('best_density_not_in_first_n_iterations', np.inf)
@@ -241,11 +390,15 @@ class MTIP2D:
                 hist = hist[1:] + [(np.where(sel, best['pair'][0], hist[-1][0]), np.where(sel, best['pair'][1], hist[-1][1]))]
                 support = np.where(sel, best['mask'], support)
             iterations.append(iteration)
+        best_pair, last_pair = best['pair'], hist[-1]
+        self.neg_center_pos = None
         if opt.get('output_density_modifiers', {}).get('shift_to_center', False):
-            raise NotImplementedError('2-D shift_to_center')
+            bF, brho, _ = self._shift_to_center(*best_pair)
+            lF, lrho, self.neg_center_pos = self._shift_to_center(*last_pair)
+            best_pair, last_pair = (bF, brho), (lF, lrho)
         err_real, err_main = np.array(err_real), np.array(err_main)
         # calc_deg2_invariant of the last density (reconstruct.py:757-765, 993): B_m = I_m (x) I_m^* (fxs_invariant_tools.py:906-914)
-        F_last = e.fourier_transform(hist[-1][1])
+        F_last = e.fourier_transform(last_pair[1])
         I_last = e.real_harmonic_forward((F_last * F_last.conj()).real)
         masked = np.array(self.rsetup.projection_matrices)           # 997-1001 (one vector per used order in 2-D)
         masked[~self.rsetup.radial_mask[list(self.rsetup.used_orders.values())]] = 0
@@ -254,10 +407,11 @@ class MTIP2D:
         n_steps = len(err_main)
         out = []
         for b in range(B):
-            out.append({'real_density': best['pair'][1][b], 'last_real_density': hist[-1][1][b], 'reciprocal_density': best['pair'][0][b],
-                        'last_reciprocal_density': hist[-1][0][b], 'final_error': float(best['err'][b]), 'initial_density': rho0[b],
+            out.append({'real_density': best_pair[1][b], 'last_real_density': last_pair[1][b], 'reciprocal_density': best_pair[0][b],
+                        'last_reciprocal_density': last_pair[0][b], 'final_error': float(best['err'][b]), 'initial_density': rho0[b],
                         'initial_support': self.initial_support.copy(),
-                        'error_dict': {'main': err_main[:, b].copy(), 'real': {'l2_projection_diff': err_real[:, b].copy()}, 'reciprocal': {}},
+                        'error_dict': {'main': err_main[:, b].copy(), 'real': {'l2_projection_diff': err_real[:, b].copy()},
+                                       'reciprocal': {n_: np.array(v_)[:, b].copy() for n_, v_ in err_recip.items()}},
                         'support_mask': best['mask'][b], 'last_support_mask': support[b], 'loop_iterations': int(np.sum(iterations) + 1),
                         'fxs_unknowns': None if unknowns is None else unknowns[b],
                         'n_particles': np.full((n_steps, 1), self.rsetup.number_of_particles), 'n_particles_gradients': np.array([]),
