@@ -291,6 +291,9 @@ int mtip2d_set_hankel_weights(mtip2d_ctx* ctx, const mtip_cdouble* forward, cons
  * projection vectors (n_used, Nq), their radial masks (n_used, Nq), reciprocal radial points (Nq), number of particles */
 int mtip2d_set_projection(mtip2d_ctx* ctx, int n_used, const int32_t* order_ids, const mtip_cdouble* projection_vectors,
                           const uint8_t* radial_mask, const double* radial_points, double n_particles);
+/* projections.reciprocal.SO_freedom for dimensions == 2 (fxs_Projections.py:744-750, 933-971): the unknown at `position` among the
+ * used orders is set to 1 in every projection; -1 switches it off (mtip2d_set_projection resets it) */
+int mtip2d_set_so_freedom(mtip2d_ctx* ctx, int position);
 /* circularHarmonicTransform_complex_forward / _inverse (mathLibrary.py:469-483) */
 int mtip2d_op_harmonic(mtip2d_ctx* ctx, const mtip_cdouble* in, mtip_cdouble* out, int inverse);
 /* circularHarmonicTransform_real_forward (485-491: of the real part of a complex grid) / _real_inverse (493-496: real grid out) */

@@ -89,8 +89,16 @@ class ReciprocalSetup2D(P2.ReciprocalProjection2D):
         self.deg2_invariants = np.array([v[:, None] * v[None, :].conj() for v in proj])                     # 631-633, fxs_invariant_tools.py:906-914
         self.fixed_intensity = None
         self.SO_order_id = None
-        if opt.get('SO_freedom', {}).get('use', False):
-            raise NotImplementedError('2-D SO_freedom')
+        self.use_SO_freedom = bool(opt.get('SO_freedom', {}).get('use', False))
+        if self.use_SO_freedom:
+            # generate_approximate_unknowns, 744-750: the unknown of the best ranked even order is set to 1 in every step
+            self.SO_order_id = int(so_ranking_2d(proj, keys, qs, opt['SO_freedom'].get('radial_high_pass', 0.2))[0][0])
+
+    def approximate_unknowns(self, I):
+        u = super().approximate_unknowns(I)
+        if self.SO_order_id is not None:
+            u[self.SO_order_id] = 1
+        return u
 
     def mtip_projection(self, I, unknowns):
         self.n_particles = float(self.number_of_particles_list[0])
@@ -101,6 +109,63 @@ class ReciprocalSetup2D(P2.ReciprocalProjection2D):
 
     project_to_modified_intensity = P.ReciprocalProjection.project_to_modified_intensity
     project_to_fixed_intensity = P.ReciprocalProjection.project_to_fixed_intensity
+
+
+def so_ranking_2d(projection_vectors, orders, radial_points, radial_high_pass=0.2):
+    """rank_projection_matrix_orders_2d, fxs_Projections.py:933-962: the even non-zero used orders by mean_q |v_m(q) q| above the
+    radial high pass, best first -> (positions among the used orders, the orders, the sort permutation)"""
+    radial_points = np.asarray(radial_points)
+    idx = int((len(radial_points) - 1) * radial_high_pass)
+    orders = np.asarray(orders)
+    order_mask = (orders % 2 == 0) & (orders != 0)
+    pv = np.asarray(projection_vectors)[order_mask, idx:].T
+    metric = np.mean(np.abs(pv * radial_points[idx:, None]), axis=0)
+    sorted_indices = np.argsort(metric)[::-1]
+    so_indices = order_mask.nonzero()[0][sorted_indices]
+    return so_indices, orders[so_indices], sorted_indices
+
+
+def remaining_so_projection_2d(projection_vectors, used_orders, radial_points, n_phi, radial_high_pass=0.2):
+    """generate_remaining_SO_projection_2D, fxs_Projections.py:1022-1095: the rotation that is left free after the best ranked order
+    fixed its phase -- a ladder over the ranked even orders, each using the rotations the ones before it left (gcd of their orders) --
+    as apply(harmonic_coefficients (Nq, n_phi), fxs_unknowns) -> coefficients * exp(i m rotation_phase)"""
+    projection_orders = np.concatenate((np.arange(int(n_phi / 2) + 1), -1 * np.arange(int(n_phi / 2) + n_phi % 2)[:0:-1]))
+    pos_orders = np.array(tuple(used_orders.keys()))
+    order_mask = (pos_orders % 2 == 0) & (pos_orders != 0)
+    harmonic_orders = pos_orders[order_mask]
+    max_order = np.max(harmonic_orders)
+    so_indices, so_orders, sorted_order_indices = so_ranking_2d(projection_vectors, pos_orders, radial_points, radial_high_pass)
+    first_order = so_orders[0]
+    remaining_rotations = first_order
+    current_order = first_order
+    free_orders_mask = True
+    angle_coeffs, angles, order_indices, gcds = (), (), (), ()
+    while remaining_rotations > 2:
+        order_multiples = np.arange(current_order, max_order + 1, current_order)
+        multiple_indices = np.where(np.isin(harmonic_orders, order_multiples))
+        free_orders_mask = free_orders_mask * ~np.isin(sorted_order_indices, multiple_indices)
+        if not free_orders_mask.any():
+            break
+        current_order_index = sorted_order_indices[free_orders_mask][0]
+        current_order = harmonic_orders[current_order_index]
+        gcd = np.gcd(remaining_rotations, current_order)
+        n_independent_rotations = remaining_rotations / gcd
+        smallest_angle = 2 * np.pi / n_independent_rotations
+        smallest_angle_coeff = np.argmin((np.arange(1, n_independent_rotations) * current_order / gcd) % n_independent_rotations) + 1
+        order_indices += (current_order_index,)
+        angle_coeffs += (smallest_angle_coeff,)
+        angles += (smallest_angle,)
+        gcds += (gcd,)
+        remaining_rotations = gcd
+
+    def apply(harmonic_coefficients, fxs_unknowns):
+        phases = (-1.j * np.log(np.asarray(fxs_unknowns)[order_mask])).real
+        rotation_phase = 0
+        for oi, angle, ac, g in zip(order_indices, angles, angle_coeffs, gcds):
+            rotation_phase -= (phases[oi] // angle) * ac * angle / g
+        return harmonic_coefficients * np.exp(1.j * projection_orders * rotation_phase)
+    apply.ladder = (order_indices, angles, angle_coeffs, gcds)
+    return apply
 
 
 class ShrinkWrap2D(P.ShrinkWrap):
@@ -178,6 +243,7 @@ class MTIP2D(OM.MTIP):
                                                         gen.get('L2_cache', 512))
         self.deg2_diff = None
         self._ranked_id = None
+        self._so_apply = None
         if 'deg2_invariant_l2_diff' in self.reciprocal_metrics:
             self.deg2_diff = Deg2InvariantDiff2D(self.rp.deg2_invariants, self.rp.used_orders, self.rp.number_of_particles_list)
         self.results = {}
@@ -193,7 +259,9 @@ class MTIP2D(OM.MTIP):
         """assemble_output_modifier, reconstruct.py:721-755 with the 2-D operators (454, misk.py:295-312, fxs_Projections.py:1419-1432):
         (reciprocal, real) -> (reciprocal * phases, IFT(FT(real) * phases)), phases = exp(+i k.c), c = centre of mass of Re(real) by
         the PolarIntegrator, returned in polar coordinates with phi in [0, 2 pi)"""
-        if not self.opt.get('output_density_modifiers', {}).get('shift_to_center', False):
+        om = self.opt.get('output_density_modifiers', {})
+        fix = bool(om.get('fix_orientation', False)) and self.rp.use_SO_freedom       # 746-752: shift_center + fix_orientation
+        if not om.get('shift_to_center', False) and not fix:
             return pair
         recip, real = np.array(pair[0]), np.array(pair[1])
         ft = self.fp.ft(real)
@@ -209,7 +277,15 @@ class MTIP2D(OM.MTIP):
         cv = np.array([center[0] * np.cos(center[1]), center[0] * np.sin(center[1])])                     # spherical_to_cartesian(vector)
         q, pq = np.meshgrid(self.fp.qs, self.fp.phis, indexing='ij')
         phases = np.exp(1j * (q * np.cos(pq) * cv[0] + q * np.sin(pq) * cv[1]))                            # opposite_direction = True
-        return (recip * phases, self.fp.ift(ft * phases))
+        out = (recip * phases, self.fp.ift(ft * phases))
+        if fix:
+            # 736-741: complex harmonic transform of both, the rotation left free by the SO order taken out, back
+            if self._so_apply is None:
+                self._so_apply = remaining_so_projection_2d(self.rp.projection_matrices, self.rp.used_orders, self.rp.radial_points, self.fp.n_phi,
+                                                            self.opt['projections']['reciprocal']['SO_freedom'].get('radial_high_pass', 0.2))
+            unk = self.results['fxs_unknowns']
+            out = tuple(P2.harmonic_inverse(self._so_apply(P2.harmonic_forward(a), unk)) for a in out)
+        return out
 
     def _reciprocal_errors(self, F, F_new, Im):
         for name in self.reciprocal_metrics:

@@ -1382,6 +1382,13 @@ def run_mtip2d_golden(extra=None, with_steps=True, save=True):
     out['initial_support'] = np.asarray(real_pr.initial_support)
     if not with_steps:
         out = {'rho0': rho0}
+    if callable(getattr(rp, 'remaining_SO_projection', False)):
+        # the `fix_remaining_SO_freedom` operator itself on seeded coefficients and unknowns of every phase quadrant
+        r5 = np.random.default_rng(55)
+        cin = cplx(r5, (4, N, n_phi))
+        unk = np.exp(1j * r5.uniform(-np.pi, np.pi, (4, M + 1)))
+        out['so_apply_in'], out['so_apply_unknowns'] = cin, unk
+        out['so_apply_out'] = np.array([rp.remaining_SO_projection(np.array(c), np.array(u)) for c, u in zip(cin, unk)])
     # single steps from a stored state
     F0 = ops['fourier_transform'](rho0)
     rho_s = ops['inverse_fourier_transform'](F0)

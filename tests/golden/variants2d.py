@@ -16,5 +16,11 @@ VARIANTS_2D = {
                                                                       'deg2_invariant_l2_diff': {'order': 2}}}}}},
     'recip_l2': {'main_loop': {'error': {'methods': {'reciprocal': {'calculate': ['l2_projection_diff']}}}}},
     'autocorr_support': {'projections': {'real': {'projections': {'support': {'initial_support': {'type': 'auto_correlation'}}}}}},
+    'so_freedom': {'projections': {'reciprocal': {'SO_freedom': {'use': True, 'radial_high_pass': 0.2}}}},
+    'so_freedom_fix': {'projections': {'reciprocal': {'SO_freedom': {'use': True, 'radial_high_pass': 0.2}}},
+                       'output_density_modifiers': {'fix_orientation': True, 'shift_to_center': True}},
+    # radial_high_pass 0.5 ranks order 4 first: the ladder of generate_remaining_SO_projection_2D (1053-1080) is not empty
+    'so_freedom_fix_hp': {'projections': {'reciprocal': {'SO_freedom': {'use': True, 'radial_high_pass': 0.5}}},
+                          'output_density_modifiers': {'fix_orientation': True}},
     'autocorr_guess': {'density_guess': {'type': 'low_resolution_autocorrelation'}, '_reference_guess': True},
 }

@@ -1329,7 +1329,7 @@ def check_mtip2d_golden_hip(g, lib_path=None):
     m.close()
 
 
-MTIP2D_VARIANTS = ('nonfxs', 'swcenter', 'shift', 'recip_deg2', 'recip_l2', 'autocorr_support')
+MTIP2D_VARIANTS = ('nonfxs', 'swcenter', 'shift', 'recip_deg2', 'recip_l2', 'autocorr_support', 'so_freedom', 'so_freedom_fix', 'so_freedom_fix_hp')
 
 
 def mtip2d_variant_problem(g, gv, name):
@@ -1362,7 +1362,15 @@ def check_mtip2d_variant_golden_oracle(g, gv, name):
     """oracle/mtip2d.py on a sub-variant of the 2-D loop against the reference's own run of it"""
     from oracle import mtip2d as O2
     data, o, ref = mtip2d_variant_problem(g, gv, name)
-    _compare_mtip2d_variant(O2.MTIP2D(o, data).phasing_loop(rho0=g['rho0']), ref, 1e-10, 1e-10)
+    m = O2.MTIP2D(o, data)
+    _compare_mtip2d_variant(m.phasing_loop(rho0=g['rho0']), ref, 1e-10, 1e-10)
+    if 'so_apply_in' in ref:                                           # the fix_remaining_SO_freedom operator on seeded inputs
+        ap = O2.remaining_so_projection_2d(m.rp.projection_matrices, m.rp.used_orders, m.rp.radial_points, m.fp.n_phi,
+                                           o['projections']['reciprocal']['SO_freedom']['radial_high_pass'])
+        for c, u, want in zip(ref['so_apply_in'], ref['so_apply_unknowns'], ref['so_apply_out']):
+            assert rel_l2(ap(c, u), want) < 1e-14
+        if name.endswith('_hp'):
+            assert any(np.abs(c - w).max() > 1 for c, w in zip(ref['so_apply_in'], ref['so_apply_out']))     # a real rotation is in the set
 
 
 def check_mtip2d_variant_golden_hip(g, gv, name, lib_path=None):
@@ -1374,6 +1382,11 @@ def check_mtip2d_variant_golden_hip(g, gv, name, lib_path=None):
     res = m.phasing_loop()
     for r in res:
         _compare_mtip2d_variant(r, ref, 1e-8, 1e-8)
+    if 'so_apply_in' in ref:
+        from xframe_amd.fxs.reconstruct2d import RemainingRotation2D
+        rot = RemainingRotation2D(m.rsetup.projection_matrices, m.rsetup.used_orders, m.engine.qs, m.engine.n_phi, m.rsetup.radial_high_pass)
+        for c, u, want in zip(ref['so_apply_in'], ref['so_apply_unknowns'], ref['so_apply_out']):
+            assert rel_l2(rot(c, u), want) < 1e-14
     m.close()
 
 

@@ -21,6 +21,7 @@ struct mtip2d_ctx {
     double2 *d_a = nullptr, *d_b = nullptr;        // (B, N, n_phi) work grids
     // projection
     int n_used = 0, zero_pos = -1, zero_id = -1;
+    int so_pos = -1;                  // SO_freedom: position (among the used orders) of the order whose unknown is set to 1, or -1
     int* d_order_ids = nullptr;                    // n_used
     double2* d_pm = nullptr;                       // (n_used, N)
     uint8_t* d_rmask = nullptr;                    // (n_used, N): radial mask of the used orders
@@ -122,7 +123,7 @@ __global__ void __launch_bounds__(256) k2d_hankel(const double2* __restrict__ c,
 __global__ void __launch_bounds__(256) k2d_project(const double2* __restrict__ I, double2* __restrict__ out, double2* __restrict__ unk,
                                                    const double2* __restrict__ pm, const uint8_t* __restrict__ rmask,
                                                    const int* __restrict__ order_ids, const double* __restrict__ q, int N, int n_coef,
-                                                   int n_used, int zero_pos, int zero_id, double inv_sqrt_np) {
+                                                   int n_used, int zero_pos, int zero_id, double inv_sqrt_np, int so_pos) {
     HIP_DYNAMIC_SHARED(double2, sm)                // n_used unknowns
     const int b = blockIdx.x;
     const double2* Ib = I + (size_t)b * N * n_coef;
@@ -132,7 +133,8 @@ __global__ void __launch_bounds__(256) k2d_project(const double2* __restrict__ I
         double2 sp = make_double2(0.0, 0.0);
         for (int qq = 0; qq < N; ++qq) sp = cadd(sp, cscale(cmulc(Ib[(size_t)qq * n_coef + id], pm[(size_t)j * N + qq]), q[qq]));
         const double a = sqrt(cabs2(sp));
-        const double2 u = (sp.x != 0.0 || sp.y != 0.0) ? make_double2(sp.x / a, sp.y / a) : make_double2(1.0, 0.0);
+        double2 u = (sp.x != 0.0 || sp.y != 0.0) ? make_double2(sp.x / a, sp.y / a) : make_double2(1.0, 0.0);
+        if (j == so_pos) u = make_double2(1.0, 0.0);                 // SO_freedom (fxs_Projections.py:744-750)
         sm[j] = u;
         unk[(size_t)b * n_used + j] = u;
     }
@@ -362,6 +364,7 @@ int mtip2d_set_projection(mtip2d_ctx* c, int n_used, const int32_t* order_ids, c
     C2_CHECK(c, c2_copy(c, c->d_q, radial_points, c->N * sizeof(double)));
     c->n_used = n_used;
     c->n_particles = n_particles;
+    c->so_pos = -1;
     return MTIP_OK;
 }
 
@@ -451,6 +454,16 @@ int mtip2d_op_fourier_transform(mtip2d_ctx* c, const mtip_cdouble* in, mtip_cdou
     return MTIP_OK;
 }
 
+int mtip2d_set_so_freedom(mtip2d_ctx* c, int position) {
+    if (!c) return MTIP_EINVAL;
+    if (position < -1 || position >= c->n_used) {
+        c->err = "so_freedom: position among the used orders of the current projection, or -1";
+        return MTIP_EINVAL;
+    }
+    c->so_pos = position;
+    return MTIP_OK;
+}
+
 int mtip2d_op_project(mtip2d_ctx* c, const mtip_cdouble* I, mtip_cdouble* out, mtip_cdouble* unknowns) {
     if (!c) return MTIP_EINVAL;
     if (c->n_used == 0) {
@@ -467,7 +480,7 @@ int mtip2d_op_project(mtip2d_ctx* c, const mtip_cdouble* I, mtip_cdouble* out, m
     C2_CHECK(c, c2_copy(c, c->d_a, I, n));
     hipLaunchKernelGGL(k2d_project, dim3((unsigned)c->B), dim3(256), (size_t)c->n_used * sizeof(double2), c->stream, (const double2*)c->d_a, c->d_b,
                        c->d_unk, (const double2*)c->d_pm, (const uint8_t*)c->d_rmask, (const int*)c->d_order_ids, (const double*)c->d_q, c->N,
-                       n_coef, c->n_used, c->zero_pos, c->zero_id, 1.0 / std::sqrt(c->n_particles));
+                       n_coef, c->n_used, c->zero_pos, c->zero_id, 1.0 / std::sqrt(c->n_particles), c->so_pos);
     C2_CHECK(c, c2_copy(c, out, c->d_b, n));
     if (unknowns) C2_CHECK(c, c2_copy(c, unknowns, c->d_unk, (size_t)c->B * c->n_used * sizeof(double2)));
     C2_CHECK(c, hipGetLastError());
@@ -548,7 +561,7 @@ int mtip2d_op_step_ex(mtip2d_ctx* c, int method, int ft_stab, double beta, const
     if (I_out) C2_CHECK(c, c2_copy(c, I_out, c->d_a, (size_t)B * N * M1 * sizeof(double2)));
     hipLaunchKernelGGL(k2d_project, dim3((unsigned)B), dim3(256), (size_t)c->n_used * sizeof(double2), c->stream, (const double2*)c->d_a, c->d_b,
                        c->d_unk, (const double2*)c->d_pm, (const uint8_t*)c->d_rmask, (const int*)c->d_order_ids, (const double*)c->d_q, N, M1,
-                       c->n_used, c->zero_pos, c->zero_id, 1.0 / std::sqrt(c->n_particles));
+                       c->n_used, c->zero_pos, c->zero_id, 1.0 / std::sqrt(c->n_particles), c->so_pos);
     hipLaunchKernelGGL(k2d_irdft, dim3(rows), dim3(256), lds, c->stream, (const double2*)c->d_b, reinterpret_cast<double*>(c->d_a),
                        (const double2*)c->d_tw, n, c->M);
     }

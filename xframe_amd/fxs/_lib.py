@@ -104,6 +104,7 @@ _SIGNATURES = {
     'mtip2d_op_project': (C.c_int, [c_void, c_void, c_void, c_void]),
     'mtip2d_set_real_constraints': (C.c_int, [c_void, C.c_uint32, C.c_double, C.c_double, C.c_double, C.c_uint32]),
     'mtip2d_set_error_weights': (C.c_int, [c_void, c_void]),
+    'mtip2d_set_so_freedom': (C.c_int, [c_void, C.c_int]),
     'mtip2d_op_step': (C.c_int, [c_void, C.c_int, C.c_int, C.c_double, c_void, c_void, c_void, c_void, c_void, c_void]),
     'mtip2d_op_step_ex': (C.c_int, [c_void, C.c_int, C.c_int, C.c_double, c_void, c_void, c_void, c_void, c_void, c_void, c_void, c_void, c_void]),
     'mtip2d_op_shrinkwrap': (C.c_int, [c_void, c_void, C.c_double, C.c_double, c_void]),

@@ -126,6 +126,10 @@ class Engine2D:
                                                 float(number_of_particles)))
         self.n_used = len(ids)
 
+    def set_so_freedom(self, position):
+        """SO_freedom (dimensions == 2): the unknown at this position among the used orders is 1 in every projection; None: off"""
+        self._ck(self.lib.mtip2d_set_so_freedom(self.ctx, -1 if position is None else int(position)))
+
     def project(self, I):
         """approximate_unknowns + mtip_projection + number-of-particles rule: (projected coefficients, unknowns)"""
         c = self._grid(I, self.M + 1)

@@ -9,8 +9,8 @@ batch of restarts (`mtip2d_op_step`, csrc/k_polar2d.hip), the shrink-wrap anothe
 shrink-wrap ramps, support bookkeeping, history and best tracking are the host logic of the reference.  Pinned by fixture G20 (the
 reference's own 2-D `MTIP` run) and, for the loop's sub-variants -- `SW_center`, `HIO_non_FXS` / `ER_non_FXS`, the reciprocal metrics
 `deg2_invariant_l2_diff` / `l2_projection_diff` (and main errors over them), the auto-correlation initial support, `shift_to_center`
--- by `tests/golden/mtip2d_variants_N12_M6.npz` (the reference's own 2-D runs of each).  Not built for 2-D: `SO_freedom`, the other
-reciprocal metrics; the `low_resolution_autocorrelation` guess raises upstream in 2-D (reconstruct.py:1186 iterates over
+-- and `SO_freedom` with the `fix_orientation` output modifier, by `tests/golden/mtip2d_variants_N12_M6.npz` (the reference's own
+2-D runs of each).  Not built for 2-D: radial rules other than `midpoint`, the other reciprocal metrics; the `low_resolution_autocorrelation` guess raises upstream in 2-D (reconstruct.py:1186 iterates over
 `low_resolution_intensity_coefficients`, which is False for dimensions == 2) and raises here."""
 import numpy as np
 
@@ -31,13 +31,60 @@ def polar_integrator_weights(rs, phis):
     return (trapz_w(np.asarray(rs)) * np.asarray(rs))[:, None] * trapz_w(np.asarray(phis))[None, :]
 
 
+def so_order_ranking(vectors, orders, qs, radial_high_pass):
+    """rank_projection_matrix_orders_2d (fxs_Projections.py:933-962): positions (among the used orders) of the even non-zero orders,
+    strongest first by mean_q |v_m(q)| q above the radial high pass; also those orders and the sorting permutation"""
+    qs, orders = np.asarray(qs), np.asarray(orders)
+    start = int((len(qs) - 1) * radial_high_pass)
+    candidates = np.flatnonzero((orders % 2 == 0) & (orders != 0))
+    strength = np.mean(np.abs(np.asarray(vectors)[candidates, start:] * qs[None, start:]), axis=1)
+    perm = np.argsort(strength)[::-1]
+    return candidates[perm], orders[candidates[perm]], perm
+
+
+class RemainingRotation2D:
+    """generate_remaining_SO_projection_2D (fxs_Projections.py:1022-1095), the `fix_remaining_SO_freedom` operator of the output
+    modifier: fixing the phase of the strongest order m0 leaves m0 rotations free; the next strongest order that is not a multiple of
+    the ones used so far takes gcd-many of them away, and so on until at most two are left.  The rotation chosen from the unknowns of
+    the last step multiplies the complex harmonic coefficients (Nq, n_phi) by exp(i m phase)."""
+
+    def __init__(self, vectors, used_orders, qs, n_phi, radial_high_pass):
+        self.m = np.concatenate((np.arange(n_phi // 2 + 1), -np.arange(n_phi // 2 + n_phi % 2)[:0:-1]))    # FFT order of the columns
+        orders = np.array(tuple(used_orders.keys()))
+        self.even = (orders % 2 == 0) & (orders != 0)
+        even_orders = orders[self.even]
+        _, ranked_orders, perm = so_order_ranking(vectors, orders, qs, radial_high_pass)
+        left, current = ranked_orders[0], ranked_orders[0]
+        free = np.ones(len(perm), bool)
+        self.rungs = []                                               # (index among the even orders, angle, coefficient, gcd)
+        while left > 2:
+            multiples = np.arange(current, even_orders.max() + 1, current)
+            free &= ~np.isin(perm, np.flatnonzero(np.isin(even_orders, multiples)))
+            if not free.any():
+                break
+            idx = perm[free][0]
+            current = even_orders[idx]
+            g = np.gcd(left, current)
+            n_rot = left / g
+            coeff = np.argmin((np.arange(1, n_rot) * current / g) % n_rot) + 1
+            self.rungs.append((idx, 2 * np.pi / n_rot, coeff, g))
+            left = g
+
+    def phase(self, unknowns):
+        ph = (-1j * np.log(np.asarray(unknowns)[self.even])).real
+        total = 0.0
+        for idx, angle, coeff, g in self.rungs:
+            total -= (ph[idx] // angle) * coeff * angle / g
+        return total
+
+    def __call__(self, coefficients, unknowns):
+        return coefficients * np.exp(1j * self.m * self.phase(unknowns))
+
+
 class ReciprocalSetup2D:
     """ReciprocalProjection.__init__ for dimensions == 2 (fxs_Projections.py:471-537) on the host"""
 
     def __init__(self, qs, data, max_order, opt):
-        for key in ('SO_freedom',):
-            if opt.get(key, {}).get('use', False):
-                raise NotImplementedError('2-D %s' % key)
         q_d = np.asarray(data['data_radial_points'], dtype=float)
         aint = np.asarray(getattr(data['average_intensity'], 'data', data['average_intensity']), dtype=float)
         self.qs = np.asarray(qs, dtype=float)
@@ -64,6 +111,11 @@ class ReciprocalSetup2D:
         self.projection_matrices = proj
         self.deg2_invariants = np.array([v[:, None] * v[None, :].conj() for v in proj])                     # 631-633, fxs_invariant_tools.py:906-914
         self.radial_mask = hs.reciprocal_radial_mask(self.qs, q_d, max_order, opt.get('q_mask', None), data)
+        so = opt.get('SO_freedom', {})
+        self.use_SO_freedom = bool(so.get('use', False))
+        self.radial_high_pass = so.get('radial_high_pass', 0.2)
+        # generate_approximate_unknowns, 744-750: the unknown of the strongest even order is 1 in every step
+        self.so_position = int(so_order_ranking(proj, keys, self.qs, self.radial_high_pass)[0][0]) if self.use_SO_freedom else None
 
 
 class MTIP2D:
@@ -89,6 +141,7 @@ class MTIP2D:
         self.shape = e.shape
         self.rsetup = rs_ = ReciprocalSetup2D(e.qs, data, self.M, opt['projections']['reciprocal'])
         e.set_projection(rs_.projection_matrices, rs_.used_orders, rs_.radial_mask, rs_.number_of_particles)
+        e.set_so_freedom(rs_.so_position)
         popt = opt['projections']['real']['projections']
         considered = opt['projections']['real']['HIO'].get('considered_projections', ['all'])
         e.set_real_constraints(*hs.real_constraint_flags(popt, considered))
@@ -392,10 +445,22 @@ class MTIP2D:
             iterations.append(iteration)
         best_pair, last_pair = best['pair'], hist[-1]
         self.neg_center_pos = None
-        if opt.get('output_density_modifiers', {}).get('shift_to_center', False):
+        om = opt.get('output_density_modifiers', {})
+        # assemble_output_modifier (reconstruct.py:721-755): shift_center, and with SO_freedom in use + fix_orientation the sketch
+        # shift_center + fix_orientation whatever shift_to_center says (746-752; 2-D only)
+        fix = bool(om.get('fix_orientation', False)) and self.rsetup.use_SO_freedom
+        if om.get('shift_to_center', False) or fix:
             bF, brho, _ = self._shift_to_center(*best_pair)
             lF, lrho, self.neg_center_pos = self._shift_to_center(*last_pair)
             best_pair, last_pair = (bF, brho), (lF, lrho)
+        if fix:
+            rot = RemainingRotation2D(self.rsetup.projection_matrices, self.rsetup.used_orders, e.qs, e.n_phi, self.rsetup.radial_high_pass)
+
+            def turn(grids):                                          # complex harmonic transforms on the device, the phases on the host
+                c = e.harmonic(grids)
+                return e.harmonic(np.stack([rot(c[b], unknowns[b]) for b in range(B)]), True)
+            best_pair = (turn(best_pair[0]), turn(best_pair[1]))
+            last_pair = (turn(last_pair[0]), turn(last_pair[1]))
         err_real, err_main = np.array(err_real), np.array(err_main)
         # calc_deg2_invariant of the last density (reconstruct.py:757-765, 993): B_m = I_m (x) I_m^* (fxs_invariant_tools.py:906-914)
         F_last = e.fourier_transform(last_pair[1])
