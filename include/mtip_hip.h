@@ -167,6 +167,11 @@ int mtip_run_async(mtip_ctx* ctx, int method, int ft_stab, int n_steps, const do
  * projections of the others (a long chain on a few CUs) run beside them -- see mtip_api.hip.  All contexts must be in the
  * same loop state a mtip_run_async call would need; n_ctx = 1 is mtip_run_async. */
 int mtip_run_group_async(mtip_ctx* const* ctxs, int n_ctx, int method, int ft_stab, int n_steps, const double* betas);
+/* ft_stab per restart for the runs that follow (ft_stab = 1 in mtip_run*): mask[n_batch] != 0 = this restart takes the
+ * add-back.  The reference decides `ft_stab: link_to_enforce_initial_support` per reconstruction process
+ * (reconstruct.py:836-850), so restarts of one batch can disagree.  NULL (default) or all set = every restart; needs the
+ * fused step (cfg.fused = 1) when the values differ. */
+int mtip_set_ft_stab_mask(mtip_ctx* ctx, const uint8_t* mask);
 int mtip_fetch_errors(mtip_ctx* ctx, int64_t first_step, int64_t n_steps, double* real_err, double* deg2_err);
 /* the main error per step (n_steps x n_batch): what best-pair tracking and the enforce_initial_support decision use */
 int mtip_fetch_main_errors(mtip_ctx* ctx, int64_t first_step, int64_t n_steps, double* main_err);

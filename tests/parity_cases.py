@@ -268,6 +268,44 @@ def check_short_trajectory_vs_oracle(g, lib_path, fused, n_hio=3, n_er=2, n_rest
     m.engine.close()
 
 
+def check_ft_stab_disagreement(g, lib_path=None):
+    """3-D loop, two restarts of ONE engine that disagree on `ft_stab: link_to_enforce_initial_support` (one has its initial support
+    enforced by the shrink-wrap, the other not -- the reference decides per reconstruction process, reconstruct.py:836-850): the
+    engine takes ft_stab per restart (mtip_set_ft_stab_mask) and each restart follows the oracle's own run of it"""
+    N, L = int(g['N']), int(g['L'])
+    data = data_from_golden(g, L)
+    link = {'ft_stab': 'link_to_enforce_initial_support', 'link_to_enforce_initial_support': {'delay': 1}}
+    opt = golden_settings(N, L, {'main_loop': {'sub_loops': {'main': {'iterations': 3, 'order': ['HIO', 'SW', 'ER'], 'methods': {
+        'HIO': dict(iterations=3, **link), 'SW': 1, 'ER': dict(iterations=2, **link)}}}}})
+    rho_a = np.asarray(g['rho0'])
+    rng = np.random.default_rng(9)
+    rho_b = rho_a * (1.0 + 2.0 * rng.random(rho_a.shape)) + 0.3 * np.abs(rho_a).max() * rng.random(rho_a.shape)
+    refs = [OM.MTIP(opt, data).phasing_loop(rho0=r) for r in (rho_a, rho_b)]
+    e3 = [r['error_dict']['main'][2] for r in refs]
+    assert max(e3) > 1.2 * min(e3), e3
+    eis = opt['projections']['real']['projections']['support']['enforce_initial_support']
+    eis['apply'], eis['if_error_bigger_than'] = True, float(np.sqrt(e3[0] * e3[1]))
+    refs = [OM.MTIP(opt, data).phasing_loop(rho0=r) for r in (rho_a, rho_b)]
+    R.MTIP.preinit(opt, data)
+    m = R.MTIP(n_restarts=2, initial_densities=[rho_a, rho_b], lib_path=lib_path, fused=True)
+    m.generate_phasing_loop()
+    seen = []
+    orig = m.engine.run
+
+    def spy(key, ft_stab, betas, **kw):
+        seen.append(ft_stab)
+        return orig(key, ft_stab, betas, **kw)
+    m.engine.run = spy
+    res = m.phasing_loop()
+    m.engine.close()
+    assert any(isinstance(f, np.ndarray) for f in seen)              # the restarts did disagree in some block
+    for r, ref in zip(res, refs):
+        assert np.allclose(r['error_dict']['main'], ref['error_dict']['main'], rtol=1e-8)
+        for k in ('real_density', 'last_real_density', 'reciprocal_density', 'last_reciprocal_density'):
+            assert rel_l2(r[k], ref[k]) < 1e-8, k
+        assert (r['last_support_mask'] != ref['last_support_mask']).sum() == 0
+
+
 def check_group_run_identical(g, lib_path, fused=True, sizes=(2, 1, 1)):
     """mtip_run_group_async (contexts of one GPU taking turns at the transforms of a step) against mtip_run_async per context:
     HIO + SW + ER + a non-FXS block, every density, error history and support bit-identical; the direct form of EngineGroup."""

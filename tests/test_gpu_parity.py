@@ -169,6 +169,12 @@ def test_config3_short_trajectory_vs_oracle():
 
 
 @pytest.mark.gpu
+def test_ft_stab_disagreement(golden_mtip16):
+    """restarts of one engine that disagree on the ft_stab link: ft_stab per restart, each follows the oracle's run of it"""
+    PC.check_ft_stab_disagreement(golden_mtip16)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('fused', [False, True])
 def test_group_run_identical(golden_mtip16, fused):
     """mtip_run_group_async (engines of one GPU taking turns at the transforms) == mtip_run_async per engine, bit for bit"""

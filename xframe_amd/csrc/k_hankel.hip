@@ -63,7 +63,7 @@ __global__ void __launch_bounds__(HT_THREADS) k_hankel_tile(const double* __rest
                                                             const double* __restrict__ W,
                                                             const HankelTile32* __restrict__ tiles, int N, int Np, int L,
                                                             int B, int poffs, double scale, int sign,
-                                                            const double* __restrict__ in_sub) {
+                                                            const double* __restrict__ in_sub, const uint8_t* __restrict__ sub_mask) {
     constexpr int HT_COLS = 16 * HT_CT;
     constexpr int HT_XS = HT_COLS + 16;
     constexpr int HT_NX = (HT_KC * HT_COLS + HT_THREADS - 1) / HT_THREADS;    // panel doubles per thread and chunk
@@ -83,7 +83,7 @@ __global__ void __launch_bounds__(HT_THREADS) k_hankel_tile(const double* __rest
     const int wrow = tid >> 5, wcol = (tid & 31) * 4;
     int xrow[HT_NX], xc[HT_NX];
     size_t xoff[HT_NX];
-    bool xok[HT_NX];
+    bool xok[HT_NX], xsub[HT_NX];        // xsub: this column's restart takes the subtraction (per-restart ft_stab; all without a mask)
 #pragma unroll
     for (int j = 0; j < HT_NX; ++j) {
         const int e = tid + j * HT_THREADS;
@@ -94,6 +94,7 @@ __global__ void __launch_bounds__(HT_THREADS) k_hankel_tile(const double* __rest
         const int b = xok[j] ? cflat / ncl : 0;
         const int within = xok[j] ? cflat - b * ncl : 0;
         xoff[j] = (size_t)b * N * nlm2 + 2 * (size_t)l * l + within;
+        xsub[j] = SUB && (sub_mask == nullptr || sub_mask[b] != 0);
     }
     // two register sets: the operands of the next TWO chunks are in flight while one is multiplied
     double rw0[HT_NW], rx0[HT_NX], rw1[HT_NW], rx1[HT_NX];
@@ -110,7 +111,7 @@ __global__ void __launch_bounds__(HT_THREADS) k_hankel_tile(const double* __rest
             const size_t o = xoff[j] + (size_t)(p0 + xrow[j] + poffs) * nlm2;
             rx[j] = ok ? in[o] : 0.0;
             if (SUB) {
-                rs[j] = ok ? in_sub[o] : 0.0;
+                rs[j] = (ok && xsub[j]) ? in_sub[o] : 0.0;
                 rx[j] -= rs[j];
             }
         }
@@ -197,13 +198,13 @@ __global__ void __launch_bounds__(HT_THREADS) k_hankel_tile(const double* __rest
 bool hankel_has_difference(const mtip_ctx* c) { return c->d_htiles32 != nullptr; }
 
 // out = H(in - in_sub) above output shell 0, H(in) on it (in_sub == nullptr: plain transform)
-void launch_hankel_mfma_sub(mtip_ctx* c, const double2* in, const double2* in_sub, double2* out, int inverse) {
+void launch_hankel_mfma_sub(mtip_ctx* c, const double2* in, const double2* in_sub, double2* out, int inverse, const uint8_t* sub_mask) {
     const dim3 grid((unsigned)c->n_htiles32, (unsigned)div_up(c->N, HT_ROWS));
 #define HT_LAUNCH(CT, SUBF)                                                                                                  \
     hipLaunchKernelGGL((k_hankel_tile<CT, SUBF>), grid, dim3(HT_THREADS), 0, c->stream, reinterpret_cast<const double*>(in), \
                        reinterpret_cast<double*>(out), (const double*)c->d_W, (const HankelTile32*)c->d_htiles32, c->N,      \
                        c->Np, c->L, c->B, c->cfg.hankel_trapz ? 1 : 0, inverse ? c->inv_scale : c->fwd_scale,                \
-                       inverse ? +1 : -1, reinterpret_cast<const double*>(in_sub))
+                       inverse ? +1 : -1, reinterpret_cast<const double*>(in_sub), sub_mask)
     if (in_sub != nullptr) {
         switch (c->htile_ct) {
             case 1: HT_LAUNCH(1, true); break;

@@ -173,6 +173,7 @@ __global__ void __launch_bounds__(SW_THREADS) k_sht_chain(ChainArgs a) {
     // (behind the staging copies: vmcnt counts in order, requested before them these loads made the copies wait)
     load_pre(wave);
     const RealFlags rflags = real_flags(a.re.rp, a.re.method);
+    const bool add_prev = EPI == EPI_REAL_UPDATE && a.re.add_prev && q > 0 && (a.re.add_mask == nullptr || a.re.add_mask[shell / Nq] != 0);
     const double wr_q = EPI == EPI_REAL_UPDATE ? a.re.wr[q] : 0.0;
     // ---- Legendre synthesis of every row (k_sht_legendre.h)
     legendre_synthesis_rows(ls, Gs, cl, ABs, a.P, a.cost, nt, L, nt >> 1, 0, wave, nw, tid & 63);
@@ -246,7 +247,7 @@ __global__ void __launch_bounds__(SW_THREADS) k_sht_chain(ChainArgs a) {
                     v = cscale(Fv, mult);
                 } else if (EPI == EPI_REAL_UPDATE) {
                     const double2 pv = pre[n1];
-                    const double2 w = (a.re.add_prev && q > 0) ? cadd(v, pv) : v;
+                    const double2 w = add_prev ? cadd(v, pv) : v;
                     double2 Pj;
                     v = real_update_point_flat(a.re.rp, rflags, a.re.beta, w, pv, ((pre_m >> n1) & 1u) != 0, Pj);
                     if (!a.re.err_use_mask || ((pre_m >> (8 + n1)) & 1u)) {   // l2_projection_diff, fxs_IO_methods.py:97-128

@@ -597,7 +597,7 @@ __global__ void __launch_bounds__(SW_THREADS) k_sht_inv_wide(const double2* __re
                     v = cscale(v, shell_scale[q]);
                 } else if (EPI == EPI_REAL_UPDATE) {
                     const double2 pv = pre[n1];
-                    const double2 w = (re.add_prev && q > 0) ? cadd(v, pv) : v;
+                    const double2 w = (re.add_prev && q > 0 && (re.add_mask == nullptr || re.add_mask[shell / Nq] != 0)) ? cadd(v, pv) : v;
                     double2 P;
                     v = real_update_point(re.rp, re.method, re.beta, w, pv, pre_s[n1] != 0, P);
                     if (pre_0[n1] != 0) {                            // l2_projection_diff, fxs_IO_methods.py:97-128

@@ -59,7 +59,7 @@ void mtip_destroy(mtip_ctx* c) {
                     c->d_err_wt, c->d_rho, c->d_Fp, c->d_slot, c->d_best_err, c->d_last_err, c->d_op_err, c->d_gq, c->d_polar_dbg, c->d_so3_d, c->d_so3_tw, c->d_so3_T, c->d_so3_S, c->d_so3_P, c->d_so3_D, c->d_so3_C, c->d_err_hist, c->d_main_hist,
                     c->d_deg2_hist, c->d_F, c->d_T1, c->d_T2, c->d_fixed, c->d_g, c->d_c[0], c->d_c[1], c->d_c[2],
                     c->d_c[3], c->d_c[4], c->d_c[5], c->d_X, c->d_Vr, c->d_U, c->d_partial, c->d_minmax, c->d_Bl,
-                    c->d_rp_DV, c->d_rp_Vt, c->d_rp_slots, c->d_c0n, c->d_mk, c->d_chain_dbg, c->d_PTc, c->d_lmc};
+                    c->d_rp_DV, c->d_rp_Vt, c->d_rp_slots, c->d_c0n, c->d_mk, c->d_chain_dbg, c->d_PTc, c->d_lmc, c->d_ftmask};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : c->prof_events) (void)hipEventDestroy(e);
@@ -590,9 +590,14 @@ static int enqueue_step(mtip_ctx* c, int method, int ft_stab, double beta, int p
     if (!(chain && fxs)) launch_sht_forward(c, c->d_Fp, cc[4], MTIP_PRE_NONE, SL_OUT);
     // rho'' = rho + IFT(F' - F) on shells > 0, IFT(F') on shell 0, using SHT(F) == Hankel(SHT(rho)) = cc[1]: with the
     // workgroup-tiled Hankel kernel the difference is taken on load and shell 0 corrected in the same pass
+    // per-restart ft_stab (mtip_set_ft_stab_mask: the reference decides the link to enforce_initial_support per reconstruction
+    // process, reconstruct.py:836-850): the restarts without it neither subtract SHT(F) here nor add rho_prev back in the epilogue
+    const uint8_t* ftm = (ft_stab && c->ftmask_mixed) ? c->d_ftmask : nullptr;
+    if (ftm && !(one_pass_diff && sht_inverse_fuses_real_update(c)))
+        FAIL(c, MTIP_ESTATE, "a per-restart ft_stab mask needs the fused one-pass step (cfg.fused, tiled Hankel kernel, real update in the SHT epilogue)");
     if (one_pass_diff) {
         ProfScope ps(c, "hankel");
-        launch_hankel_mfma_sub(c, cc[4], cc[1], cc[5], 1);
+        launch_hankel_mfma_sub(c, cc[4], cc[1], cc[5], 1, ftm);
     } else {
         launch_hankel(c, cc[4], cc[5], 1);
     }
@@ -615,6 +620,7 @@ static int enqueue_step(mtip_ctx* c, int method, int ft_stab, double beta, int p
             ru.real.method = method;
             ru.real.err_use_mask = c->err_use_mask;
             ru.real.add_prev = 1;
+            ru.real.add_mask = ftm;
             ru.real.beta = beta;
             if (chain && one_pass_diff) {
                 // the new density goes to slot SL_OUT, which k_finish_step makes the current one: its SHT is the next step's
@@ -754,6 +760,27 @@ int mtip_run_group_async(mtip_ctx* const* ctxs, int n_ctx, int method, int ft_st
     for (int i = 0; i < n_ctx; ++i) {
         const int r = post_launch(ctxs[i], "mtip_run_group");
         if (r) return r;
+    }
+    return MTIP_OK;
+}
+
+int mtip_set_ft_stab_mask(mtip_ctx* c, const uint8_t* mask) {
+    CTX_CHECK(c);
+    (void)hipSetDevice(c->device);
+    bool any = false, all = true;
+    if (mask)
+        for (int b = 0; b < c->B; ++b) {
+            any = any || mask[b] != 0;
+            all = all && mask[b] != 0;
+        }
+    c->ftmask_mixed = mask != nullptr && any && !all;
+    if (mask != nullptr && !any) FAIL(c, MTIP_EINVAL, "ft_stab mask without any restart set: run the steps with ft_stab = 0 instead");
+    if (c->ftmask_mixed) {
+        if (!c->d_ftmask) {
+            const int r = dev_alloc(c, &c->d_ftmask, (size_t)c->B);
+            if (r) return r;
+        }
+        MTIP_HIP_CHECK(c, mtip_copy(c, c->d_ftmask, mask, (size_t)c->B, hipMemcpyHostToDevice));
     }
     return MTIP_OK;
 }

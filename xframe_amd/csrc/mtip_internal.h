@@ -169,6 +169,7 @@ struct RealEpi {
     double* partial = nullptr;         // (B, Nq, 2)
     RealParams rp{};
     int method = 0, err_use_mask = 0, add_prev = 0;
+    const uint8_t* add_mask = nullptr; // (B) per-restart ft_stab (the add-back only where set), or nullptr: every restart
     double beta = 0.0;
 };
 
@@ -191,6 +192,8 @@ struct mtip_ctx {
     double* d_PT = nullptr;                           // (nt/2, npairs) theta-major Legendre table (fused SHT)
     double* d_PTc = nullptr;                          // (nt/2, 768) the same table in the chunk layout of k_sht_chain's Legendre sums
     int* d_lmc = nullptr;                             // (768) l | m << 8 of slot u * 256 + t, -1: none
+    uint8_t* d_ftmask = nullptr;                      // (B) per-restart ft_stab of the next runs (mtip_set_ft_stab_mask)
+    bool ftmask_mixed = false;                        // the mask has both values: steps with ft_stab take it per restart
     hipEvent_t turn_ev = nullptr;                     // mtip_run_group_async: end of this context's latest transform block
     int chain_chunks = 0;                             // chunks (threads of an accumulation group with work) in that layout; 0: it does not fit 256
     int* d_lmtab = nullptr;                           // (npairs) l | m << 8
@@ -340,7 +343,7 @@ void launch_sht_chain(mtip_ctx* c, const double2* coeff, double2* grid, const In
 // Hankel
 void launch_hankel(mtip_ctx* c, const double2* in, double2* out, int inverse);
 bool hankel_has_difference(const mtip_ctx* c);       // launch_hankel_mfma_sub is available (workgroup-tiled kernel)
-void launch_hankel_mfma_sub(mtip_ctx* c, const double2* in, const double2* in_sub, double2* out, int inverse);
+void launch_hankel_mfma_sub(mtip_ctx* c, const double2* in, const double2* in_sub, double2* out, int inverse, const uint8_t* sub_mask = nullptr);
 int build_jacobi_schedule(mtip_ctx* c, int kmax);    // k_proj.hip: resident-column pairing schedule, verified on the host
 int jacobi_groups(int k);                            // pair-groups a round of that schedule keeps busy for k columns (<= jsched_ps: the table's row length)
 int build_hankel_tiles(mtip_ctx* c);

@@ -65,6 +65,7 @@ _SIGNATURES = {
     'mtip_select_best_where': (C.c_int, [c_void, c_void]),
     'mtip_run': (C.c_int, [c_void, C.c_int, C.c_int, C.c_int, c_void, c_void, c_void]),
     'mtip_run_async': (C.c_int, [c_void, C.c_int, C.c_int, C.c_int, c_void]),
+    'mtip_set_ft_stab_mask': (C.c_int, [c_void, c_void]),
     'mtip_run_group_async': (C.c_int, [c_void, C.c_int, C.c_int, C.c_int, C.c_int, c_void]),
     'mtip_fetch_errors': (C.c_int, [c_void, C.c_int64, C.c_int64, c_void, c_void]),
     'mtip_fetch_main_errors': (C.c_int, [c_void, C.c_int64, C.c_int64, c_void]),

@@ -534,11 +534,32 @@ class Engine:
             assert w.shape == (self.B,)
             self._ck(self.lib.mtip_select_best_where(self.ctx, _lib.ptr(w)))
 
+    def set_ft_stab_mask(self, mask):
+        """ft_stab per restart for the runs that follow (bool per restart), None = every restart (mtip_set_ft_stab_mask)"""
+        m = None if mask is None else np.ascontiguousarray(np.asarray(mask, dtype=bool).astype(np.uint8))
+        assert m is None or m.shape == (self.B,)
+        self._ck(self.lib.mtip_set_ft_stab_mask(self.ctx, _lib.ptr(m)))
+        self._ft_mask_set = m is not None
+
     def run(self, method, ft_stab, betas, fetch=True):
+        """n = len(betas) steps of `method`; ft_stab: bool, or a bool per restart (the reference links ft_stab to the shrink-wrap's
+        enforce decision per reconstruction process: restarts of a batch may disagree)"""
         betas = _lib.as_f64(np.atleast_1d(betas))
         n = len(betas)
+        mixed = None
+        if isinstance(ft_stab, np.ndarray):
+            flags = np.asarray(ft_stab, dtype=bool).reshape(self.B)
+            if flags.all() or not flags.any():
+                ft_stab = bool(flags.all())
+            else:
+                mixed, ft_stab = flags, True
+        if mixed is not None:
+            self.set_ft_stab_mask(mixed)
+        elif getattr(self, '_ft_mask_set', False):
+            self.set_ft_stab_mask(None)                              # a plain flag again: every restart
         if self.group is not None:
-            # side by side with other engines of this GPU: the group enqueues everybody's steps in turn order (EngineGroup)
+            # side by side with other engines of this GPU: the group enqueues everybody's steps in turn order (EngineGroup); a
+            # per-restart ft_stab mask is state of this engine's context, the call itself says ft_stab = 1
             best = np.empty(self.B)
             first = C.c_int64(0)
             if fetch:

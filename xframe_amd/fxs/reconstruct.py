@@ -166,7 +166,7 @@ class MTIP:
 
     @staticmethod
     def _change_to_ft_stab(popt, name, eis_list):
-        """reconstruct.py:836-850 (per-batch decision; all restarts share the schedule)."""
+        """reconstruct.py:836-850: the reference decides per reconstruction process -- a bool when the restarts agree, else one per restart."""
         if name[-8:] == '_ft_stab' or 'ft_stab' not in popt:
             return False
         v = popt['ft_stab']
@@ -178,7 +178,7 @@ class MTIP:
                 recent = np.array(eis_list[-delay:])            # (delay, B)
                 flags = ~(recent == True).any(axis=0)          # noqa: E712
                 if flags.all() != flags.any():
-                    raise NotImplementedError('restarts of one batch disagree on ft_stab linking')
+                    return flags                                # the restarts disagree: a flag per restart (Engine.run takes it)
                 return bool(flags.all())
         return False
 
