@@ -165,7 +165,8 @@ int mtip_run_async(mtip_ctx* ctx, int method, int ft_stab, int n_steps, const do
  * reconstruct.py:104 `n_gpu_workers`, one stream each): the same steps, every context's results bit-identical to its own
  * mtip_run_async, enqueued so that the contexts take turns at the transforms of a step (which fill the chip) while the
  * projections of the others (a long chain on a few CUs) run beside them -- see mtip_api.hip.  All contexts must be in the
- * same loop state a mtip_run_async call would need; n_ctx = 1 is mtip_run_async. */
+ * same loop state a mtip_run_async call would need; n_ctx = 1 is mtip_run_async.  On an error return the failing context holds
+ * the message (mtip_last_error) and the contexts may have advanced by different numbers of steps (mtip_get_best_error reports each). */
 int mtip_run_group_async(mtip_ctx* const* ctxs, int n_ctx, int method, int ft_stab, int n_steps, const double* betas);
 /* ft_stab per restart for the runs that follow (ft_stab = 1 in mtip_run*): mask[n_batch] != 0 = this restart takes the
  * add-back.  The reference decides `ft_stab: link_to_enforce_initial_support` per reconstruction process
