@@ -353,6 +353,66 @@ def check_group_run_identical(g, lib_path, fused=True, sizes=(2, 1, 1)):
             assert np.array_equal(x, y)
 
 
+def check_engine_group_rendezvous(g, lib_path):
+    """EngineGroup's rendezvous form (one host thread per engine, as ProjectWorker's restart groups): same steps asked by all ->
+    one group call; different steps -> each on its own; a member that leaves is not waited for; a member that never arrives is not
+    waited for longer than `patience`.  Every engine ends bit-identical to an engine that ran the same calls alone."""
+    import threading
+    from xframe_amd.fxs.engine import EngineGroup
+    N, L = int(g['N']), int(g['L'])
+    data = data_from_golden(g, L)
+    opt = golden_settings(N, L)
+
+    def make(scale):
+        e = Engine(opt, data, n_batch=1, lib_path=lib_path, fused=True)
+        e.set_density(0, g['rho0'] * scale)
+        e.init_state()
+        return e
+    plans = [[('HIO', True, [0.45, 0.45]), ('ER', True, [0.5]), ('HIO', True, [0.4])],           # engine 0
+             [('HIO', True, [0.45, 0.45]), ('ER', False, [0.5]), None]]                          # engine 1: differs at call 2, leaves before call 3
+    alone = []
+    for i, plan in enumerate(plans):
+        e = make(1.0 + 0.2 * i)
+        for c in plan:
+            if c is not None:
+                e.run(c[0], c[1], np.array(c[2]), fetch=False)
+        alone.append(e.density(0))
+        e.close()
+    engines = [make(1.0), make(1.2)]
+    grp = EngineGroup(patience=20.0)
+    for e in engines:
+        grp.attach(e)
+    errors = []
+
+    def worker(e, plan):
+        try:
+            for c in plan:
+                if c is None:
+                    grp.leave(e)
+                    return
+                e.run(c[0], c[1], np.array(c[2]), fetch=False)
+        except Exception as ex:                                      # noqa: BLE001
+            errors.append(ex)
+    th = [threading.Thread(target=worker, args=(e, p)) for e, p in zip(engines, plans)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(60.0)
+    assert not errors and not any(t.is_alive() for t in th), errors
+    assert grp.calls == {'group': 1, 'single': 3}, grp.calls          # call 1 together; call 2 apart (2 singles); call 3 alone
+    for e, want in zip(engines, alone):
+        assert np.array_equal(e.density(0), want)
+    # patience: engine 1 never arrives
+    grp2 = EngineGroup(patience=0.3)
+    for e in engines:
+        e.group = None
+        grp2.attach(e)
+    engines[0].run('ER', True, np.array([0.5]), fetch=False)
+    assert grp2.calls == {'group': 0, 'single': 1}
+    for e in engines:
+        e.close()
+
+
 def check_group_run_identical_synthetic(cfg, lib_path=None, sizes=(2, 1, 1), n_hio=4, n_er=3):
     """check_group_run_identical at a BASELINE size on synthetic invariants (GPU: the chained kernels and k_rproj of the metric)"""
     import xframe_amd.fxs.hostsetup as hs

@@ -56,6 +56,10 @@ def test_short_trajectory_vs_oracle(emul_lib, golden_mtip16, fused):
     PC.check_short_trajectory_vs_oracle(golden_mtip16, emul_lib, fused)
 
 
+def test_engine_group_rendezvous(emul_lib, golden_mtip16):
+    PC.check_engine_group_rendezvous(golden_mtip16, emul_lib)
+
+
 def test_ft_stab_disagreement(emul_lib, golden_mtip16):
     PC.check_ft_stab_disagreement(golden_mtip16, emul_lib)
 
