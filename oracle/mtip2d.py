@@ -214,9 +214,9 @@ class MTIP2D(OM.MTIP):
         if not isinstance(max_q, float):
             max_q = float(np.max(data['data_radial_points']))
         self.max_q = max_q
-        assert opt['fourier_transform']['type'] == 'midpoint'
-        dr = self.kappa * N / max_q / N
-        self.fp = P2.PolarFourierPair(N, M, max_q, self.kappa, weights_r_max=self.kappa * N / max_q - dr / 2)    # r_max = max(r_p), reconstruct.py:329
+        mode = opt['fourier_transform']['type']
+        r_top = float(np.max(P2.radial_grids_2d(max_q, N, self.kappa, mode)[0]))
+        self.fp = P2.PolarFourierPair(N, M, max_q, self.kappa, weights_r_max=r_top, mode=mode)              # r_max = max(r_p), reconstruct.py:329
         self.sht = _RealHarmonic(self.fp.n_phi)
         self.shape = (N, self.fp.n_phi)
         self.rp = ReciprocalSetup2D(self.fp.qs, data, M, opt['projections']['reciprocal'])

@@ -65,6 +65,79 @@ def assemble_weights_mid(weights, orders, r_max, reciprocity_coefficient):
     return {'forward': w * fpre, 'inverse': w * ipre}
 
 
+def polar_raw_weights(orders, n_radial_points, reciprocity_coefficient, mode='midpoint'):
+    """the workers behind generate_weightDict for dimensions = 2 (hankel_transforms.py): midpoint 411-424, trapz 335-347 (sum over
+    p = 1..N-1), gauss 492-507 (Gauss-Legendre nodes and weights on p = k = x + 1), Zernike 133-176 (sum over p = 1..N-1) with the
+    arguments the loader's call chain gives it -- generate_weightDict hands the reciprocity coefficient on as `expansion_limit` (26,
+    52-62): the expansion stops at max(kappa, M) and the Bessel arguments use the default pi"""
+    N = n_radial_points
+    ms = np.asarray(orders)
+    if mode == 'midpoint':
+        return polar_mid_weights(orders, N, reciprocity_coefficient)
+    if mode == 'trapz':
+        ps, ks = np.arange(1, N), np.arange(N)
+        return ps[None, :, None] * jv(ms[:, None, None] * np.ones((1, N - 1, N)), ks[None, None, :] * ps[None, :, None] * reciprocity_coefficient / N)
+    if mode == 'gauss':
+        from scipy.special import roots_legendre
+        xi, wg = roots_legendre(N)
+        ps = ks = xi + 1
+        return ps[None, :, None] * jv(ms[:, None, None] * np.ones((1, N, N)), ks[None, None, :] * ps[None, :, None] * reciprocity_coefficient * N / 4) * wg[None, :, None]
+    if mode == 'Zernike':
+        from scipy.special import eval_jacobi
+        lim, rc = max(reciprocity_coefficient, ms.max()), np.pi
+        ps, ks = np.arange(1, N), np.arange(N)
+        x = ps / N
+        w = np.zeros((len(ms), N - 1, N))
+        for i, m in enumerate(ms):
+            sv = np.arange(m, lim + 1, 2)
+            half = (sv - m) / 2
+            Z = ((-1) ** half)[:, None] * (x ** m)[None, :] * eval_jacobi(half[:, None], m, 0, (1 - 2 * x ** 2)[None, :])   # mathLibrary.py:805-819, D = 2
+            pref = (-1) ** half * (2 * sv + 2)
+            Jk = jv((sv + 1)[:, None] * np.ones((1, N - 1)), (ks[1:] * rc)[None, :])
+            w[i, :, 1:] = np.einsum('s,sp,sk->pk', pref, Z, Jk)
+            if m == 0:
+                w[i, :, 0] = rc
+        c_kp = np.empty((N - 1, N))
+        c_kp[:, 1:] = ps[:, None] / ks[None, 1:]
+        c_kp[:, 0] = ps
+        return w * c_kp[None]
+    raise NotImplementedError(mode)
+
+
+def assemble_weights_2d(weights, orders, r_max, reciprocity_coefficient, mode='midpoint'):
+    """assemble_weights for dimensions = 2: midpoint 426-452 / trapz 349-375 (cutoff / N)^2, gauss 509-535 (cutoff / 2)^2, Zernike
+    270-300 (cutoff / N)^2 / pi with the sign vector (-+i)^|m| for the negative orders too (its `all_orders` is built without the sign)"""
+    orders = np.asarray(orders)
+    N = weights.shape[-1]
+    q_max = reciprocity_coefficient * N / r_max
+    all_orders = np.concatenate((orders, orders[:0:-1] if mode == 'Zernike' else -orders[:0:-1]))
+    if mode == 'gauss':
+        fs, qs_ = (r_max / 2) ** 2, (q_max / 2) ** 2
+    elif mode == 'Zernike':
+        fs, qs_ = (r_max / N) ** 2 / np.pi, (q_max / N) ** 2 / np.pi
+    else:
+        fs, qs_ = (r_max / N) ** 2, (q_max / N) ** 2
+    w = np.concatenate((weights, (-1.0) ** orders[:0:-1, None, None] * weights[:0:-1]), axis=0)
+    w = np.moveaxis(w, 0, 2)
+    return {'forward': w * ((-1.j) ** (all_orders[None, None, :]) * fs), 'inverse': w * ((1.j) ** (all_orders[None, None, :]) * qs_),
+            'skip_first': mode in ('trapz', 'Zernike')}
+
+
+def radial_grids_2d(max_q, n, kappa, mode):
+    """the radial points of the polar grid pairs (ft_grid_pairs.py:312-349: the same radial functions as the spherical pairs)"""
+    r_cut = kappa * n / max_q
+    if mode == 'midpoint':
+        dr, dq = r_cut / n, max_q / n
+        return np.linspace(dr / 2, r_cut - dr / 2, num=n, endpoint=True), np.linspace(dq / 2, max_q - dq / 2, num=n, endpoint=True)
+    if mode in ('trapz', 'Zernike'):
+        return np.linspace(0, r_cut, n), np.linspace(0, max_q, n)
+    if mode == 'gauss':
+        from scipy.special import roots_legendre
+        xs = roots_legendre(n)[0]
+        return r_cut / 2 * xs + r_cut / 2, max_q / 2 * xs + max_q / 2
+    raise NotImplementedError(mode)
+
+
 def polar_ht(w, used_orders):
     """generate_polar_ht, midpoint branch (629-640): HT_m(f_m)(k) = sum_p f_m(p) w_pkm; orders outside `used_orders` are zeroed"""
     fw, iw = w['forward'], w['inverse']
@@ -72,13 +145,15 @@ def polar_ht(w, used_orders):
     all_abs = np.concatenate((np.arange(n_orders), np.arange(n_orders)[:0:-1]))
     unused = ~np.isin(all_abs, used_orders)
 
+    first = 1 if w.get('skip_first', False) else 0       # trapz / Zernike: the sums leave out shell 0 (ht_modes[:2], 619-628)
+
     def zht(c):
-        out = np.sum(fw * c[:, None, :], axis=0)
+        out = np.sum(fw * c[first:, None, :], axis=0)
         out[:, unused] = 0
         return out
 
     def izht(c):
-        out = np.sum(iw * c[:, None, :], axis=0)
+        out = np.sum(iw * c[first:, None, :], axis=0)
         out[:, unused] = 0
         return out
     return zht, izht, unused
@@ -87,20 +162,19 @@ def polar_ht(w, used_orders):
 class PolarFourierPair:
     """generate_ft for dimensions = 2 (fourier_transforms.py:49-88) on the midpoint grid pair (ft_grid_pairs.py:282-291, 325-336)"""
 
-    def __init__(self, n_radial_points, max_order, max_q, reciprocity_coefficient=2.0, used_orders=None, weights_r_max=None):
+    def __init__(self, n_radial_points, max_order, max_q, reciprocity_coefficient=2.0, used_orders=None, weights_r_max=None, mode='midpoint'):
         self.N, self.M, self.kappa = n_radial_points, max_order, reciprocity_coefficient
         self.n_phi = 2 * max_order + 1                          # harmonic_transforms.py:44-47
         self.q_max = float(max_q)
         self.r_max = reciprocity_coefficient * self.N / self.q_max
-        dr, dq = self.r_max / self.N, self.q_max / self.N
-        self.rs = np.linspace(dr / 2, self.r_max - dr / 2, num=self.N, endpoint=True)
-        self.qs = np.linspace(dq / 2, self.q_max - dq / 2, num=self.N, endpoint=True)
+        self.mode = mode
+        self.rs, self.qs = radial_grids_2d(self.q_max, self.N, reciprocity_coefficient, mode)
         self.phis = np.arange(self.n_phi) / self.n_phi * 2 * np.pi
         self.orders = np.arange(max_order + 1)
-        self.raw_weights = polar_mid_weights(self.orders, self.N, reciprocity_coefficient)
+        self.raw_weights = polar_raw_weights(self.orders, self.N, reciprocity_coefficient, mode)
         # the phasing loop hands generate_ft max(r_p), not the cutoff (reconstruct.py:329): `weights_r_max`
-        self.weights = assemble_weights_mid(self.raw_weights, self.orders, self.r_max if weights_r_max is None else weights_r_max,
-                                            reciprocity_coefficient)
+        self.weights = assemble_weights_2d(self.raw_weights, self.orders, self.r_max if weights_r_max is None else weights_r_max,
+                                           reciprocity_coefficient, mode)
         self.zht, self.izht, self.unused = polar_ht(self.weights, self.orders if used_orders is None else np.asarray(used_orders))
 
     def ft(self, data):

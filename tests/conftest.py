@@ -41,6 +41,11 @@ def golden_mtip2d():
 
 
 @pytest.fixture(scope='session')
+def golden_polar2d_rules():
+    return np.load(os.path.join(GOLDEN, 'polar2d_rules.npz'))
+
+
+@pytest.fixture(scope='session')
 def golden_mtip2d_variants():
     return np.load(os.path.join(GOLDEN, 'mtip2d_variants_N12_M6.npz'))
 

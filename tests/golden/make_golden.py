@@ -1203,6 +1203,57 @@ def main_polar2d():
     print('polar 2-D fixture:', len(out), 'arrays')
 
 
+def main_polar2d_rules():
+    """tests/golden/polar2d_rules.npz (G23): the 2-D (polar) radial rules besides midpoint -- trapz, gauss, Zernike: the grid pair
+    (ft_grid_pairs.py:312-323, 338-349), the raw weights as the loader builds them (generate_weightDict, hankel_transforms.py:22-33,
+    133-176, 335-347, 492-507), their assembly (270-300, 349-375, 509-535), the Hankel pair (602-640) and the Fourier pair of generate_ft
+    on a seeded grid"""
+    mods = bootstrap()
+    ml = mods['xframe.library.mathLibrary']
+    ml.shtns = ShAdapter
+    pl = mods['xframe.library.pythonLibrary']
+    st = mods['xframe.settings']
+    from oracle import mtip as OM
+    from xframe_amd.fxs import synthetic as S
+    o = OM.deep_update(OM.default_settings(), S.config_overrides(1))
+    st.project = pl.DictNamespace.dict_to_dictnamespace(o)
+    ht = importlib.import_module('xframe.projects.fxs.projectLibrary.hankel_transforms')
+    hts = importlib.import_module('xframe.projects.fxs.projectLibrary.harmonic_transforms')
+    fts = importlib.import_module('xframe.projects.fxs.projectLibrary.fourier_transforms')
+    gp = importlib.import_module('xframe.projects.fxs.projectLibrary.ft_grid_pairs')
+    rng = np.random.default_rng(2323)
+    N, M, kappa, max_q = 12, 6, 2.0, 0.9
+    n_phi = 2 * M + 1
+    out = {'N': np.array(N), 'M': np.array(M), 'kappa': np.array(kappa), 'max_q': np.array(max_q)}
+    x = cplx(rng, (N, n_phi))
+    out['x'] = x
+    orders = np.arange(M + 1)
+    cht = hts.HarmonicTransform('complex', {'dimensions': 2, 'max_order': M})
+    r_max = kappa * N / max_q
+    for mode in ('trapz', 'gauss', 'Zernike'):
+        grid = gp.get_grid({**o['fourier_transform'], 'type': mode, 'dimensions': 2, 'n_radial_points': N, 'max_q': max_q,
+                            'phis': np.arange(n_phi) / n_phi * 2 * np.pi, 'reciprocity_coefficient': kappa})
+        out[mode + '_rs'], out[mode + '_qs'] = np.asarray(grid.realGrid[:, 0, 0]), np.asarray(grid.reciprocalGrid[:, 0, 0])
+        # the workers of generate_weightDict (its comm module only spreads them over processes), with the arguments its call chain gives
+        # them: generate_weightDict hands the reciprocity coefficient to generate_weightDict_zernike as `expansion_limit` (26, 52-62)
+        if mode == 'trapz':
+            w_raw = ht.calc_polar_trapz_weights(orders, N, kappa)
+        elif mode == 'gauss':
+            w_raw = ht.calc_polar_gauss_weights(orders, N, kappa)
+        else:
+            w_raw = ht.calc_polar_zernike_weights(orders, N, max(kappa, M), np.pi)
+        out[mode + '_raw'] = np.asarray(w_raw)
+        w = ht.assemble_weights(w_raw, orders, r_max, reciprocity_coefficient=kappa, dimensions=2, mode=mode)
+        out[mode + '_forward'], out[mode + '_inverse'] = w['forward'], w['inverse']
+        zht, izht = ht.generate_ht(w_raw, orders, r_max, reciprocity_coefficient=kappa, dimensions=2, mode=mode)
+        out[mode + '_hankel_fwd'], out[mode + '_hankel_inv'] = np.array(zht(x)), np.array(izht(x))
+        ft, ift = fts.generate_ft(r_max, {'weights': w_raw, 'posHarmOrders': orders}, cht, 2, pos_orders=orders,
+                                  reciprocity_coefficient=kappa, mode=mode)
+        out[mode + '_ft'], out[mode + '_ift'] = np.array(ft(x)), np.array(ift(x))
+    np.savez_compressed(os.path.join(HERE, 'polar2d_rules.npz'), **out)
+    print('polar 2-D radial rules fixture:', len(out), 'arrays;', {k: np.shape(v) for k, v in out.items() if k.endswith('_raw')})
+
+
 # ---- (f-4) the non-default reciprocal metrics ------------------------------------------------------------------------------------
 def main_metrics():
     """tests/golden/metrics_ops.npz (G19): the reference's `_generate_fqc_3d`, `_generate_II_3d`, `_generate_ccd_diff_3d`
@@ -1558,6 +1609,8 @@ if __name__ == '__main__':
         main_metrics()
     elif len(sys.argv) > 1 and sys.argv[1] == 'mtip2d':
         main_mtip2d()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'polar2d_rules':
+        main_polar2d_rules()
     elif len(sys.argv) > 1 and sys.argv[1] == 'mtip2d_variants':
         main_mtip2d_variants()
     elif len(sys.argv) > 1 and sys.argv[1] == 'radial_rules':

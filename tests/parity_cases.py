@@ -1344,6 +1344,35 @@ def check_invariant_metrics_golden_hip(g, lib_path=None):
     e.close()
 
 
+def check_polar2d_rules_golden(g, lib_path=None, device=True):
+    """the 2-D radial rules trapz / gauss / Zernike against the reference's own functions (fixture G23): grids, raw and assembled
+    weights, the Hankel pair and the Fourier pair -- the oracle, the product's host tables and (device=True) the device transforms"""
+    from oracle import polar2d as P2
+    from xframe_amd.fxs import polar2d as X2
+    N, M, kappa, max_q = int(g['N']), int(g['M']), float(g['kappa']), float(g['max_q'])
+    x = g['x']
+    for mode in ('trapz', 'gauss', 'Zernike'):
+        fp = P2.PolarFourierPair(N, M, max_q, kappa, mode=mode)
+        assert np.array_equal(fp.rs, g[mode + '_rs']) and np.array_equal(fp.qs, g[mode + '_qs'])
+        assert rel_l2(fp.raw_weights, g[mode + '_raw']) < 1e-14
+        assert rel_l2(fp.weights['forward'], g[mode + '_forward']) < 1e-14 and rel_l2(fp.weights['inverse'], g[mode + '_inverse']) < 1e-14
+        assert rel_l2(fp.zht(x), g[mode + '_hankel_fwd']) < 1e-13 and rel_l2(fp.izht(x), g[mode + '_hankel_inv']) < 1e-13
+        assert rel_l2(fp.ft(x), g[mode + '_ft']) < 1e-13 and rel_l2(fp.ift(x), g[mode + '_ift']) < 1e-13
+        raw = X2.polar_raw_weights(np.arange(M + 1), N, kappa, mode)
+        assert rel_l2(raw, g[mode + '_raw']) < 1e-14
+        fw, iw = X2.assemble_weights_2d(raw, np.arange(M + 1), kappa * N / max_q, kappa, mode)
+        skip = 1 if g[mode + '_forward'].shape[0] == N - 1 else 0
+        assert rel_l2(fw[skip:], g[mode + '_forward']) < 1e-14 and rel_l2(iw[skip:], g[mode + '_inverse']) < 1e-14
+        assert not skip or (np.abs(fw[0]).max() == 0 and np.abs(iw[0]).max() == 0)
+        if device:
+            e = X2.Engine2D(N, M, max_q, kappa, n_batch=2, lib_path=lib_path, mode=mode)
+            assert np.array_equal(e.rs, g[mode + '_rs']) and np.array_equal(e.qs, g[mode + '_qs'])
+            for b in range(2):
+                assert rel_l2(e.hankel(x)[b], g[mode + '_hankel_fwd']) < 1e-12 and rel_l2(e.hankel(x, True)[b], g[mode + '_hankel_inv']) < 1e-12
+                assert rel_l2(e.fourier_transform(x)[b], g[mode + '_ft']) < 1e-12 and rel_l2(e.fourier_transform(x, True)[b], g[mode + '_ift']) < 1e-12
+            e.close()
+
+
 def mtip2d_problem(g):
     """data dict and settings of the 2-D loop fixture G20"""
     N, M = int(g['N']), int(g['M'])
@@ -1569,6 +1598,7 @@ SETTINGS_VARIANTS_2D = dict(
         'HIO': {'iterations': 3, 'ft_stab': 'link_to_enforce_initial_support', 'link_to_enforce_initial_support': {'delay': 1}},
         'ER': {'iterations': 2, 'ft_stab': False}}}}}},
     er_only={'main_loop': {'sub_loops': {'main': {'order': ['ER'], 'methods': {'ER': {'iterations': 4, 'ft_stab': True}}}}}},
+    rule_trapz={'fourier_transform': {'type': 'trapz'}}, rule_gauss={'fourier_transform': {'type': 'gauss'}},
     best_reselected={'main_loop': {'sub_loops': {'main': {'best_density_not_in_first_n_iterations': 0}}}})
 
 

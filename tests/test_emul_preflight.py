@@ -195,6 +195,10 @@ def test_mtip2d_variants_golden(emul_lib, golden_mtip2d, golden_mtip2d_variants,
     PC.check_mtip2d_variant_golden_hip(golden_mtip2d, golden_mtip2d_variants, name, emul_lib)
 
 
+def test_polar2d_radial_rules(emul_lib, golden_polar2d_rules):
+    PC.check_polar2d_rules_golden(golden_polar2d_rules, emul_lib)
+
+
 def test_mtip2d_ft_stab_disagreement(emul_lib, golden_mtip2d):
     PC.check_mtip2d_ft_stab_disagreement(golden_mtip2d, emul_lib)
 

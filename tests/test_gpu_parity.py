@@ -258,6 +258,11 @@ def test_mtip2d_variants_golden(golden_mtip2d, golden_mtip2d_variants, name):
     PC.check_mtip2d_variant_golden_hip(golden_mtip2d, golden_mtip2d_variants, name)
 
 
+def test_polar2d_radial_rules(golden_polar2d_rules):
+    """2-D trapz / gauss / Zernike: device Hankel and Fourier pairs against the reference's own functions (fixture G23)"""
+    PC.check_polar2d_rules_golden(golden_polar2d_rules)
+
+
 def test_mtip2d_ft_stab_disagreement(golden_mtip2d):
     """restarts of one batch that disagree on the ft_stab link: each one follows the oracle's run of it"""
     PC.check_mtip2d_ft_stab_disagreement(golden_mtip2d)
@@ -274,7 +279,7 @@ def test_mtip2d_worker_vs_oracle(golden_mtip2d, N, M):
 
 
 @pytest.mark.parametrize('name', ['limit_imag', 'value_lo_hi', 'no_enforce', 'n_particles', 'q_mask_region', 'error_inside_support', 'ft_stab_linked',
-                                  'best_reselected'])
+                                  'best_reselected', 'rule_trapz', 'rule_gauss'])
 def test_mtip2d_settings_vs_oracle(golden_mtip2d, name):
     """settings switches of the 2-D loop against the oracle (pinned at 0.0 by the reference's own 2-D run, G20)"""
     PC.check_mtip2d_settings_vs_oracle(golden_mtip2d, None, name)

@@ -316,3 +316,8 @@ def test_g22_mtip2d_variants_oracle(golden_mtip2d, golden_mtip2d_variants, name)
     """G22: the 2-D loop's sub-variants (SW_center, *_non_FXS, reciprocal metrics, auto-correlation support, shift_to_center) -- the
     oracle against the reference's own 2-D runs of them"""
     _PC.check_mtip2d_variant_golden_oracle(golden_mtip2d, golden_mtip2d_variants, name)
+
+
+def test_g23_polar2d_radial_rules(golden_polar2d_rules):
+    """G23: the 2-D trapz / gauss / Zernike rules -- oracle and the product's host weight tables against the reference's own functions"""
+    _PC.check_polar2d_rules_golden(golden_polar2d_rules, device=False)

@@ -32,20 +32,72 @@ def assemble_weights_mid(weights, orders, r_max, reciprocity_coefficient):
     return (w * ((-1.j) ** all_orders[None, None, :] * (r_max / N) ** 2), w * ((1.j) ** all_orders[None, None, :] * (q_max / N) ** 2))
 
 
+def polar_raw_weights(orders, n, kappa, mode='midpoint'):
+    """raw polar Hankel weights [m, p, k] of a radial rule, as the reference's loader builds them for dimensions = 2: `midpoint`
+    (hankel_transforms.py:411-424), `trapz` (335-347) and `Zernike` (133-176) sum over p = 1..N-1, `gauss` (492-507) over the
+    Gauss-Legendre nodes.  Zernike: the loader passes the reciprocity coefficient on as `expansion_limit` (26, 52-62), so the expansion
+    stops at max(kappa, M) and the Bessel arguments use pi (the same quirk as in 3-D, hostsetup._zernike_raw_weights)"""
+    ms = np.asarray(orders, dtype=float)
+    if mode == 'midpoint':
+        return polar_mid_weights(orders, n, kappa)
+    if mode == 'trapz':
+        ps, ks = np.arange(1, n), np.arange(n)
+        return ps[None, :, None] * jv(ms[:, None, None], ks[None, None, :] * ps[None, :, None] * kappa / n)
+    if mode == 'gauss':
+        from scipy.special import roots_legendre
+        xi, wg = roots_legendre(n)
+        node = xi + 1
+        return node[None, :, None] * wg[None, :, None] * jv(ms[:, None, None], node[None, None, :] * node[None, :, None] * kappa * n / 4)
+    if mode == 'Zernike':
+        from scipy.special import eval_jacobi
+        limit = max(kappa, ms.max())
+        ps, ks = np.arange(1, n), np.arange(n)
+        x = ps / n
+        out = np.zeros((len(ms), n - 1, n))
+        for i, m in enumerate(ms):
+            terms = np.arange(m, limit + 1, 2)
+            j = (terms - m) / 2
+            radial = (x ** m)[None, :] * eval_jacobi(j[:, None], m, 0, (1 - 2 * x * x)[None, :])        # (-1)^j R^m_s(x), mathLibrary.py:805-819 with D = 2
+            out[i, :, 1:] = np.einsum('s,sp,sk->pk', 2 * terms + 2, radial, jv((terms + 1)[:, None], (ks[1:] * np.pi)[None, :]))
+            if m == 0:
+                out[i, :, 0] = np.pi
+        out[:, :, 1:] *= (ps[:, None] / ks[None, 1:])[None]
+        out[:, :, 0] *= ps[None, :]
+        return out
+    raise NotImplementedError(f"2-D fourier_transform.type {mode!r}: 'midpoint', 'trapz', 'gauss', 'Zernike'")
+
+
+def assemble_weights_2d(weights, orders, r_max, kappa, mode='midpoint'):
+    """(forward, inverse) complex weights (p, k, all orders 0..M, -M..-1), N x N x (2M + 1): assemble_weights for dimensions = 2
+    (midpoint 426-452, trapz 349-375, gauss 509-535, Zernike 270-300); the rules that leave out shell 0 of their input get a zero row
+    for it, so that the device contraction is the same N x N sum for every rule"""
+    orders = np.asarray(orders)
+    n = weights.shape[-1]
+    q_max = kappa * n / r_max
+    signed = np.concatenate((orders, orders[:0:-1] if mode == 'Zernike' else -orders[:0:-1]))       # (Zernike's sign vector has no signs)
+    fs, iv = {'gauss': ((r_max / 2) ** 2, (q_max / 2) ** 2),
+              'Zernike': ((r_max / n) ** 2 / np.pi, (q_max / n) ** 2 / np.pi)}.get(mode, ((r_max / n) ** 2, (q_max / n) ** 2))
+    w = np.concatenate((weights, (-1.0) ** orders[:0:-1, None, None] * weights[:0:-1]), axis=0)
+    if w.shape[1] == n - 1:
+        w = np.concatenate((np.zeros((w.shape[0], 1, n)), w), axis=1)
+    w = np.moveaxis(w, 0, 2)
+    return w * ((-1.j) ** signed[None, None, :] * fs), w * ((1.j) ** signed[None, None, :] * iv)
+
+
 class Engine2D:
     """transforms (and, after ``set_projection``, the reciprocal projection) of the 2-D variant for batches of ``n_batch`` grids"""
 
     def __init__(self, n_radial_points, max_order, max_q, reciprocity_coefficient=2.0, n_batch=1, device=0, lib_path=None, used_orders=None,
-                 weights_r_max=None):
+                 weights_r_max=None, mode='midpoint'):
         self.lib = _lib.load(lib_path)
         self.N, self.M, self.B = int(n_radial_points), int(max_order), int(n_batch)
         self.n_phi = 2 * self.M + 1                              # harmonic_transforms.py:44-47
         self.kappa = float(reciprocity_coefficient)
         self.q_max = float(max_q)
         self.r_max = self.kappa * self.N / self.q_max            # mathLibrary.py:1169-1176
-        dr, dq = self.r_max / self.N, self.q_max / self.N
-        self.rs = np.linspace(dr / 2, self.r_max - dr / 2, num=self.N, endpoint=True)
-        self.qs = np.linspace(dq / 2, self.q_max - dq / 2, num=self.N, endpoint=True)
+        from .hostsetup import radial_grids
+        self.mode = mode
+        self.rs, self.qs = radial_grids(self.q_max, self.N, self.kappa, mode)      # the polar pairs use the spherical pairs' radial functions (ft_grid_pairs.py:312-349)
         self.phis = np.arange(self.n_phi) / self.n_phi * 2 * np.pi
         self.shape = (self.N, self.n_phi)
         if self.lib.mtip_device_count() <= 0:
@@ -55,8 +107,8 @@ class Engine2D:
             raise _lib.MtipError('mtip2d_create failed (sizes: n_phi odd, 3..2047; a visible device)')
         orders = np.arange(self.M + 1)
         # (the phasing loop hands generate_ft max(r_p) instead of the cutoff, reconstruct.py:329: `weights_r_max`)
-        fw, iw = assemble_weights_mid(polar_mid_weights(orders, self.N, self.kappa), orders,
-                                      self.r_max if weights_r_max is None else float(weights_r_max), self.kappa)
+        fw, iw = assemble_weights_2d(polar_raw_weights(orders, self.N, self.kappa, mode), orders,
+                                     self.r_max if weights_r_max is None else float(weights_r_max), self.kappa, mode)
         all_abs = np.concatenate((orders, orders[:0:-1]))
         unused = ~np.isin(all_abs, orders if used_orders is None else np.asarray(used_orders))     # hankel_transforms.py:611-613
         self._ck(self.lib.mtip2d_set_hankel_weights(self.ctx, _lib.ptr(_lib.as_c128(fw)), _lib.ptr(_lib.as_c128(iw)), _lib.ptr(_lib.as_u8(unused))))

@@ -10,7 +10,8 @@ shrink-wrap ramps, support bookkeeping, history and best tracking are the host l
 reference's own 2-D `MTIP` run) and, for the loop's sub-variants -- `SW_center`, `HIO_non_FXS` / `ER_non_FXS`, the reciprocal metrics
 `deg2_invariant_l2_diff` / `l2_projection_diff` (and main errors over them), the auto-correlation initial support, `shift_to_center`
 -- and `SO_freedom` with the `fix_orientation` output modifier, by `tests/golden/mtip2d_variants_N12_M6.npz` (the reference's own
-2-D runs of each).  Not built for 2-D: radial rules other than `midpoint`, the other reciprocal metrics; the `low_resolution_autocorrelation` guess raises upstream in 2-D (reconstruct.py:1186 iterates over
+2-D runs of each); the radial rules `trapz`, `gauss`, `Zernike` are host weight tables for the same device contraction (fixture G23 from
+the reference's own functions).  Not built for 2-D: the other reciprocal metrics; the `low_resolution_autocorrelation` guess raises upstream in 2-D (reconstruct.py:1186 iterates over
 `low_resolution_intensity_coefficients`, which is False for dimensions == 2) and raises here."""
 import numpy as np
 
@@ -128,16 +129,15 @@ class MTIP2D:
             raise ValueError('MTIP2D is the dimensions == 2 loop')
         g = opt['grid']
         self.N, self.M = int(g['n_radial_points']), int(g['max_order'])
-        if opt['fourier_transform']['type'] != 'midpoint':
-            raise NotImplementedError("2-D fourier_transform.type %r: 'midpoint' is built" % (opt['fourier_transform']['type'],))
+        mode = opt['fourier_transform']['type']                       # midpoint, trapz, gauss, Zernike (polar2d.polar_raw_weights raises otherwise)
         kappa = reciprocity_coefficient(opt['fourier_transform'])
         max_q = g['max_q']
         if not isinstance(max_q, float):
             max_q = float(np.max(data['data_radial_points']))
         self.B = int(n_restarts)
-        dr = kappa / max_q
+        r_top = float(np.max(hs.radial_grids(max_q, self.N, kappa, mode)[0]))
         self.engine = e = Engine2D(self.N, self.M, max_q, kappa, n_batch=self.B, device=device, lib_path=lib_path,
-                                   weights_r_max=kappa * self.N / max_q - dr / 2)                           # r_max = max(r_p), reconstruct.py:329
+                                   weights_r_max=r_top, mode=mode)                                          # r_max = max(r_p), reconstruct.py:329
         self.shape = e.shape
         self.rsetup = rs_ = ReciprocalSetup2D(e.qs, data, self.M, opt['projections']['reciprocal'])
         e.set_projection(rs_.projection_matrices, rs_.used_orders, rs_.radial_mask, rs_.number_of_particles)
