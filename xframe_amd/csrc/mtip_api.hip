@@ -723,10 +723,11 @@ int mtip_run_group_async(mtip_ctx* const* ctxs, int n_ctx, int method, int ft_st
         if (!c->turn_ev) MTIP_HIP_CHECK(c, hipEventCreateWithFlags(&c->turn_ev, hipEventDisableTiming | hipEventDisableSystemFence));
     }
     hipEvent_t prev = nullptr, prev2 = nullptr;     // end of the block before this one in the ring, and of the one before that
-    // MTIP_TURN_LAG = 1: a block waits for the block right before it (strict turns: the launch gaps inside a block, ~7 us x 6 kernels,
-    // are then idle chip time); 2 (default): for the one before that -- at most two contexts are in their transforms at a time, one
-    // fills the other's gaps and tails.  Measured, {3, 3, 2} restarts at 128 x L32: schedule 0.543 ms per step without turns, 0.592 with
-    // lag 1, 0.528 with lag 2; the HIO window (bound by one context's chain, not by the chip) 0.60 in all three.
+    // MTIP_TURN_LAG = 1: a block waits for the block right before it (strict turns: three stream-to-stream hand-overs of ~10 us per
+    // period on the critical path, and the half-empty second round of every 384-workgroup kernel is idle chip time); 2 (default): for
+    // the one before that -- at most two contexts are in their transforms at a time, one fills the other's tails.  Measured, {3, 3, 2}
+    // restarts at 128 x L32: schedule 0.543 ms per step without turns, 0.592 with lag 1, 0.528 with lag 2; the HIO window (the chain of
+    // one context is as long as the three transform blocks together) 0.59-0.60 in all three.
     const int lag = getenv("MTIP_TURN_LAG") && atoi(getenv("MTIP_TURN_LAG")) == 1 ? 1 : 2;
     auto turn = [&](mtip_ctx* c, bool tail, bool head, int s) -> int {
         hipEvent_t w = lag >= 2 ? prev2 : prev;
