@@ -2,8 +2,9 @@
 (``xframe/library/mathLibrary.py:469-496``), the polar Hankel pair with midpoint weights (``hankel_transforms.py:411-424, 300-362,
 602-640``), the Fourier pair ``generate_ft`` builds from them (``fourier_transforms.py:49-88``) on the polar midpoint grid pair
 (``ft_grid_pairs.py:282-291, 325-336``) and the 2-D reciprocal projection (``fxs_Projections.py:723-745, 803-826, 855-863``),
-through the ``mtip2d_*`` entry points of ``include/mtip_hip.h`` (``csrc/k_polar2d.hip``).  The 2-D phasing LOOP is not wired
-(DESIGN section 6); no CPU fallback."""
+through the ``mtip2d_*`` entry points of ``include/mtip_hip.h`` (``csrc/k_polar2d.hip``); the radial rules besides midpoint (trapz,
+gauss, Zernike: ``hankel_transforms.py:133-176, 335-375, 492-535``) are host weight tables for the same device contraction.  The 2-D
+phasing loop on these operators is ``reconstruct2d.py``; no CPU fallback."""
 import ctypes as C
 
 import numpy as np
